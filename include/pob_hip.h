@@ -1,0 +1,94 @@
+/* pob_hip.h -- C ABI of the MI355X-native witness generator for the proof_of_burn / spend circuits.
+ *
+ * Drop-in boundary.  In the reference, the path "input.json -> witness -> .wtns" is the
+ * circom-emitted calculator invoked as a process (reference Makefile:4-5:
+ *     ./main_proof_of_burn input.json witness.wtns ; ./main_spend input.json witness.wtns
+ * and tests/test.py:60-64 for gadget mains).  There is no in-process FFI in the reference; the functions
+ * below are what a binding for that path would call: one handle per (GPU, circuit instantiation), inputs
+ * as flat arrays in the declaration order of the circuit's `signal input`s, public outputs / pass-fail /
+ * .wtns out.  Plain pointers and sizes only; every buffer is caller-allocated; no callbacks; a handle is
+ * bound to one GPU and is not thread-safe (one process per GPU).  All functions return 0 on success or a
+ * negative code; pob_strerror() gives the text.
+ */
+#ifndef POB_HIP_H
+#define POB_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pob_ctx* pob_handle;
+
+enum { POB_CIRCUIT_PROOF_OF_BURN = 0, POB_CIRCUIT_SPEND = 1 };
+enum { POB_OK = 0, POB_E_ARG = -1, POB_E_HIP = -2, POB_E_NOMEM = -3, POB_E_STATE = -4, POB_E_IO = -5 };
+
+typedef struct {
+    uint64_t n_witness;          /* W: O0 wires incl. the constant-1 wire (= nWitness of the .wtns)            */
+    uint64_t n_bit, n_sm, n_fr;  /* wires per storage class (policy.hpp)                                        */
+    uint32_t n_fr_inputs, n_sm_inputs, n_outputs;
+    uint32_t n_units, n_sponges, n_perms, n_stages, max_batch;
+    uint64_t group_bytes;        /* HBM-resident bytes of the compact witness vector per 64 witnesses           */
+    uint64_t keccak_bit_wires;   /* wires handled by the bit-sliced Keccak kernels                              */
+} pob_info_t;
+
+/* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference
+ * circuits/main_proof_of_burn.circom:27, circuits/main_spend.circom:6, Makefile:2-3).
+ * params: template parameters as canonical 4x64-bit LE limbs each:
+ *   ProofOfBurn: maxNumLayers, maxNodeBlocks, maxHeaderBlocks, minLeafAddressNibbles, amountBytes,
+ *                powMinimumZeroBytes, maxIntendedBalance, maxActualBalance   (proof_of_burn.circom:34)
+ *   Spend:       maxAmountBytes                                              (spend.circom:32)        */
+int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint32_t max_batch, pob_handle* out);
+void pob_close(pob_handle h);
+int pob_get_info(pob_handle h, pob_info_t* info);
+/* Layout planner only (no GPU touched): wire / class counts of an instantiation, e.g. to size buffers. */
+int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* info);
+const char* pob_strerror(pob_handle h);
+
+/* Replaces the emitted loader (loadJson; reference tests/test.py:57-59 writes input.json).  Witness-major:
+ *   fr_inputs[n][n_fr_inputs][32]  canonical LE field elements, circuit declaration order of the FR-class inputs
+ *     ProofOfBurn: burnKey, actualBalance, intendedBalance, revealAmount, burnExtraCommitment, _proofExtraCommitment
+ *     Spend:       burnKey, balance, withdrawnBalance, extraCommitment
+ *   sm_inputs[n][n_sm_inputs]      int32, declaration order of the small inputs
+ *     ProofOfBurn: numLeafAddressNibbles, layers[L][136*NB], layerLens[L], numLayers, blockHeader[136*HB],
+ *                  blockHeaderLen, byteSecurityRelax      (values >= 2^31 must be rejected by the caller:
+ *                  every one of them is range-constrained to <= 16 bits in-circuit)
+ * Host pointers; the copy to HBM is synchronous.                                                                */
+int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n);
+
+/* Replaces the run of the calculator (all `<==` / `<--` / `===`; reference Makefile:4-5): enqueues every stage on
+ * `stream` (a hipStream_t, NULL = the handle's own stream) for the n uploaded inputs.  Asynchronous.              */
+int pob_generate(pob_handle h, void* stream);
+/* Per-gate constraint evaluator over the resident witness vector (north star; the reference checks inline,
+ * e.g. assert.circom:46,62,78, divide.circom:32): re-reads every wire, asynchronous.                             */
+int pob_constraint_check(pob_handle h, void* stream);
+int pob_sync(pob_handle h);
+
+/* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.
+ * status[i] = 0 ok, else (template id << 12 | source line) of the first failing assert; outputs[i][32] = public
+ * output (commitment) canonical LE.  check_status / bad_wire (may be NULL): result of pob_constraint_check:
+ * first failing === site and lowest wire whose stored value contradicts its definition (0xFFFFFFFF = none).      */
+int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* check_status, uint32_t* bad_wire);
+/* Device-resident results for the RCCL gather: status u32[max_batch_padded], outputs u8[max_batch_padded][32]. */
+int pob_results_device(pob_handle h, void** d_status, void** d_outputs);
+
+/* Replaces writeBinWitness (patch point `fclose(write_ptr)` at reference tests/test.py:36): expands witness `idx`
+ * of the batch to canonical 32-byte LE values.  pob_emit_witness: payload only (32*W bytes) into host memory;
+ * pob_write_wtns: full iden3 .wtns file.                                                                         */
+int pob_emit_witness(pob_handle h, uint32_t idx, uint8_t* dst, uint64_t cap);
+int pob_write_wtns(pob_handle h, uint32_t idx, const char* path);
+
+/* Measurement: average duration (ms, HIP events on `stream`) of `iters` back-to-back launches of one kernel over
+ * the current batch.  which: 0 = Keccak round expansion (generate), 1 = Keccak round constraint evaluation,
+ * 2 = G-unit constraint evaluation, 3 = sponge chain (generate).                                               */
+int pob_time_kernel(pob_handle h, int which, int iters, void* stream, float* avg_ms);
+
+/* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */
+int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
+
+/* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */
+void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,841 @@
+// Circuit templates of the reference (circuits/utils/*.circom + the circomlib templates they include),
+// written once over a policy P (policy.hpp): layout planning, witness generation, constraint evaluation
+// and .wtns emission are four instantiations of the SAME code, so the O0 wire order is stated once.
+//
+// Conventions
+//   * lane = witness: scalar signal values are per-lane (S / F) or lane masks (B); arrays are passed as
+//     references to wires that were already written (SmRef / BitRef) and re-read through L2.
+//   * own signals are declared first, in circom's O0 order: outputs | inputs | intermediates (declaration
+//     order); sub-components follow in initialisation order.  Comments give
+//     `[out | in | mid] || children` and the reference file:line.
+//   * `<==`  -> p.put(ref, expr)   `<--` -> p.hint(ref, value)   `===`/assert -> p.require(mask, code)
+#pragma once
+#include "policy.hpp"
+
+#ifdef __HIPCC__
+#define GD __host__ __device__
+#else
+#define GD
+#endif
+
+// ============================================================================ circomlib: gates.circom
+template <class P> HD B gXOR(P& p, B a, B b) { BitRef o = p.bits(3); a = p.put(o + 1, a); b = p.put(o + 2, b); return p.put(o, a ^ b); }
+template <class P> HD B gAND(P& p, B a, B b) { BitRef o = p.bits(3); a = p.put(o + 1, a); b = p.put(o + 2, b); return p.put(o, a & b); }
+template <class P> HD B gOR(P& p, B a, B b) { BitRef o = p.bits(3); a = p.put(o + 1, a); b = p.put(o + 2, b); return p.put(o, a | b); }
+
+// ============================================================================ circomlib: bitify.circom
+// Num2Bits(n)  [out[n] | in];  out[i] <-- (in>>i)&1;  sum out[i] 2^i === in   (n <= 31 here)
+template <class P> GD BitRef gNum2BitsS(P& p, int n, S in) {
+    BitRef o = p.bits(n); SmRef i = p.sms(1);
+    S x = p.put(i, in);
+    uint32_t acc = 0;
+    for (int k = 0; k < n; k++) {
+        B b = p.hint(o + k, p.ballot(((uint32_t)x >> k) & 1));
+        acc |= (uint32_t)p.bit(b) << k;
+    }
+    p.require(p.ballot((uint32_t)x == acc), FAILCODE(T_NUM2BITS, 38));   // negative / too wide values fail here
+    return o;
+}
+// field-element flavour (n <= 254)
+template <class P> GD BitRef gNum2BitsF(P& p, int n, const F& in) {
+    BitRef o = p.bits(n); FrRef i = p.frs(1);
+    F x = p.put(i, in);
+    F c = fr_from_mont(x), acc = fr_zero();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 32; k++) {
+            int idx = 32 * j + k;
+            if (idx < n) { B b = p.hint(o + idx, p.ballot((c.l[j] >> k) & 1)); w |= (uint32_t)p.bit(b) << k; }
+        }
+        acc.l[j] = w;
+    }
+    bool ok = fr_eq(acc, c) || (n >= 254 && fr_geq_p(acc) && fr_eq(fr_sub_p(acc), c));   // sum === in (mod p)
+    p.require(p.ballot(ok), FAILCODE(T_NUM2BITS, 38));
+    return o;
+}
+// Bits2Num(8)  [out | in[8]]
+template <class P> HD S gBits2Num8(P& p, BitRef src) {
+    SmRef o = p.sms(1); BitRef in = p.bits(8);
+    S v = 0;
+    for (int k = 0; k < 8; k++) { B b = p.put(in + k, p.get(src + k)); v |= (S)p.bit(b) << k; }
+    return p.put(o, v);
+}
+
+// ============================================================================ circomlib: comparators.circom
+// IsZero  [out | in | inv];  inv <-- in!=0 ? 1/in : 0;  out <== -in*inv+1;  in*out === 0
+template <class P> HD B gIsZeroS(P& p, S in) {
+    BitRef o = p.bits(1); SmRef i = p.sms(1); SiRef v = p.sis(1);
+    S x = p.put(i, in);
+    S k = p.hint_inv(v, x);                               // stored code k means the field element k^-1
+    // out = 1 - x/k must be representable as the stored bit: k == 0 (out = 1) or k == x (out = 0)
+    p.require(p.ballot(k == 0 || k == x), FAILCODE(T_ISZERO, 30));
+    B out = p.put(o, p.ballot(k == 0));
+    p.require(p.ballot(x == 0) | ~out, FAILCODE(T_ISZERO, 31));   // in*out === 0
+    return out;
+}
+template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) {
+    BitRef o = p.bits(1); FrRef i = p.frs(1); FrRef v = p.frs(1);
+    F x = p.put(i, in);
+    F iv;
+    if (P::is_gen && !inv_is_stored) iv = p.hint(v, fr_inv(x));
+    else if (P::is_gen) iv = p.get(v);                    // pre-computed by a batched inversion
+    else iv = p.hint(v, x);
+    F t = fr_mul(x, iv);                                  // in*inv (Montgomery)
+    bool t0 = fr_is_zero(t), t1 = fr_eq(t, fr_one_mont());
+    p.require(p.ballot(t0 || t1), FAILCODE(T_ISZERO, 30));
+    B out = p.put(o, p.ballot(t0));
+    p.require(p.ballot(fr_is_zero(x)) | ~out, FAILCODE(T_ISZERO, 31));
+    return out;
+}
+// IsEqual  [out | in[2]] || IsZero(in[1]-in[0])
+template <class P> HD B gIsEqualS(P& p, S a, S b) {
+    BitRef o = p.bits(1); SmRef in = p.sms(2);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    return p.put(o, gIsZeroS(p, (S)((uint32_t)b - (uint32_t)a)));
+}
+template <class P> GD B gIsEqualF(P& p, const F& a, const F& b, bool inv_is_stored = false) {
+    BitRef o = p.bits(1); FrRef in = p.frs(2);
+    F x = p.put(in, a), y = p.put(in + 1, b);
+    return p.put(o, gIsZeroF(p, fr_sub(y, x), inv_is_stored));
+}
+// LessThan(n)  [out | in[2]] || Num2Bits(n+1)(in0 + 2^n - in1);  out <== 1 - bit n
+template <class P> GD B gLessThanS(P& p, int n, S a, S b) {
+    BitRef o = p.bits(1); SmRef in = p.sms(2);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    BitRef nb = gNum2BitsS(p, n + 1, (S)((uint32_t)a + (1u << n) - (uint32_t)b));
+    return p.put(o, ~p.get(nb + n));
+}
+template <class P> GD B gLessThanF(P& p, int n, const F& a, const F& b) {
+    BitRef o = p.bits(1); FrRef in = p.frs(2);
+    F x = p.put(in, a), y = p.put(in + 1, b);
+    Fr e = fr_zero(); e.l[n >> 5] = 1u << (n & 31);       // 2^n canonical (n <= 252)
+    BitRef nb = gNum2BitsF(p, n + 1, fr_sub(fr_add(x, fr_to_mont(e)), y));
+    return p.put(o, ~p.get(nb + n));
+}
+// LessEqThan(n) [out | in[2]] || LessThan(n)(in0, in1+1);  GreaterEqThan(n) || LessThan(n)(in1, in0+1)
+template <class P> GD B gLessEqThanS(P& p, int n, S a, S b) {
+    BitRef o = p.bits(1); SmRef in = p.sms(2);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    return p.put(o, gLessThanS(p, n, a, (S)((uint32_t)b + 1u)));
+}
+template <class P> GD B gGreaterEqThanS(P& p, int n, S a, S b) {
+    BitRef o = p.bits(1); SmRef in = p.sms(2);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    return p.put(o, gLessThanS(p, n, b, (S)((uint32_t)a + 1u)));
+}
+template <class P> GD B gLessEqThanF(P& p, int n, const F& a, const F& b) {
+    BitRef o = p.bits(1); FrRef in = p.frs(2);
+    F x = p.put(in, a), y = p.put(in + 1, b);
+    return p.put(o, gLessThanF(p, n, x, fr_add(y, fr_one_mont())));
+}
+template <class P> GD B gGreaterEqThanF(P& p, int n, const F& a, const F& b) {
+    BitRef o = p.bits(1); FrRef in = p.frs(2);
+    F x = p.put(in, a), y = p.put(in + 1, b);
+    return p.put(o, gLessThanF(p, n, y, fr_add(x, fr_one_mont())));
+}
+
+// MultiAND(n)  [out | in[n]];  n>2: ands[0]=MultiAND(n\2), ands[1]=MultiAND(n-n\2), and2=AND (initialisation order)
+template <class P, int N> struct MultiANDg {
+    static HD B run(P& p, const B* in) {
+        BitRef o = p.bits(1); BitRef i = p.bits(N);
+        B v[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = p.put(i + k, in[k]);
+        B a = MultiANDg<P, N / 2>::run(p, v);
+        B b = MultiANDg<P, N - N / 2>::run(p, v + N / 2);
+        return p.put(o, gAND(p, a, b));
+    }
+};
+template <class P> struct MultiANDg<P, 1> {
+    static HD B run(P& p, const B* in) { BitRef o = p.bits(1); BitRef i = p.bits(1); B v = p.put(i, in[0]); return p.put(o, v); }
+};
+template <class P> struct MultiANDg<P, 2> {
+    static HD B run(P& p, const B* in) {
+        BitRef o = p.bits(1); BitRef i = p.bits(2);
+        B a = p.put(i, in[0]), b = p.put(i + 1, in[1]);
+        return p.put(o, gAND(p, a, b));
+    }
+};
+
+// ============================================================================ circomlib: mux1.circom
+// Mux1 [out | c[2], s] || MultiMux1(1) [out[1] | c[1][2], s];  out = (c1-c0)*s + c0
+template <class P> HD S gMux1S(P& p, S c0, S c1, B s) {
+    SmRef o = p.sms(1); SmRef c = p.sms(2); BitRef sr = p.bits(1);
+    c0 = p.put(c, c0); c1 = p.put(c + 1, c1); s = p.put(sr, s);
+    SmRef mo = p.sms(1); SmRef mc = p.sms(2); BitRef ms = p.bits(1);
+    S d0 = p.put(mc, c0), d1 = p.put(mc + 1, c1); B ss = p.put(ms, s);
+    return p.put(o, p.put(mo, p.bit(ss) ? d1 : d0));
+}
+// RlpInteger's use (integer.circom:90): c[0] small, c[1] = the 248-bit input; the result is always < 256
+template <class P> GD S gMux1SF(P& p, S c0, const F& c1, B s) {
+    SmRef o = p.sms(1); SmRef cs = p.sms(1); FrRef cf = p.frs(1); BitRef sr = p.bits(1);
+    c0 = p.put(cs, c0); F f1 = p.put(cf, c1); s = p.put(sr, s);
+    SmRef mo = p.sms(1); SmRef mcs = p.sms(1); FrRef mcf = p.frs(1); BitRef ms = p.bits(1);
+    S d0 = p.put(mcs, c0); F g1 = p.put(mcf, f1); B ss = p.put(ms, s);
+    S lo = (S)fr_from_mont(g1).l[0];
+    return p.put(o, p.put(mo, p.bit(ss) ? lo : d0));
+}
+
+// ============================================================================ circomlib: compconstant / aliascheck / Num2Bits_strict
+// CompConstant(ct = p-1)  [out | in[254] | parts[127], sout] || Num2Bits(135)
+template <class P> GD B gCompConstantPm1(P& p, BitRef src) {
+    BitRef o = p.bits(1); BitRef in = p.bits(254); FrRef parts = p.frs(127); FrRef sout = p.frs(1);
+    const uint32_t PM1[8] = {0xf0000000u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    for (int k = 0; k < 254; k++) p.put(in + k, p.get(src + k));
+    // a, b, e as canonical 256-bit integers kept in Montgomery form
+    Fr bc = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0}};
+    F b = fr_to_mont(bc), a = fr_one_mont(), e = fr_one_mont(), sum = fr_zero();
+    for (int i = 0; i < 127; i++) {
+        uint32_t clsb = (PM1[(2 * i) >> 5] >> ((2 * i) & 31)) & 1, cmsb = (PM1[(2 * i + 1) >> 5] >> ((2 * i + 1) & 31)) & 1;
+        bool sl = p.bit(p.get(in + 2 * i)), sm = p.bit(p.get(in + 2 * i + 1));
+        F v;
+        if (!cmsb && !clsb) v = (sm && sl) ? b : ((sm || sl) ? b : fr_zero());          // -b*sm*sl + b*sm + b*sl
+        else if (!cmsb && clsb) {                                                         // a*sm*sl - a*sl + b*sm - a*sm + a
+            v = a; if (sm && sl) v = fr_add(v, a); if (sl) v = fr_sub(v, a); if (sm) { v = fr_add(v, b); v = fr_sub(v, a); }
+        } else if (cmsb && !clsb) {                                                       // b*sm*sl - a*sm + a
+            v = a; if (sm && sl) v = fr_add(v, b); if (sm) v = fr_sub(v, a);
+        } else v = (sm && sl) ? fr_zero() : a;                                            // -a*sm*sl + a
+        sum = fr_add(sum, p.put(parts + i, v));
+        b = fr_sub(b, e); a = fr_add(a, e); e = fr_add(e, e);
+    }
+    F so = p.put(sout, sum);
+    BitRef nb = gNum2BitsF(p, 135, so);
+    return p.put(o, p.get(nb + 127));
+}
+// AliasCheck [ | in[254]] || CompConstant(-1);  out === 0
+template <class P> GD void gAliasCheck(P& p, BitRef src) {
+    BitRef in = p.bits(254);
+    for (int k = 0; k < 254; k++) p.put(in + k, p.get(src + k));
+    B gt = gCompConstantPm1(p, in);
+    p.require(~gt, FAILCODE(T_ALIASCHECK, 31));
+}
+// Num2Bits_strict [out[254] | in] || Num2Bits(254), AliasCheck   (initialisation order, see oracle header)
+template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in) {
+    BitRef o = p.bits(254); FrRef i = p.frs(1);
+    F x = p.put(i, in);
+    BitRef nb = gNum2BitsF(p, 254, x);
+    for (int k = 0; k < 254; k++) p.put(o + k, p.get(nb + k));
+    gAliasCheck(p, o);
+    return o;
+}
+
+// ============================================================================ circomlib: poseidon.circom (optimised schedule)
+// table offsets: tools/gen_poseidon.py -> poseidon_consts.h (C | S | M | P per t, Montgomery)
+struct PosOff { uint32_t C, S, M, Pm; int rp; };
+template <class P> HD F gSigma(P& p, const F& in) {   // [out | in | in2, in4]
+    FrRef o = p.frs(1), i = p.frs(1), m = p.frs(2);
+    F x = p.put(i, in);
+    F x2 = p.put(m, fr_sqr(x)), x4 = p.put(m + 1, fr_sqr(x2));
+    return p.put(o, fr_mul(x4, x));
+}
+template <class P, int T> GD void gArk(P& p, const PosOff& k, int r, F* st) {   // [out[t] | in[t]]
+    FrRef o = p.frs(T), i = p.frs(T);
+#pragma unroll
+    for (int j = 0; j < T; j++) { F x = p.put(i + j, st[j]); st[j] = p.put(o + j, fr_add(x, p.kconst(k.C + r + j))); }
+}
+template <class P, int T> GD void gMix(P& p, uint32_t mat, F* st) {             // out[i] = sum_j A[i][j] in[j]
+    FrRef o = p.frs(T), i = p.frs(T);
+    F x[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) x[j] = p.put(i + j, st[j]);
+#pragma unroll
+    for (int a = 0; a < T; a++) {
+        F acc = fr_zero();
+#pragma unroll
+        for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(mat + a * T + j), x[j]));
+        st[a] = p.put(o + a, acc);
+    }
+}
+template <class P, int T> GD void gMixS(P& p, const PosOff& k, int r, F* st) {
+    FrRef o = p.frs(T), i = p.frs(T);
+    F x[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) x[j] = p.put(i + j, st[j]);
+    uint32_t base = k.S + (2 * T - 1) * r;
+    F acc = fr_zero();
+#pragma unroll
+    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(base + j), x[j]));
+    st[0] = p.put(o, acc);
+#pragma unroll
+    for (int j = 1; j < T; j++) st[j] = p.put(o + j, fr_add(x[j], fr_mul(x[0], p.kconst(base + T + j - 1))));
+}
+// Poseidon(T-1) [out | inputs[T-1]] || PoseidonEx [out[1] | inputs[T-1], initialState] || ark0; 3x{T Sigma, ark, mix(M)};
+// T Sigma, ark4, mix(P); RP x {sigmaP, mixS}; 3x{T Sigma, ark, mix(M)}; T Sigma; mixLast [out | in[T]]
+template <class P, int T> GD F gPoseidon(P& p, const PosOff& k, const F* inputs) {
+    FrRef o = p.frs(1), in = p.frs(T - 1);
+    F st[T];
+    st[0] = fr_zero();
+#pragma unroll
+    for (int j = 1; j < T; j++) st[j] = p.put(in + (j - 1), inputs[j - 1]);
+    FrRef eo = p.frs(1), ein = p.frs(T - 1), einit = p.frs(1);
+#pragma unroll
+    for (int j = 1; j < T; j++) st[j] = p.put(ein + (j - 1), st[j]);
+    st[0] = p.put(einit, st[0]);
+    gArk<P, T>(p, k, 0, st);
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
+        gArk<P, T>(p, k, (r + 1) * T, st);
+        gMix<P, T>(p, k.M, st);
+    }
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
+    gArk<P, T>(p, k, 4 * T, st);
+    gMix<P, T>(p, k.Pm, st);
+    for (int r = 0; r < k.rp; r++) {
+        st[0] = fr_add(gSigma(p, st[0]), p.kconst(k.C + 5 * T + r));
+        gMixS<P, T>(p, k, r, st);
+    }
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
+        gArk<P, T>(p, k, 5 * T + k.rp + r * T, st);
+        gMix<P, T>(p, k.M, st);
+    }
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
+    FrRef lo = p.frs(1), li = p.frs(T);
+    F acc = fr_zero();
+#pragma unroll
+    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(k.M + j), p.put(li + j, st[j])));
+    F h = p.put(lo, acc);
+    return p.put(o, p.put(eo, h));
+}
+
+// ============================================================================ circuits/utils/assert.circom
+// AssertBits(B) :13-17  [ | in | bits[B]] || Num2Bits(B)
+template <class P> GD void gAssertBitsS(P& p, int nb, S in) {
+    SmRef i = p.sms(1); BitRef bits = p.bits(nb);
+    in = p.put(i, in);
+    BitRef c = gNum2BitsS(p, nb, in);
+    for (int k = 0; k < nb; k++) p.put(bits + k, p.get(c + k));
+}
+template <class P> GD void gAssertBitsF(P& p, int nb, const F& in) {
+    FrRef i = p.frs(1); BitRef bits = p.bits(nb);
+    F x = p.put(i, in);
+    BitRef c = gNum2BitsF(p, nb, x);
+    for (int k = 0; k < nb; k++) p.put(bits + k, p.get(c + k));
+}
+// AssertByteString(N) :26-31  [ | in[N]] || AssertBits(8) x N
+template <class P> GD void gAssertByteString(P& p, int N, SmRef src) {
+    SmRef in = p.sms(N);
+    for (int i = 0; i < N; i++) gAssertBitsS(p, 8, p.put(in + i, p.get(src + i)));
+}
+// AssertLessThan(B) :40-47 / AssertLessEqThan :56-63 / AssertGreaterEqThan :72-79   [ | a, b | out]; out === 1
+template <class P> GD void gAssertLessThanS(P& p, int nb, S a, S b) {
+    SmRef in = p.sms(2); BitRef o = p.bits(1);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    gAssertBitsS(p, nb, a); gAssertBitsS(p, nb, b);
+    p.require(p.put(o, gLessThanS(p, nb, a, b)), FAILCODE(T_ASSERT_LT, 46));
+}
+template <class P> GD void gAssertLessEqThanS(P& p, int nb, S a, S b) {
+    SmRef in = p.sms(2); BitRef o = p.bits(1);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    gAssertBitsS(p, nb, a); gAssertBitsS(p, nb, b);
+    p.require(p.put(o, gLessEqThanS(p, nb, a, b)), FAILCODE(T_ASSERT_LE, 62));
+}
+template <class P> GD void gAssertGreaterEqThanS(P& p, int nb, S a, S b) {
+    SmRef in = p.sms(2); BitRef o = p.bits(1);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    gAssertBitsS(p, nb, a); gAssertBitsS(p, nb, b);
+    p.require(p.put(o, gGreaterEqThanS(p, nb, a, b)), FAILCODE(T_ASSERT_GE, 78));
+}
+template <class P> GD void gAssertLessEqThanF(P& p, int nb, const F& a, const F& b) {
+    FrRef in = p.frs(2); BitRef o = p.bits(1);
+    F x = p.put(in, a), y = p.put(in + 1, b);
+    gAssertBitsF(p, nb, x); gAssertBitsF(p, nb, y);
+    p.require(p.put(o, gLessEqThanF(p, nb, x, y)), FAILCODE(T_ASSERT_LE, 62));
+}
+template <class P> GD void gAssertGreaterEqThanF(P& p, int nb, const F& a, const F& b) {
+    FrRef in = p.frs(2); BitRef o = p.bits(1);
+    F x = p.put(in, a), y = p.put(in + 1, b);
+    gAssertBitsF(p, nb, x); gAssertBitsF(p, nb, y);
+    p.require(p.put(o, gGreaterEqThanF(p, nb, x, y)), FAILCODE(T_ASSERT_GE, 78));
+}
+
+// ============================================================================ circuits/utils/array.circom
+// Filter(N) :26-39  [out[N] | in | isEq[N]] || IsEqual([i, in]) x N;  out[i] = out[i-1]*(1-isEq[i])
+template <class P> GD BitRef gFilter(P& p, int N, S in) {
+    BitRef o = p.bits(N); SmRef i = p.sms(1); BitRef isEq = p.bits(N);
+    in = p.put(i, in);
+    B prev = ~(B)0;
+    for (int k = 0; k < N; k++) {
+        B e = p.put(isEq + k, gIsEqualS(p, (S)k, in));
+        prev = p.put(o + k, prev & ~e);
+    }
+    return o;
+}
+// Fit(M,N) :47-57  [out[N] | in[M]]
+template <class P> GD SmRef gFitS(P& p, int M, int N, SmRef src) {
+    SmRef o = p.sms(N), in = p.sms(M);
+    for (int i = 0; i < M; i++) { S v = p.put(in + i, p.get(src + i)); if (i < N) p.put(o + i, v); }
+    for (int i = M; i < N; i++) p.put(o + i, 0);
+    return o;
+}
+template <class P> GD BitRef gFitB(P& p, int M, int N, BitRef src) {
+    BitRef o = p.bits(N), in = p.bits(M);
+    for (int i = 0; i < M; i++) { B v = p.put(in + i, p.get(src + i)); if (i < N) p.put(o + i, v); }
+    for (int i = M; i < N; i++) p.put(o + i, 0);
+    return o;
+}
+// Flatten(M,N) :64-72 and Reshape(M,N) :79-87 are the identity on row-major data  [out[MN] | in[MN]]
+template <class P> GD SmRef gFlattenS(P& p, int n, SmRef src) {
+    SmRef o = p.sms(n), in = p.sms(n);
+    for (int i = 0; i < n; i++) p.put(o + i, p.put(in + i, p.get(src + i)));
+    return o;
+}
+template <class P> GD BitRef gFlattenB(P& p, int n, BitRef src) {
+    BitRef o = p.bits(n), in = p.bits(n);
+    for (int i = 0; i < n; i++) p.put(o + i, p.put(in + i, p.get(src + i)));
+    return o;
+}
+// Reverse(N) :94-100  [out[N] | in[N]]
+template <class P> GD SmRef gReverseS(P& p, int N, SmRef src) {
+    SmRef o = p.sms(N), in = p.sms(N);
+    for (int i = 0; i < N; i++) p.put(o + (N - 1 - i), p.put(in + i, p.get(src + i)));
+    return o;
+}
+
+// ============================================================================ circuits/utils/divide.circom:17-33
+// [out, rem | a, b] || AssertLessThan(N)(rem, b), AssertLessEqThan(N)(out, a);  out*b + rem === a
+template <class P> GD void gDivide(P& p, int N, S a, S b, S& q, S& r) {
+    SmRef o = p.sms(2), in = p.sms(2);
+    a = p.put(in, a); b = p.put(in + 1, b);
+    uint32_t ua = (uint32_t)a, ub = (uint32_t)b;
+    q = p.hint(o, (S)(ub ? ua / ub : 0));
+    r = p.hint(o + 1, (S)(ub ? ua % ub : 0));
+    gAssertLessThanS(p, N, r, b);
+    gAssertLessEqThanS(p, N, q, a);
+    p.require(p.ballot((int64_t)q * b + r == (int64_t)a), FAILCODE(T_DIVIDE, 32));
+}
+
+// ============================================================================ circuits/utils/selector.circom
+// Selector(n) :21-46  [out | vals[n], select | isEq[n], sum[n+1]] || IsEqual([select, i]) x n;  sum isEq === 1
+template <class P> GD S gSelectorS(P& p, int n, SmRef src, S select) {
+    SmRef o = p.sms(1), vals = p.sms(n), sel = p.sms(1); BitRef isEq = p.bits(n); SmRef sum = p.sms(n + 1);
+    select = p.put(sel, select);
+    S acc = p.put(sum, 0), cnt = 0;
+    for (int i = 0; i < n; i++) {
+        S v = p.put(vals + i, p.get(src + i));
+        B e = p.put(isEq + i, gIsEqualS(p, select, (S)i));
+        bool hit = p.bit(e);
+        cnt += hit;
+        acc = p.put(sum + i + 1, acc + (hit ? v : 0));
+    }
+    p.require(p.ballot(cnt == 1), FAILCODE(T_SELECTOR, 43));
+    return p.put(o, acc);
+}
+// same template on BIT-valued data (Final's SelectorArray2D over Keccak states): all-mask arithmetic
+template <class P> GD B gSelectorB(P& p, int n, BitRef src, S select) {
+    BitRef o = p.bits(1), vals = p.bits(n); SmRef sel = p.sms(1); BitRef isEq = p.bits(n), sum = p.bits(n + 1);
+    select = p.put(sel, select);
+    B acc = p.put(sum, 0), any = 0, multi = 0;
+    for (int i = 0; i < n; i++) {
+        B v = p.put(vals + i, p.get(src + i));
+        B e = p.put(isEq + i, gIsEqualS(p, select, (S)i));
+        multi |= any & e; any |= e;
+        acc = p.put(sum + i + 1, acc | (e & v));
+    }
+    p.require(any & ~multi, FAILCODE(T_SELECTOR, 43));
+    return p.put(o, acc);
+}
+// SelectorArray1D(n, q) :62-77  [out[q] | arrays[n][q], select | arraysT[q][n]] || Selector(n) x q
+template <class P> GD SmRef gSelectorArray1D(P& p, int n, int q, SmRef src, S select) {
+    SmRef o = p.sms(q), arr = p.sms(n * q), sel = p.sms(1), T = p.sms(q * n);
+    select = p.put(sel, select);
+    for (int i = 0; i < n; i++) for (int j = 0; j < q; j++) p.put(T + (j * n + i), p.put(arr + (i * q + j), p.get(src + (i * q + j))));
+    for (int j = 0; j < q; j++) p.put(o + j, gSelectorS(p, n, T + j * n, select));
+    return o;
+}
+
+// ============================================================================ circuits/utils/shift.circom
+// ShiftLeft(n) :17-37  [out[n] | in[n], count | isEq[n][n], temp[n][n]] || AssertLessEqThan(16)(count, n), IsEqual([i, j-count]) x n^2
+template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count) {
+    SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(n * n); SmRef temp = p.sms(n * n);
+    count = p.put(cn, count);
+    for (int j = 0; j < n; j++) p.put(in + j, p.get(src + j));
+    gAssertLessEqThanS(p, 16, count, (S)n);
+    for (int i = 0; i < n; i++) {
+        S acc = 0;
+        for (int j = 0; j < n; j++) {
+            B e = p.put(isEq + (i * n + j), gIsEqualS(p, (S)i, (S)(j - count)));
+            acc += p.put(temp + (i * n + j), p.bit(e) ? p.get(in + j) : 0);
+        }
+        p.put(o + i, acc);
+    }
+    return o;
+}
+// ShiftRight(n, ms) :51-75  [out[n+ms] | in[n], count | isEq[ms+1], temps[ms+1][n]] || AssertLessEqThan(16)(count, ms), IsEqual([i, count]) x (ms+1)
+template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count) {
+    SmRef o = p.sms(n + ms), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(ms + 1); SmRef temps = p.sms((ms + 1) * n);
+    count = p.put(cn, count);
+    for (int j = 0; j < n; j++) p.put(in + j, p.get(src + j));
+    gAssertLessEqThanS(p, 16, count, (S)ms);
+    for (int i = 0; i <= ms; i++) {
+        B e = p.put(isEq + i, gIsEqualS(p, (S)i, count));
+        bool hit = p.bit(e);
+        for (int j = 0; j < n; j++) p.put(temps + (i * n + j), hit ? p.get(in + j) : 0);
+    }
+    for (int t = 0; t < n + ms; t++) {           // out[t] = sum_{i+j=t} temps[i][j]
+        S acc = 0;
+        int i0 = t - (n - 1) > 0 ? t - (n - 1) : 0, i1 = t < ms ? t : ms;
+        for (int i = i0; i <= i1; i++) acc += p.get(temps + (i * n + (t - i)));
+        p.put(o + t, acc);
+    }
+    return o;
+}
+
+// ============================================================================ circuits/utils/concat.circom
+// Mask(n) :18-30  [out[n] | in[n], count | filter[n]] || Filter(n)
+template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
+    SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef flt = p.bits(n);
+    count = p.put(cn, count);
+    BitRef f = gFilter(p, n, count);
+    for (int i = 0; i < n; i++) {
+        B fb = p.put(flt + i, p.get(f + i));
+        S v = p.put(in + i, p.get(src + i));
+        p.put(o + i, p.bit(fb) ? v : 0);
+    }
+    return o;
+}
+// Concat(A,B) :47-83  [out[A+B], outLen | a[A], aLen, b[B], bLen | maskedA[A], maskedB[B], shiftedB[A+B]]
+//   || AssertLessEqThan(16) x2, Mask(A), Mask(B), ShiftRight(B, A)
+template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef b, S bLen, S& outLen) {
+    SmRef o = p.sms(La + Lb), ol = p.sms(1), ia = p.sms(La), ial = p.sms(1), ib = p.sms(Lb), ibl = p.sms(1);
+    SmRef mA = p.sms(La), mB = p.sms(Lb), sB = p.sms(La + Lb);
+    for (int i = 0; i < La; i++) p.put(ia + i, p.get(a + i));
+    aLen = p.put(ial, aLen);
+    for (int i = 0; i < Lb; i++) p.put(ib + i, p.get(b + i));
+    bLen = p.put(ibl, bLen);
+    gAssertLessEqThanS(p, 16, aLen, (S)La);
+    gAssertLessEqThanS(p, 16, bLen, (S)Lb);
+    SmRef x = gMask(p, La, ia, aLen);
+    for (int i = 0; i < La; i++) p.put(mA + i, p.get(x + i));
+    x = gMask(p, Lb, ib, bLen);
+    for (int i = 0; i < Lb; i++) p.put(mB + i, p.get(x + i));
+    x = gShiftRight(p, Lb, La, mB, aLen);
+    for (int i = 0; i < La + Lb; i++) {
+        S s = p.put(sB + i, p.get(x + i));
+        p.put(o + i, i < La ? p.get(mA + i) + s : s);
+    }
+    outLen = p.put(ol, aLen + bLen);
+    return o;
+}
+
+// ============================================================================ circuits/utils/convert.circom
+// LittleEndianBytes2Num(N<=31) :12-26  [out | in[N]] || AssertByteString(N)
+template <class P> GD F gLittleEndianBytes2NumF(P& p, int N, SmRef src) {
+    FrRef o = p.frs(1); SmRef in = p.sms(N);
+    Fr c = fr_zero();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) { int idx = 4 * j + k; if (idx < N) w |= ((uint32_t)p.put(in + idx, p.get(src + idx)) & 0xffu) << (8 * k); }
+        c.l[j] = w;
+    }
+    gAssertByteString(p, N, in);          // (values >= 256 fail here, so masking above never hides an error)
+    return p.put(o, fr_to_mont(c));
+}
+// BigEndianBytes2Num(N) :33-39  [out | in[N] | inReversed[N]] || Reverse(N), LittleEndianBytes2Num(N)
+template <class P> GD F gBigEndianBytes2NumF(P& p, int N, SmRef src) {
+    FrRef o = p.frs(1); SmRef in = p.sms(N), rev = p.sms(N);
+    for (int i = 0; i < N; i++) p.put(in + i, p.get(src + i));
+    SmRef r = gReverseS(p, N, in);
+    for (int i = 0; i < N; i++) p.put(rev + i, p.get(r + i));
+    return p.put(o, gLittleEndianBytes2NumF(p, N, rev));
+}
+// Num2BitsSafe(N) :46-56
+template <class P> GD BitRef gNum2BitsSafeF(P& p, int N, const F& in) {
+    if (N >= 254) {   // [out[N] | in | bitsStrict[254]] || Num2Bits_strict, Fit(254, N)
+        BitRef o = p.bits(N); FrRef i = p.frs(1); BitRef bs = p.bits(254);
+        F x = p.put(i, in);
+        BitRef s = gNum2BitsStrict(p, x);
+        for (int k = 0; k < 254; k++) p.put(bs + k, p.get(s + k));
+        BitRef f = gFitB(p, 254, N, bs);
+        for (int k = 0; k < N; k++) p.put(o + k, p.get(f + k));
+        return o;
+    }
+    BitRef o = p.bits(N); FrRef i = p.frs(1);   // [out[N] | in] || Num2Bits(N)
+    F x = p.put(i, in);
+    BitRef nb = gNum2BitsF(p, N, x);
+    for (int k = 0; k < N; k++) p.put(o + k, p.get(nb + k));
+    return o;
+}
+// Num2LittleEndianBytes(N) :69-83  [out[N] | in | bits[8N], byteArrays[N][8]] || Num2BitsSafe(8N), Reshape(N,8), Bits2Num(8) x N
+template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in) {
+    SmRef o = p.sms(N); FrRef i = p.frs(1); BitRef bits = p.bits(8 * N), ba = p.bits(8 * N);
+    F x = p.put(i, in);
+    BitRef s = gNum2BitsSafeF(p, 8 * N, x);
+    for (int k = 0; k < 8 * N; k++) p.put(bits + k, p.get(s + k));
+    BitRef r = gFlattenB(p, 8 * N, bits);
+    for (int k = 0; k < 8 * N; k++) p.put(ba + k, p.get(r + k));
+    for (int j = 0; j < N; j++) p.put(o + j, gBits2Num8(p, ba + 8 * j));
+    return o;
+}
+// Num2BigEndianBytes(N) :90-96  [out[N] | in | littleEndian[N]] || Num2LittleEndianBytes(N), Reverse(N)
+template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in) {
+    SmRef o = p.sms(N); FrRef i = p.frs(1); SmRef le = p.sms(N);
+    F x = p.put(i, in);
+    SmRef l = gNum2LittleEndianBytesF(p, N, x);
+    for (int j = 0; j < N; j++) p.put(le + j, p.get(l + j));
+    SmRef r = gReverseS(p, N, le);
+    for (int j = 0; j < N; j++) p.put(o + j, p.get(r + j));
+    return o;
+}
+// Bytes2Nibbles(N) :103-121  [out[2N] | in[N] | inDecomposed[N][8]] || Num2Bits(8) x N
+template <class P> GD SmRef gBytes2Nibbles(P& p, int N, SmRef src) {
+    SmRef o = p.sms(2 * N), in = p.sms(N); BitRef dec = p.bits(8 * N);
+    for (int i = 0; i < N; i++) {
+        S v = p.put(in + i, p.get(src + i));
+        BitRef nb = gNum2BitsS(p, 8, v);
+        S lo = 0, hi = 0;
+        for (int k = 0; k < 8; k++) {
+            bool b = p.bit(p.put(dec + (8 * i + k), p.get(nb + k)));
+            if (k < 4) lo |= (S)b << k; else hi |= (S)b << (k - 4);
+        }
+        p.put(o + 2 * i, hi); p.put(o + 2 * i + 1, lo);
+    }
+    return o;
+}
+// Nibbles2Bytes(n) :132-141  [bytes[n] | nibbles[2n]] || AssertBits(4) x 2n
+template <class P> GD SmRef gNibbles2Bytes(P& p, int n, SmRef src) {
+    SmRef o = p.sms(n), nib = p.sms(2 * n);
+    for (int i = 0; i < 2 * n; i++) p.put(nib + i, p.get(src + i));
+    for (int i = 0; i < n; i++) {
+        S a = p.get(nib + 2 * i), b = p.get(nib + 2 * i + 1);
+        gAssertBitsS(p, 4, a); gAssertBitsS(p, 4, b);
+        p.put(o + i, a * 16 + b);
+    }
+    return o;
+}
+
+// ============================================================================ circuits/utils/substring_check.circom:24-100
+// [out | mainInput[mm], mainLen, subInput[sl] | subInputNum, M[mm+1], exists[k], isLastIndex[k], allowed[k+1], sums[k+1], doesNotExist]
+// || AssertByteString(sl), AssertByteString(mm), AssertLessEqThan(16) x2, LittleEndianBytes2Num(sl), {IsEqual, IsEqual} x k, IsZero
+// The MPT layer-inclusion check: M[i+1] = mainInput[i]*256^i + M[i]; exists[i] = (sub*256^i == M[i+sl]-M[i]).
+template <class P> GD B gSubstringCheck(P& p, int mm, int sl, SmRef mainSrc, S mainLen, SmRef subSrc) {
+    const int k = mm - sl + 1;
+    BitRef o = p.bits(1); SmRef mi = p.sms(mm), ml = p.sms(1), si = p.sms(sl);
+    FrRef num = p.frs(1), M = p.frs(mm + 1); BitRef ex = p.bits(k), isl = p.bits(k), alw = p.bits(k + 1); SmRef sums = p.sms(k + 1); BitRef dne = p.bits(1);
+    for (int i = 0; i < mm; i++) p.put(mi + i, p.get(mainSrc + i));
+    mainLen = p.put(ml, mainLen);
+    for (int i = 0; i < sl; i++) p.put(si + i, p.get(subSrc + i));
+    gAssertByteString(p, sl, si);
+    gAssertByteString(p, mm, mi);
+    gAssertLessEqThanS(p, 16, mainLen, (S)mm);
+    gAssertLessEqThanS(p, 16, (S)sl, mainLen);
+    F subNum = p.put(num, gLittleEndianBytes2NumF(p, sl, si));
+    const F c256 = fr_from_i64(256);
+    {   // M[] prefix sums (:45-49)
+        F pw = fr_one_mont(), acc = p.put(M, fr_zero());
+        for (int i = 0; i < mm; i++) {
+            acc = p.put(M + i + 1, fr_add(fr_mul(fr_from_i64(p.get(mi + i)), pw), acc));
+            pw = fr_mul(pw, c256);
+        }
+    }
+    // per i the loop below instantiates IsEqualS (2 BIT, 4 SM) then IsEqualF (2 BIT, 4 FR: in0, in1, isz.in, isz.inv)
+    const FrRef f0 = {p.cur.w + 7, p.cur.f};         // first IsEqualF.in[0]: 6 wires of IsEqualS + IsEqualF.out precede it
+    if (P::is_gen) {
+        // Montgomery batch inversion of the k operands d_i = (M[i+sl]-M[i]) - sub*256^i, using the witness' own
+        // isz.in / isz.inv slots as scratch: pass 1 stores d_i and the running product, pass 2 walks back.
+        F pw = fr_one_mont(), run = fr_one_mont();
+        for (int i = 0; i < k; i++) {
+            F d = fr_sub(fr_sub(p.get(M + i + sl), p.get(M + i)), fr_mul(subNum, pw));
+            FrRef din = {f0.w + 12 * i + 3, f0.i + 4 * i + 2}, dinv = {din.w + 1, din.i + 1};
+            p.raw_put(din, d);
+            p.raw_put(dinv, run);                       // product of the non-zero d_j, j < i
+            if (!fr_is_zero(d)) run = fr_mul(run, d);
+            pw = fr_mul(pw, c256);
+        }
+        F inv = fr_inv(run);
+        for (int i = k - 1; i >= 0; i--) {
+            FrRef din = {f0.w + 12 * i + 3, f0.i + 4 * i + 2}, dinv = {din.w + 1, din.i + 1};
+            F d = p.get(din), pre = p.get(dinv);
+            bool z = fr_is_zero(d);
+            p.raw_put(dinv, z ? fr_zero() : fr_mul(inv, pre));
+            if (!z) inv = fr_mul(inv, d);
+        }
+    }
+    B allowed = p.put(alw, ~(B)0);
+    S sum = p.put(sums, 0);
+    F pw = fr_one_mont();
+    for (int i = 0; i < k; i++) {
+        B last = p.put(isl + i, gIsEqualS(p, (S)i, (S)(mainLen - sl + 1)));                 // :87
+        allowed = p.put(alw + i + 1, allowed & ~last);
+        B e = p.put(ex + i, gIsEqualF(p, fr_mul(subNum, pw), fr_sub(p.get(M + i + sl), p.get(M + i)), true));   // :91
+        sum = p.put(sums + i + 1, sum + (S)p.bit(allowed & e));
+        pw = fr_mul(pw, c256);
+    }
+    B none = p.put(dne, gIsZeroS(p, sum));
+    return p.put(o, ~none);
+}
+
+// ============================================================================ circuits/utils/rlp/integer.circom
+// CountBytes(N) :16-49  [len | bytes[N] | isZero[N], stillZero[N]] || IsZero x N
+template <class P> GD S gCountBytes(P& p, int N, SmRef src) {
+    SmRef o = p.sms(1), by = p.sms(N); BitRef iz = p.bits(N), sz = p.bits(N);
+    for (int i = 0; i < N; i++) p.put(iz + i, gIsZeroS(p, p.put(by + i, p.get(src + i))));
+    B still = ~(B)0; S lead = 0;
+    for (int i = 0; i < N; i++) { still = p.put(sz + i, still & p.get(iz + i)); lead += (S)p.bit(still); }
+    return p.put(o, N - lead);
+}
+// RlpInteger(N) :67-110  [out[N+1], outLen | in | bytes[N], length, bigEndian[N], isSingleByte, isZero, firstRlpByte]
+// || Num2BigEndianBytes(N), CountBytes(N), ShiftLeft(N), LessThan(8N), IsZero, Mux1
+template <class P> GD SmRef gRlpInteger(P& p, int N, const F& in, S& outLen) {
+    SmRef o = p.sms(N + 1), ol = p.sms(1); FrRef i = p.frs(1); SmRef by = p.sms(N), len = p.sms(1), be = p.sms(N);
+    BitRef isb = p.bits(1), isz = p.bits(1); SmRef frb = p.sms(1);
+    F x = p.put(i, in);
+    SmRef r = gNum2BigEndianBytesF(p, N, x);
+    for (int j = 0; j < N; j++) p.put(by + j, p.get(r + j));
+    S length = p.put(len, gCountBytes(p, N, by));
+    r = gShiftLeft(p, N, by, N - length);
+    for (int j = 0; j < N; j++) p.put(be + j, p.get(r + j));
+    B single = p.put(isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
+    B zero = p.put(isz, gIsZeroF(p, x));
+    S first = p.put(frb, gMux1SF(p, 0x80 + length, x, single));
+    bool sb = p.bit(single), zb = p.bit(zero);
+    p.put(o, first + (zb ? 0x80 : 0));
+    for (int j = 1; j < N + 1; j++) p.put(o + j, sb ? 0 : p.get(be + (j - 1)));
+    outLen = p.put(ol, (sb ? 0 : 1) + length + (zb ? 1 : 0));
+    return o;
+}
+// RlpEmptyAccount(mb) rlp/empty_account.circom:20-134
+// [out[70+mb], outLen | balance | prefixedNonceAndBalanceRlp[4+mb], prefixedNonceAndBalanceRlpLen, balanceRlp[mb+1], balanceRlpLen,
+//  nonceAndBalanceRlpLen, storageAndCodeHashRlp[66]] || RlpInteger(mb), Concat(4+mb, 66)
+HD uint8_t empty_account_tail(int i) {   // 0xa0|keccak(rlp(""))|0xa0|keccak("")   (empty_account.circom:9-10)
+    const uint8_t t[66] = {0xa0, 0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45, 0xe6, 0x92, 0xc0, 0xf8, 0x6e, 0x5b, 0x48, 0xe0, 0x1b, 0x99,
+                           0x6c, 0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21, 0xa0, 0xc5, 0xd2, 0x46, 0x01, 0x86, 0xf7, 0x23, 0x3c, 0x92, 0x7e,
+                           0x7d, 0xb2, 0xdc, 0xc7, 0x03, 0xc0, 0xe5, 0x00, 0xb6, 0x53, 0xca, 0x82, 0x27, 0x3b, 0x7b, 0xfa, 0xd8, 0x04, 0x5d, 0x85, 0xa4, 0x70};
+    return t[i];
+}
+template <class P> GD SmRef gRlpEmptyAccount(P& p, int mb, const F& balance, S& outLen) {
+    SmRef o = p.sms(70 + mb), ol = p.sms(1); FrRef ib = p.frs(1);
+    SmRef pn = p.sms(4 + mb), pnl = p.sms(1), br = p.sms(mb + 1), brl = p.sms(1), nbl = p.sms(1), sc = p.sms(66);
+    F bal = p.put(ib, balance);
+    p.put(pn + 2, 0x80);
+    S blen;
+    SmRef r = gRlpInteger(p, mb, bal, blen);
+    for (int j = 0; j < mb + 1; j++) p.put(pn + 3 + j, p.put(br + j, p.get(r + j)));
+    blen = p.put(brl, blen);
+    S nb = p.put(nbl, 1 + blen);
+    S pl = p.put(pnl, 2 + nb);
+    for (int j = 0; j < 66; j++) p.put(sc + j, (S)empty_account_tail(j));
+    p.put(pn, 0xf8);
+    p.put(pn + 1, nb + 66);
+    S clen;
+    SmRef c = gConcat(p, 4 + mb, 66, pn, pl, sc, (S)66, clen);
+    for (int j = 0; j < 70 + mb; j++) p.put(o + j, p.get(c + j));
+    outLen = p.put(ol, clen);
+    return o;
+}
+
+// ============================================================================ circuits/utils/rlp/merkle_patricia_trie_leaf.circom
+// TruncatedAddressHash(b) :50-90
+// [out[b+1], outLen | addressHashNibbles[2b], addressHashNibblesLen | div, rem, shifted[2b], outNibbles[2b+2], temp[2b-1]]
+// || AssertLessEqThan(7), Divide(7), ShiftLeft(2b), Mux1 x (2b-1), Nibbles2Bytes(b+1);  temp[] is never assigned (:76) -> 0
+template <class P> GD SmRef gTruncatedAddressHash(P& p, int b, SmRef src, S len, S& outLen) {
+    const int n2 = 2 * b;
+    SmRef o = p.sms(b + 1), ol = p.sms(1), in = p.sms(n2), il = p.sms(1), dv = p.sms(1), rm = p.sms(1), shf = p.sms(n2), on = p.sms(n2 + 2), tmp = p.sms(n2 - 1);
+    for (int i = 0; i < n2; i++) p.put(in + i, p.get(src + i));
+    len = p.put(il, len);
+    for (int i = 0; i < n2 - 1; i++) p.put(tmp + i, 0);
+    gAssertLessEqThanS(p, 7, len, (S)n2);
+    S q, r;
+    gDivide(p, 7, len, (S)2, q, r);
+    q = p.put(dv, q); r = p.put(rm, r);
+    SmRef s = gShiftLeft(p, n2, in, n2 - len);
+    for (int i = 0; i < n2; i++) p.put(shf + i, p.get(s + i));
+    p.put(on, 2 + r);
+    p.put(on + 1, r * p.get(shf));
+    B rbit = p.ballot(r & 1);
+    for (int i = 0; i < n2; i++) {
+        if (i < n2 - 1) p.put(on + i + 2, gMux1S(p, p.get(shf + i), p.get(shf + i + 1), rbit));
+        else p.put(on + i + 2, (1 - r) * p.get(shf + i));
+    }
+    SmRef by = gNibbles2Bytes(p, b + 1, on);
+    for (int i = 0; i < b + 1; i++) p.put(o + i, p.get(by + i));
+    outLen = p.put(ol, 1 + q);
+    return o;
+}
+// RlpMerklePatriciaTrieLeaf(ab, bb) :102-189
+template <class P> GD SmRef gRlpMptLeaf(P& p, int ab, int bb, SmRef nibSrc, S nibLen, const F& balance, S& outLen) {
+    const int maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
+    SmRef o = p.sms(maxOut), ol = p.sms(1), in = p.sms(2 * ab), inl = p.sms(1); FrRef ib = p.frs(1);
+    SmRef key = p.sms(maxKey), keyLen = p.sms(1), acc = p.sms(maxAcc), accLen = p.sms(1), pk = p.sms(maxPK), pkLen = p.sms(1), val = p.sms(maxVal), valLen = p.sms(1);
+    for (int i = 0; i < 2 * ab; i++) p.put(in + i, p.get(nibSrc + i));
+    nibLen = p.put(inl, nibLen);
+    F bal = p.put(ib, balance);
+    S kl;
+    SmRef r = gTruncatedAddressHash(p, ab, in, nibLen, kl);
+    for (int i = 0; i < maxKey; i++) p.put(key + i, p.get(r + i));
+    kl = p.put(keyLen, kl);
+    gAssertGreaterEqThanS(p, 16, kl, (S)2);                                   // :151
+    S al;
+    r = gRlpEmptyAccount(p, bb, bal, al);
+    for (int i = 0; i < maxAcc; i++) p.put(acc + i, p.get(r + i));
+    al = p.put(accLen, al);
+    p.put(val, 0xb8); p.put(val + 1, al);
+    for (int i = 0; i < maxAcc; i++) p.put(val + 2 + i, p.get(acc + i));
+    S vl = p.put(valLen, 2 + al);
+    p.put(pk, 0xf8); p.put(pk + 1, (kl + 1) + vl); p.put(pk + 2, 0x80 + kl);
+    for (int i = 0; i < maxKey; i++) p.put(pk + 3 + i, p.get(key + i));
+    S pl = p.put(pkLen, 3 + kl);
+    S cl;
+    SmRef c = gConcat(p, maxPK, maxVal, pk, pl, val, vl, cl);
+    for (int i = 0; i < maxOut; i++) p.put(o + i, p.get(c + i));
+    outLen = p.put(ol, cl);
+    return o;
+}
+// IsInRange(B) :196-207  [out | lower, value, upper | lowerLteValue, valueLteUpper] || AssertBits x3, LessEqThan x2
+template <class P> GD B gIsInRange(P& p, int nb, S lo, S v, S hi) {
+    BitRef o = p.bits(1); SmRef in = p.sms(3); BitRef mid = p.bits(2);
+    lo = p.put(in, lo); v = p.put(in + 1, v); hi = p.put(in + 2, hi);
+    gAssertBitsS(p, nb, lo); gAssertBitsS(p, nb, v); gAssertBitsS(p, nb, hi);
+    B a = p.put(mid, gLessEqThanS(p, nb, lo, v));
+    B b = p.put(mid + 1, gLessEqThanS(p, nb, v, hi));
+    return p.put(o, a & b);
+}
+// LeafDetector(N) :247-294
+template <class P> GD B gLeafDetector(P& p, int N, SmRef src, S layerLen) {
+    BitRef o = p.bits(1); SmRef layer = p.sms(N), ll = p.sms(1);
+    // intermediates in declaration order (:255-287)
+    BitRef leafPrefixIsF8 = p.bits(1); SmRef totalLength = p.sms(1); BitRef isConsistentWithLayerLen = p.bits(1); SmRef keyPrefix = p.sms(1);
+    BitRef keyPrefixIsValid = p.bits(1), keyIsMultiByte = p.bits(1); SmRef keyExtraLen = p.sms(1), keyLen = p.sms(1), valueWrapperPrefix = p.sms(1);
+    BitRef valueWrapperPrefixIsB8 = p.bits(1); SmRef valueWrapperLen = p.sms(1), valuePrefix = p.sms(1); BitRef valuePrefixIsF8 = p.bits(1);
+    SmRef valueLen = p.sms(1); BitRef isValueWrapperLenConsistent = p.bits(1), isKeyValueLenEqualWithLayerLen = p.bits(1);
+    for (int i = 0; i < N; i++) p.put(layer + i, p.get(src + i));
+    layerLen = p.put(ll, layerLen);
+    gAssertLessEqThanS(p, 16, layerLen, (S)N);
+    B m[7];
+    m[0] = p.put(leafPrefixIsF8, gIsEqualS(p, p.get(layer), (S)0xf8));
+    S tl = p.put(totalLength, p.get(layer + 1));
+    m[1] = p.put(isConsistentWithLayerLen, gIsEqualS(p, tl + 2, layerLen));
+    S kp = p.put(keyPrefix, p.get(layer + 2));
+    m[2] = p.put(keyPrefixIsValid, gLessEqThanS(p, 16, kp, (S)0xb7));
+    B multi = p.put(keyIsMultiByte, gIsInRange(p, 16, (S)0x81, kp, (S)0xb7));
+    S kel = p.put(keyExtraLen, p.bit(multi) ? kp - 0x80 : 0);
+    S kl = p.put(keyLen, 1 + kel);
+    S vwp = p.put(valueWrapperPrefix, gSelectorS(p, N, layer, 2 + kl + 0));
+    m[3] = p.put(valueWrapperPrefixIsB8, gIsEqualS(p, vwp, (S)0xb8));
+    S vwl = p.put(valueWrapperLen, gSelectorS(p, N, layer, 2 + kl + 1));
+    S vp = p.put(valuePrefix, gSelectorS(p, N, layer, 2 + kl + 2));
+    m[5] = p.put(valuePrefixIsF8, gIsEqualS(p, vp, (S)0xf8));
+    S vl = p.put(valueLen, gSelectorS(p, N, layer, 2 + kl + 2 + 1));
+    m[4] = p.put(isValueWrapperLenConsistent, gIsEqualS(p, vwl, vl + 2));
+    m[6] = p.put(isKeyValueLenEqualWithLayerLen, gIsEqualS(p, kl + vl + 6, layerLen));
+    return p.put(o, MultiANDg<P, 7>::run(p, m));
+}
+
+// ============================================================================ circuits/utils/burn_address.circom:47-58
+// BurnAddress  [addressBytes[20] | burnKey, revealAmount, burnExtraCommitment | hash, hashBytes[32]] || Poseidon(4), Num2BigEndianBytes(32), Fit(32,20)
+template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec) {
+    SmRef o = p.sms(20); FrRef in = p.frs(3), h = p.frs(1); SmRef hb = p.sms(32);
+    F pin[4]; pin[0] = prefix0; pin[1] = p.put(in, bk); pin[2] = p.put(in + 1, ra); pin[3] = p.put(in + 2, bec);
+    F hash = p.put(h, gPoseidon<P, 5>(p, k5, pin));
+    SmRef r = gNum2BigEndianBytesF(p, 32, hash);
+    for (int i = 0; i < 32; i++) p.put(hb + i, p.get(r + i));
+    r = gFitS(p, 32, 20, hb);
+    for (int i = 0; i < 20; i++) p.put(o + i, p.get(r + i));
+    return o;
+}

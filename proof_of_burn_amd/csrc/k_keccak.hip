@@ -1,0 +1,13 @@
+#include "keccak_kernels.hpp"
+void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st) {
+    if (check) hipLaunchKernelGGL(k_chain<true>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
+    else hipLaunchKernelGGL(k_chain<false>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
+}
+void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
+    if (check) hipLaunchKernelGGL(k_rounds<true>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
+    else hipLaunchKernelGGL(k_rounds<false>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
+}
+void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
+    uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_emit_bits, dim3(blocks), dim3(256), 0, st, G, out, wire_base, bit_base, count, sel);
+}

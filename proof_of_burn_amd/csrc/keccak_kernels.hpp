@@ -1,0 +1,276 @@
+// Bit-sliced Keccak-f[1600] witness expansion / constraint evaluation (keccak.circom:19-367).
+//
+// Layout: one wavefront = one (64-witness group, sponge/permutation, round); LANE = BIT POSITION k of the
+// 64-bit Keccak lane, and each 64-bit register word holds bit k of that Keccak lane for the 64 witnesses
+// of the group.  theta/chi/iota are plain 64-bit ALU ops on those words, the rho rotations are cross-lane
+// permutes (ds_bpermute), and every `signal x[64]` array of the circuit is ONE coalesced 512-byte
+// store/load (lane k <-> wire x[k]).  The O0 wire offsets below restate the component tree of
+// KeccakfRound: own signals, then children in instantiation order.
+//
+// One templated walker (`round_walk`) visits all 102 656 wires of a round; `GenIO` stores them, `CheckIO`
+// loads them and ORs every mismatch into a per-witness mask: generator and constraint evaluator cannot
+// disagree about the layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels_common.hpp"
+
+__device__ __constant__ u64 KECCAK_RC_DEV[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+// RhoPi's lane walk (keccak.circom:195): out[rot[i+1]] = rotl(in[rot[i]], ((i+1)(i+2)/2) % 64)
+__host__ __device__ constexpr int krot_(int i) {
+    constexpr int t[25] = {1, 10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    return t[i];
+}
+#define KROT(i) krot_(i)
+
+struct GenIO {
+    u64* base; uint32_t lane;
+    __device__ __forceinline__ void arr(uint32_t off, u64 v) const { base[off + lane] = v; }
+    __device__ __forceinline__ void gate(uint32_t off, u64 o, u64 a, u64 b) const {   // XOR/AND/OR component k: (out, a, b)
+        u64* q = base + off + 3 * lane; q[0] = o; q[1] = a; q[2] = b;
+    }
+};
+struct CheckIO {
+    const u64* base; uint32_t lane; u64 bad;
+    __device__ __forceinline__ void arr(uint32_t off, u64 v) { bad |= base[off + lane] ^ v; }
+    __device__ __forceinline__ void gate(uint32_t off, u64 o, u64 a, u64 b) {
+        const u64* q = base + off + 3 * lane; bad |= (q[0] ^ o) | (q[1] ^ a) | (q[2] ^ b);
+        asm volatile("" : "+v"(bad));        // opaque point: stops LLVM from reassociating one 4800-term OR tree (compile time)
+    }
+};
+
+// value held by lane (lane - r) mod 64  (rotl by r in bit-position space)
+__device__ __forceinline__ u64 lane_rotl(u64 v, int r, uint32_t lane) {
+    int src = (int)((lane - (uint32_t)r) & 63u);
+    uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// XorArray/OrArray/AndArray(64) block: [out | a | b | 64 x (o,a,b)]
+template <class IO> __device__ __forceinline__ void garr(IO& io, uint32_t off, u64 o, u64 a, u64 b) {
+    io.arr(off, o); io.arr(off + 64, a); io.arr(off + 128, b); io.gate(off + 192, o, a, b);
+}
+
+// the bare permutation round on the bit-sliced state (no wires)
+__device__ __forceinline__ void round_native(u64* a, int r, uint32_t lane) {
+    u64 c[5], d[5], b[25];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ lane_rotl(c[(x + 1) % 5], 1, lane);
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+    b[0] = a[0];
+#pragma unroll
+    for (int i = 0; i < 24; i++) b[KROT(i + 1)] = lane_rotl(a[KROT(i)], ((i + 1) * (i + 2) / 2) % 64, lane);
+#pragma unroll
+    for (int i = 0; i < 25; i++) { const int y = i / 5 * 5; a[i] = b[i] ^ (~b[y + (i + 1) % 5] & b[y + (i + 2) % 5]); }
+    a[0] ^= ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL;
+}
+
+// KeccakfRound(r) keccak.circom:290-297: every wire of the block at `io.base`, from the round input `in`.
+template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64* in, int r, u64* out) {
+    const uint32_t lane = io.lane;
+    u64 th[25], rp[25], ch[25];
+    // ---- own: out@0 in@1600 theta@3200 rhopi@4800 chi@6400
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.arr(1600 + 64 * i, in[i]);
+    // ---- Theta @8000 (:151-170): out@0 in@1600 c@3200 d@3520 | Xor5 x5 @3840 (2112 each) | D x5 @14400 (1408 each) | XorArray x25 @21440
+    {
+        const uint32_t T = 8000;
+        u64 C[5], Dv[5];
+#pragma unroll
+        for (int i = 0; i < 25; i++) io.arr(T + 1600 + 64 * i, in[i]);
+#pragma unroll
+        for (int x = 0; x < 5; x++) {   // Xor5(64) :58-70  [out | a,b,c,d,e | xor_ab, xor_abc, xor_abcd] || XorArray x4
+            const uint32_t X = T + 3840 + 2112 * x;
+            const u64 a = in[x], b = in[5 + x], c = in[10 + x], d = in[15 + x], e = in[20 + x];
+            const u64 ab = a ^ b, abc = ab ^ c, abcd = abc ^ d, o = abcd ^ e;
+            io.arr(X, o); io.arr(X + 64, a); io.arr(X + 128, b); io.arr(X + 192, c); io.arr(X + 256, d); io.arr(X + 320, e);
+            io.arr(X + 384, ab); io.arr(X + 448, abc); io.arr(X + 512, abcd);
+            garr(io, X + 576, ab, a, b); garr(io, X + 960, abc, ab, c); garr(io, X + 1344, abcd, abc, d); garr(io, X + 1728, o, abcd, e);
+            C[x] = o; io.arr(T + 3200 + 64 * x, o);
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++) {   // D :135-144  [out | a, b | aux0, aux1, aux2] || ShL(64,1), ShR(64,63), OrArray, XorArray
+            const uint32_t Dd = T + 14400 + 1408 * x;
+            const u64 a = C[(x + 1) % 5], b = C[(x + 4) % 5];
+            const u64 rot = lane_rotl(a, 1, lane);
+            const u64 aux0 = lane >= 1 ? rot : 0, aux1 = lane < 1 ? rot : 0, aux2 = aux0 | aux1, o = b ^ aux2;
+            io.arr(Dd, o); io.arr(Dd + 64, a); io.arr(Dd + 128, b); io.arr(Dd + 192, aux0); io.arr(Dd + 256, aux1); io.arr(Dd + 320, aux2);
+            io.arr(Dd + 384, aux0); io.arr(Dd + 448, a);          // ShL(64,1)  [out | in]
+            io.arr(Dd + 512, aux1); io.arr(Dd + 576, a);          // ShR(64,63)
+            garr(io, Dd + 640, aux2, aux0, aux1); garr(io, Dd + 1024, o, b, aux2);
+            Dv[x] = o; io.arr(T + 3520 + 64 * x, o);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) {   // :165-169, i outer, j inner
+                const int idx = i + 5 * j;
+                const u64 o = in[idx] ^ Dv[i];
+                garr(io, T + 21440 + 384 * (i * 5 + j), o, in[idx], Dv[i]);
+                th[idx] = o; io.arr(T + 64 * idx, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.arr(3200 + 64 * i, th[i]);
+    // ---- RhoPi @39040 (:191-204): out@0 in@1600 | stepRhoPi x24 @3200 (896 each): [out | a | aux0, aux1] || ShR, ShL, OrArray
+    {
+        const uint32_t Rb = 39040;
+#pragma unroll
+        for (int i = 0; i < 25; i++) io.arr(Rb + 1600 + 64 * i, th[i]);
+        rp[0] = th[0]; io.arr(Rb, th[0]);
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            const uint32_t S_ = Rb + 3200 + 896 * i;
+            const int shl = ((i + 1) * (i + 2) / 2) % 64;
+            const u64 a = th[KROT(i)];
+            const u64 rot = lane_rotl(a, shl, lane);
+            const u64 aux0 = (int)lane < shl ? rot : 0;          // ShR(64, 64-shl): out[k] = a[k + 64 - shl]
+            const u64 aux1 = (int)lane >= shl ? rot : 0;         // ShL(64, shl):    out[k] = a[k - shl]
+            const u64 o = aux0 | aux1;
+            io.arr(S_, o); io.arr(S_ + 64, a); io.arr(S_ + 128, aux0); io.arr(S_ + 192, aux1);
+            io.arr(S_ + 256, aux0); io.arr(S_ + 320, a);
+            io.arr(S_ + 384, aux1); io.arr(S_ + 448, a);
+            garr(io, S_ + 512, o, aux0, aux1);
+            rp[KROT(i + 1)] = o; io.arr(Rb + 64 * KROT(i + 1), o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.arr(4800 + 64 * i, rp[i]);
+    // ---- Chi @63744 (:228-241): out@0 in@1600 | stepChi x25 @3200 (1280 each): [out | a,b,c | bXor, bc] || NotArray, AndArray, XorArray
+    {
+        const uint32_t Cb = 63744;
+#pragma unroll
+        for (int i = 0; i < 25; i++) io.arr(Cb + 1600 + 64 * i, rp[i]);
+#pragma unroll
+        for (int i = 0; i < 25; i++) {
+            const uint32_t C_ = Cb + 3200 + 1280 * i;
+            const int y = i / 5 * 5;
+            const u64 a = rp[i], b = rp[y + (i + 1) % 5], c = rp[y + (i + 2) % 5];
+            const u64 bx = ~b, bc = bx & c, o = a ^ bc;
+            io.arr(C_, o); io.arr(C_ + 64, a); io.arr(C_ + 128, b); io.arr(C_ + 192, c); io.arr(C_ + 256, bx); io.arr(C_ + 320, bc);
+            io.arr(C_ + 384, bx); io.arr(C_ + 448, b);           // NotArray [out | a]
+            garr(io, C_ + 512, bc, bx, c); garr(io, C_ + 896, o, a, bc);
+            ch[i] = o; io.arr(Cb + 64 * i, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.arr(6400 + 64 * i, ch[i]);
+    // ---- Iota(r) @98944 (:273-283): out@0 in@1600 roundConstants@3200 | RoundConstants @3264 | XorArray @3328
+    {
+        const uint32_t Ib = 98944;
+        const u64 rc = ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 25; i++) io.arr(Ib + 1600 + 64 * i, ch[i]);
+        io.arr(Ib + 3200, rc); io.arr(Ib + 3264, rc);
+        const u64 o = ch[0] ^ rc;
+        garr(io, Ib + 3328, o, ch[0], rc);
+        out[0] = o;
+#pragma unroll
+        for (int i = 1; i < 25; i++) out[i] = ch[i];
+#pragma unroll
+        for (int i = 0; i < 25; i++) io.arr(Ib + 64 * i, out[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.arr(64 * i, out[i]);
+}
+
+// Keccakf block offsets (:356-367): out@0 in@1600 midRound[25]@3200 | KeccakfRound(r) @43200 + r*102656
+#define KF_MID 3200u
+#define KF_ROUNDS 43200u
+// Absorb block offsets (:304-323): out@0 s@1600 block@3200 aux@4288 | XorArray x17 @5888 | Keccakf @12416
+#define AB_KECCAKF (ABSORB_OWN + 17u * 384u)
+
+
+// Sponge chain (Final/Absorb, keccak.circom:304-349): everything of Keccak(n)/Final(n)/Absorb x n EXCEPT the 24 round
+// blocks and the output selector: Keccak.in, Final.in, Final.s[0..n], Absorb own wires + 17 XorArrays, Keccakf in/out/midRound.
+template <bool CHECK> __global__ void __launch_bounds__(64) k_chain(KArgs A) {
+    const uint32_t lane = threadIdx.x;
+    const SpongeDesc sp = A.sponges[A.first + blockIdx.x];
+    u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    u64 st[25], bad = 0;
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    auto put = [&](uint32_t idx, u64 v) { if (CHECK) bad |= G[idx + lane] ^ v; else G[idx + lane] = v; };
+    for (uint32_t b = 0; b < sp.n; b++) {
+        const uint32_t Ab = sp.abs_b + b * ABSORB_WIRES;
+        u64 blk[17], aux[25];
+#pragma unroll
+        for (int i = 0; i < 17; i++) blk[i] = G[sp.src_b + b * 1088 + 64 * i + lane];
+#pragma unroll
+        for (int i = 0; i < 25; i++) { put(sp.fs_b + b * 1600 + 64 * i, st[i]); put(Ab + 1600 + 64 * i, st[i]); }
+#pragma unroll
+        for (int i = 0; i < 17; i++) {
+            put(sp.kin_b + b * 1088 + 64 * i, blk[i]); put(sp.fin_b + b * 1088 + 64 * i, blk[i]); put(Ab + 3200 + 64 * i, blk[i]);
+            const u64 o = st[i] ^ blk[i];
+            const uint32_t X = Ab + ABSORB_OWN + 384 * i;
+            put(X, o); put(X + 64, st[i]); put(X + 128, blk[i]);
+            if (CHECK) { const u64* q = G + X + 192 + 3 * lane; bad |= (q[0] ^ o) | (q[1] ^ st[i]) | (q[2] ^ blk[i]); }
+            else { u64* q = G + X + 192 + 3 * lane; q[0] = o; q[1] = st[i]; q[2] = blk[i]; }
+            aux[i] = o;
+        }
+#pragma unroll
+        for (int i = 17; i < 25; i++) aux[i] = st[i];
+        const uint32_t Kf = Ab + AB_KECCAKF;
+#pragma unroll
+        for (int i = 0; i < 25; i++) { put(Ab + 4288 + 64 * i, aux[i]); put(Kf + 1600 + 64 * i, aux[i]); put(Kf + KF_MID + 64 * i, aux[i]); st[i] = aux[i]; }
+        for (int r = 0; r < 24; r++) {
+            round_native(st, r, lane);
+#pragma unroll
+            for (int i = 0; i < 25; i++) put(Kf + KF_MID + 1600 * (r + 1) + 64 * i, st[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 25; i++) { put(Kf + 64 * i, st[i]); put(Ab + 64 * i, st[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) put(sp.fs_b + sp.n * 1600 + 64 * i, st[i]);
+    if (CHECK) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
+        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w);
+    }
+}
+
+// One KeccakfRound block per wavefront: grid.x = (permutation, round), grid.y = group.  Reads midRound[r] (written by
+// k_chain), writes (GenIO) or verifies (CheckIO) the 102 656 wires of the round.  This is the HBM-streaming kernel.
+template <bool CHECK> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pi = A.first + blockIdx.x / 24, r = blockIdx.x % 24;
+    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
+    const uint32_t Kf = sp.abs_b + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF;
+    u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    u64 in[25], out[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) in[i] = G[Kf + KF_MID + 1600 * r + 64 * i + lane];
+    if (CHECK) {
+        CheckIO io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane; io.bad = 0;
+        round_walk(io, in, (int)r, out);
+        u64 bad = io.bad;
+#pragma unroll
+        for (int i = 0; i < 25; i++) bad |= out[i] ^ G[Kf + KF_MID + 1600 * (r + 1) + 64 * i + lane];   // midRound[r+1] <== round.out
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
+        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
+    } else {
+        GenIO io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane;
+        round_walk(io, in, (int)r, out);
+    }
+}
+
+// .wtns expansion of a contiguous run of BIT wires for witness `sel` of one group: 8 B in, 32 B out per wire.
+__global__ void __launch_bounds__(256) k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)((G[bit_base + t] >> sel) & 1);
+        uint4* q = (uint4*)(out + (uint64_t)(wire_base + t) * 32);
+        q[0] = make_uint4(v, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
+    }
+}

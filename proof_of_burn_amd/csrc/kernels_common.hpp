@@ -1,0 +1,38 @@
+// Kernel argument blocks and host-callable launchers shared by the translation units of libpob_hip.so.
+// The library is split so the heavy template instantiations (generator / constraint evaluator / emitter of the
+// G units, Keccak kernels) compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "circuits.hpp"
+
+typedef unsigned long long u64;
+
+struct GArgs {
+    const UnitDesc* units; const uint32_t* order; uint32_t first;
+    const CircuitLayout* L; KBRefs* kbs;
+    uint64_t* bits; int32_t* sm; uint32_t* fr;
+    uint64_t bits_stride, sm_stride, fr_stride;       // elements per group
+    const uint32_t* pos_tab; const uint32_t* inv_lut;
+    const uint8_t* in_fr; const int32_t* in_sm; uint32_t nfr_in, nsm_in;
+    uint32_t* status; uint32_t* chk_status; uint32_t* bad_wire;
+    uint8_t* emit_out; uint32_t emit_sel, emit_group;
+    uint32_t stage_lds;                                // 1: stage the Poseidon table in LDS (dynamic shared memory)
+};
+struct KArgs {
+    u64* bits;                 // BIT slabs, all groups
+    uint64_t group_stride;     // words per group
+    const SpongeDesc* sponges;
+    const uint32_t* perm_sponge;   // flattened (sponge, block) list for the round kernels
+    const uint32_t* perm_block;
+    uint32_t* bad_wire;        // per witness: lowest inconsistent wire (CheckIO)
+    uint32_t first, count;
+};
+
+// grid = (nunits, ngroups) wavefronts; lds = bytes of dynamic LDS (Poseidon table) or 0
+void launch_g_gen(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit(const GArgs& A, uint32_t nunits, hipStream_t st);
+void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
+void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
+void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);

@@ -1,0 +1,441 @@
+// libpob_hip.so -- host side: layout planner, stage scheduler and the C ABI of include/pob_hip.h.
+// Build: proof_of_burn_amd/build.py (hipcc --offload-arch=gfx950, one object per .hip file, linked -shared).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pob_hip.h"
+#include "kernels_common.hpp"
+
+
+__global__ void k_init_invlut(uint32_t* lut) {   // canonical inverses of -4096..4096
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > 8192) return;
+    Fr c = fr_from_mont(fr_inv(fr_from_i64((int64_t)t - 4096)));
+    for (int j = 0; j < 8; j++) lut[t * 8 + j] = c.l[j];
+}
+// status/outputs of the batch: commitment FR (Montgomery) -> canonical LE; 0xFFFFFFFF -> 0 (ok)
+__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, const uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t n) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const uint32_t g = w / 64, lane = w % 64;
+    Fr m;
+    for (int k = 0; k < 8; k++) m.l[k] = fr[(uint64_t)g * fr_stride + (uint64_t)out_idx * 512 + k * 64 + lane];
+    Fr c = fr_from_mont(m);
+    for (int k = 0; k < 8; k++) ((uint32_t*)(outputs + (uint64_t)w * 32))[k] = c.l[k];
+    uint32_t s = status_raw[w];
+    status[w] = s == 0xFFFFFFFFu ? 0 : s;
+}
+__global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
+
+// ------------------------------------------------------------------------------------------------ host side
+struct pob_ctx {
+    int device = 0, circuit = 0;
+    Plan plan;
+    uint32_t max_batch = 0, groups = 0, n = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    // device memory
+    uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr;
+    UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr; KBRefs* d_kbs = nullptr;
+    SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
+    uint32_t *d_pos = nullptr, *d_inv = nullptr;
+    uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
+    uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr; uint8_t* d_outputs = nullptr;
+    uint8_t* d_emit = nullptr;
+    // schedule
+    std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
+    struct Seg { uint32_t stage, lds, first, count; };
+    std::vector<Seg> segs;
+    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
+    std::vector<KSeg> ksegs;
+    uint32_t nperms = 0;
+    bool generated = false;
+};
+
+#define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
+
+static bool unit_uses_poseidon(uint32_t kind) { return kind == U_POB_POSEIDONS || kind == U_BAH_PRE || kind == U_SP_HEAD; }
+
+static Fr limbs_to_mont(const uint64_t* l) {
+    Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+    return fr_to_mont(c);
+}
+
+static GArgs gargs(pob_ctx* h) {
+    GArgs A; memset(&A, 0, sizeof A);
+    A.units = h->d_units; A.order = h->d_order; A.L = h->d_L; A.kbs = h->d_kbs;
+    A.bits = h->d_bits; A.sm = h->d_sm; A.fr = h->d_fr;
+    A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
+    A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.in_fr = h->d_in_fr; A.in_sm = h->d_in_sm;
+    A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
+    A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
+    return A;
+}
+static KArgs kargs(pob_ctx* h) {
+    KArgs K; memset(&K, 0, sizeof K);
+    K.bits = (u64*)h->d_bits; K.group_stride = h->plan.total.b; K.sponges = h->d_sponges;
+    K.perm_sponge = h->d_perm_sponge; K.perm_block = h->d_perm_block; K.bad_wire = h->d_bad;
+    return K;
+}
+
+static int make_plan(Plan& plan, std::string& err, int circuit, const uint64_t* params, int nparams) {
+    if (circuit == POB_CIRCUIT_PROOF_OF_BURN) {
+        if (nparams != 8) { err = "ProofOfBurn takes 8 template parameters"; return POB_E_ARG; }
+        PobParams prm;
+        prm.L = (int)params[0]; prm.NB = (int)params[4]; prm.HB = (int)params[8]; prm.minNib = (int)params[12];
+        prm.amountBytes = (int)params[16]; prm.powZero = (int)params[20];
+        prm.maxIntended = limbs_to_mont(params + 24); prm.maxActual = limbs_to_mont(params + 28);
+        if (prm.L < 2 || prm.L > 64 || prm.NB < 1 || prm.NB > 16 || prm.HB < 1 || prm.HB > 32 || prm.amountBytes < 1 || prm.amountBytes > 31 ||
+            4 + prm.L > MAX_KB) { err = "unsupported ProofOfBurn parameters"; return POB_E_ARG; }
+        plan.plan_pob(prm);
+    } else if (circuit == POB_CIRCUIT_SPEND) {
+        if (nparams != 1 || params[0] < 1 || params[0] > 31) { err = "Spend takes maxAmountBytes in 1..31"; return POB_E_ARG; }
+        SpendParams sp; sp.maxAmountBytes = (int)params[0];
+        plan.plan_spend(sp);
+    } else { err = "unknown circuit"; return POB_E_ARG; }
+    return POB_OK;
+}
+static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_info_t* info) {
+    info->n_witness = pl.total.w; info->n_bit = pl.total.b; info->n_sm = pl.total.s; info->n_fr = pl.total.f;
+    info->n_fr_inputs = pl.nfr_in; info->n_sm_inputs = pl.nsm_in; info->n_outputs = 1;
+    info->n_units = (uint32_t)pl.units.size(); info->n_sponges = (uint32_t)pl.sponges.size(); info->n_perms = nperms;
+    info->n_stages = pl.max_stage + 1; info->max_batch = max_batch;
+    info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;
+    info->keccak_bit_wires = 0;
+    for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
+}
+
+extern "C" {
+
+int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* info) {
+    if (!info) return POB_E_ARG;
+    Plan* plan = new Plan(); std::string err;
+    int rc = make_plan(*plan, err, circuit, params, nparams);
+    if (rc == POB_OK) { uint32_t np = 0; for (const SpongeDesc& sd : plan->sponges) np += sd.n; fill_info(*plan, np, 0, info); }
+    delete plan;
+    return rc;
+}
+
+const char* pob_strerror(pob_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint32_t max_batch, pob_handle* out) {
+    if (!out || max_batch == 0) return POB_E_ARG;
+    pob_ctx* h = new pob_ctx();
+    *out = h;
+    h->device = device; h->circuit = circuit; h->max_batch = max_batch; h->groups = (max_batch + 63) / 64;
+    { int prc = make_plan(h->plan, h->err, circuit, params, nparams); if (prc) return prc; }
+    Plan& pl = h->plan;
+    {   // POSEIDON_PREFIX + 0/1/2  (constants.circom:3-14) = keccak("EIP-7503") mod p
+        const uint64_t pre[4] = {0xf0363f983d892f7eULL, 0xd115b780980a6b46ULL, 0x007d2482cd46cec2ULL, 0x0ba44186ee7876b8ULL};
+        Fr base = limbs_to_mont(pre);
+        pl.L.prefix[0] = base; pl.L.prefix[1] = fr_add(base, fr_one_mont()); pl.L.prefix[2] = fr_add(pl.L.prefix[1], fr_one_mont());
+    }
+    // ---- schedule: sponges sorted by stage, perms flattened; units grouped by (stage, needs LDS table)
+    std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [](const SpongeDesc& a, const SpongeDesc& b) { return a.stage < b.stage; });
+    std::vector<uint32_t> perm_sponge, perm_block;
+    for (uint32_t s = 0; s <= pl.max_stage; s++) {
+        for (uint32_t lds = 0; lds < 2; lds++) {
+            pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
+            for (uint32_t u = 0; u < pl.units.size(); u++)
+                if (pl.units[u].stage == s && (uint32_t)unit_uses_poseidon(pl.units[u].kind) == lds) h->order.push_back(u);
+            sg.count = (uint32_t)h->order.size() - sg.first;
+            if (sg.count) h->segs.push_back(sg);
+        }
+        pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0};
+        bool first = true;
+        for (uint32_t i = 0; i < pl.sponges.size(); i++) if (pl.sponges[i].stage == s) {
+            if (first) { ks.sp_first = i; first = false; }
+            ks.sp_count++;
+            for (uint32_t b = 0; b < pl.sponges[i].n; b++) { perm_sponge.push_back(i); perm_block.push_back(b); }
+        }
+        ks.perm_count = (uint32_t)perm_sponge.size() - ks.perm_first;
+        if (ks.sp_count) h->ksegs.push_back(ks);
+    }
+    h->nperms = (uint32_t)perm_sponge.size();
+
+    HIPC(hipSetDevice(device));
+    HIPC(hipStreamCreate(&h->stream));
+    const uint64_t G = h->groups, npad = G * 64;
+    HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
+    HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
+    HIPC(hipMalloc(&h->d_fr, G * (uint64_t)pl.total.f * 2048));
+    HIPC(hipMalloc(&h->d_units, pl.units.size() * sizeof(UnitDesc)));
+    HIPC(hipMalloc(&h->d_order, h->order.size() * sizeof(uint32_t)));
+    HIPC(hipMalloc(&h->d_L, sizeof(CircuitLayout)));
+    HIPC(hipMalloc(&h->d_kbs, sizeof(KBRefs) * MAX_KB));
+    HIPC(hipMalloc(&h->d_sponges, std::max<size_t>(pl.sponges.size(), 1) * sizeof(SpongeDesc)));
+    HIPC(hipMalloc(&h->d_perm_sponge, std::max<size_t>(h->nperms, 1) * 4));
+    HIPC(hipMalloc(&h->d_perm_block, std::max<size_t>(h->nperms, 1) * 4));
+    HIPC(hipMalloc(&h->d_pos, sizeof(POS_TABLE_MONT)));
+    HIPC(hipMalloc(&h->d_inv, 8193 * 32));
+    HIPC(hipMalloc(&h->d_in_fr, npad * (uint64_t)pl.nfr_in * 32));
+    HIPC(hipMalloc(&h->d_in_sm, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
+    HIPC(hipMalloc(&h->d_status_raw, npad * 4)); HIPC(hipMalloc(&h->d_status, npad * 4));
+    HIPC(hipMalloc(&h->d_chk, npad * 4)); HIPC(hipMalloc(&h->d_bad, npad * 4));
+    HIPC(hipMalloc(&h->d_outputs, npad * 32));
+    HIPC(hipMemcpy(h->d_units, pl.units.data(), pl.units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(h->d_order, h->order.data(), h->order.size() * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(h->d_L, &pl.L, sizeof(CircuitLayout), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(h->d_kbs, pl.kbs, sizeof(KBRefs) * MAX_KB, hipMemcpyHostToDevice));
+    if (!pl.sponges.empty()) HIPC(hipMemcpy(h->d_sponges, pl.sponges.data(), pl.sponges.size() * sizeof(SpongeDesc), hipMemcpyHostToDevice));
+    if (h->nperms) {
+        HIPC(hipMemcpy(h->d_perm_sponge, perm_sponge.data(), h->nperms * 4, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(h->d_perm_block, perm_block.data(), h->nperms * 4, hipMemcpyHostToDevice));
+    }
+    HIPC(hipMemcpy(h->d_pos, POS_TABLE_MONT, sizeof(POS_TABLE_MONT), hipMemcpyHostToDevice));
+    HIPC(hipMemset(h->d_in_fr, 0, npad * (uint64_t)pl.nfr_in * 32));
+    HIPC(hipMemset(h->d_in_sm, 0, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
+    HIPC(hipMemset(h->d_status_raw, 0xFF, npad * 4)); HIPC(hipMemset(h->d_chk, 0xFF, npad * 4)); HIPC(hipMemset(h->d_bad, 0xFF, npad * 4));
+    hipLaunchKernelGGL(k_init_invlut, dim3((8193 + 63) / 64), dim3(64), 0, h->stream, h->d_inv);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return POB_OK;
+}
+
+void pob_close(pob_handle h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_kbs, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
+                    h->d_inv, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_emit};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int pob_get_info(pob_handle h, pob_info_t* info) {
+    if (!h || !info) return POB_E_ARG;
+    fill_info(h->plan, h->nperms, h->max_batch, info);
+    return POB_OK;
+}
+
+int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n) {
+    if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipMemcpy(h->d_in_fr, fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice));
+    if (h->plan.nsm_in) HIPC(hipMemcpy(h->d_in_sm, sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice));
+    h->n = n; h->generated = false;
+    return POB_OK;
+}
+
+int pob_generate(pob_handle h, void* stream_) {
+    if (!h || h->n == 0) return POB_E_STATE;
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    const uint32_t G = (h->n + 63) / 64;
+    HIPC(hipMemsetAsync(h->d_status_raw, 0xFF, (uint64_t)h->groups * 64 * 4, st));
+    GArgs A = gargs(h);
+    KArgs K = kargs(h);
+    size_t si = 0, ki = 0;
+    for (uint32_t s = 0; s <= h->plan.max_stage; s++) {
+        for (; si < h->segs.size() && h->segs[si].stage == s; si++) {
+            A.first = h->segs[si].first; A.stage_lds = h->segs[si].lds;
+            launch_g_gen(A, h->segs[si].count, G, st);
+        }
+        for (; ki < h->ksegs.size() && h->ksegs[ki].stage == s; ki++) {
+            K.first = h->ksegs[ki].sp_first;
+            launch_k_chain(K, false, h->ksegs[ki].sp_count, G, st);
+            K.first = h->ksegs[ki].perm_first;
+            launch_k_rounds(K, false, h->ksegs[ki].perm_count, G, st);
+        }
+    }
+    const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
+    hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs, G * 64);
+    HIPC(hipGetLastError());
+    h->generated = true;
+    return POB_OK;
+}
+
+int pob_constraint_check(pob_handle h, void* stream_) {
+    if (!h || !h->generated) return POB_E_STATE;
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    const uint32_t G = (h->n + 63) / 64;
+    HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
+    HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
+    GArgs A = gargs(h);
+    for (const pob_ctx::Seg& sg : h->segs) {
+        A.first = sg.first; A.stage_lds = sg.lds;
+        launch_g_check(A, sg.count, G, st);
+    }
+    KArgs K = kargs(h);
+    if (!h->plan.sponges.empty()) {
+        K.first = 0;
+        launch_k_chain(K, true, (uint32_t)h->plan.sponges.size(), G, st);
+        launch_k_rounds(K, true, h->nperms, G, st);
+    }
+    HIPC(hipGetLastError());
+    return POB_OK;
+}
+
+int pob_sync(pob_handle h) {
+    if (!h) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipDeviceSynchronize());
+    return POB_OK;
+}
+
+int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* check_status, uint32_t* bad_wire) {
+    if (!h || !h->generated) return POB_E_STATE;
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipDeviceSynchronize());
+    if (status) HIPC(hipMemcpy(status, h->d_status, (uint64_t)h->n * 4, hipMemcpyDeviceToHost));
+    if (outputs) HIPC(hipMemcpy(outputs, h->d_outputs, (uint64_t)h->n * 32, hipMemcpyDeviceToHost));
+    if (check_status) HIPC(hipMemcpy(check_status, h->d_chk, (uint64_t)h->n * 4, hipMemcpyDeviceToHost));
+    if (bad_wire) HIPC(hipMemcpy(bad_wire, h->d_bad, (uint64_t)h->n * 4, hipMemcpyDeviceToHost));
+    return POB_OK;
+}
+
+int pob_results_device(pob_handle h, void** d_status, void** d_outputs) {
+    if (!h) return POB_E_ARG;
+    if (d_status) *d_status = h->d_status;
+    if (d_outputs) *d_outputs = h->d_outputs;
+    return POB_OK;
+}
+
+static int emit_to_device(pob_ctx* h, uint32_t idx) {
+    if (!h->generated || idx >= h->n) return POB_E_STATE;
+    HIPC(hipSetDevice(h->device));
+    const uint64_t bytes = (uint64_t)h->plan.total.w * 32;
+    if (!h->d_emit) HIPC(hipMalloc(&h->d_emit, bytes));
+    hipStream_t st = h->stream;
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemsetAsync(h->d_emit, 0xEE, bytes, st));              // any wire nobody owns stays 0xEE.. (not a field element)
+    const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    HIPC(hipMemcpyAsync(h->d_emit, one, 32, hipMemcpyHostToDevice, st));   // wire 0 = 1
+    GArgs A = gargs(h);
+    A.emit_out = h->d_emit; A.emit_sel = idx % 64; A.emit_group = idx / 64;
+    for (const pob_ctx::Seg& sg : h->segs) {
+        A.first = sg.first; A.stage_lds = sg.lds;
+        launch_g_emit(A, sg.count, st);
+    }
+    const u64* Gp = (const u64*)h->d_bits + (uint64_t)(idx / 64) * h->plan.total.b;
+    for (const SpongeDesc& s : h->plan.sponges) {
+        const uint32_t rng[4][3] = {{s.kin_w, s.kin_b, s.n * 1088}, {s.fin_w, s.fin_b, s.n * 1088}, {s.fs_w, s.fs_b, (s.n + 1) * 1600}, {s.abs_w, s.abs_b, s.n * ABSORB_WIRES}};
+        for (int k = 0; k < 4; k++) {
+            launch_k_emit_bits(Gp, h->d_emit, rng[k][0], rng[k][1], rng[k][2], idx % 64, st);
+        }
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(st));
+    return POB_OK;
+}
+
+int pob_emit_witness(pob_handle h, uint32_t idx, uint8_t* dst, uint64_t cap) {
+    if (!h || !dst) return POB_E_ARG;
+    const uint64_t bytes = (uint64_t)h->plan.total.w * 32;
+    if (cap < bytes) { h->err = "destination too small"; return POB_E_ARG; }
+    int rc = emit_to_device(h, idx);
+    if (rc) return rc;
+    HIPC(hipMemcpy(dst, h->d_emit, bytes, hipMemcpyDeviceToHost));
+    return POB_OK;
+}
+
+int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
+    if (!h || !path) return POB_E_ARG;
+    int rc = emit_to_device(h, idx);
+    if (rc) return rc;
+    const uint64_t W = h->plan.total.w, bytes = W * 32;
+    FILE* f = fopen(path, "wb");
+    if (!f) { h->err = std::string("cannot open ") + path; return POB_E_IO; }
+    // iden3 .wtns container: "wtns" v2, 2 sections: (1) n8=32, prime, nWitness  (2) values
+    uint8_t hdr[76];
+    const uint64_t P64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    uint32_t u32; uint64_t u64v;
+    memcpy(hdr, "wtns", 4); u32 = 2; memcpy(hdr + 4, &u32, 4); memcpy(hdr + 8, &u32, 4);
+    u32 = 1; memcpy(hdr + 12, &u32, 4); u64v = 40; memcpy(hdr + 16, &u64v, 8);
+    u32 = 32; memcpy(hdr + 24, &u32, 4); memcpy(hdr + 28, P64, 32); u32 = (uint32_t)W; memcpy(hdr + 60, &u32, 4);
+    u32 = 2; memcpy(hdr + 64, &u32, 4); u64v = bytes; memcpy(hdr + 68, &u64v, 8);
+    bool ok = fwrite(hdr, 1, 76, f) == 76;
+    const uint64_t CH = 256ull << 20;
+    uint8_t* stage = nullptr;
+    if (hipHostMalloc((void**)&stage, CH, hipHostMallocDefault) != hipSuccess) { fclose(f); h->err = "hipHostMalloc failed"; return POB_E_NOMEM; }
+    for (uint64_t off = 0; ok && off < bytes; off += CH) {
+        uint64_t n = std::min(CH, bytes - off);
+        if (hipMemcpy(stage, h->d_emit + off, n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(stage, 1, n, f) == n;
+    }
+    hipHostFree(stage);
+    fclose(f);
+    if (!ok) { h->err = "write failed"; return POB_E_IO; }
+    return POB_OK;
+}
+
+int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* avg_ms) {
+    if (!h || !h->generated || iters < 1 || !avg_ms) return POB_E_STATE;
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    const uint32_t G = (h->n + 63) / 64;
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    KArgs K = kargs(h); K.first = 0;
+    GArgs A = gargs(h);
+    HIPC(hipEventRecord(e0, st));
+    for (int it = 0; it < iters; it++) {
+        if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
+        else if (which == 1) launch_k_rounds(K, true, h->nperms, G, st);
+        else if (which == 2) {
+            for (const pob_ctx::Seg& sg : h->segs) {
+                A.first = sg.first; A.stage_lds = sg.lds;
+                launch_g_check(A, sg.count, G, st);
+            }
+        } else launch_k_chain(K, false, (uint32_t)h->plan.sponges.size(), G, st);
+    }
+    HIPC(hipEventRecord(e1, st));
+    HIPC(hipEventSynchronize(e1));
+    float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return POB_OK;
+}
+
+int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask) {
+    if (!h || group >= h->groups || bit_index >= h->plan.total.b) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, h->stream, h->d_bits + (uint64_t)group * h->plan.total.b + bit_index, mask);
+    HIPC(hipStreamSynchronize(h->stream));
+    return POB_OK;
+}
+
+// ---- host Keccak-256 (FIPS-202 permutation, original 0x01 padding) for input producers
+static const int KROT_H[25] = {1, 10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+static uint64_t rotl64h(uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; }
+static void keccak_f_host(uint64_t a[25]) {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+        0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    for (int r = 0; r < 24; r++) {
+        uint64_t c[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; x++) { uint64_t d = c[(x + 4) % 5] ^ rotl64h(c[(x + 1) % 5], 1); for (int y = 0; y < 25; y += 5) a[x + y] ^= d; }
+        b[0] = a[0];
+        for (int i = 0; i < 24; i++) b[KROT_H[i + 1]] = rotl64h(a[KROT_H[i]], ((i + 1) * (i + 2) / 2) % 64);
+        for (int i = 0; i < 25; i++) { int y = i / 5 * 5; a[i] = b[i] ^ (~b[y + (i + 1) % 5] & b[y + (i + 2) % 5]); }
+        a[0] ^= RC[r];
+    }
+}
+void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]) {
+    uint64_t st[25]; memset(st, 0, sizeof st);
+    uint8_t blk[136];
+    for (uint64_t off = 0;; off += 136) {
+        uint64_t n = len - off < 136 ? len - off : 136;
+        memset(blk, 0, 136); if (n) memcpy(blk, msg + off, n);
+        const bool last = n < 136;
+        if (last) { blk[n] ^= 0x01; blk[135] ^= 0x80; }
+        for (int i = 0; i < 17; i++) { uint64_t v; memcpy(&v, blk + 8 * i, 8); st[i] ^= v; }
+        keccak_f_host(st);
+        if (last) break;
+    }
+    memcpy(out, st, 32);
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// Witness-vector layout + execution policies.
+//
+// The O0 witness of the reference circuits (every declared signal is a wire; reference Makefile:2-3)
+// is kept resident in HBM in a COMPACT TYPED form, one slab per group of 64 witnesses (= one
+// wavefront, lane = witness):
+//
+//   BIT  wires (provably 0/1 in a valid witness; 99.4 % of all wires, all of Keccak):
+//        one uint64 per wire per group; bit l = value in witness l.  This is exactly the format of a
+//        CDNA wave lane-mask (VCC/EXEC), so gate logic on BIT wires is one 64-bit scalar op for 64
+//        witnesses and a comparison result becomes a wire with one v_cmp (ballot).
+//   SM   wires (bytes, lengths, small signed differences): int32 [wire][64 lanes] (256 B rows).
+//   SI   wires (IsZero.inv of an SM operand): stored in the SM array as the operand k itself; the
+//        wire's value is k^-1 mod p (0 for k = 0), decoded through a table when a .wtns is emitted.
+//   FR   wires (genuine field elements): 8 x uint32 limb planes [wire][limb][64 lanes], Montgomery form.
+//
+// Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
+// run of same-class wires (e.g. a whole Keccak-f block, 2 506 944 BIT wires) is contiguous in HBM.
+//
+// Every circuit template is written ONCE as `template <class P>` code (gadgets.hpp) and instantiated
+// with four policies:
+//   CountP  (host)   only advances the cursor: layout planner, no memory traffic;
+//   GenP    (device) computes values and stores them                          -> witness generation;
+//   CheckP  (device) re-reads every wire and verifies it against its defining expression evaluated
+//                    on the STORED operands (and every ===)                   -> constraint evaluator;
+//   EmitP   (device) re-reads every wire and writes it as a canonical 32-byte LE field element
+//                    at its O0 wire index                                     -> .wtns emitter.
+#pragma once
+#include <stdint.h>
+#include "fr_dev.hpp"
+
+typedef uint64_t B;   // BIT value: lane mask over the 64 witnesses of the group (wave-uniform)
+typedef int32_t S;    // SM value of this lane's witness
+typedef Fr F;         // FR value (Montgomery) of this lane's witness
+
+struct Cur { uint32_t w, b, s, f; };   // next free: wire index, BIT rank, SM rank, FR rank
+struct BitRef { uint32_t w, i; HD BitRef operator+(uint32_t k) const { BitRef r = {w + k, i + k}; return r; } };
+struct SmRef  { uint32_t w, i; HD SmRef  operator+(uint32_t k) const { SmRef  r = {w + k, i + k}; return r; } };
+struct SiRef  { uint32_t w, i; HD SiRef  operator+(uint32_t k) const { SiRef  r = {w + k, i + k}; return r; } };
+struct FrRef  { uint32_t w, i; HD FrRef  operator+(uint32_t k) const { FrRef  r = {w + k, i + k}; return r; } };
+
+// failure codes: (template id << 12) | source line of the failing assert / === in the reference circuits
+enum : uint32_t {
+    T_NUM2BITS = 1, T_ISZERO, T_ALIASCHECK, T_ASSERT_LT, T_ASSERT_LE, T_ASSERT_GE, T_DIVIDE, T_SELECTOR,
+    T_POW, T_POB, T_INPUT, T_COMPCONST, T_MISC
+};
+#define FAILCODE(tpl, line) (((uint32_t)(tpl) << 12) | (uint32_t)(line))
+
+struct PolBase {
+    Cur cur;
+    HD BitRef bits(uint32_t n) { BitRef r = {cur.w, cur.b}; cur.w += n; cur.b += n; return r; }
+    HD SmRef sms(uint32_t n) { SmRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
+    HD SiRef sis(uint32_t n) { SiRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
+    HD FrRef frs(uint32_t n) { FrRef r = {cur.w, cur.f}; cur.w += n; cur.f += n; return r; }
+    HD void skip_bits(uint32_t n) { cur.w += n; cur.b += n; }
+};
+
+// ------------------------------------------------------------------ host-side layout planner policy
+struct CountP : PolBase {
+    static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
+    HD B put(BitRef, B v) { return v; }
+    HD S put(SmRef, S v) { return v; }
+    HD F put(FrRef, const F& v) { return v; }
+    HD B hint(BitRef, B v) { return v; }
+    HD S hint(SmRef, S v) { return v; }
+    HD F hint(FrRef, const F& v) { return v; }
+    HD S hint_inv(SiRef, S v) { return v; }
+    HD B get(BitRef) { return 0; }
+    HD S get(SmRef) { return 0; }
+    HD F get(FrRef) { return fr_zero(); }
+    HD void raw_put(FrRef, const F&) {}
+    HD B ballot(bool) { return 0; }
+    HD bool bit(B) { return false; }
+    HD void require(B, uint32_t) {}
+    HD F kconst(uint32_t) { return fr_zero(); }   // Poseidon table entry (Montgomery)
+    HD F input_fr(uint32_t) { return fr_zero(); }
+    HD S input_sm(uint32_t) { return 0; }
+    HD uint32_t lane_id() { return 0; }
+};
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------ device policies
+struct DevMem {
+    uint64_t* bits;     // this group's BIT slab
+    int32_t* sm;        // this group's SM slab  [NS][64]
+    uint32_t* fr;       // this group's FR slab  [NF][8][64]
+    const uint32_t* pos_tab;  // Poseidon table (Montgomery, [idx][8]) -- LDS copy when staged
+    const uint32_t* inv_lut;  // canonical inverses of -4096..4096, [k+4096][8]
+    const uint8_t* in_fr;     // this group's packed inputs: FR inputs [64 lanes][nfr][32 B canonical LE]
+    const int32_t* in_sm;     //                              SM inputs [64 lanes][nsm]
+    uint32_t nfr_in, nsm_in;
+    uint32_t lane;
+};
+
+struct DevPol : PolBase {
+    DevMem m;
+    __device__ __forceinline__ B ballot(bool pred) { return __ballot(pred); }
+    __device__ __forceinline__ bool bit(B v) { return (v >> m.lane) & 1; }
+    __device__ __forceinline__ uint32_t lane_id() { return m.lane; }
+    __device__ __forceinline__ B ld(BitRef r) { return m.bits[r.i]; }
+    __device__ __forceinline__ S ld(SmRef r) { return m.sm[(size_t)r.i * 64 + m.lane]; }
+    __device__ __forceinline__ S ld(SiRef r) { return m.sm[(size_t)r.i * 64 + m.lane]; }
+    __device__ __forceinline__ F ld(FrRef r) {
+        F v; const uint32_t* q = m.fr + (size_t)r.i * 512 + m.lane;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = q[k * 64];
+        return v;
+    }
+    __device__ __forceinline__ void st(BitRef r, B v) { if (m.lane == 0) m.bits[r.i] = v; }
+    __device__ __forceinline__ void st(SmRef r, S v) { m.sm[(size_t)r.i * 64 + m.lane] = v; }
+    __device__ __forceinline__ void st(SiRef r, S v) { m.sm[(size_t)r.i * 64 + m.lane] = v; }
+    __device__ __forceinline__ void st(FrRef r, const F& v) {
+        uint32_t* q = m.fr + (size_t)r.i * 512 + m.lane;
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k * 64] = v.l[k];
+    }
+    __device__ __forceinline__ B get(BitRef r) { return ld(r); }
+    __device__ __forceinline__ S get(SmRef r) { return ld(r); }
+    __device__ __forceinline__ F get(FrRef r) { return ld(r); }
+    __device__ __forceinline__ F kconst(uint32_t idx) {
+        F v; const uint32_t* q = m.pos_tab + (size_t)idx * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = q[k];
+        return v;
+    }
+    __device__ __forceinline__ F input_fr(uint32_t k) {   // canonical LE bytes -> Montgomery
+        const uint32_t* q = (const uint32_t*)(m.in_fr + ((size_t)m.lane * m.nfr_in + k) * 32);
+        F c;
+#pragma unroll
+        for (int j = 0; j < 8; j++) c.l[j] = q[j];
+        return fr_to_mont(c);
+    }
+    __device__ __forceinline__ S input_sm(uint32_t k) { return m.in_sm[(size_t)m.lane * m.nsm_in + k]; }
+};
+
+struct GenP : DevPol {
+    static constexpr bool is_gen = true, is_check = false, is_emit = false, is_count = false;
+    uint32_t status;   // this lane's first failing assert (0 = none yet)
+    __device__ __forceinline__ B put(BitRef r, B v) { st(r, v); return v; }
+    __device__ __forceinline__ S put(SmRef r, S v) { st(r, v); return v; }
+    __device__ __forceinline__ F put(FrRef r, const F& v) { st(r, v); return v; }
+    __device__ __forceinline__ B hint(BitRef r, B v) { st(r, v); return v; }
+    __device__ __forceinline__ S hint(SmRef r, S v) { st(r, v); return v; }
+    __device__ __forceinline__ F hint(FrRef r, const F& v) { st(r, v); return v; }
+    __device__ __forceinline__ S hint_inv(SiRef r, S v) { st(r, v); return v; }
+    __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
+    __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
+};
+
+// Constraint evaluator: `put` = "this wire must equal this expression of stored wires".
+struct CheckP : DevPol {
+    static constexpr bool is_gen = false, is_check = true, is_emit = false, is_count = false;
+    uint32_t status;     // first failing === site of this lane
+    uint32_t bad_wire;   // lowest wire index whose stored value contradicts its definition (per lane)
+    __device__ __forceinline__ void mark(bool bad, uint32_t w) { if (bad && w < bad_wire) bad_wire = w; }
+    __device__ __forceinline__ B put(BitRef r, B v) { B s = ld(r); mark(((s ^ v) >> m.lane) & 1, r.w); return s; }
+    __device__ __forceinline__ S put(SmRef r, S v) { S s = ld(r); mark(s != v, r.w); return s; }
+    __device__ __forceinline__ F put(FrRef r, const F& v) { F s = ld(r); mark(!fr_eq(s, v), r.w); return s; }
+    __device__ __forceinline__ B hint(BitRef r, B) { return ld(r); }
+    __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
+    __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
+    __device__ __forceinline__ S hint_inv(SiRef r, S) { return ld(r); }
+    __device__ __forceinline__ void raw_put(FrRef, const F&) {}
+    __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
+};
+
+// .wtns emitter for ONE witness of the group (lane `sel`): canonical 32-byte LE value at wire index.
+struct EmitP : DevPol {
+    static constexpr bool is_gen = false, is_check = false, is_emit = true, is_count = false;
+    uint8_t* out;      // canonical witness payload, 32 B per wire
+    uint32_t sel;
+    __device__ __forceinline__ void w32(uint32_t w, const F& canon) {
+        uint4* q = (uint4*)(out + (size_t)w * 32);
+        q[0] = make_uint4(canon.l[0], canon.l[1], canon.l[2], canon.l[3]);
+        q[1] = make_uint4(canon.l[4], canon.l[5], canon.l[6], canon.l[7]);
+    }
+    __device__ __forceinline__ F small(S k) {
+        Fr c = {{(uint32_t)(k < 0 ? -k : k), 0, 0, 0, 0, 0, 0, 0}};
+        return (k < 0) ? fr_sub(fr_zero(), c) : c;     // canonical arithmetic: p - |k|
+    }
+    __device__ __forceinline__ B put(BitRef r, B) {
+        B s = ld(r);
+        if (m.lane == 0) { Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(r.w, c); }
+        return s;
+    }
+    __device__ __forceinline__ S put(SmRef r, S) { S s = ld(r); if (m.lane == sel) w32(r.w, small(s)); return s; }
+    __device__ __forceinline__ F put(FrRef r, const F&) { F s = ld(r); if (m.lane == sel) w32(r.w, fr_from_mont(s)); return s; }
+    __device__ __forceinline__ B hint(BitRef r, B v) { return put(r, v); }
+    __device__ __forceinline__ S hint(SmRef r, S v) { return put(r, v); }
+    __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
+    __device__ __forceinline__ S hint_inv(SiRef r, S) {
+        S k = ld(r);
+        if (m.lane == sel) {
+            F c;
+            if (k >= -4096 && k <= 4096) {
+                const uint32_t* q = m.inv_lut + (size_t)(k + 4096) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++) c.l[j] = q[j];
+            } else {
+                c = fr_from_mont(fr_inv(fr_from_i64(k)));
+            }
+            w32(r.w, c);
+        }
+        return k;
+    }
+    __device__ __forceinline__ void raw_put(FrRef, const F&) {}
+    __device__ __forceinline__ void require(B, uint32_t) {}
+};
+#endif  // __HIPCC__

@@ -1,0 +1,35 @@
+"""`run(main, test_cases)` with the signature and semantics of the reference harness (tests/test.py:6-75),
+executed on the HIP calculator instead of `circom -c` + the emitted binary.  Supports the two circuits that
+have a `component main` in the reference (ProofOfBurn(...), Spend(...)); gadget-level mains are covered by
+the CPU oracle in tests/ (they are not on the GPU hot path).
+"""
+from .witness import WitnessCalculator
+
+
+def run(main, test_cases):
+    print()
+    print(f"Testing {main}")
+    print("=" * 20)
+    calc = WitnessCalculator(main, max_batch=max(1, len(test_cases)))
+    try:
+        # malformed inputs (missing keys / wrong shapes) abort the reference binary => None
+        good, results = [], [None] * len(test_cases)
+        for i, (case, _) in enumerate(test_cases):
+            try:
+                calc.pack([case])
+                good.append(i)
+            except (KeyError, ValueError, TypeError):
+                pass
+        if good:
+            res = calc.calculate([test_cases[i][0] for i in good])
+            for i, r in zip(good, res):
+                results[i] = r.outputs if r.ok else None
+        for (case, expected), got in zip(test_cases, results):
+            if got is None:
+                if expected is not None:
+                    raise Exception("Expected null!")
+            elif got != expected:
+                raise Exception(f"Unexpected output! {got} != {expected}")
+        return results
+    finally:
+        calc.close()

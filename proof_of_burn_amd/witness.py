@@ -1,0 +1,350 @@
+"""Host side of the MI355X witness generator: the reference's calculator interface over the C ABI.
+
+Mirrors the reference boundary:
+  * which circuit = the `component main = ...;` string (reference tests/test.py:31,
+    circuits/main_proof_of_burn.circom:27, circuits/main_spend.circom:6);
+  * inputs = the input.json dict with the circuit's `signal input` names
+    (proof_of_burn.circom:43-72, spend.circom:33-36; producer tests/main.py:160-178), values as JSON ints or
+    decimal / 0x strings, reduced mod p;
+  * out = public output signals as ints, or failure (reference: any stderr output, tests/test.py:65-68),
+    and an iden3 `.wtns` file (reference Makefile:4-5: `./main_proof_of_burn input.json witness.wtns`).
+
+All arithmetic happens in libpob_hip.so (hand-written HIP, include/pob_hip.h).  There is NO CPU fallback:
+if the library is missing or no GPU is visible, construction fails.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import re
+from dataclasses import dataclass
+from typing import Iterable, Sequence
+
+import numpy as np
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpob_hip.so")
+
+POB_FR_INPUTS = ["burnKey", "actualBalance", "intendedBalance", "revealAmount", "burnExtraCommitment", "_proofExtraCommitment"]
+POB_SM_INPUTS = ["numLeafAddressNibbles", "layers", "layerLens", "numLayers", "blockHeader", "blockHeaderLen", "byteSecurityRelax"]
+SPEND_FR_INPUTS = ["burnKey", "balance", "withdrawnBalance", "extraCommitment"]
+
+# failure-code template ids (csrc/policy.hpp)
+_TPL = {1: "Num2Bits", 2: "IsZero", 3: "AliasCheck", 4: "AssertLessThan", 5: "AssertLessEqThan", 6: "AssertGreaterEqThan",
+        7: "Divide", 8: "Selector", 9: "ProofOfWorkChecker", 10: "ProofOfBurn", 11: "input", 12: "CompConstant", 13: "misc"}
+FAIL_INPUT_RANGE = (11 << 12) | 1
+
+
+class PobInfo(ctypes.Structure):
+    _fields_ = [("n_witness", ctypes.c_uint64), ("n_bit", ctypes.c_uint64), ("n_sm", ctypes.c_uint64), ("n_fr", ctypes.c_uint64),
+                ("n_fr_inputs", ctypes.c_uint32), ("n_sm_inputs", ctypes.c_uint32), ("n_outputs", ctypes.c_uint32),
+                ("n_units", ctypes.c_uint32), ("n_sponges", ctypes.c_uint32), ("n_perms", ctypes.c_uint32),
+                ("n_stages", ctypes.c_uint32), ("max_batch", ctypes.c_uint32),
+                ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libpob_hip.so and declare the prototypes of include/pob_hip.h.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u32p, u8p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)
+    lib.pob_open.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(vp)]
+    lib.pob_close.argtypes = [vp]
+    lib.pob_close.restype = None
+    lib.pob_get_info.argtypes = [vp, ctypes.POINTER(PobInfo)]
+    lib.pob_plan_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.POINTER(PobInfo)]
+    lib.pob_strerror.argtypes = [vp]
+    lib.pob_strerror.restype = ctypes.c_char_p
+    lib.pob_upload_inputs.argtypes = [vp, vp, vp, ctypes.c_uint32]
+    lib.pob_generate.argtypes = [vp, vp]
+    lib.pob_constraint_check.argtypes = [vp, vp]
+    lib.pob_sync.argtypes = [vp]
+    lib.pob_results.argtypes = [vp, vp, vp, vp, vp]
+    lib.pob_results_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.pob_emit_witness.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64]
+    lib.pob_write_wtns.argtypes = [vp, ctypes.c_uint32, ctypes.c_char_p]
+    lib.pob_time_kernel.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.pob_debug_xor_bits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
+    lib.pob_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
+    lib.pob_keccak256.restype = None
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_generate",
+                    "pob_constraint_check", "pob_sync", "pob_results", "pob_results_device", "pob_emit_witness",
+                    "pob_write_wtns", "pob_time_kernel", "pob_debug_xor_bits", "pob_keccak256"]
+
+
+def plan_info(main: str) -> PobInfo:
+    """wire / storage-class counts of an instantiation from the host-side layout planner (no GPU needed)"""
+    name, params = parse_main(main)
+    circuit = {"ProofOfBurn": 0, "Spend": 1}[name]
+    arr = (ctypes.c_uint64 * (4 * len(params)))()
+    for i, v in enumerate(params):
+        for k in range(4):
+            arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    info = PobInfo()
+    rc = load_library().pob_plan_info(circuit, arr, len(params), ctypes.byref(info))
+    if rc != 0:
+        raise ValueError(f"pob_plan_info rc={rc}")
+    return info
+
+
+def keccak256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    load_library().pob_keccak256(bytes(data), len(data), out)
+    return out.raw
+
+
+def parse_main(main: str):
+    """'ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)' -> ('ProofOfBurn', [16, 4, ...]) (reference tests/test.py:31)."""
+    m = re.fullmatch(r"\s*(\w+)\s*\((.*)\)\s*;?\s*", main, flags=re.S)
+    if not m:
+        raise ValueError(f"not a template instantiation: {main!r}")
+    params = []
+    if m.group(2).strip():
+        for a in m.group(2).split(","):
+            if not re.fullmatch(r"[\d\s\*\+\-\(\)]+", a):
+                raise ValueError(f"unsupported template argument {a!r}")
+            params.append(int(eval(a, {"__builtins__": {}})))
+    return m.group(1), params
+
+
+def to_field(v) -> int:
+    """input.json scalar -> canonical Fr (the emitted loader accepts JSON numbers and base-10 / 0x strings, mod p)."""
+    if isinstance(v, bool):
+        return int(v)
+    if isinstance(v, (int, np.integer)):
+        return int(v) % P
+    if isinstance(v, str):
+        return int(v, 16 if v.lower().startswith("0x") else 10) % P
+    raise TypeError(f"unsupported input value {v!r}")
+
+
+def _scalar(v):
+    """the reference's tests pass scalars as 1-element arrays too (tests/testcases/divide.py:4)"""
+    while isinstance(v, (list, tuple)) and len(v) == 1:
+        v = v[0]
+    return to_field(v)
+
+
+def _flat(v, out):
+    if isinstance(v, (list, tuple, np.ndarray)):
+        for x in v:
+            _flat(x, out)
+    else:
+        out.append(to_field(v))
+
+
+@dataclass
+class Result:
+    status: int                 # 0 = ok; else (template id << 12) | source line of the first failing assert
+    outputs: list | None        # public output signals (None when failed) -- tests/test.py:40-47,65-68
+    check_status: int | None = None
+    bad_wire: int | None = None
+
+    @property
+    def ok(self) -> bool:
+        return self.status == 0
+
+    def message(self) -> str:
+        if self.status == 0:
+            return ""
+        return f"Failed assert in template {_TPL.get(self.status >> 12, '?')} line {self.status & 0xFFF}"
+
+
+class WitnessCalculator:
+    """One (GPU, circuit instantiation) calculator: `./main_proof_of_burn` / `./main_spend` as an object."""
+
+    def __init__(self, main: str, max_batch: int = 64, device: int = 0):
+        name, params = parse_main(main) if isinstance(main, str) else main
+        self.name, self.params = name, list(params)
+        if name == "ProofOfBurn":
+            if len(params) != 8:
+                raise ValueError("ProofOfBurn(maxNumLayers, maxNodeBlocks, maxHeaderBlocks, minLeafAddressNibbles, amountBytes, "
+                                 "powMinimumZeroBytes, maxIntendedBalance, maxActualBalance)")
+            circuit = 0
+            self.L, self.NB, self.HB = params[0], params[1], params[2]
+        elif name == "Spend":
+            circuit = 1
+        else:
+            raise NotImplementedError(f"the HIP calculator implements the two `component main` circuits (ProofOfBurn, Spend); got {name}")
+        self.lib = load_library()
+        arr = (ctypes.c_uint64 * (4 * len(params)))()
+        for i, v in enumerate(params):
+            for k in range(4):
+                arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        self.h = ctypes.c_void_p()
+        rc = self.lib.pob_open(device, circuit, arr, len(params), max_batch, ctypes.byref(self.h))
+        if rc != 0:
+            msg = self.lib.pob_strerror(self.h).decode() if self.h else "pob_open failed"
+            raise RuntimeError(f"pob_open: {msg} (rc={rc})")
+        self.info = PobInfo()
+        self._ck(self.lib.pob_get_info(self.h, ctypes.byref(self.info)))
+        self.max_batch = max_batch
+        self.n = 0
+        self._forced = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libpob_hip: {self.lib.pob_strerror(self.h).decode()} (rc={rc})")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pob_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def nwitness(self) -> int:
+        return int(self.info.n_witness)
+
+    # ------------------------------------------------------------------ input packing (the emitted loadJson)
+    def pack(self, inputs: Sequence[dict]):
+        """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n])"""
+        n = len(inputs)
+        nfr, nsm = self.info.n_fr_inputs, self.info.n_sm_inputs
+        fr = np.zeros((n, nfr, 32), dtype=np.uint8)
+        sm = np.zeros((n, max(nsm, 1)), dtype=np.int32)
+        forced = np.zeros(n, dtype=np.uint32)
+        fr_names = POB_FR_INPUTS if self.name == "ProofOfBurn" else SPEND_FR_INPUTS
+        sm_names = POB_SM_INPUTS if self.name == "ProofOfBurn" else []
+        shapes = {}
+        if self.name == "ProofOfBurn":
+            shapes = {"layers": self.L * self.NB * 136, "layerLens": self.L, "blockHeader": self.HB * 136}
+        for w, d in enumerate(inputs):
+            keys = set(d.keys())
+            want = set(fr_names) | set(sm_names)
+            if keys != want:
+                raise KeyError(f"input {w}: missing {sorted(want - keys)} unexpected {sorted(keys - want)}")
+            for k, name in enumerate(fr_names):
+                fr[w, k] = np.frombuffer(_scalar(d[name]).to_bytes(32, "little"), dtype=np.uint8)
+            col = 0
+            for name in sm_names:
+                if name in shapes:
+                    vals = []
+                    _flat(d[name], vals)
+                    if len(vals) != shapes[name]:
+                        raise ValueError(f"input {w}: {name} has {len(vals)} elements, circuit expects {shapes[name]}")
+                else:
+                    vals = [_scalar(d[name])]
+                a = np.array([v if v < (1 << 31) else -1 for v in vals], dtype=np.int64)
+                if (a < 0).any():      # not representable as a small input: every such input is range-checked in-circuit
+                    forced[w] = FAIL_INPUT_RANGE
+                    a[a < 0] = 0x7FFFFFFF
+                sm[w, col:col + len(vals)] = a.astype(np.int32)
+                col += len(vals)
+            assert col == nsm
+        return fr, sm, forced
+
+    # ------------------------------------------------------------------ the calculator
+    def upload(self, inputs: Sequence[dict]):
+        fr, sm, forced = self.pack(inputs)
+        self.upload_packed(fr, sm, forced)
+
+    def upload_packed(self, fr: np.ndarray, sm: np.ndarray, forced: np.ndarray | None = None):
+        n = fr.shape[0]
+        if n > self.max_batch:
+            raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
+        fr = np.ascontiguousarray(fr, dtype=np.uint8)
+        sm = np.ascontiguousarray(sm, dtype=np.int32)
+        self._ck(self.lib.pob_upload_inputs(self.h, fr.ctypes.data, sm.ctypes.data, n))
+        self.n = n
+        self._forced = forced if forced is not None else np.zeros(n, dtype=np.uint32)
+
+    def generate(self, stream: int | None = None):
+        self._ck(self.lib.pob_generate(self.h, ctypes.c_void_p(stream) if stream else None))
+
+    def constraint_check(self, stream: int | None = None):
+        self._ck(self.lib.pob_constraint_check(self.h, ctypes.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        self._ck(self.lib.pob_sync(self.h))
+
+    def results(self, with_check: bool = False) -> list[Result]:
+        n = self.n
+        status = np.zeros(n, dtype=np.uint32)
+        outs = np.zeros((n, 32), dtype=np.uint8)
+        chk = np.zeros(n, dtype=np.uint32)
+        bad = np.zeros(n, dtype=np.uint32)
+        self._ck(self.lib.pob_results(self.h, status.ctypes.data, outs.ctypes.data,
+                                      chk.ctypes.data if with_check else None, bad.ctypes.data if with_check else None))
+        res = []
+        for i in range(n):
+            st = int(self._forced[i]) or int(status[i])
+            out = None if st else [int.from_bytes(outs[i].tobytes(), "little")]
+            r = Result(st, out)
+            if with_check:
+                r.check_status = 0 if chk[i] == 0xFFFFFFFF else int(chk[i])
+                r.bad_wire = None if bad[i] == 0xFFFFFFFF else int(bad[i])
+            res.append(r)
+        return res
+
+    def calculate(self, inputs: dict | Sequence[dict], check: bool = False) -> list[Result]:
+        """input.json dict(s) -> per-witness Result; the whole batch runs on the GPU."""
+        if isinstance(inputs, dict):
+            inputs = [inputs]
+        self.upload(inputs)
+        self.generate()
+        if check:
+            self.constraint_check()
+        return self.results(with_check=check)
+
+    def witness_payload(self, idx: int = 0) -> np.ndarray:
+        """canonical 32-byte LE values of witness `idx` (the .wtns section 2 payload) as a uint8 array"""
+        out = np.empty(32 * self.nwitness, dtype=np.uint8)
+        self._ck(self.lib.pob_emit_witness(self.h, idx, out.ctypes.data, out.nbytes))
+        return out
+
+    def write_wtns(self, idx: int, path: str):
+        self._ck(self.lib.pob_write_wtns(self.h, idx, os.fsencode(path)))
+
+    def time_kernel(self, which: int, iters: int = 5, stream: int | None = None) -> float:
+        ms = ctypes.c_float()
+        self._ck(self.lib.pob_time_kernel(self.h, which, iters, ctypes.c_void_p(stream) if stream else None, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def results_device_ptrs(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self._ck(self.lib.pob_results_device(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+
+def wtns_header(nwitness: int) -> bytes:
+    """iden3 .wtns preamble; pob_write_wtns writes the same bytes natively."""
+    return (b"wtns" + (2).to_bytes(4, "little") + (2).to_bytes(4, "little") + (1).to_bytes(4, "little") + (40).to_bytes(8, "little")
+            + (32).to_bytes(4, "little") + P.to_bytes(32, "little") + nwitness.to_bytes(4, "little")
+            + (2).to_bytes(4, "little") + (32 * nwitness).to_bytes(8, "little"))
+
+
+def calculate_witness(main: str, input_json: str | dict, wtns_path: str | None = None, device: int = 0) -> Result:
+    """`./<circuit> input.json witness.wtns` (reference Makefile:4-5) as a function."""
+    inp = input_json
+    if isinstance(input_json, (str, os.PathLike)):
+        with open(input_json) as f:
+            inp = json.load(f)
+    calc = WitnessCalculator(main, max_batch=1, device=device)
+    try:
+        r = calc.calculate(inp)[0]
+        if r.ok and wtns_path:
+            calc.write_wtns(0, wtns_path)
+        return r
+    finally:
+        calc.close()
