@@ -87,6 +87,10 @@ int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_
 
 /* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */
 void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]);
+/* Input producer's proof-of-work (reference tests/main.py:47-56): first key >= start_key (256-bit big-endian counter)
+ * with keccak256(key | postfix)[0:zero_bytes] == 0; returns the number of increments or -1.                      */
+int64_t pob_pow_search(const uint8_t start_key[32], const uint8_t* postfix, uint32_t postfix_len, uint32_t zero_bytes,
+                       uint64_t max_tries, uint8_t out_key[32]);
 
 #ifdef __cplusplus
 }

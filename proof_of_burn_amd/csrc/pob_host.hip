@@ -438,4 +438,23 @@ void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]) {
     memcpy(out, st, 32);
 }
 
+// Proof-of-work search of the input producer (reference tests/main.py:47-56): smallest key >= start (big-endian 256-bit
+// counter) such that keccak256(key | postfix) starts with `zero_bytes` zero bytes.  Host helper; returns tries or -1.
+int64_t pob_pow_search(const uint8_t start_key[32], const uint8_t* postfix, uint32_t postfix_len, uint32_t zero_bytes, uint64_t max_tries, uint8_t out_key[32]) {
+    if (postfix_len > 100 || zero_bytes > 8) return -1;
+    uint8_t msg[136];
+    memcpy(msg, start_key, 32); memcpy(msg + 32, postfix, postfix_len);
+    const uint32_t len = 32 + postfix_len;
+    for (uint64_t t = 0; t < max_tries; t++) {
+        uint8_t blk[136]; memset(blk, 0, 136); memcpy(blk, msg, len); blk[len] ^= 0x01; blk[135] ^= 0x80;
+        uint64_t st[25]; memset(st, 0, sizeof st);
+        for (int i = 0; i < 17; i++) { uint64_t v; memcpy(&v, blk + 8 * i, 8); st[i] = v; }
+        keccak_f_host(st);
+        const uint64_t mask = zero_bytes == 8 ? ~0ULL : ((1ULL << (8 * zero_bytes)) - 1);
+        if ((st[0] & mask) == 0) { memcpy(out_key, msg, 32); return (int64_t)t; }
+        for (int i = 31; i >= 0; i--) if (++msg[i]) break;      // big-endian increment
+    }
+    return -1;
+}
+
 }  // extern "C"
