@@ -1,12 +1,17 @@
 // Top-level circuits (ProofOfBurn, Spend) and the Keccak wrapper, cut into UNITS.
 //
-// A unit = a run of consecutive sub-components of one template that one wavefront (64 witnesses)
-// executes start to finish; its UnitDesc carries the O0 cursor where its first wire lives.  The same
-// `unit_run<P>` body serves the host planner (P = CountP: advances the cursor, fills the descriptors),
-// the generator (GenP), the constraint evaluator (CheckP) and the .wtns emitter (EmitP).
-// Units of one STAGE are independent; a unit only reads wires written in earlier stages (or by itself).
-// Keccak sponges run between G stages on the bit-sliced kernels (keccak_kernels.hpp).
+// A unit = a piece of the component tree that one wavefront (64 witnesses, lane = witness) executes start to finish;
+// its UnitDesc carries the O0 cursor where its first wire lives.  The same `unit_run<P>` body serves the host planner
+// (P = CountP), the generator (GenP), the constraint evaluator (CheckP) and the .wtns emitter (EmitP).  Units of one STAGE are
+// independent; a unit only reads wires written in earlier stages (or by itself).  Keccak sponges run between G stages on
+// the bit-sliced kernels (keccak_kernels.hpp).
+//
+// Large templates are cut into RANGE units (byte ranges of KeccakBytes/AssertByteString, selector ranges, ShiftLeft rows,
+// SubstringCheck position ranges) so that a stage consists of thousands of short wavefronts instead of a few long ones.
+// Range units jump to their wires with cursor arithmetic (fixed footprint per array element); the host planner validates
+// every such jump against the monolithic template walked by CountP (`expect_cursor`), so the wire order keeps ONE definition.
 #pragma once
+#include <string.h>
 #include "gadgets.hpp"
 #include "poseidon_consts.h"
 
@@ -17,13 +22,21 @@
 
 enum UnitKind : uint32_t {
     U_POB_INPUT = 1, U_POB_RANGE, U_POB_LAYER_ASSERT, U_POB_HDR_ASSERT, U_POB_POSEIDONS, U_BAH_PRE, U_BAH_POST,
-    U_KB_PRE, U_KB_SELROW, U_KB_POST, U_POB_N2B, U_PC_PRE, U_PC_POST, U_POB_LASTLAYER, U_POB_LASTLEN, U_POB_LEAF,
-    U_POB_LAYER_POST, U_POB_LASTLEAF, U_POB_RLPLEAF, U_POW_PRE, U_POW_POST, U_POB_FINAL,
-    U_SP_INPUT, U_SP_HEAD, U_SP_FINAL
+    U_KB_HEAD, U_KB_RANGE, U_KB_SELROW, U_KB_POST, U_POB_N2B, U_PC_PRE, U_PC_POST, U_POB_LASTLAYER, U_POB_LASTLAYER_RANGE,
+    U_POB_LASTLEN, U_POB_LEAF, U_POB_LAYER_POST, U_SC_M, U_SC_RANGE, U_SC_SUMS, U_POB_LASTLEAF,
+    U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE,
+    U_SP_INPUT, U_SP_HEAD
 };
 
 struct PobParams { int L, NB, HB, minNib, amountBytes, powZero; Fr maxIntended, maxActual; };   // Montgomery
 struct SpendParams { int maxAmountBytes; };
+
+// footprints {wires, BIT, SM, FR} of fixed-size components
+HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k}; return r; }
+#define FP_ISEQ_S (Cur{6, 2, 4, 0})          // IsEqual [out | in[2]] + IsZero [out | in | inv]
+#define FP_ISEQ_F (Cur{6, 2, 0, 4})
+#define FP_ABITS8 (Cur{18, 16, 2, 0})        // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]
+#define FP_N2B8 (Cur{9, 8, 1, 0})
 
 // references to main's own wires (proof_of_burn.circom:41-72 in/out, :113-200 intermediates)
 struct PobMain {
@@ -41,32 +54,49 @@ struct SpendMain {   // spend.circom:33-38, :43-49
     FrRef commitment, burnKey, balance, withdrawnBalance, extraCommitment, coin, remainingCoin;
     SmRef coinBytes, withdrawnBalanceBytes, remainingCoinBytes, extraCommitmentBytes;
 };
-// KeccakBytes own wires + the Keccak/Final/SelectorArray2D wires its G units touch
+// KeccakBytes own wires, Pad's own wires, and the Keccak/Final/SelectorArray2D wires its G units touch
 struct KBRefs {
     SmRef out, in, inLen, padded, numBlocks; BitRef inBitsArray, inBits, inBlocks, outBits, outBytes;
+    SmRef pad_o, pad_nb, pad_in, pad_il, pad_dv, pad_rm; BitRef pad_flt, pad_isEq, pad_isLast;
+    Cur c_loop;                       // first IsEqual of Pad's isEq loop; then m isLast IsEquals, m Num2Bits(8), Flatten(m,8)
     BitRef k_out, k_in; SmRef k_blocks; BitRef k_finalState, f_out, f_in; SmRef f_blocks; BitRef f_s;
     uint32_t abs_w, abs_b;
     BitRef sel_out, sel_arrays; SmRef sel_select; BitRef sel_T;
     uint32_t mb, index;
 };
+// SubstringCheck instance (substring_check.circom:24-100)
+struct ScRefs {
+    BitRef out; SmRef mi, ml, si; FrRef num, M; BitRef ex, isl, alw; SmRef sums; BitRef dne;
+    Cur c_abs_sub, c_abs_main, c_after_abs, c_loop, c_tail;
+    SmRef abs_main_in;
+};
+// RlpMerklePatriciaTrieLeaf(32, amountBytes) of proof_of_burn.circom:198 and the nested templates whose wires are split over units
+struct RlRefs {
+    SmRef o, ol, in, inl; FrRef bal; SmRef key, keyLen, acc, accLen, pk, pkLen, val, valLen;      // own (:102-189)
+    SmRef t_o, t_ol, t_in, t_il, t_dv, t_rm, t_shf, t_on, t_tmp;                                     // TruncatedAddressHash own (:50-90)
+    SmRef s_o, s_in, s_cn; BitRef s_isEq; SmRef s_temp;                                              // ShiftLeft(64) own (shift.circom:17-37)
+    Cur c_sl_iseq, c_mux, c_age, c_acc, c_concat;
+};
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
-
 struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; };
 
-// everything a unit body needs besides the policy; lives in device memory, read-only
+#define MAX_KB 72
+#define MAX_SC 64
+// everything a unit body needs besides the policy; lives in device memory, read-only on the device
 struct CircuitLayout {
     int circuit;                  // 0 = ProofOfBurn, 1 = Spend
     PobParams pob; SpendParams spend;
     PobMain pm; SpendMain sm;
     Fr prefix[3];                 // POSEIDON_PREFIX + 0/1/2 (constants.circom:3-14), Montgomery
-    // unit-structured sub-templates (refs to their own wires)
     struct { SmRef nibbles; FrRef in; SmRef addressBytes, block, hash; uint32_t kb; } bah;
     struct { FrRef out; SmRef in, flat, block, hash, reduced; uint32_t kb; int N, nb; } pc;
     struct { FrRef in; SmRef mzb, keyBytes, raBytes, becBytes, eip, hin, block, keccak; BitRef sbz; uint32_t kb; } pw;
-    uint32_t kb_hdr, kb_layer0;   // indices into kbs[]
-    uint32_t nkb;
+    struct { SmRef out, arr, sel, T; Cur c_sel0; } ll;                   // SelectorArray1D(L, 136*NB) of :142
+    RlRefs rl;
+    uint32_t kb_hdr, kb_layer0, nkb, nsc;
+    KBRefs kbs[MAX_KB];
+    ScRefs scs[MAX_SC];
 };
-#define MAX_KB 24
 
 HD PosOff pos_off(int t) {
     PosOff k;
@@ -76,58 +106,66 @@ HD PosOff pos_off(int t) {
     return k;
 }
 
-// ---------------------------------------------------------------------------- keccak.circom: Pad / KeccakBytes
-// Pad(mb, 136) :412-446  [out[m], numBlocks | in[m], inLen | div, rem, filter[m+1], isEq[m], isLast[m]]
-// || Divide(16)(inLen, 136), AssertLessEqThan(16)(numBlocks, mb), IsEqual([i, inLen]) x m, IsEqual([i, numBlocks*136-1]) x m
-template <class P> GD SmRef gPad(P& p, int mb, SmRef src, S inLen, S& numBlocks) {
-    const int m = 136 * mb;
-    SmRef o = p.sms(m), nbr = p.sms(1), in = p.sms(m), il = p.sms(1), dv = p.sms(1), rm = p.sms(1);
-    BitRef flt = p.bits(m + 1), isEq = p.bits(m), isLast = p.bits(m);
-    for (int i = 0; i < m; i++) p.put(in + i, p.get(src + i));
-    inLen = p.put(il, inLen);
-    S q, r;
-    gDivide(p, 16, inLen, (S)136, q, r);
-    q = p.put(dv, q); p.put(rm, r);
-    S nb = p.put(nbr, q + 1);
-    gAssertLessEqThanS(p, 16, nb, (S)mb);
-    B f = p.put(flt, ~(B)0);
-    for (int i = 0; i < m; i++) {
-        B e = p.put(isEq + i, gIsEqualS(p, (S)i, inLen));
-        f = p.put(flt + i + 1, f & ~e);
+// ---------------------------------------------------------------------------- AssertByteString(N) in ranges (assert.circom:26-31)
+// own in[N] is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8
+template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint32_t lo, uint32_t hi) {
+    for (uint32_t i = lo; i < hi; i++) {
+        p.cur = cur_add(c0, FP_ABITS8, i);
+        gAssertBitsS(p, 8, p.put(own_in + i, p.get(src + i)));
     }
-    for (int i = 0; i < m; i++) {
-        B l = p.put(isLast + i, gIsEqualS(p, (S)i, (S)(nb * 136 - 1)));
-        S v = (p.bit(p.get(flt + i + 1)) ? p.get(in + i) : 0) + (S)p.bit(p.get(isEq + i)) + (p.bit(l) ? 0x80 : 0);
-        p.put(o + i, v);
-    }
-    numBlocks = nb;
-    return o;
 }
-// KeccakBytes(mb) :454-489, part before the sponge:
+
+// ---------------------------------------------------------------------------- keccak.circom: Pad / KeccakBytes
+// KeccakBytes(mb) :454-489 up to Pad's loops:
 // [out[32] | in[m], inLen | padded[m], numBlocks, inBitsArray[m][8], inBits[8m], inBlocks[mb][17][64], outBits[256], outBytes[32][8]]
-// || AssertLessThan(16)(inLen, m), Pad, Num2Bits(8) x m, Flatten(m,8), [Keccak(mb)], ...
-template <class P> GD void kb_pre(P& p, int mb, SmRef src, S inLen, KBRefs& r) {
-    const int m = 136 * mb;
+// || AssertLessThan(16)(inLen, m), Pad(mb,136) :412-446 [out[m], numBlocks | in[m], inLen | div, rem, filter[m+1], isEq[m], isLast[m]]
+//    || Divide(16)(inLen,136), AssertLessEqThan(16)(numBlocks, mb), IsEqual([i,inLen]) x m, IsEqual([i,numBlocks*136-1]) x m
+// || Num2Bits(8) x m, Flatten(m,8), Keccak(mb), Reshape(32,8), Bits2Num(8) x 32
+template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
+    const uint32_t m = 136 * mb;
     r.mb = mb;
     r.out = p.sms(32); r.in = p.sms(m); r.inLen = p.sms(1); r.padded = p.sms(m); r.numBlocks = p.sms(1);
     r.inBitsArray = p.bits(8 * m); r.inBits = p.bits(8 * m); r.inBlocks = p.bits(8 * m); r.outBits = p.bits(256); r.outBytes = p.bits(256);
-    for (int i = 0; i < m; i++) p.put(r.in + i, p.get(src + i));
     inLen = p.put(r.inLen, inLen);
     gAssertLessThanS(p, 16, inLen, (S)m);
-    S nb;
-    SmRef po = gPad(p, mb, r.in, inLen, nb);
+    r.pad_o = p.sms(m); r.pad_nb = p.sms(1); r.pad_in = p.sms(m); r.pad_il = p.sms(1); r.pad_dv = p.sms(1); r.pad_rm = p.sms(1);
+    r.pad_flt = p.bits(m + 1); r.pad_isEq = p.bits(m); r.pad_isLast = p.bits(m);
+    inLen = p.put(r.pad_il, inLen);
+    S q, rem;
+    gDivide(p, 16, inLen, (S)136, q, rem);
+    q = p.put(r.pad_dv, q); p.put(r.pad_rm, rem);
+    S nb = p.put(r.pad_nb, q + 1);
+    gAssertLessEqThanS(p, 16, nb, (S)mb);
     p.put(r.numBlocks, nb);
-    for (int i = 0; i < m; i++) {
-        BitRef b = gNum2BitsS(p, 8, p.put(r.padded + i, p.get(po + i)));
-        for (int k = 0; k < 8; k++) p.put(r.inBitsArray + (8 * i + k), p.get(b + k));
-    }
-    BitRef f = gFlattenB(p, 8 * m, r.inBitsArray);
-    for (int j = 0; j < 8 * m; j++) p.put(r.inBlocks + j, p.put(r.inBits + j, p.get(f + j)));
+    p.put(r.pad_flt, ~(B)0);
+    r.c_loop = p.cur;
+    p.cur = cur_add(cur_add(cur_add(p.cur, FP_ISEQ_S, 2 * m), FP_N2B8, m), Cur{16u * m, 16u * m, 0, 0}, 1);   // -> Keccak(mb)
 }
-template <class P> GD void kb_pre_at(P& p, int mb, SmRef src, S inLen, KBRefs* kbs, uint32_t idx) {
-    KBRefs r = kbs[idx];
-    kb_pre(p, mb, src, inLen, r);
-    if (P::is_count) kbs[idx] = r;      // only the host planner records the references
+template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t lo, uint32_t hi) {
+    const uint32_t m = 136 * r.mb;
+    const S inLen = p.get(r.inLen), nb = p.get(r.numBlocks);
+    const Cur cF = cur_add(cur_add(r.c_loop, FP_ISEQ_S, 2 * m), FP_N2B8, m);      // Flatten(m,8): [out[8m] | in[8m]]
+    const BitRef flat_o = {cF.w, cF.b}, flat_i = {cF.w + 8 * m, cF.b + 8 * m};
+    // filter[i] = prod_{j<i}(1 - isEq[j]) = [inLen >= i] (unsigned: an out-of-range inLen never hits); the evaluator re-reads it
+    B f = P::is_gen ? p.ballot((uint32_t)inLen >= lo) : p.get(r.pad_flt + lo);
+    for (uint32_t i = lo; i < hi; i++) {
+        S v = p.put(r.pad_in + i, p.put(r.in + i, p.get(src + i)));
+        p.cur = cur_add(r.c_loop, FP_ISEQ_S, i);
+        B e = p.put(r.pad_isEq + i, gIsEqualS(p, (S)i, inLen));
+        f = p.put(r.pad_flt + i + 1, f & ~e);
+        p.cur = cur_add(r.c_loop, FP_ISEQ_S, m + i);
+        B l = p.put(r.pad_isLast + i, gIsEqualS(p, (S)i, (S)(nb * 136 - 1)));
+        S pv = p.put(r.padded + i, p.put(r.pad_o + i, (p.bit(f) ? v : 0) + (S)p.bit(e) + (p.bit(l) ? 0x80 : 0)));
+        p.cur = cur_add(cur_add(r.c_loop, FP_ISEQ_S, 2 * m), FP_N2B8, i);
+        B bits[8];
+        gNum2Bits8(p, pv, bits);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t j = 8 * i + k;
+            B b = p.put(r.inBitsArray + j, bits[k]);
+            b = p.put(flat_i + j, b); b = p.put(flat_o + j, b); b = p.put(r.inBits + j, b); p.put(r.inBlocks + j, b);
+        }
+    }
 }
 // Keccak(n) :374-385 / Final(n) :330-349 own wires + the n Absorb blocks (K kernels) + SelectorArray2D own wires.
 template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
@@ -138,13 +176,13 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
     p.skip_bits(n * ABSORB_WIRES);
     r.sel_out = p.bits(1600); r.sel_arrays = p.bits((n + 1) * 1600); r.sel_select = p.sms(1); r.sel_T = p.bits(1600 * (n + 1));
 }
-// one row (64 selectors) of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs
-template <class P> GD void kb_selrow(P& p, const KBRefs& r, int row) {
-    const int n1 = r.mb + 1;
+// selectors [j0, j1) of row `row` of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs
+template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
+    const uint32_t n1 = r.mb + 1;
     S blocks = p.get(r.numBlocks);
-    for (int j = 0; j < 64; j++) {
+    for (uint32_t j = j0; j < j1; j++) {
         const uint32_t idx = row * 64 + j;
-        for (int k = 0; k < n1; k++) p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), p.get(r.f_s + (k * 1600 + idx))));
+        for (uint32_t k = 0; k < n1; k++) p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), p.get(r.f_s + (k * 1600 + idx))));
         B o = gSelectorB(p, n1, r.sel_T + idx * n1, blocks);
         o = p.put(r.sel_out + idx, o);
         o = p.put(r.f_out + idx, o);
@@ -152,43 +190,42 @@ template <class P> GD void kb_selrow(P& p, const KBRefs& r, int row) {
         if (idx < 256) p.put(r.k_out + idx, o);
     }
 }
-// part after the sponge: Reshape(32,8), Bits2Num(8) x 32 and the copy into the parent's array
+// part after the sponge: Keccak/Final/selector `blocks` inputs, Reshape(32,8) [out | in], Bits2Num(8) x 32 [out | in[8]] and the
+// copy into the parent's array.  Values are threaded through registers (no read-back of just-written wires).
 template <class P> GD void kb_post(P& p, const KBRefs& r, SmRef dst, bool has_dst) {
     const int n1 = r.mb + 1;
     S nb = p.get(r.numBlocks);
     p.put(r.k_blocks, nb); p.put(r.f_blocks, nb); p.put(r.sel_select, nb);
-    for (int j = 0; j < 256; j++) {
-        B v;
-        if (P::is_gen) { v = 0; for (int k = 0; k < n1; k++) v |= p.ballot(nb == k) & p.get(r.f_s + (k * 1600 + j)); }   // s[blocks] (:348)
-        else v = p.get(r.k_out + j);
-        p.put(r.outBits + j, v);
-    }
-    BitRef rs = gFlattenB(p, 256, r.outBits);
-    for (int j = 0; j < 256; j++) p.put(r.outBytes + j, p.get(rs + j));
+    BitRef rs_o = p.bits(256), rs_i = p.bits(256);
     for (int i = 0; i < 32; i++) {
-        S by = p.put(r.out + i, gBits2Num8(p, r.outBytes + 8 * i));
+        SmRef b2n_o = p.sms(1); BitRef b2n_i = p.bits(8);
+        S by = 0;
+        for (int k = 0; k < 8; k++) {
+            const int j = 8 * i + k;
+            B v;
+            if (P::is_gen) { v = 0; for (int q = 0; q < n1; q++) v |= p.ballot(nb == q) & p.get(r.f_s + (q * 1600 + j)); }   // s[blocks] (:348)
+            else v = p.get(r.k_out + j);
+            v = p.put(r.outBits + j, v); v = p.put(rs_i + j, v); v = p.put(rs_o + j, v); v = p.put(r.outBytes + j, v); v = p.put(b2n_i + k, v);
+            by |= (S)p.bit(v) << k;
+        }
+        by = p.put(r.out + i, p.put(b2n_o, by));
         if (has_dst) p.put(dst + i, by);
     }
 }
 
 // ---------------------------------------------------------------------------- unit bodies
-template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout& L, KBRefs* kbs) {
+template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
     const PobMain& M = L.pm;
     const PobParams& prm = L.pob;
     const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
     p.cur = d.cur;
     switch (d.kind) {
-    case U_POB_INPUT: {   // main inputs from the packed batch buffer (FR inputs 0..5, SM inputs in declaration order)
-        p.put(M.burnKey, p.input_fr(0)); p.put(M.actualBalance, p.input_fr(1)); p.put(M.intendedBalance, p.input_fr(2));
-        p.put(M.revealAmount, p.input_fr(3)); p.put(M.burnExtraCommitment, p.input_fr(4)); p.put(M.proofExtraCommitment, p.input_fr(5));
-        uint32_t k = 0;
-        p.put(M.numLeafAddressNibbles, p.input_sm(k++));
-        for (int i = 0; i < prm.L * LB; i++) p.put(M.layers + i, p.input_sm(k++));
-        for (int i = 0; i < prm.L; i++) p.put(M.layerLens + i, p.input_sm(k++));
-        p.put(M.numLayers, p.input_sm(k++));
-        for (int i = 0; i < HBy; i++) p.put(M.blockHeader + i, p.input_sm(k++));
-        p.put(M.blockHeaderLen, p.input_sm(k++));
-        p.put(M.byteSecurityRelax, p.input_sm(k++));
+    case U_POB_INPUT: {   // main inputs from the packed batch buffer; a[0..1] = range of SM inputs (declaration order, contiguous SM ranks)
+        if (d.a[0] == 0) {
+            p.put(M.burnKey, p.input_fr(0)); p.put(M.actualBalance, p.input_fr(1)); p.put(M.intendedBalance, p.input_fr(2));
+            p.put(M.revealAmount, p.input_fr(3)); p.put(M.burnExtraCommitment, p.input_fr(4)); p.put(M.proofExtraCommitment, p.input_fr(5));
+        }
+        for (uint32_t k = d.a[0]; k < d.a[1]; k++) { SmRef r = {M.numLeafAddressNibbles.w + k, M.numLeafAddressNibbles.i + k}; p.put(r, p.input_sm(k)); }
     } break;
     case U_POB_RANGE: {   // proof_of_burn.circom:84-97
         const int AB8 = prm.amountBytes * 8;
@@ -202,15 +239,16 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
         gAssertBitsF(p, AB8, reveal);
         gAssertLessEqThanF(p, AB8, reveal, intended);
     } break;
-    case U_POB_LAYER_ASSERT: {   // :99-103
-        const int i = d.a[0];
-        gAssertLessThanS(p, 16, p.get(M.layerLens + i), (S)(LB * 8));
-        gAssertByteString(p, LB, M.layers + i * LB);
-    } break;
-    case U_POB_HDR_ASSERT: {     // :105-106, stateRoot copy :125-129
+    case U_POB_LAYER_ASSERT:     // :101 (the AssertByteString of :102 runs as U_ABS_RANGE units)
+        gAssertLessThanS(p, 16, p.get(M.layerLens + d.a[0]), (S)(LB * 8));
+        break;
+    case U_POB_HDR_ASSERT:       // :105, stateRoot copy :125-129
         gAssertLessThanS(p, 16, p.get(M.blockHeaderLen), (S)(HBy * 8));
-        gAssertByteString(p, HBy, M.blockHeader);
         for (int i = 0; i < 32; i++) p.put(M.stateRoot + i, p.get(M.blockHeader + 91 + i));
+        break;
+    case U_ABS_RANGE: {          // cur = first AssertBits(8) child; a = own_in (w,i), src (w,i), lo, hi
+        SmRef own = {d.a[0], d.a[1]}, src = {d.a[2], d.a[3]};
+        abs_range(p, d.cur, own, src, d.a[4], d.a[5]);
     } break;
     case U_POB_POSEIDONS: {      // :113, :116
         F bk = p.get(M.burnKey);
@@ -225,20 +263,31 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
         for (int i = 0; i < 20; i++) p.put(L.bah.addressBytes + i, p.get(ab + i));
         SmRef f = gFitS(p, 20, 136, L.bah.addressBytes);
         for (int i = 0; i < 136; i++) p.put(L.bah.block + i, p.get(f + i));
-        kb_pre_at(p, 1, L.bah.block, (S)20, kbs, L.bah.kb);
+        KBRefs r = L.kbs[L.bah.kb];
+        kb_head(p, 1, (S)20, r);
+        if (P::is_count) L.kbs[L.bah.kb] = r;
+        const Cur after = p.cur;
+        kb_range(p, r, L.bah.block, 0, 136);
+        p.cur = after;
     } break;
     case U_BAH_POST: {           // :82 Bytes2Nibbles(32) + main.addressHashNibbles (:119)
         SmRef nb = gBytes2Nibbles(p, 32, L.bah.hash);
         for (int i = 0; i < 64; i++) p.put(M.addressHashNibbles + i, p.put(L.bah.nibbles + i, p.get(nb + i)));
     } break;
-    case U_KB_PRE: {             // a[0] = kb index, a[1] = src SM ref (wire, idx), a[3] = len ref
-        SmRef src = {d.a[1], d.a[2]}, len = {d.a[3], d.a[4]};
-        kb_pre_at(p, kbs[d.a[0]].mb, src, p.get(len), kbs, d.a[0]);
+    case U_KB_HEAD: {            // a[0] = kb index, a[1..2] = inLen ref
+        SmRef len = {d.a[1], d.a[2]};
+        KBRefs r = L.kbs[d.a[0]];
+        kb_head(p, r.mb, p.get(len), r);
+        if (P::is_count) L.kbs[d.a[0]] = r;
     } break;
-    case U_KB_SELROW: kb_selrow(p, kbs[d.a[0]], d.a[1]); break;
+    case U_KB_RANGE: {           // a[0] = kb index, a[1..2] = src ref, a[3..4] = byte range
+        SmRef src = {d.a[1], d.a[2]};
+        kb_range(p, L.kbs[d.a[0]], src, d.a[3], d.a[4]);
+    } break;
+    case U_KB_SELROW: kb_selrow(p, L.kbs[d.a[0]], d.a[1], d.a[2], d.a[3]); break;
     case U_KB_POST: {
         SmRef dst = {d.a[1], d.a[2]};
-        kb_post(p, kbs[d.a[0]], dst, d.a[3] != 0);
+        kb_post(p, L.kbs[d.a[0]], dst, d.a[3] != 0);
     } break;
     case U_POB_N2B: {            // :132-136  Num2BigEndianBytes(32) of nullifier, remainingCoin, revealAmount, burnExtraCommitment, _proofExtraCommitment
         const int j = d.a[0];
@@ -260,7 +309,12 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
         for (int i = 0; i < 32 * N; i++) p.put(L.pc.flat + i, p.get(f + i));
         f = gFitS(p, 32 * N, 136 * L.pc.nb, L.pc.flat);
         for (int i = 0; i < 136 * L.pc.nb; i++) p.put(L.pc.block + i, p.get(f + i));
-        kb_pre_at(p, L.pc.nb, L.pc.block, (S)(32 * N), kbs, L.pc.kb);
+        KBRefs r = L.kbs[L.pc.kb];
+        kb_head(p, L.pc.nb, (S)(32 * N), r);
+        if (P::is_count) L.kbs[L.pc.kb] = r;
+        const Cur after = p.cur;
+        kb_range(p, r, L.pc.block, 0, 136 * L.pc.nb);
+        p.cur = after;
     } break;
     case U_PC_POST: {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
         SmRef f = gFitS(p, 32, 31, L.pc.hash);
@@ -268,9 +322,19 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
         F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
         p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
     } break;
-    case U_POB_LASTLAYER: {      // :142-143
-        SmRef r = gSelectorArray1D(p, prm.L, LB, M.layers, p.get(M.numLayers) - 1);
-        for (int i = 0; i < LB; i++) p.put(M.lastLayer + i, p.get(r + i));
+    case U_POB_LASTLAYER:        // :142-143 SelectorArray1D(L, LB): the select input; selectors run as range units
+        p.put(L.ll.sel, p.get(M.numLayers) - 1);
+        break;
+    case U_POB_LASTLAYER_RANGE: {   // selectors [a0, a1) of SelectorArray1D (selector.circom:62-77); Selector(n) footprint {9n+3, 3n, 6n+3, 0}
+        const uint32_t n = prm.L, q = LB;
+        const Cur fp = {9 * n + 3, 3 * n, 6 * n + 3, 0};
+        S select = p.get(M.numLayers) - 1;
+        for (uint32_t j = d.a[0]; j < d.a[1]; j++) {
+            for (uint32_t i = 0; i < n; i++) p.put(L.ll.T + (j * n + i), p.put(L.ll.arr + (i * q + j), p.get(M.layers + (i * q + j))));
+            p.cur = cur_add(L.ll.c_sel0, fp, j);
+            S v = p.put(L.ll.out + j, gSelectorS(p, n, L.ll.T + j * n, select));
+            p.put(M.lastLayer + j, v);
+        }
     } break;
     case U_POB_LASTLEN: {        // :146, :150
         S nl = p.get(M.numLayers);
@@ -282,29 +346,181 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
         const int i = d.a[0];
         p.put(M.isLeaf + i, gLeafDetector(p, LB, M.layers + i * LB, p.get(M.layerLens + i)));
     } break;
-    case U_POB_LAYER_POST: {     // :166-180  Fit(32,31), SubstringCheck, (1-sc)*exists === 0
+    case U_POB_LAYER_POST: {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
+                                 // AssertLessEqThan x2, LittleEndianBytes2Num(sl); AssertByteString(mm) runs as U_ABS_RANGE units
         const int i = d.a[0];
         SmRef f = gFitS(p, 32, 31, M.layerKeccaks + 32 * i);
         for (int k = 0; k < 31; k++) p.put(M.reducedLayerKeccaks + (31 * i + k), p.get(f + k));
         if (i > 0) {
-            B sc = p.put(M.substringCheckers + (i - 1), gSubstringCheck(p, LB, 31, M.layers + (i - 1) * LB, p.get(M.layerLens + (i - 1)), M.reducedLayerKeccaks + 31 * i));
-            p.require(sc | ~p.get(M.layerExists + i), FAILCODE(T_POB, 179));
+            ScRefs sc = L.scs[i];
+            const int mm = LB, sl = 31, kk = mm - sl + 1;
+            sc.out = p.bits(1); sc.mi = p.sms(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
+            sc.num = p.frs(1); sc.M = p.frs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
+            for (int k = 0; k < mm; k++) p.put(sc.mi + k, p.get(M.layers + ((i - 1) * LB + k)));
+            S mainLen = p.put(sc.ml, p.get(M.layerLens + (i - 1)));
+            for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
+            sc.c_abs_sub = p.cur;
+            gAssertByteString(p, sl, sc.si);
+            sc.abs_main_in = p.sms(mm);
+            sc.c_abs_main = p.cur;
+            p.cur = cur_add(p.cur, FP_ABITS8, mm);
+            sc.c_after_abs = p.cur;
+            gAssertLessEqThanS(p, 16, mainLen, (S)mm);
+            gAssertLessEqThanS(p, 16, (S)sl, mainLen);
+            p.put(sc.num, gLittleEndianBytes2NumF(p, sl, sc.si));
+            sc.c_loop = p.cur;
+            p.cur = cur_add(cur_add(p.cur, FP_ISEQ_S, kk), FP_ISEQ_F, kk);
+            sc.c_tail = p.cur;
+            p.cur = cur_add(p.cur, Cur{3, 1, 2, 0}, 1);            // the final IsZero
+            if (P::is_count) L.scs[i] = sc;
         }
+    } break;
+    case U_SC_M: {               // M[i+1] <== mainInput[i]*256^i + M[i]  (substring_check.circom:45-49); reads the source bytes
+        const ScRefs& sc = L.scs[d.a[0]];
+        const F c256 = fr_from_i64(256);
+        F pw = fr_one_mont(), acc = p.put(sc.M, fr_zero());
+        for (int k = 0; k < LB; k++) {
+            acc = p.put(sc.M + k + 1, fr_add(fr_mul(fr_from_i64(p.get(M.layers + ((d.a[0] - 1) * LB + k))), pw), acc));
+            pw = fr_mul(pw, c256);
+        }
+    } break;
+    case U_SC_RANGE: {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
+        const ScRefs& sc = L.scs[d.a[0]];
+        const uint32_t lo = d.a[1], hi = d.a[2], sl = 31;
+        const S mainLen = p.get(sc.ml);
+        const F subNum = p.get(sc.num), c256 = fr_from_i64(256);
+        F pw0 = fr_one_mont();
+        { F base = c256; for (uint32_t e = lo; e; e >>= 1) { if (e & 1) pw0 = fr_mul(pw0, base); base = fr_sqr(base); } }   // 256^lo
+        // FR wires of position i's IsEqual(exists): 0 = in[0], 1 = in[1], 2 = isz.in, 3 = isz.inv
+        auto fref = [&](uint32_t i, uint32_t which) {
+            Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i + 1), FP_ISEQ_F, i);
+            FrRef r = {c.w + 1 + which + (which >= 2 ? 1u : 0u), c.f + which};
+            return r;
+        };
+        if (P::is_gen) {         // Montgomery batch inversion over this range, scratch = the witness' own isz.in / isz.inv slots
+            F pw = pw0, run = fr_one_mont();
+            for (uint32_t i = lo; i < hi; i++) {
+                F dd = fr_sub(fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), fr_mul(subNum, pw));
+                p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
+                if (!fr_is_zero(dd)) run = fr_mul(run, dd);
+                pw = fr_mul(pw, c256);
+            }
+            F inv = fr_inv(run);
+            for (uint32_t i = hi; i-- > lo;) {
+                F dd = p.get(fref(i, 2)), pre = p.get(fref(i, 3));
+                const bool z = fr_is_zero(dd);
+                p.raw_put(fref(i, 3), z ? fr_zero() : fr_mul(inv, pre));
+                if (!z) inv = fr_mul(inv, dd);
+            }
+        }
+        // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
+        const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
+        B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
+        F pw = pw0;
+        for (uint32_t i = lo; i < hi; i++) {
+            p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
+            B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
+            allowed = p.put(sc.alw + i + 1, allowed & ~last);
+            p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, pw), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
+            pw = fr_mul(pw, c256);
+        }
+    } break;
+    case U_SC_SUMS: {            // sums[] (:94), doesNotExist, out (:98-99), substringCheckers[i-1] and the constraint of proof_of_burn.circom:179
+        const uint32_t i = d.a[0];
+        const ScRefs& sc = L.scs[i];
+        const uint32_t kk = LB - 31 + 1;
+        p.put(sc.alw, ~(B)0);
+        S sum = p.put(sc.sums, 0);
+        for (uint32_t k = 0; k < kk; k++) sum = p.put(sc.sums + k + 1, sum + (S)p.bit(p.get(sc.alw + k + 1) & p.get(sc.ex + k)));
+        p.cur = sc.c_tail;
+        B none = p.put(sc.dne, gIsZeroS(p, sum));
+        B out = p.put(M.substringCheckers + (i - 1), p.put(sc.out, ~none));
+        p.require(out | ~p.get(M.layerExists + i), FAILCODE(T_POB, 179));
     } break;
     case U_POB_LASTLEAF:         // :187
         p.put(M.isLastLayerLeaf, gLeafDetector(p, LB, M.lastLayer, p.get(M.lastLayerLen)));
         break;
-    case U_POB_RLPLEAF: {        // :198-200
-        S ll;
-        SmRef r = gRlpMptLeaf(p, 32, prm.amountBytes, M.addressHashNibbles, p.get(M.numLeafAddressNibbles), p.get(M.actualBalance), ll);
-        for (int i = 0; i < 139; i++) p.put(M.leaf + i, p.get(r + i));
-        p.put(M.leafLen, ll);
+    case U_RL_A: {               // RlpMerklePatriciaTrieLeaf(32, AB) :102-189, part 1: own inputs, TruncatedAddressHash(32) :50-90 head
+                                 // (AssertLessEqThan(7), Divide(7)) and ShiftLeft(64) head (shift.circom:17-24)
+        RlRefs R = L.rl;
+        const int ab = 32, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
+        R.o = p.sms(maxOut); R.ol = p.sms(1); R.in = p.sms(2 * ab); R.inl = p.sms(1); R.bal = p.frs(1);
+        R.key = p.sms(maxKey); R.keyLen = p.sms(1); R.acc = p.sms(maxAcc); R.accLen = p.sms(1); R.pk = p.sms(maxPK); R.pkLen = p.sms(1); R.val = p.sms(maxVal); R.valLen = p.sms(1);
+        for (int i = 0; i < 2 * ab; i++) p.put(R.in + i, p.get(M.addressHashNibbles + i));
+        S nibLen = p.put(R.inl, p.get(M.numLeafAddressNibbles));
+        p.put(R.bal, p.get(M.actualBalance));
+        const int n2 = 2 * ab;
+        R.t_o = p.sms(ab + 1); R.t_ol = p.sms(1); R.t_in = p.sms(n2); R.t_il = p.sms(1); R.t_dv = p.sms(1); R.t_rm = p.sms(1); R.t_shf = p.sms(n2); R.t_on = p.sms(n2 + 2); R.t_tmp = p.sms(n2 - 1);
+        for (int i = 0; i < n2; i++) p.put(R.t_in + i, p.get(M.addressHashNibbles + i));
+        nibLen = p.put(R.t_il, nibLen);
+        for (int i = 0; i < n2 - 1; i++) p.put(R.t_tmp + i, 0);
+        gAssertLessEqThanS(p, 7, nibLen, (S)n2);
+        S q, r;
+        gDivide(p, 7, nibLen, (S)2, q, r);
+        p.put(R.t_dv, q); p.put(R.t_rm, r);
+        R.s_o = p.sms(n2); R.s_in = p.sms(n2); R.s_cn = p.sms(1); R.s_isEq = p.bits(n2 * n2); R.s_temp = p.sms(n2 * n2);
+        for (int i = 0; i < n2; i++) p.put(R.s_in + i, p.get(M.addressHashNibbles + i));
+        S count = p.put(R.s_cn, n2 - nibLen);
+        gAssertLessEqThanS(p, 16, count, (S)n2);
+        R.c_sl_iseq = p.cur;
+        p.cur = cur_add(p.cur, FP_ISEQ_S, n2 * n2);
+        R.c_mux = p.cur;
+        if (P::is_count) { Cur a = L.rl.c_age, b = L.rl.c_acc, c = L.rl.c_concat; L.rl = R; L.rl.c_age = a; L.rl.c_acc = b; L.rl.c_concat = c; }
+    } break;
+    case U_RL_SLROW: {           // rows [a0, a1) of ShiftLeft(64) (shift.circom:27-36): out[i] = sum_j in[j]*(i == j - count)
+        const RlRefs& R = L.rl;
+        const uint32_t n = 64;
+        const S count = (S)n - p.get(M.numLeafAddressNibbles);
+        for (uint32_t i = d.a[0]; i < d.a[1]; i++) {
+            S acc = 0;
+            p.cur = cur_add(R.c_sl_iseq, FP_ISEQ_S, i * n);
+            for (uint32_t j = 0; j < n; j++) {
+                B e = p.put(R.s_isEq + (i * n + j), gIsEqualS(p, (S)i, (S)((S)j - count)));
+                acc += p.put(R.s_temp + (i * n + j), p.bit(e) ? p.get(M.addressHashNibbles + j) : 0);
+            }
+            p.put(R.s_o + i, acc);
+        }
+    } break;
+    case U_RL_ACC: {             // RlpEmptyAccount(AB)(balance) (rlp/empty_account.circom:20-134) + copy into the leaf's own wires (:153-155)
+        const RlRefs& R = L.rl;
+        const int maxAcc = 4 + prm.amountBytes + 66;
+        S al;
+        SmRef r = gRlpEmptyAccount(p, prm.amountBytes, p.get(M.actualBalance), al);
+        for (int i = 0; i < maxAcc; i++) p.put(R.acc + i, p.get(r + i));
+        p.put(R.accLen, al);
+    } break;
+    case U_RL_B: {               // rest of TruncatedAddressHash (:62-90), AssertGreaterEqThan (:151), prefixes (:166-181), Concat (:183-188)
+        const RlRefs& R = L.rl;
+        const int ab = 32, n2 = 64, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
+        for (int i = 0; i < n2; i++) p.put(R.t_shf + i, p.get(R.s_o + i));
+        const S r = p.get(R.t_rm), q = p.get(R.t_dv);
+        p.put(R.t_on, 2 + r);
+        p.put(R.t_on + 1, r * p.get(R.t_shf));
+        const B rbit = p.ballot(r & 1);
+        p.cur = R.c_mux;
+        for (int i = 0; i < n2; i++) {
+            if (i < n2 - 1) p.put(R.t_on + i + 2, gMux1S(p, p.get(R.t_shf + i), p.get(R.t_shf + i + 1), rbit));
+            else p.put(R.t_on + i + 2, (1 - r) * p.get(R.t_shf + i));
+        }
+        SmRef by = gNibbles2Bytes(p, ab + 1, R.t_on);
+        for (int i = 0; i < ab + 1; i++) p.put(R.key + i, p.put(R.t_o + i, p.get(by + i)));
+        const S kl = p.put(R.keyLen, p.put(R.t_ol, 1 + q));
+        gAssertGreaterEqThanS(p, 16, kl, (S)2);
+        const S al = p.get(R.accLen);
+        p.put(R.val, 0xb8); p.put(R.val + 1, al);
+        for (int i = 0; i < maxAcc; i++) p.put(R.val + 2 + i, p.get(R.acc + i));
+        const S vl = p.put(R.valLen, 2 + al);
+        p.put(R.pk, 0xf8); p.put(R.pk + 1, (kl + 1) + vl); p.put(R.pk + 2, 0x80 + kl);
+        for (int i = 0; i < maxKey; i++) p.put(R.pk + 3 + i, p.get(R.key + i));
+        const S pl = p.put(R.pkLen, 3 + kl);
+        p.cur = R.c_concat;
+        S cl;
+        SmRef c = gConcat(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl);
+        for (int i = 0; i < maxOut; i++) p.put(M.leaf + i, p.put(R.o + i, p.get(c + i)));
+        p.put(M.leafLen, p.put(R.ol, cl));
     } break;
     case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
-        F bk, ra, bec;
-        if (L.circuit == 0) { bk = p.get(M.burnKey); ra = p.get(M.revealAmount); bec = p.get(M.burnExtraCommitment); }
-        else { bk = ra = bec = fr_zero(); }
-        bk = p.put(L.pw.in, bk); ra = p.put(L.pw.in + 1, ra); bec = p.put(L.pw.in + 2, bec);
+        F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
         p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
         SmRef r = gNum2BigEndianBytesF(p, 32, bk);
         for (int i = 0; i < 32; i++) p.put(L.pw.keyBytes + i, p.get(r + i));
@@ -322,7 +538,12 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
         }
         SmRef f = gFitS(p, 104, 136, L.pw.hin);
         for (int i = 0; i < 136; i++) p.put(L.pw.block + i, p.get(f + i));
-        kb_pre_at(p, 1, L.pw.block, (S)104, kbs, L.pw.kb);
+        KBRefs kr = L.kbs[L.pw.kb];
+        kb_head(p, 1, (S)104, kr);
+        if (P::is_count) L.kbs[L.pw.kb] = kr;
+        const Cur after = p.cur;
+        kb_range(p, kr, L.pw.block, 0, 136);
+        p.cur = after;
     } break;
     case U_POW_POST: {           // :73-79
         BitRef f = gFilter(p, 32, p.get(L.pw.mzb));
@@ -369,49 +590,80 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, const CircuitLayout
 }
 
 // ---------------------------------------------------------------------------- host planner
+#include <algorithm>
+#include <stdexcept>
+#include <string>
 #include <vector>
 struct Plan {
     CircuitLayout L;
     std::vector<UnitDesc> units;
     std::vector<SpongeDesc> sponges;
-    KBRefs kbs[MAX_KB];
     Cur total;            // = counts (total.w = nWitness)
     uint32_t nfr_in, nsm_in, max_stage;
     CountP p;
 
-    void unit(uint32_t kind, uint32_t stage, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0) {
-        UnitDesc d; d.kind = kind; d.stage = stage; d.cur = p.cur; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = 0;
+    static bool same(Cur a, Cur b) { return a.w == b.w && a.b == b.b && a.s == b.s && a.f == b.f; }
+    // the monolithic template (gadgets.hpp) walked by CountP must end where the split units say it ends
+    void expect_cursor(const char* what, Cur got, Cur want) {
+        if (!same(got, want)) throw std::runtime_error(std::string("layout planner: split units disagree with the monolithic template: ") + what);
+    }
+    void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0) {
+        UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5;
         units.push_back(d);
-        unit_run(p, d, L, kbs);            // CountP: advances p.cur over the unit's wires, fills kbs[] refs
         if (stage > max_stage) max_stage = stage;
     }
-    // KeccakBytes whose "pre" part already ran inside the current unit: sponge + selector rows + post
-    void keccak_tail(uint32_t kb, uint32_t pre_stage, SmRef dst, bool has_dst) {
-        KBRefs& r = kbs[kb];
+    void unit(uint32_t kind, uint32_t stage, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0) {
+        record(kind, stage, p.cur, a0, a1, a2, a3, a4);
+        const UnitDesc d = units.back();
+        unit_run(p, d, L);                 // CountP: advances p.cur over the unit's wires, fills the reference tables
+    }
+    // AssertByteString(N)(src) as range units; p.cur = start of the AssertByteString block
+    void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32) {
+        CountP chk; chk.cur = p.cur; gAssertByteString(chk, (int)N, src);
+        SmRef own = p.sms(N);
+        const Cur c0 = p.cur;
+        for (uint32_t lo = 0; lo < N; lo += chunk) record(U_ABS_RANGE, stage, c0, own.w, own.i, src.w, src.i, lo, std::min(lo + chunk, N));
+        p.cur = cur_add(c0, FP_ABITS8, N);
+        expect_cursor("AssertByteString", p.cur, chk.cur);
+    }
+    // sponge + selector rows + post of a KeccakBytes whose head/ranges are planned; p.cur = start of the Keccak(mb) block
+    void keccak_tail(uint32_t kb, uint32_t range_stage, SmRef dst, bool has_dst) {
+        KBRefs& r = L.kbs[kb];
         r.index = kb;
         kb_declare_keccak(p, r);
-        SpongeDesc s; s.n = r.mb; s.stage = pre_stage + 1; s.src_b = r.inBlocks.i; s.src_w = r.inBlocks.w;
+        SpongeDesc s; s.n = r.mb; s.stage = range_stage + 1; s.src_b = r.inBlocks.i; s.src_w = r.inBlocks.w;
         s.kin_b = r.k_in.i; s.kin_w = r.k_in.w; s.fin_b = r.f_in.i; s.fin_w = r.f_in.w; s.fs_b = r.f_s.i; s.fs_w = r.f_s.w; s.abs_b = r.abs_b; s.abs_w = r.abs_w;
         sponges.push_back(s);
-        for (uint32_t row = 0; row < 25; row++) unit(U_KB_SELROW, pre_stage + 2, kb, row);
-        unit(U_KB_POST, pre_stage + 2, kb, dst.w, dst.i, has_dst ? 1 : 0);
-        if (pre_stage + 1 > max_stage) max_stage = pre_stage + 1;
+        const uint32_t split = r.mb >= 8 ? 4 : 1;            // the selectors of a row are split when a selector is long
+        for (uint32_t row = 0; row < 25; row++) {
+            const Cur c0 = p.cur;
+            CountP q; q.cur = c0; kb_selrow(q, r, row, 0, 64);
+            const Cur fp = {(q.cur.w - c0.w) / 64, (q.cur.b - c0.b) / 64, (q.cur.s - c0.s) / 64, 0};
+            for (uint32_t k = 0; k < split; k++) record(U_KB_SELROW, range_stage + 2, cur_add(c0, fp, k * (64 / split)), kb, row, k * (64 / split), (k + 1) * (64 / split));
+            p.cur = q.cur;
+        }
+        unit(U_KB_POST, range_stage + 2, kb, dst.w, dst.i, has_dst ? 1 : 0);
+        if (range_stage + 1 > max_stage) max_stage = range_stage + 1;
     }
-    void keccak_bytes(uint32_t kb, int mb, uint32_t pre_stage, SmRef src, SmRef len, SmRef dst) {
-        kbs[kb].mb = mb;
-        unit(U_KB_PRE, pre_stage, kb, src.w, src.i, len.w, len.i);
-        keccak_tail(kb, pre_stage, dst, true);
+    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst) {
+        L.kbs[kb].mb = mb;
+        const Cur start = p.cur;
+        unit(U_KB_HEAD, stage, kb, len.w, len.i);
+        const uint32_t m = 136 * mb;
+        for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage + 1, start, kb, src.w, src.i, lo, std::min(lo + 16, m));
+        keccak_tail(kb, stage + 1, dst, true);
     }
     void public_commitment(int N, uint32_t pre_stage) {   // public_commitment.circom:18-42
         L.pc.N = N; L.pc.nb = N * 32 / 136 + ((N * 32) % 136 != 0);
         L.pc.out = p.frs(1); L.pc.in = p.sms(32 * N); L.pc.flat = p.sms(32 * N); L.pc.block = p.sms(136 * L.pc.nb); L.pc.hash = p.sms(32); L.pc.reduced = p.sms(31);
-        L.pc.kb = L.nkb++; kbs[L.pc.kb].mb = L.pc.nb;
+        L.pc.kb = L.nkb++; L.kbs[L.pc.kb].mb = L.pc.nb;
         unit(U_PC_PRE, pre_stage);
         keccak_tail(L.pc.kb, pre_stage, L.pc.hash, true);
         unit(U_PC_POST, pre_stage + 3);
     }
 
     void plan_pob(const PobParams& prm) {
+        memset(&L, 0, sizeof L);
         L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
         PobMain& M = L.pm;
         const int Ln = prm.L, LB = 136 * prm.NB, HBy = 136 * prm.HB;
@@ -427,44 +679,90 @@ struct Plan {
         M.isLastLayerLeaf = p.bits(1); M.leaf = p.sms(139); M.leafLen = p.sms(1);
         nfr_in = 6; nsm_in = 1 + Ln * LB + Ln + 1 + HBy + 2;
 
-        unit(U_POB_INPUT, 0);
+        // stages: 0 inputs | 1 heads, byte asserts, selectors, leaf detectors | 2 KeccakBytes byte ranges, embedded pre parts
+        //         | 3 sponges A | 4 output selector rows, posts | 5 consumers | 6 sponge B, ... | 10 final ===
+        for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
         unit(U_POB_RANGE, 1);
-        for (int i = 0; i < Ln; i++) unit(U_POB_LAYER_ASSERT, 1, i);
-        unit(U_POB_HDR_ASSERT, 1);
+        for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, 1, i); abs_units(1, LB, M.layers + i * LB); }
+        unit(U_POB_HDR_ASSERT, 1); abs_units(1, HBy, M.blockHeader);
         unit(U_POB_POSEIDONS, 1);
         {   // BurnAddressHash :119
             L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
             L.bah.kb = L.nkb++;
-            unit(U_BAH_PRE, 1);
-            keccak_tail(L.bah.kb, 1, L.bah.hash, true);
-            unit(U_BAH_POST, 4);
+            unit(U_BAH_PRE, 2);
+            keccak_tail(L.bah.kb, 2, L.bah.hash, true);
+            unit(U_BAH_POST, 5);
         }
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 1, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122
-        for (int j = 0; j < 5; j++) unit(U_POB_N2B, 3, j);                                      // :132-136
-        public_commitment(6, 4);                                                                // :137
-        unit(U_POB_LASTLAYER, 1);
+        for (int j = 0; j < 5; j++) unit(U_POB_N2B, 2, j);                                      // :132-136
+        public_commitment(6, 5);                                                                // :137  (pre 5, sponge 6, rows/post 7, commitment 8)
+        {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
+            CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
+            L.ll.out = p.sms(LB); L.ll.arr = p.sms(Ln * LB); L.ll.sel = p.sms(1); L.ll.T = p.sms(LB * Ln);
+            unit(U_POB_LASTLAYER, 1);
+            L.ll.c_sel0 = p.cur;
+            const Cur fp = {9u * Ln + 3, 3u * Ln, 6u * Ln + 3, 0};
+            for (uint32_t j = 0; j < (uint32_t)LB; j += 16) record(U_POB_LASTLAYER_RANGE, 1, p.cur, j, std::min<uint32_t>(j + 16, LB));
+            p.cur = cur_add(p.cur, fp, LB);
+            expect_cursor("SelectorArray1D", p.cur, chk.cur);
+        }
         unit(U_POB_LASTLEN, 1);
         L.kb_layer0 = L.nkb; L.nkb += Ln;
+        L.nsc = Ln;
         for (int i = 0; i < Ln; i++) {                                                          // :157-181
             unit(U_POB_LEAF, 1, i);
             keccak_bytes(L.kb_layer0 + i, prm.NB, 1, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i);
-            unit(U_POB_LAYER_POST, 4, i);
+            const Cur start = p.cur;
+            unit(U_POB_LAYER_POST, 5, i);
+            if (i > 0) {
+                const ScRefs sc = L.scs[i];
+                CountP chk; chk.cur = start; { gFitS(chk, 32, 31, M.layerKeccaks); gSubstringCheck(chk, LB, 31, M.layers, 0, M.reducedLayerKeccaks); }
+                expect_cursor("SubstringCheck", p.cur, chk.cur);
+                const SmRef src = M.layers + (i - 1) * LB;
+                for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32)
+                    record(U_ABS_RANGE, 5, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
+                record(U_SC_M, 5, start, i);
+                const uint32_t kk = LB - 31 + 1;
+                for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
+                record(U_SC_SUMS, 7, sc.c_tail, i);
+            }
         }
-        unit(U_POB_LASTLEAF, 3);                                                                // :187
-        unit(U_POB_RLPLEAF, 5);                                                                 // :198
+        unit(U_POB_LASTLEAF, 2);                                                                // :187 (lastLayer is written in stage 1)
+        {   // RlpMerklePatriciaTrieLeaf :198  (needs addressHashNibbles, written in stage 5)
+            const Cur start = p.cur;
+            CountP chk; chk.cur = start; { S ll; gRlpMptLeaf(chk, 32, prm.amountBytes, M.addressHashNibbles, 0, fr_zero(), ll); }
+            unit(U_RL_A, 6);
+            RlRefs& R = L.rl;
+            for (uint32_t i = 0; i < 64; i += 4) record(U_RL_SLROW, 6, R.c_sl_iseq, i, i + 4);
+            // after ShiftLeft: Mux1 x 63, Nibbles2Bytes(33), AssertGreaterEqThan(16), RlpEmptyAccount, Concat
+            CountP q; q.cur = R.c_mux;
+            for (int i = 0; i < 63; i++) gMux1S(q, 0, 0, 0);
+            gNibbles2Bytes(q, 33, R.t_on);
+            R.c_age = q.cur;
+            gAssertGreaterEqThanS(q, 16, 0, 2);
+            R.c_acc = q.cur;
+            { S al; gRlpEmptyAccount(q, prm.amountBytes, fr_zero(), al); }
+            R.c_concat = q.cur;
+            { S cl; gConcat(q, 2 + 1 + 33, 2 + 4 + prm.amountBytes + 66, R.pk, 0, R.val, 0, cl); }
+            expect_cursor("RlpMerklePatriciaTrieLeaf", q.cur, chk.cur);
+            record(U_RL_ACC, 6, R.c_acc);
+            record(U_RL_B, 7, R.c_mux);
+            p.cur = chk.cur;
+        }
         {   // ProofOfWorkChecker :211
             L.pw.in = p.frs(3); L.pw.mzb = p.sms(1); L.pw.keyBytes = p.sms(32); L.pw.raBytes = p.sms(32); L.pw.becBytes = p.sms(32); L.pw.eip = p.sms(8);
             L.pw.hin = p.sms(104); L.pw.block = p.sms(136); L.pw.keccak = p.sms(32); L.pw.sbz = p.bits(32);
             L.pw.kb = L.nkb++;
-            unit(U_POW_PRE, 1);
-            keccak_tail(L.pw.kb, 1, L.pw.keccak, true);
-            unit(U_POW_POST, 4);
+            unit(U_POW_PRE, 2);
+            keccak_tail(L.pw.kb, 2, L.pw.keccak, true);
+            unit(U_POW_POST, 5);
         }
-        unit(U_POB_FINAL, 8);
+        unit(U_POB_FINAL, 10);
         total = p.cur;
     }
     void plan_spend(const SpendParams& prm) {
+        memset(&L, 0, sizeof L);
         L.circuit = 1; L.spend = prm; L.nkb = 0; max_stage = 0;
         L.pob = PobParams{1, 1, 1, 0, prm.maxAmountBytes, 0, fr_zero(), fr_zero()};
         SpendMain& M = L.sm;

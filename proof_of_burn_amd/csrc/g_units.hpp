@@ -25,7 +25,7 @@ template <class P> __global__ void __launch_bounds__(64) g_units(GArgs A) {
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; }
     const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];
-    unit_run<P>(p, d, *A.L, A.kbs);
+    unit_run<P>(p, d, *A.L);
     if constexpr (P::is_gen) { if (p.status) atomicMin(&A.status[g * 64 + lane], p.status); }
     if constexpr (P::is_check) {
         if (p.status) atomicMin(&A.chk_status[g * 64 + lane], p.status);

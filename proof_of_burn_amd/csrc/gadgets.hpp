@@ -25,16 +25,32 @@ template <class P> HD B gOR(P& p, B a, B b) { BitRef o = p.bits(3); a = p.put(o 
 
 // ============================================================================ circomlib: bitify.circom
 // Num2Bits(n)  [out[n] | in];  out[i] <-- (in>>i)&1;  sum out[i] 2^i === in   (n <= 31 here)
-template <class P> GD BitRef gNum2BitsS(P& p, int n, S in) {
+// `top`: value of out[n-1]; `also`: a second array that must equal out[] (the caller's copy) -- both avoid re-reading
+// just-written wires through memory.
+template <class P> GD BitRef gNum2BitsS(P& p, int n, S in, B* top = nullptr, const BitRef* also = nullptr) {
     BitRef o = p.bits(n); SmRef i = p.sms(1);
     S x = p.put(i, in);
     uint32_t acc = 0;
     for (int k = 0; k < n; k++) {
         B b = p.hint(o + k, p.ballot(((uint32_t)x >> k) & 1));
         acc |= (uint32_t)p.bit(b) << k;
+        if (also) p.put(*also + k, b);
+        if (top) *top = b;
     }
     p.require(p.ballot((uint32_t)x == acc), FAILCODE(T_NUM2BITS, 38));   // negative / too wide values fail here
     return o;
+}
+// Num2Bits(8) with the 8 output masks returned in registers (fully unrolled)
+template <class P> HD void gNum2Bits8(P& p, S in, B* outv) {
+    BitRef o = p.bits(8); SmRef i = p.sms(1);
+    S x = p.put(i, in);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        outv[k] = p.hint(o + k, p.ballot(((uint32_t)x >> k) & 1));
+        acc |= (uint32_t)p.bit(outv[k]) << k;
+    }
+    p.require(p.ballot((uint32_t)x == acc), FAILCODE(T_NUM2BITS, 38));
 }
 // field-element flavour (n <= 254)
 template <class P> GD BitRef gNum2BitsF(P& p, int n, const F& in) {
@@ -103,8 +119,9 @@ template <class P> GD B gIsEqualF(P& p, const F& a, const F& b, bool inv_is_stor
 template <class P> GD B gLessThanS(P& p, int n, S a, S b) {
     BitRef o = p.bits(1); SmRef in = p.sms(2);
     a = p.put(in, a); b = p.put(in + 1, b);
-    BitRef nb = gNum2BitsS(p, n + 1, (S)((uint32_t)a + (1u << n) - (uint32_t)b));
-    return p.put(o, ~p.get(nb + n));
+    B top;
+    gNum2BitsS(p, n + 1, (S)((uint32_t)a + (1u << n) - (uint32_t)b), &top);
+    return p.put(o, ~top);
 }
 template <class P> GD B gLessThanF(P& p, int n, const F& a, const F& b) {
     BitRef o = p.bits(1); FrRef in = p.frs(2);
@@ -308,8 +325,7 @@ template <class P, int T> GD F gPoseidon(P& p, const PosOff& k, const F* inputs)
 template <class P> GD void gAssertBitsS(P& p, int nb, S in) {
     SmRef i = p.sms(1); BitRef bits = p.bits(nb);
     in = p.put(i, in);
-    BitRef c = gNum2BitsS(p, nb, in);
-    for (int k = 0; k < nb; k++) p.put(bits + k, p.get(c + k));
+    gNum2BitsS(p, nb, in, nullptr, &bits);
 }
 template <class P> GD void gAssertBitsF(P& p, int nb, const F& in) {
     FrRef i = p.frs(1); BitRef bits = p.bits(nb);
@@ -588,10 +604,12 @@ template <class P> GD SmRef gBytes2Nibbles(P& p, int N, SmRef src) {
     SmRef o = p.sms(2 * N), in = p.sms(N); BitRef dec = p.bits(8 * N);
     for (int i = 0; i < N; i++) {
         S v = p.put(in + i, p.get(src + i));
-        BitRef nb = gNum2BitsS(p, 8, v);
+        B bv[8];
+        gNum2Bits8(p, v, bv);
         S lo = 0, hi = 0;
+#pragma unroll
         for (int k = 0; k < 8; k++) {
-            bool b = p.bit(p.put(dec + (8 * i + k), p.get(nb + k)));
+            bool b = p.bit(p.put(dec + (8 * i + k), bv[k]));
             if (k < 4) lo |= (S)b << k; else hi |= (S)b << (k - 4);
         }
         p.put(o + 2 * i, hi); p.put(o + 2 * i + 1, lo);

@@ -1,6 +1,7 @@
 #include "keccak_kernels.hpp"
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st) {
-    if (check) hipLaunchKernelGGL(k_chain<true>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
+    // check: nsponges is the number of PERMUTATIONS (local evaluation, one wavefront per (sponge, block))
+    if (check) hipLaunchKernelGGL(k_chain_check, dim3(nsponges, ngroups), dim3(64), 0, st, K);
     else hipLaunchKernelGGL(k_chain<false>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
 }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {

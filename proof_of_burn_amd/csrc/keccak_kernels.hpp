@@ -240,6 +240,40 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_chain(KArgs A) {
     }
 }
 
+// Constraint evaluation of the same wires, LOCAL per permutation (every relation of Absorb/Final/Keccakf's own wires is
+// between stored wires, so no permutation needs to be recomputed): grid.x = (sponge, block), grid.y = group.
+__global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pi = A.first + blockIdx.x;
+    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
+    const uint32_t b = A.perm_block[pi];
+    const u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    const uint32_t Ab = sp.abs_b + b * ABSORB_WIRES, Kf = Ab + AB_KECCAKF;
+    u64 bad = 0;
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        const u64 st = G[sp.fs_b + b * 1600 + 64 * i + lane];                    // Final.s[b]
+        if (b == 0) bad |= st;                                                     // s[0] <== 0  (:337-341)
+        bad |= G[Ab + 1600 + 64 * i + lane] ^ st;                                  // Absorb.s
+        u64 aux = st;
+        if (i < 17) {
+            const u64 blk = G[sp.src_b + b * 1088 + 64 * i + lane];                // KeccakBytes.inBlocks
+            bad |= (G[sp.kin_b + b * 1088 + 64 * i + lane] ^ blk) | (G[sp.fin_b + b * 1088 + 64 * i + lane] ^ blk) | (G[Ab + 3200 + 64 * i + lane] ^ blk);
+            const u64 o = st ^ blk;
+            const uint32_t X = Ab + ABSORB_OWN + 384 * i;
+            const u64* q = G + X + 192 + 3 * lane;
+            bad |= (G[X + lane] ^ o) | (G[X + 64 + lane] ^ st) | (G[X + 128 + lane] ^ blk) | (q[0] ^ o) | (q[1] ^ st) | (q[2] ^ blk);
+            aux = o;
+        }
+        bad |= (G[Ab + 4288 + 64 * i + lane] ^ aux) | (G[Kf + 1600 + 64 * i + lane] ^ aux) | (G[Kf + KF_MID + 64 * i + lane] ^ aux);
+        const u64 last = G[Kf + KF_MID + 1600 * 24 + 64 * i + lane];               // midRound[24]
+        bad |= (G[Kf + 64 * i + lane] ^ last) | (G[Ab + 64 * i + lane] ^ last) | (G[sp.fs_b + (b + 1) * 1600 + 64 * i + lane] ^ last);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
+    if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
+}
+
 // One KeccakfRound block per wavefront: grid.x = (permutation, round), grid.y = group.  Reads midRound[r] (written by
 // k_chain), writes (GenIO) or verifies (CheckIO) the 102 656 wires of the round.  This is the HBM-streaming kernel.
 template <bool CHECK> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {

@@ -10,7 +10,7 @@ typedef unsigned long long u64;
 
 struct GArgs {
     const UnitDesc* units; const uint32_t* order; uint32_t first;
-    const CircuitLayout* L; KBRefs* kbs;
+    CircuitLayout* L;                                  // read-only on the device (only the host planner writes reference tables)
     uint64_t* bits; int32_t* sm; uint32_t* fr;
     uint64_t bits_stride, sm_stride, fr_stride;       // elements per group
     const uint32_t* pos_tab; const uint32_t* inv_lut;

@@ -42,7 +42,7 @@ struct pob_ctx {
     hipStream_t stream = nullptr;
     // device memory
     uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr;
-    UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr; KBRefs* d_kbs = nullptr;
+    UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr;
     uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
@@ -69,7 +69,7 @@ static Fr limbs_to_mont(const uint64_t* l) {
 
 static GArgs gargs(pob_ctx* h) {
     GArgs A; memset(&A, 0, sizeof A);
-    A.units = h->d_units; A.order = h->d_order; A.L = h->d_L; A.kbs = h->d_kbs;
+    A.units = h->d_units; A.order = h->d_order; A.L = h->d_L;
     A.bits = h->d_bits; A.sm = h->d_sm; A.fr = h->d_fr;
     A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
     A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.in_fr = h->d_in_fr; A.in_sm = h->d_in_sm;
@@ -92,7 +92,7 @@ static int make_plan(Plan& plan, std::string& err, int circuit, const uint64_t* 
         prm.amountBytes = (int)params[16]; prm.powZero = (int)params[20];
         prm.maxIntended = limbs_to_mont(params + 24); prm.maxActual = limbs_to_mont(params + 28);
         if (prm.L < 2 || prm.L > 64 || prm.NB < 1 || prm.NB > 16 || prm.HB < 1 || prm.HB > 32 || prm.amountBytes < 1 || prm.amountBytes > 31 ||
-            4 + prm.L > MAX_KB) { err = "unsupported ProofOfBurn parameters"; return POB_E_ARG; }
+            4 + prm.L > MAX_KB || prm.L > MAX_SC) { err = "unsupported ProofOfBurn parameters"; return POB_E_ARG; }
         plan.plan_pob(prm);
     } else if (circuit == POB_CIRCUIT_SPEND) {
         if (nparams != 1 || params[0] < 1 || params[0] > 31) { err = "Spend takes maxAmountBytes in 1..31"; return POB_E_ARG; }
@@ -116,7 +116,8 @@ extern "C" {
 int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* info) {
     if (!info) return POB_E_ARG;
     Plan* plan = new Plan(); std::string err;
-    int rc = make_plan(*plan, err, circuit, params, nparams);
+    int rc;
+    try { rc = make_plan(*plan, err, circuit, params, nparams); } catch (const std::exception& e) { fprintf(stderr, "%s\n", e.what()); rc = POB_E_STATE; }
     if (rc == POB_OK) { uint32_t np = 0; for (const SpongeDesc& sd : plan->sponges) np += sd.n; fill_info(*plan, np, 0, info); }
     delete plan;
     return rc;
@@ -129,7 +130,8 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     pob_ctx* h = new pob_ctx();
     *out = h;
     h->device = device; h->circuit = circuit; h->max_batch = max_batch; h->groups = (max_batch + 63) / 64;
-    { int prc = make_plan(h->plan, h->err, circuit, params, nparams); if (prc) return prc; }
+    try { int prc = make_plan(h->plan, h->err, circuit, params, nparams); if (prc) return prc; }
+    catch (const std::exception& e) { h->err = e.what(); return POB_E_STATE; }
     Plan& pl = h->plan;
     {   // POSEIDON_PREFIX + 0/1/2  (constants.circom:3-14) = keccak("EIP-7503") mod p
         const uint64_t pre[4] = {0xf0363f983d892f7eULL, 0xd115b780980a6b46ULL, 0x007d2482cd46cec2ULL, 0x0ba44186ee7876b8ULL};
@@ -168,7 +170,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_units, pl.units.size() * sizeof(UnitDesc)));
     HIPC(hipMalloc(&h->d_order, h->order.size() * sizeof(uint32_t)));
     HIPC(hipMalloc(&h->d_L, sizeof(CircuitLayout)));
-    HIPC(hipMalloc(&h->d_kbs, sizeof(KBRefs) * MAX_KB));
     HIPC(hipMalloc(&h->d_sponges, std::max<size_t>(pl.sponges.size(), 1) * sizeof(SpongeDesc)));
     HIPC(hipMalloc(&h->d_perm_sponge, std::max<size_t>(h->nperms, 1) * 4));
     HIPC(hipMalloc(&h->d_perm_block, std::max<size_t>(h->nperms, 1) * 4));
@@ -182,7 +183,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMemcpy(h->d_units, pl.units.data(), pl.units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_order, h->order.data(), h->order.size() * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_L, &pl.L, sizeof(CircuitLayout), hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(h->d_kbs, pl.kbs, sizeof(KBRefs) * MAX_KB, hipMemcpyHostToDevice));
     if (!pl.sponges.empty()) HIPC(hipMemcpy(h->d_sponges, pl.sponges.data(), pl.sponges.size() * sizeof(SpongeDesc), hipMemcpyHostToDevice));
     if (h->nperms) {
         HIPC(hipMemcpy(h->d_perm_sponge, perm_sponge.data(), h->nperms * 4, hipMemcpyHostToDevice));
@@ -201,7 +201,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
-    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_kbs, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
+    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
                     h->d_inv, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_emit};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -266,7 +266,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     KArgs K = kargs(h);
     if (!h->plan.sponges.empty()) {
         K.first = 0;
-        launch_k_chain(K, true, (uint32_t)h->plan.sponges.size(), G, st);
+        launch_k_chain(K, true, h->nperms, G, st);
         launch_k_rounds(K, true, h->nperms, G, st);
     }
     HIPC(hipGetLastError());
