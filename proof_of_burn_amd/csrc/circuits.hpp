@@ -24,7 +24,7 @@ enum UnitKind : uint32_t {
     U_POB_INPUT = 1, U_POB_RANGE, U_POB_LAYER_ASSERT, U_POB_HDR_ASSERT, U_POB_POSEIDONS, U_BAH_PRE, U_BAH_POST,
     U_KB_HEAD, U_KB_RANGE, U_KB_SELROW, U_KB_POST, U_POB_N2B, U_PC_PRE, U_PC_POST, U_POB_LASTLAYER, U_POB_LASTLAYER_RANGE,
     U_POB_LASTLEN, U_POB_LEAF, U_POB_LAYER_POST, U_SC_M, U_SC_RANGE, U_SC_SUMS, U_POB_LASTLEAF,
-    U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE,
+    U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE, U_LD_HEAD, U_LD_SELR, U_LD_TAIL, U_POB_INPUT_FR,
     U_SP_INPUT, U_SP_HEAD
 };
 
@@ -77,6 +77,15 @@ struct RlRefs {
     SmRef s_o, s_in, s_cn; BitRef s_isEq; SmRef s_temp;                                              // ShiftLeft(64) own (shift.circom:17-37)
     Cur c_sl_iseq, c_mux, c_age, c_acc, c_concat;
 };
+// LeafDetector(N) instance (rlp/merkle_patricia_trie_leaf.circom:247-294), cut into head / selector ranges / tail
+struct LdRefs {
+    BitRef isLeaf; SmRef layer, ll;
+    BitRef leafPrefixIsF8; SmRef totalLength; BitRef isConsistentWithLayerLen; SmRef keyPrefix; BitRef keyPrefixIsValid, keyIsMultiByte;
+    SmRef keyExtraLen, keyLen, valueWrapperPrefix; BitRef valueWrapperPrefixIsB8; SmRef valueWrapperLen, valuePrefix; BitRef valuePrefixIsF8;
+    SmRef valueLen; BitRef isValueWrapperLenConsistent, isKeyValueLenEqualWithLayerLen;
+    Cur c_sel[4], c_eq[4], c_mand, c_end;
+    SmRef src, len_src; BitRef dst;
+};
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
 struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; };
 
@@ -96,6 +105,7 @@ struct CircuitLayout {
     uint32_t kb_hdr, kb_layer0, nkb, nsc;
     KBRefs kbs[MAX_KB];
     ScRefs scs[MAX_SC];
+    LdRefs lds[MAX_SC + 1];
 };
 
 HD PosOff pos_off(int t) {
@@ -182,12 +192,33 @@ template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32
     S blocks = p.get(r.numBlocks);
     for (uint32_t j = j0; j < j1; j++) {
         const uint32_t idx = row * 64 + j;
-        for (uint32_t k = 0; k < n1; k++) p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), p.get(r.f_s + (k * 1600 + idx))));
-        B o = gSelectorB(p, n1, r.sel_T + idx * n1, blocks);
-        o = p.put(r.sel_out + idx, o);
-        o = p.put(r.f_out + idx, o);
-        o = p.put(r.k_finalState + idx, o);
-        if (idx < 256) p.put(r.k_out + idx, o);
+        if (n1 <= 17) {          // all n1 candidate state words first (independent loads), then nothing but stores
+            B v[17];
+#pragma unroll
+            for (uint32_t k = 0; k < 17; k++) v[k] = k < n1 ? p.get(r.f_s + (k * 1600 + idx)) : 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 17; k++) if (k < n1) v[k] = p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), v[k]));
+            // Selector(n1) on BIT data (selector.circom:21-46): [out | vals[n1], select | isEq[n1], sum[n1+1]] || IsEqual x n1
+            BitRef o = p.bits(1), vals = p.bits(n1); SmRef sel = p.sms(1); BitRef isEq = p.bits(n1), sum = p.bits(n1 + 1);
+            S select = p.put(sel, blocks);
+            B acc = p.put(sum, 0), any = 0, multi = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 17; k++) if (k < n1) {
+                B val = p.put(vals + k, v[k]);
+                B e = p.put(isEq + k, gIsEqualS(p, select, (S)k));
+                multi |= any & e; any |= e;
+                acc = p.put(sum + k + 1, acc | (e & val));
+            }
+            p.require(any & ~multi, FAILCODE(T_SELECTOR, 43));
+            B out = p.put(o, acc);
+            out = p.put(r.sel_out + idx, out); out = p.put(r.f_out + idx, out); out = p.put(r.k_finalState + idx, out);
+            if (idx < 256) p.put(r.k_out + idx, out);
+        } else {
+            for (uint32_t k = 0; k < n1; k++) p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), p.get(r.f_s + (k * 1600 + idx))));
+            B o = gSelectorB(p, n1, r.sel_T + idx * n1, blocks);
+            o = p.put(r.sel_out + idx, o); o = p.put(r.f_out + idx, o); o = p.put(r.k_finalState + idx, o);
+            if (idx < 256) p.put(r.k_out + idx, o);
+        }
     }
 }
 // part after the sponge: Keccak/Final/selector `blocks` inputs, Reshape(32,8) [out | in], Bits2Num(8) x 32 [out | in[8]] and the
@@ -213,32 +244,37 @@ template <class P> GD void kb_post(P& p, const KBRefs& r, SmRef dst, bool has_ds
     }
 }
 
+
+// Selector(N) block at cursor c (selector.circom:21-46): [out | vals[N], select | isEq[N], sum[N+1]] || IsEqual x N
+struct SelBlk { SmRef o, vals, sel; BitRef isEq; SmRef sum; Cur kids; };
+HD SelBlk sel_blk(Cur c, uint32_t N) {
+    SelBlk s;
+    s.o = SmRef{c.w, c.s}; s.vals = SmRef{c.w + 1, c.s + 1}; s.sel = SmRef{c.w + 1 + N, c.s + 1 + N};
+    s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum = SmRef{c.w + 2 + 2 * N, c.s + 2 + N};
+    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f};
+    return s;
+}
+HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; }
+
 // ---------------------------------------------------------------------------- unit bodies
-template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
+// Units are split in two kernels by register appetite: LIGHT units touch only BIT/SM wires (few VGPRs -> high occupancy,
+// which is what hides the store/load latency of this lane-per-witness code); HEAVY units do BN254 arithmetic.
+HD bool unit_is_heavy(uint32_t k) {
+    return k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_POB_N2B || k == U_PC_POST || k == U_POB_LAYER_POST ||
+           k == U_SC_M || k == U_SC_RANGE || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == U_SP_HEAD;
+}
+HD bool unit_uses_lds(uint32_t k) { return k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD; }   // Poseidon table staged in LDS
+
+template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout& L) {
     const PobMain& M = L.pm;
     const PobParams& prm = L.pob;
     const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
+    (void)M; (void)LB; (void)HBy;
     p.cur = d.cur;
     switch (d.kind) {
-    case U_POB_INPUT: {   // main inputs from the packed batch buffer; a[0..1] = range of SM inputs (declaration order, contiguous SM ranks)
-        if (d.a[0] == 0) {
-            p.put(M.burnKey, p.input_fr(0)); p.put(M.actualBalance, p.input_fr(1)); p.put(M.intendedBalance, p.input_fr(2));
-            p.put(M.revealAmount, p.input_fr(3)); p.put(M.burnExtraCommitment, p.input_fr(4)); p.put(M.proofExtraCommitment, p.input_fr(5));
-        }
+    case U_POB_INPUT:     // SM main inputs [a0, a1) from the packed batch buffer (declaration order = contiguous SM ranks)
         for (uint32_t k = d.a[0]; k < d.a[1]; k++) { SmRef r = {M.numLeafAddressNibbles.w + k, M.numLeafAddressNibbles.i + k}; p.put(r, p.input_sm(k)); }
-    } break;
-    case U_POB_RANGE: {   // proof_of_burn.circom:84-97
-        const int AB8 = prm.amountBytes * 8;
-        F intended = p.get(M.intendedBalance), actual = p.get(M.actualBalance), reveal = p.get(M.revealAmount);
-        gAssertLessEqThanF(p, AB8, intended, prm.maxIntended);
-        gAssertLessEqThanF(p, AB8, actual, prm.maxActual);
-        gAssertLessEqThanF(p, AB8, intended, actual);
-        S relax = p.get(M.byteSecurityRelax);
-        gAssertLessEqThanS(p, 16, (S)((uint32_t)relax * 2u), (S)prm.minNib);
-        gAssertGreaterEqThanS(p, 16, p.get(M.numLeafAddressNibbles), (S)((uint32_t)prm.minNib - (uint32_t)relax * 2u));
-        gAssertBitsF(p, AB8, reveal);
-        gAssertLessEqThanF(p, AB8, reveal, intended);
-    } break;
+        break;
     case U_POB_LAYER_ASSERT:     // :101 (the AssertByteString of :102 runs as U_ABS_RANGE units)
         gAssertLessThanS(p, 16, p.get(M.layerLens + d.a[0]), (S)(LB * 8));
         break;
@@ -249,26 +285,6 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
     case U_ABS_RANGE: {          // cur = first AssertBits(8) child; a = own_in (w,i), src (w,i), lo, hi
         SmRef own = {d.a[0], d.a[1]}, src = {d.a[2], d.a[3]};
         abs_range(p, d.cur, own, src, d.a[4], d.a[5]);
-    } break;
-    case U_POB_POSEIDONS: {      // :113, :116
-        F bk = p.get(M.burnKey);
-        F in3[3] = {L.prefix[2], bk, fr_sub(p.get(M.intendedBalance), p.get(M.revealAmount))};
-        p.put(M.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
-        F in2[2] = {L.prefix[1], bk};
-        p.put(M.nullifier, gPoseidon<P, 3>(p, pos_off(3), in2));
-    } break;
-    case U_BAH_PRE: {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
-        F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
-        SmRef ab = gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec);
-        for (int i = 0; i < 20; i++) p.put(L.bah.addressBytes + i, p.get(ab + i));
-        SmRef f = gFitS(p, 20, 136, L.bah.addressBytes);
-        for (int i = 0; i < 136; i++) p.put(L.bah.block + i, p.get(f + i));
-        KBRefs r = L.kbs[L.bah.kb];
-        kb_head(p, 1, (S)20, r);
-        if (P::is_count) L.kbs[L.bah.kb] = r;
-        const Cur after = p.cur;
-        kb_range(p, r, L.bah.block, 0, 136);
-        p.cur = after;
     } break;
     case U_BAH_POST: {           // :82 Bytes2Nibbles(32) + main.addressHashNibbles (:119)
         SmRef nb = gBytes2Nibbles(p, 32, L.bah.hash);
@@ -289,13 +305,6 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
         SmRef dst = {d.a[1], d.a[2]};
         kb_post(p, L.kbs[d.a[0]], dst, d.a[3] != 0);
     } break;
-    case U_POB_N2B: {            // :132-136  Num2BigEndianBytes(32) of nullifier, remainingCoin, revealAmount, burnExtraCommitment, _proofExtraCommitment
-        const int j = d.a[0];
-        FrRef src = j == 0 ? M.nullifier : j == 1 ? M.remainingCoin : j == 2 ? M.revealAmount : j == 3 ? M.burnExtraCommitment : M.proofExtraCommitment;
-        SmRef dst = j == 0 ? M.nullifierBytes : j == 1 ? M.remainingCoinBytes : j == 2 ? M.revealAmountBytes : j == 3 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
-        SmRef r = gNum2BigEndianBytesF(p, 32, p.get(src));
-        for (int i = 0; i < 32; i++) p.put(dst + i, p.get(r + i));
-    } break;
     case U_PC_PRE: {             // PublicCommitment(N) public_commitment.circom:18-36 up to the sponge
         const int N = L.pc.N;
         for (int j = 0; j < N; j++) {
@@ -312,15 +321,6 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
         KBRefs r = L.kbs[L.pc.kb];
         kb_head(p, L.pc.nb, (S)(32 * N), r);
         if (P::is_count) L.kbs[L.pc.kb] = r;
-        const Cur after = p.cur;
-        kb_range(p, r, L.pc.block, 0, 136 * L.pc.nb);
-        p.cur = after;
-    } break;
-    case U_PC_POST: {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
-        SmRef f = gFitS(p, 32, 31, L.pc.hash);
-        for (int i = 0; i < 31; i++) p.put(L.pc.reduced + i, p.get(f + i));
-        F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
-        p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
     } break;
     case U_POB_LASTLAYER:        // :142-143 SelectorArray1D(L, LB): the select input; selectors run as range units
         p.put(L.ll.sel, p.get(M.numLayers) - 1);
@@ -346,85 +346,6 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
         const int i = d.a[0];
         p.put(M.isLeaf + i, gLeafDetector(p, LB, M.layers + i * LB, p.get(M.layerLens + i)));
     } break;
-    case U_POB_LAYER_POST: {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
-                                 // AssertLessEqThan x2, LittleEndianBytes2Num(sl); AssertByteString(mm) runs as U_ABS_RANGE units
-        const int i = d.a[0];
-        SmRef f = gFitS(p, 32, 31, M.layerKeccaks + 32 * i);
-        for (int k = 0; k < 31; k++) p.put(M.reducedLayerKeccaks + (31 * i + k), p.get(f + k));
-        if (i > 0) {
-            ScRefs sc = L.scs[i];
-            const int mm = LB, sl = 31, kk = mm - sl + 1;
-            sc.out = p.bits(1); sc.mi = p.sms(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
-            sc.num = p.frs(1); sc.M = p.frs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
-            for (int k = 0; k < mm; k++) p.put(sc.mi + k, p.get(M.layers + ((i - 1) * LB + k)));
-            S mainLen = p.put(sc.ml, p.get(M.layerLens + (i - 1)));
-            for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
-            sc.c_abs_sub = p.cur;
-            gAssertByteString(p, sl, sc.si);
-            sc.abs_main_in = p.sms(mm);
-            sc.c_abs_main = p.cur;
-            p.cur = cur_add(p.cur, FP_ABITS8, mm);
-            sc.c_after_abs = p.cur;
-            gAssertLessEqThanS(p, 16, mainLen, (S)mm);
-            gAssertLessEqThanS(p, 16, (S)sl, mainLen);
-            p.put(sc.num, gLittleEndianBytes2NumF(p, sl, sc.si));
-            sc.c_loop = p.cur;
-            p.cur = cur_add(cur_add(p.cur, FP_ISEQ_S, kk), FP_ISEQ_F, kk);
-            sc.c_tail = p.cur;
-            p.cur = cur_add(p.cur, Cur{3, 1, 2, 0}, 1);            // the final IsZero
-            if (P::is_count) L.scs[i] = sc;
-        }
-    } break;
-    case U_SC_M: {               // M[i+1] <== mainInput[i]*256^i + M[i]  (substring_check.circom:45-49); reads the source bytes
-        const ScRefs& sc = L.scs[d.a[0]];
-        const F c256 = fr_from_i64(256);
-        F pw = fr_one_mont(), acc = p.put(sc.M, fr_zero());
-        for (int k = 0; k < LB; k++) {
-            acc = p.put(sc.M + k + 1, fr_add(fr_mul(fr_from_i64(p.get(M.layers + ((d.a[0] - 1) * LB + k))), pw), acc));
-            pw = fr_mul(pw, c256);
-        }
-    } break;
-    case U_SC_RANGE: {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
-        const ScRefs& sc = L.scs[d.a[0]];
-        const uint32_t lo = d.a[1], hi = d.a[2], sl = 31;
-        const S mainLen = p.get(sc.ml);
-        const F subNum = p.get(sc.num), c256 = fr_from_i64(256);
-        F pw0 = fr_one_mont();
-        { F base = c256; for (uint32_t e = lo; e; e >>= 1) { if (e & 1) pw0 = fr_mul(pw0, base); base = fr_sqr(base); } }   // 256^lo
-        // FR wires of position i's IsEqual(exists): 0 = in[0], 1 = in[1], 2 = isz.in, 3 = isz.inv
-        auto fref = [&](uint32_t i, uint32_t which) {
-            Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i + 1), FP_ISEQ_F, i);
-            FrRef r = {c.w + 1 + which + (which >= 2 ? 1u : 0u), c.f + which};
-            return r;
-        };
-        if (P::is_gen) {         // Montgomery batch inversion over this range, scratch = the witness' own isz.in / isz.inv slots
-            F pw = pw0, run = fr_one_mont();
-            for (uint32_t i = lo; i < hi; i++) {
-                F dd = fr_sub(fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), fr_mul(subNum, pw));
-                p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
-                if (!fr_is_zero(dd)) run = fr_mul(run, dd);
-                pw = fr_mul(pw, c256);
-            }
-            F inv = fr_inv(run);
-            for (uint32_t i = hi; i-- > lo;) {
-                F dd = p.get(fref(i, 2)), pre = p.get(fref(i, 3));
-                const bool z = fr_is_zero(dd);
-                p.raw_put(fref(i, 3), z ? fr_zero() : fr_mul(inv, pre));
-                if (!z) inv = fr_mul(inv, dd);
-            }
-        }
-        // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
-        const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
-        B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
-        F pw = pw0;
-        for (uint32_t i = lo; i < hi; i++) {
-            p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
-            B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
-            allowed = p.put(sc.alw + i + 1, allowed & ~last);
-            p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, pw), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
-            pw = fr_mul(pw, c256);
-        }
-    } break;
     case U_SC_SUMS: {            // sums[] (:94), doesNotExist, out (:98-99), substringCheckers[i-1] and the constraint of proof_of_burn.circom:179
         const uint32_t i = d.a[0];
         const ScRefs& sc = L.scs[i];
@@ -440,6 +361,70 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
     case U_POB_LASTLEAF:         // :187
         p.put(M.isLastLayerLeaf, gLeafDetector(p, LB, M.lastLayer, p.get(M.lastLayerLen)));
         break;
+    case U_LD_HEAD: {            // LeafDetector(N) :247-278 up to keyLen; selector heads (select input, sum[0], range check)
+        LdRefs R = L.lds[d.a[0]];
+        const uint32_t N = LB;
+        R.isLeaf = p.bits(1); R.layer = p.sms(N); R.ll = p.sms(1);
+        R.leafPrefixIsF8 = p.bits(1); R.totalLength = p.sms(1); R.isConsistentWithLayerLen = p.bits(1); R.keyPrefix = p.sms(1);
+        R.keyPrefixIsValid = p.bits(1); R.keyIsMultiByte = p.bits(1); R.keyExtraLen = p.sms(1); R.keyLen = p.sms(1); R.valueWrapperPrefix = p.sms(1);
+        R.valueWrapperPrefixIsB8 = p.bits(1); R.valueWrapperLen = p.sms(1); R.valuePrefix = p.sms(1); R.valuePrefixIsF8 = p.bits(1);
+        R.valueLen = p.sms(1); R.isValueWrapperLenConsistent = p.bits(1); R.isKeyValueLenEqualWithLayerLen = p.bits(1);
+        for (uint32_t i = 0; i < N; i++) p.put(R.layer + i, p.get(R.src + i));
+        const S layerLen = p.put(R.ll, p.get(R.len_src));
+        gAssertLessEqThanS(p, 16, layerLen, (S)N);
+        p.put(R.leafPrefixIsF8, gIsEqualS(p, p.get(R.src), (S)0xf8));
+        const S tl = p.put(R.totalLength, p.get(R.src + 1));
+        p.put(R.isConsistentWithLayerLen, gIsEqualS(p, tl + 2, layerLen));
+        const S kp = p.put(R.keyPrefix, p.get(R.src + 2));
+        p.put(R.keyPrefixIsValid, gLessEqThanS(p, 16, kp, (S)0xb7));
+        const B multi = p.put(R.keyIsMultiByte, gIsInRange(p, 16, (S)0x81, kp, (S)0xb7));
+        const S kel = p.put(R.keyExtraLen, p.bit(multi) ? kp - 0x80 : 0);
+        const S kl = p.put(R.keyLen, 1 + kel);
+        const Cur fp = sel_fp(N);
+        R.c_sel[0] = p.cur; R.c_eq[0] = cur_add(R.c_sel[0], fp, 1); R.c_sel[1] = cur_add(R.c_eq[0], FP_ISEQ_S, 1); R.c_sel[2] = cur_add(R.c_sel[1], fp, 1);
+        R.c_eq[1] = cur_add(R.c_sel[2], fp, 1); R.c_sel[3] = cur_add(R.c_eq[1], FP_ISEQ_S, 1); R.c_eq[2] = cur_add(R.c_sel[3], fp, 1);
+        R.c_eq[3] = cur_add(R.c_eq[2], FP_ISEQ_S, 1); R.c_mand = cur_add(R.c_eq[3], FP_ISEQ_S, 1);
+        for (uint32_t k = 0; k < 4; k++) {
+            const SelBlk sb = sel_blk(R.c_sel[k], N);
+            const S select = p.put(sb.sel, 2 + kl + (S)k);
+            p.put(sb.sum, 0);
+            p.require(p.ballot((uint32_t)select < N), FAILCODE(T_SELECTOR, 43));      // sum isEq === 1  <=>  0 <= select < N
+        }
+        { B m[7] = {0, 0, 0, 0, 0, 0, 0}; p.cur = R.c_mand; CountP q; q.cur = p.cur; MultiANDg<CountP, 7>::run(q, m); R.c_end = q.cur; }
+        p.cur = R.c_end;
+        if (P::is_count) L.lds[d.a[0]] = R;
+    } break;
+    case U_LD_SELR: {            // entries [a2, a3) of selector a1 of LeafDetector a0; sum[i] = [select < i] * vals[select]
+        const LdRefs& R = L.lds[d.a[0]];
+        const uint32_t N = LB, which = d.a[1], lo = d.a[2], hi = d.a[3];
+        const SelBlk sb = sel_blk(R.c_sel[which], N);
+        const S select = 2 + p.get(R.keyLen) + (S)which;
+        S acc;
+        if (P::is_gen) { const uint32_t us = (uint32_t)select; acc = us < lo ? p.get(R.src + us) : 0; }
+        else acc = p.get(sb.sum + lo);
+        for (uint32_t i = lo; i < hi; i++) {
+            const S v = p.put(sb.vals + i, p.get(R.src + i));
+            p.cur = cur_add(sb.kids, FP_ISEQ_S, i);
+            const B e = p.put(sb.isEq + i, gIsEqualS(p, select, (S)i));
+            acc = p.put(sb.sum + i + 1, acc + (p.bit(e) ? v : 0));
+        }
+        if (hi == N) {
+            const SmRef dst = which == 0 ? R.valueWrapperPrefix : which == 1 ? R.valueWrapperLen : which == 2 ? R.valuePrefix : R.valueLen;
+            p.put(dst, p.put(sb.o, acc));
+        }
+    } break;
+    case U_LD_TAIL: {            // :280-293 the four IsEquals after the selectors, MultiAND(7), isLeaf
+        const LdRefs& R = L.lds[d.a[0]];
+        const S kl = p.get(R.keyLen), ll = p.get(R.ll), vwp = p.get(R.valueWrapperPrefix), vwl = p.get(R.valueWrapperLen), vp = p.get(R.valuePrefix), vl = p.get(R.valueLen);
+        B m[7];
+        m[0] = p.get(R.leafPrefixIsF8); m[1] = p.get(R.isConsistentWithLayerLen); m[2] = p.get(R.keyPrefixIsValid);
+        p.cur = R.c_eq[0]; m[3] = p.put(R.valueWrapperPrefixIsB8, gIsEqualS(p, vwp, (S)0xb8));
+        p.cur = R.c_eq[1]; m[5] = p.put(R.valuePrefixIsF8, gIsEqualS(p, vp, (S)0xf8));
+        p.cur = R.c_eq[2]; m[4] = p.put(R.isValueWrapperLenConsistent, gIsEqualS(p, vwl, vl + 2));
+        p.cur = R.c_eq[3]; m[6] = p.put(R.isKeyValueLenEqualWithLayerLen, gIsEqualS(p, kl + vl + 6, ll));
+        p.cur = R.c_mand;
+        p.put(R.dst, p.put(R.isLeaf, MultiANDg<P, 7>::run(p, m)));
+    } break;
     case U_RL_A: {               // RlpMerklePatriciaTrieLeaf(32, AB) :102-189, part 1: own inputs, TruncatedAddressHash(32) :50-90 head
                                  // (AssertLessEqThan(7), Divide(7)) and ShiftLeft(64) head (shift.circom:17-24)
         RlRefs R = L.rl;
@@ -481,14 +466,6 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
             p.put(R.s_o + i, acc);
         }
     } break;
-    case U_RL_ACC: {             // RlpEmptyAccount(AB)(balance) (rlp/empty_account.circom:20-134) + copy into the leaf's own wires (:153-155)
-        const RlRefs& R = L.rl;
-        const int maxAcc = 4 + prm.amountBytes + 66;
-        S al;
-        SmRef r = gRlpEmptyAccount(p, prm.amountBytes, p.get(M.actualBalance), al);
-        for (int i = 0; i < maxAcc; i++) p.put(R.acc + i, p.get(r + i));
-        p.put(R.accLen, al);
-    } break;
     case U_RL_B: {               // rest of TruncatedAddressHash (:62-90), AssertGreaterEqThan (:151), prefixes (:166-181), Concat (:183-188)
         const RlRefs& R = L.rl;
         const int ab = 32, n2 = 64, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
@@ -519,6 +496,164 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
         for (int i = 0; i < maxOut; i++) p.put(M.leaf + i, p.put(R.o + i, p.get(c + i)));
         p.put(M.leafLen, p.put(R.ol, cl));
     } break;
+    case U_POW_POST: {           // :73-79
+        BitRef f = gFilter(p, 32, p.get(L.pw.mzb));
+        for (int i = 0; i < 32; i++) {
+            B z = p.put(L.pw.sbz + i, p.get(f + i));
+            p.require(p.ballot(p.get(L.pw.keccak + i) == 0) | ~z, FAILCODE(T_POW, 79));
+        }
+    } break;
+    case U_POB_FINAL: {          // :186, :188, :191-193, :203-206
+        S cnt = 0;
+        for (int i = 0; i < prm.L; i++) cnt += (S)p.bit(p.get(M.isLeaf + i));
+        p.require(p.ballot(cnt == 1), FAILCODE(T_POB, 186));
+        p.require(p.get(M.isLastLayerLeaf), FAILCODE(T_POB, 188));
+        bool ok = true;
+        for (int i = 0; i < 32; i++) ok = ok && (p.get(M.layerKeccaks + i) == p.get(M.stateRoot + i));
+        p.require(p.ballot(ok), FAILCODE(T_POB, 192));
+        ok = true;
+        for (int i = 0; i < 139; i++) ok = ok && (p.get(M.leaf + i) == p.get(M.lastLayer + i));
+        p.require(p.ballot(ok), FAILCODE(T_POB, 204));
+        p.require(p.ballot(p.get(M.leafLen) == p.get(M.lastLayerLen)), FAILCODE(T_POB, 206));
+    } break;
+    default: break;
+    }
+}
+template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout& L) {
+    const PobMain& M = L.pm;
+    const PobParams& prm = L.pob;
+    const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
+    (void)M; (void)LB; (void)HBy;
+    p.cur = d.cur;
+    switch (d.kind) {
+    case U_POB_INPUT_FR:  // FR main inputs (canonical LE -> Montgomery)
+        p.put(M.burnKey, p.input_fr(0)); p.put(M.actualBalance, p.input_fr(1)); p.put(M.intendedBalance, p.input_fr(2));
+        p.put(M.revealAmount, p.input_fr(3)); p.put(M.burnExtraCommitment, p.input_fr(4)); p.put(M.proofExtraCommitment, p.input_fr(5));
+        break;
+    case U_POB_RANGE: {   // proof_of_burn.circom:84-97
+        const int AB8 = prm.amountBytes * 8;
+        F intended = p.get(M.intendedBalance), actual = p.get(M.actualBalance), reveal = p.get(M.revealAmount);
+        gAssertLessEqThanF(p, AB8, intended, prm.maxIntended);
+        gAssertLessEqThanF(p, AB8, actual, prm.maxActual);
+        gAssertLessEqThanF(p, AB8, intended, actual);
+        S relax = p.get(M.byteSecurityRelax);
+        gAssertLessEqThanS(p, 16, (S)((uint32_t)relax * 2u), (S)prm.minNib);
+        gAssertGreaterEqThanS(p, 16, p.get(M.numLeafAddressNibbles), (S)((uint32_t)prm.minNib - (uint32_t)relax * 2u));
+        gAssertBitsF(p, AB8, reveal);
+        gAssertLessEqThanF(p, AB8, reveal, intended);
+    } break;
+    case U_POB_POSEIDONS: {      // :113, :116
+        F bk = p.get(M.burnKey);
+        F in3[3] = {L.prefix[2], bk, fr_sub(p.get(M.intendedBalance), p.get(M.revealAmount))};
+        p.put(M.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
+        F in2[2] = {L.prefix[1], bk};
+        p.put(M.nullifier, gPoseidon<P, 3>(p, pos_off(3), in2));
+    } break;
+    case U_BAH_PRE: {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
+        F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
+        SmRef ab = gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec);
+        for (int i = 0; i < 20; i++) p.put(L.bah.addressBytes + i, p.get(ab + i));
+        SmRef f = gFitS(p, 20, 136, L.bah.addressBytes);
+        for (int i = 0; i < 136; i++) p.put(L.bah.block + i, p.get(f + i));
+        KBRefs r = L.kbs[L.bah.kb];
+        kb_head(p, 1, (S)20, r);
+        if (P::is_count) L.kbs[L.bah.kb] = r;
+    } break;
+    case U_POB_N2B: {            // :132-136  Num2BigEndianBytes(32) of nullifier, remainingCoin, revealAmount, burnExtraCommitment, _proofExtraCommitment
+        const int j = d.a[0];
+        FrRef src = j == 0 ? M.nullifier : j == 1 ? M.remainingCoin : j == 2 ? M.revealAmount : j == 3 ? M.burnExtraCommitment : M.proofExtraCommitment;
+        SmRef dst = j == 0 ? M.nullifierBytes : j == 1 ? M.remainingCoinBytes : j == 2 ? M.revealAmountBytes : j == 3 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
+        SmRef r = gNum2BigEndianBytesF(p, 32, p.get(src));
+        for (int i = 0; i < 32; i++) p.put(dst + i, p.get(r + i));
+    } break;
+    case U_PC_POST: {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
+        SmRef f = gFitS(p, 32, 31, L.pc.hash);
+        for (int i = 0; i < 31; i++) p.put(L.pc.reduced + i, p.get(f + i));
+        F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
+        p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
+    } break;
+    case U_POB_LAYER_POST: {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
+                                 // AssertLessEqThan x2, LittleEndianBytes2Num(sl); AssertByteString(mm) runs as U_ABS_RANGE units
+        const int i = d.a[0];
+        SmRef f = gFitS(p, 32, 31, M.layerKeccaks + 32 * i);
+        for (int k = 0; k < 31; k++) p.put(M.reducedLayerKeccaks + (31 * i + k), p.get(f + k));
+        if (i > 0) {
+            ScRefs sc = L.scs[i];
+            const int mm = LB, sl = 31, kk = mm - sl + 1;
+            sc.out = p.bits(1); sc.mi = p.sms(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
+            sc.num = p.frs(1); sc.M = p.frs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
+            for (int k = 0; k < mm; k++) p.put(sc.mi + k, p.get(M.layers + ((i - 1) * LB + k)));
+            S mainLen = p.put(sc.ml, p.get(M.layerLens + (i - 1)));
+            for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
+            sc.c_abs_sub = p.cur;
+            gAssertByteString(p, sl, sc.si);
+            sc.abs_main_in = p.sms(mm);
+            sc.c_abs_main = p.cur;
+            p.cur = cur_add(p.cur, FP_ABITS8, mm);
+            sc.c_after_abs = p.cur;
+            gAssertLessEqThanS(p, 16, mainLen, (S)mm);
+            gAssertLessEqThanS(p, 16, (S)sl, mainLen);
+            p.put(sc.num, gLittleEndianBytes2NumF(p, sl, sc.si));
+            sc.c_loop = p.cur;
+            p.cur = cur_add(cur_add(p.cur, FP_ISEQ_S, kk), FP_ISEQ_F, kk);
+            sc.c_tail = p.cur;
+            p.cur = cur_add(p.cur, Cur{3, 1, 2, 0}, 1);            // the final IsZero
+            if (P::is_count) L.scs[i] = sc;
+        }
+    } break;
+    case U_SC_M: {               // M[i+1] <== mainInput[i]*256^i + M[i]  (substring_check.circom:45-49); reads the source bytes;
+                                 // 256^i comes from a table in "double Montgomery" form so that byte * 256^i is ONE Montgomery product
+        const ScRefs& sc = L.scs[d.a[0]];
+        F acc = p.put(sc.M, fr_zero());
+        for (int k = 0; k < LB; k++) {
+            Fr b = {{(uint32_t)p.get(M.layers + ((d.a[0] - 1) * LB + k)), 0, 0, 0, 0, 0, 0, 0}};
+            acc = p.put(sc.M + k + 1, fr_add(fr_mul(b, p.k256r(k)), acc));
+        }
+    } break;
+    case U_SC_RANGE: {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
+        const ScRefs& sc = L.scs[d.a[0]];
+        const uint32_t lo = d.a[1], hi = d.a[2], sl = 31;
+        const S mainLen = p.get(sc.ml);
+        const F subNum = p.get(sc.num);
+        // FR wires of position i's IsEqual(exists): 0 = in[0], 1 = in[1], 2 = isz.in, 3 = isz.inv
+        auto fref = [&](uint32_t i, uint32_t which) {
+            Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i + 1), FP_ISEQ_F, i);
+            FrRef r = {c.w + 1 + which + (which >= 2 ? 1u : 0u), c.f + which};
+            return r;
+        };
+        if (P::is_gen) {         // Montgomery batch inversion over this range, scratch = the witness' own isz.in / isz.inv slots
+            F run = fr_one_mont();
+            for (uint32_t i = lo; i < hi; i++) {
+                F dd = fr_sub(fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), fr_mul(subNum, p.k256(i)));
+                p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
+                if (!fr_is_zero(dd)) run = fr_mul(run, dd);
+            }
+            F inv = fr_inv(run);
+            for (uint32_t i = hi; i-- > lo;) {
+                F dd = p.get(fref(i, 2)), pre = p.get(fref(i, 3));
+                const bool z = fr_is_zero(dd);
+                p.raw_put(fref(i, 3), z ? fr_zero() : fr_mul(inv, pre));
+                if (!z) inv = fr_mul(inv, dd);
+            }
+        }
+        // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
+        const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
+        B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
+        for (uint32_t i = lo; i < hi; i++) {
+            p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
+            B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
+            allowed = p.put(sc.alw + i + 1, allowed & ~last);
+            p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, p.k256(i)), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
+        }
+    } break;
+    case U_RL_ACC: {             // RlpEmptyAccount(AB)(balance) (rlp/empty_account.circom:20-134) + copy into the leaf's own wires (:153-155)
+        const RlRefs& R = L.rl;
+        const int maxAcc = 4 + prm.amountBytes + 66;
+        S al;
+        SmRef r = gRlpEmptyAccount(p, prm.amountBytes, p.get(M.actualBalance), al);
+        for (int i = 0; i < maxAcc; i++) p.put(R.acc + i, p.get(r + i));
+        p.put(R.accLen, al);
+    } break;
     case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
         F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
         p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
@@ -541,29 +676,6 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
         KBRefs kr = L.kbs[L.pw.kb];
         kb_head(p, 1, (S)104, kr);
         if (P::is_count) L.kbs[L.pw.kb] = kr;
-        const Cur after = p.cur;
-        kb_range(p, kr, L.pw.block, 0, 136);
-        p.cur = after;
-    } break;
-    case U_POW_POST: {           // :73-79
-        BitRef f = gFilter(p, 32, p.get(L.pw.mzb));
-        for (int i = 0; i < 32; i++) {
-            B z = p.put(L.pw.sbz + i, p.get(f + i));
-            p.require(p.ballot(p.get(L.pw.keccak + i) == 0) | ~z, FAILCODE(T_POW, 79));
-        }
-    } break;
-    case U_POB_FINAL: {          // :186, :188, :191-193, :203-206
-        S cnt = 0;
-        for (int i = 0; i < prm.L; i++) cnt += (S)p.bit(p.get(M.isLeaf + i));
-        p.require(p.ballot(cnt == 1), FAILCODE(T_POB, 186));
-        p.require(p.get(M.isLastLayerLeaf), FAILCODE(T_POB, 188));
-        bool ok = true;
-        for (int i = 0; i < 32; i++) ok = ok && (p.get(M.layerKeccaks + i) == p.get(M.stateRoot + i));
-        p.require(p.ballot(ok), FAILCODE(T_POB, 192));
-        ok = true;
-        for (int i = 0; i < 139; i++) ok = ok && (p.get(M.leaf + i) == p.get(M.lastLayer + i));
-        p.require(p.ballot(ok), FAILCODE(T_POB, 204));
-        p.require(p.ballot(p.get(M.leafLen) == p.get(M.lastLayerLen)), FAILCODE(T_POB, 206));
     } break;
     case U_SP_INPUT: {
         p.put(L.sm.burnKey, p.input_fr(0)); p.put(L.sm.balance, p.input_fr(1));
@@ -587,6 +699,9 @@ template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
     } break;
     default: break;
     }
+}
+template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
+    if (unit_is_heavy(d.kind)) unit_run_heavy(p, d, L); else unit_run_light(p, d, L);
 }
 
 // ---------------------------------------------------------------------------- host planner
@@ -653,13 +768,29 @@ struct Plan {
         for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage + 1, start, kb, src.w, src.i, lo, std::min(lo + 16, m));
         keccak_tail(kb, stage + 1, dst, true);
     }
+    // byte-range units of a KeccakBytes whose head ran inside another unit at `head_stage`
+    void kb_ranges(uint32_t kb, uint32_t stage, SmRef src) {
+        const uint32_t m = 136 * L.kbs[kb].mb;
+        for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage, p.cur, kb, src.w, src.i, lo, std::min(lo + 16, m));
+    }
+    // LeafDetector(N)(src, len) -> dst, as head (stage), 4 selectors x ranges (stage+1), tail (stage+2)
+    void leaf_detector(uint32_t inst, uint32_t stage, SmRef src, SmRef len, BitRef dst) {
+        const uint32_t N = 136 * L.pob.NB;
+        CountP chk; chk.cur = p.cur; gLeafDetector(chk, (int)N, src, 0);
+        L.lds[inst].src = src; L.lds[inst].len_src = len; L.lds[inst].dst = dst;
+        unit(U_LD_HEAD, stage, inst);
+        expect_cursor("LeafDetector", p.cur, chk.cur);
+        for (uint32_t k = 0; k < 4; k++) for (uint32_t lo = 0; lo < N; lo += 136) record(U_LD_SELR, stage + 1, p.cur, inst, k, lo, std::min(lo + 136, N));
+        record(U_LD_TAIL, stage + 2, p.cur, inst);
+    }
     void public_commitment(int N, uint32_t pre_stage) {   // public_commitment.circom:18-42
         L.pc.N = N; L.pc.nb = N * 32 / 136 + ((N * 32) % 136 != 0);
         L.pc.out = p.frs(1); L.pc.in = p.sms(32 * N); L.pc.flat = p.sms(32 * N); L.pc.block = p.sms(136 * L.pc.nb); L.pc.hash = p.sms(32); L.pc.reduced = p.sms(31);
         L.pc.kb = L.nkb++; L.kbs[L.pc.kb].mb = L.pc.nb;
         unit(U_PC_PRE, pre_stage);
-        keccak_tail(L.pc.kb, pre_stage, L.pc.hash, true);
-        unit(U_PC_POST, pre_stage + 3);
+        kb_ranges(L.pc.kb, pre_stage + 1, L.pc.block);
+        keccak_tail(L.pc.kb, pre_stage + 1, L.pc.hash, true);
+        unit(U_PC_POST, pre_stage + 4);
     }
 
     void plan_pob(const PobParams& prm) {
@@ -681,6 +812,7 @@ struct Plan {
 
         // stages: 0 inputs | 1 heads, byte asserts, selectors, leaf detectors | 2 KeccakBytes byte ranges, embedded pre parts
         //         | 3 sponges A | 4 output selector rows, posts | 5 consumers | 6 sponge B, ... | 10 final ===
+        unit(U_POB_INPUT_FR, 0);
         for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
         unit(U_POB_RANGE, 1);
         for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, 1, i); abs_units(1, LB, M.layers + i * LB); }
@@ -689,14 +821,15 @@ struct Plan {
         {   // BurnAddressHash :119
             L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
             L.bah.kb = L.nkb++;
-            unit(U_BAH_PRE, 2);
+            unit(U_BAH_PRE, 1);
+            kb_ranges(L.bah.kb, 2, L.bah.block);
             keccak_tail(L.bah.kb, 2, L.bah.hash, true);
             unit(U_BAH_POST, 5);
         }
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 1, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122
         for (int j = 0; j < 5; j++) unit(U_POB_N2B, 2, j);                                      // :132-136
-        public_commitment(6, 5);                                                                // :137  (pre 5, sponge 6, rows/post 7, commitment 8)
+        public_commitment(6, 5);                                                                // :137  (pre 5, ranges 6, sponge 7, rows/post 8, commitment 9)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
             CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
             L.ll.out = p.sms(LB); L.ll.arr = p.sms(Ln * LB); L.ll.sel = p.sms(1); L.ll.T = p.sms(LB * Ln);
@@ -711,7 +844,7 @@ struct Plan {
         L.kb_layer0 = L.nkb; L.nkb += Ln;
         L.nsc = Ln;
         for (int i = 0; i < Ln; i++) {                                                          // :157-181
-            unit(U_POB_LEAF, 1, i);
+            leaf_detector(i, 1, M.layers + i * LB, M.layerLens + i, M.isLeaf + i);
             keccak_bytes(L.kb_layer0 + i, prm.NB, 1, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i);
             const Cur start = p.cur;
             unit(U_POB_LAYER_POST, 5, i);
@@ -724,11 +857,11 @@ struct Plan {
                     record(U_ABS_RANGE, 5, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
                 record(U_SC_M, 5, start, i);
                 const uint32_t kk = LB - 31 + 1;
-                for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
+                for (uint32_t lo = 0; lo < kk; lo += 128) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 128, kk));
                 record(U_SC_SUMS, 7, sc.c_tail, i);
             }
         }
-        unit(U_POB_LASTLEAF, 2);                                                                // :187 (lastLayer is written in stage 1)
+        leaf_detector(Ln, 2, M.lastLayer, M.lastLayerLen, M.isLastLayerLeaf);                    // :187 (lastLayer is written in stage 1)
         {   // RlpMerklePatriciaTrieLeaf :198  (needs addressHashNibbles, written in stage 5)
             const Cur start = p.cur;
             CountP chk; chk.cur = start; { S ll; gRlpMptLeaf(chk, 32, prm.amountBytes, M.addressHashNibbles, 0, fr_zero(), ll); }
@@ -754,7 +887,8 @@ struct Plan {
             L.pw.in = p.frs(3); L.pw.mzb = p.sms(1); L.pw.keyBytes = p.sms(32); L.pw.raBytes = p.sms(32); L.pw.becBytes = p.sms(32); L.pw.eip = p.sms(8);
             L.pw.hin = p.sms(104); L.pw.block = p.sms(136); L.pw.keccak = p.sms(32); L.pw.sbz = p.bits(32);
             L.pw.kb = L.nkb++;
-            unit(U_POW_PRE, 2);
+            unit(U_POW_PRE, 1);
+            kb_ranges(L.pw.kb, 2, L.pw.block);
             keccak_tail(L.pw.kb, 2, L.pw.keccak, true);
             unit(U_POW_POST, 5);
         }

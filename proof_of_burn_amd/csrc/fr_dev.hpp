@@ -79,7 +79,8 @@ HD Fr fr_sub(const Fr& a, const Fr& b) {
 HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
 
 // Montgomery product a*b*2^-256 mod p, CIOS over 32-bit limbs.
-HDN Fr fr_mul(const Fr& a, const Fr& b) {
+// by value: a non-inlined call passes the operands in 16 VGPRs and returns in 8 (by-reference would go through scratch)
+HDN Fr fr_mul(Fr a, Fr b) {
     const uint32_t P[8] = FR_P_LIMBS;
     uint32_t t[10];
 #pragma unroll
@@ -112,7 +113,7 @@ HD Fr fr_from_i64(int64_t k) {
     return k < 0 ? fr_neg(m) : m;
 }
 // x^(p-2) by square-and-multiply over the fixed exponent; 0 -> 0.
-HDN Fr fr_inv(const Fr& a) {
+HDN Fr fr_inv(Fr a) {
     const uint32_t P[8] = FR_P_LIMBS;
     Fr acc = fr_one_mont();
     for (int i = 253; i >= 0; i--) {

@@ -4,19 +4,19 @@
 
 extern __shared__ uint32_t g_lds[];
 
-template <class P> __global__ void __launch_bounds__(64) g_units(GArgs A) {
+template <class P, bool HEAVY> __global__ void __launch_bounds__(64) g_units(GArgs A) {
     const uint32_t lane = threadIdx.x;
     const uint32_t g = P::is_emit ? A.emit_group : blockIdx.y;
     P p;
     p.m.bits = A.bits + (uint64_t)g * A.bits_stride;
     p.m.sm = A.sm + (uint64_t)g * A.sm_stride;
     p.m.fr = A.fr + (uint64_t)g * A.fr_stride;
-    p.m.inv_lut = A.inv_lut;
+    p.m.inv_lut = A.inv_lut; p.m.pow256 = A.pow256; p.m.npow256 = A.npow256;
     p.m.nfr_in = A.nfr_in; p.m.nsm_in = A.nsm_in;
     p.m.in_fr = A.in_fr + (uint64_t)g * 64 * A.nfr_in * 32;
     p.m.in_sm = A.in_sm + (uint64_t)g * 64 * A.nsm_in;
     p.m.lane = lane;
-    if (A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
+    if (HEAVY && A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
         for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];
         __syncthreads();
         p.m.pos_tab = g_lds;
@@ -25,7 +25,7 @@ template <class P> __global__ void __launch_bounds__(64) g_units(GArgs A) {
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; }
     const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];
-    unit_run<P>(p, d, *A.L);
+    if constexpr (HEAVY) unit_run_heavy<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
     if constexpr (P::is_gen) { if (p.status) atomicMin(&A.status[g * 64 + lane], p.status); }
     if constexpr (P::is_check) {
         if (p.status) atomicMin(&A.chk_status[g * 64 + lane], p.status);

@@ -13,7 +13,7 @@
 #include "policy.hpp"
 
 #ifdef __HIPCC__
-#define GD __host__ __device__
+#define GD __host__ __device__ __forceinline__   // the policy object must stay in registers: one non-inlined callee taking P& forces it (and every p.cur/p.m access) through memory
 #else
 #define GD
 #endif

@@ -13,7 +13,7 @@ struct GArgs {
     CircuitLayout* L;                                  // read-only on the device (only the host planner writes reference tables)
     uint64_t* bits; int32_t* sm; uint32_t* fr;
     uint64_t bits_stride, sm_stride, fr_stride;       // elements per group
-    const uint32_t* pos_tab; const uint32_t* inv_lut;
+    const uint32_t* pos_tab; const uint32_t* inv_lut; const uint32_t* pow256; uint32_t npow256;
     const uint8_t* in_fr; const int32_t* in_sm; uint32_t nfr_in, nsm_in;
     uint32_t* status; uint32_t* chk_status; uint32_t* bad_wire;
     uint8_t* emit_out; uint32_t emit_sel, emit_group;
@@ -30,9 +30,13 @@ struct KArgs {
 };
 
 // grid = (nunits, ngroups) wavefronts; lds = bytes of dynamic LDS (Poseidon table) or 0
-void launch_g_gen(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_check(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_emit(const GArgs& A, uint32_t nunits, hipStream_t st);
+void launch_g_gen(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit(const GArgs& A, bool heavy, uint32_t nunits, hipStream_t st);
+void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_gen_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);

@@ -44,14 +44,15 @@ struct pob_ctx {
     uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr;
     UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
-    uint32_t *d_pos = nullptr, *d_inv = nullptr;
+    uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
     uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr; uint8_t* d_outputs = nullptr;
     uint8_t* d_emit = nullptr;
     // schedule
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
-    std::vector<Seg> segs;
+    std::vector<Seg> segs, all_segs;                   // per (stage, lds) for generation; all units at once for check/emit
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
     std::vector<KSeg> ksegs;
     uint32_t nperms = 0;
@@ -60,7 +61,14 @@ struct pob_ctx {
 
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
-static bool unit_uses_poseidon(uint32_t kind) { return kind == U_POB_POSEIDONS || kind == U_BAH_PRE || kind == U_SP_HEAD; }
+void launch_g_gen(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+    if (heavy) launch_g_gen_heavy(A, nunits, ngroups, st); else launch_g_gen_light(A, nunits, ngroups, st);
+}
+void launch_g_check(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+    if (heavy) launch_g_check_heavy(A, nunits, ngroups, st); else launch_g_check_light(A, nunits, ngroups, st);
+}
+// unit class: 0 = light, 1 = heavy, 2 = heavy + Poseidon table in LDS
+static uint32_t unit_class(uint32_t kind) { return unit_uses_lds(kind) ? 2 : unit_is_heavy(kind) ? 1 : 0; }
 
 static Fr limbs_to_mont(const uint64_t* l) {
     Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
@@ -72,7 +80,7 @@ static GArgs gargs(pob_ctx* h) {
     A.units = h->d_units; A.order = h->d_order; A.L = h->d_L;
     A.bits = h->d_bits; A.sm = h->d_sm; A.fr = h->d_fr;
     A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
-    A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.in_fr = h->d_in_fr; A.in_sm = h->d_in_sm;
+    A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr; A.in_sm = h->d_in_sm;
     A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
     A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
     return A;
@@ -142,10 +150,10 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [](const SpongeDesc& a, const SpongeDesc& b) { return a.stage < b.stage; });
     std::vector<uint32_t> perm_sponge, perm_block;
     for (uint32_t s = 0; s <= pl.max_stage; s++) {
-        for (uint32_t lds = 0; lds < 2; lds++) {
+        for (uint32_t lds = 3; lds-- > 0;) {              // heavy (Fr) units first: they run on the second stream beside the light ones
             pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
             for (uint32_t u = 0; u < pl.units.size(); u++)
-                if (pl.units[u].stage == s && (uint32_t)unit_uses_poseidon(pl.units[u].kind) == lds) h->order.push_back(u);
+                if (pl.units[u].stage == s && unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
             sg.count = (uint32_t)h->order.size() - sg.first;
             if (sg.count) h->segs.push_back(sg);
         }
@@ -160,9 +168,17 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         if (ks.sp_count) h->ksegs.push_back(ks);
     }
     h->nperms = (uint32_t)perm_sponge.size();
+    for (uint32_t lds = 0; lds < 3; lds++) {             // every unit once, grouped only by class (constraint evaluation / emission)
+        pob_ctx::Seg sg{0, lds, (uint32_t)h->order.size(), 0};
+        for (uint32_t u = 0; u < pl.units.size(); u++) if (unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
+        sg.count = (uint32_t)h->order.size() - sg.first;
+        if (sg.count) h->all_segs.push_back(sg);
+    }
 
     HIPC(hipSetDevice(device));
     HIPC(hipStreamCreate(&h->stream));
+    HIPC(hipStreamCreate(&h->stream2));
+    HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
@@ -175,6 +191,15 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_perm_block, std::max<size_t>(h->nperms, 1) * 4));
     HIPC(hipMalloc(&h->d_pos, sizeof(POS_TABLE_MONT)));
     HIPC(hipMalloc(&h->d_inv, 8193 * 32));
+    {   // 256^i (Montgomery) and 256^i * R^2 for i < 136*NB (SubstringCheck's M[] / exists[], substring_check.circom:45-49,91)
+        h->npow256 = 136u * (uint32_t)std::max(pl.L.pob.NB, 1);
+        std::vector<Fr> tab(2 * (size_t)h->npow256);
+        const Fr c256 = fr_from_i64(256);
+        Fr pw = fr_one_mont();
+        for (uint32_t i = 0; i < h->npow256; i++) { tab[i] = pw; tab[h->npow256 + i] = fr_to_mont(pw); pw = fr_mul(pw, c256); }
+        HIPC(hipMalloc(&h->d_pow256, tab.size() * sizeof(Fr)));
+        HIPC(hipMemcpy(h->d_pow256, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    }
     HIPC(hipMalloc(&h->d_in_fr, npad * (uint64_t)pl.nfr_in * 32));
     HIPC(hipMalloc(&h->d_in_sm, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
     HIPC(hipMalloc(&h->d_status_raw, npad * 4)); HIPC(hipMalloc(&h->d_status, npad * 4));
@@ -202,9 +227,12 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_emit};
+                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_emit};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->stream2) hipStreamDestroy(h->stream2);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -233,10 +261,17 @@ int pob_generate(pob_handle h, void* stream_) {
     KArgs K = kargs(h);
     size_t si = 0, ki = 0;
     for (uint32_t s = 0; s <= h->plan.max_stage; s++) {
+        // heavy (BN254) units run on the second stream beside the stage's light units; the Poseidon ones stage their table in LDS
+        bool forked = false;
         for (; si < h->segs.size() && h->segs[si].stage == s; si++) {
-            A.first = h->segs[si].first; A.stage_lds = h->segs[si].lds;
-            launch_g_gen(A, h->segs[si].count, G, st);
+            A.first = h->segs[si].first; A.stage_lds = h->segs[si].lds == 2;
+            if (h->segs[si].lds) {
+                if (!forked) { HIPC(hipEventRecord(h->ev_fork, st)); HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
+                launch_g_gen(A, true, h->segs[si].count, G, h->stream2);
+                forked = true;
+            } else launch_g_gen(A, false, h->segs[si].count, G, st);
         }
+        if (forked) { HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); }
         for (; ki < h->ksegs.size() && h->ksegs[ki].stage == s; ki++) {
             K.first = h->ksegs[ki].sp_first;
             launch_k_chain(K, false, h->ksegs[ki].sp_count, G, st);
@@ -259,16 +294,24 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
-    for (const pob_ctx::Seg& sg : h->segs) {
-        A.first = sg.first; A.stage_lds = sg.lds;
-        launch_g_check(A, sg.count, G, st);
+    bool forked = false;
+    for (size_t k = h->all_segs.size(); k-- > 0;) {      // no dependencies between units here: one launch per class, heavy ones on stream 2
+        const pob_ctx::Seg& sg = h->all_segs[k];
+        A.first = sg.first; A.stage_lds = sg.lds == 2;
+        if (sg.lds) {
+            if (!forked) { HIPC(hipEventRecord(h->ev_fork, st)); HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
+            launch_g_check(A, true, sg.count, G, h->stream2);
+            forked = true;
+        } else launch_g_check(A, false, sg.count, G, st);
     }
+    if (forked) HIPC(hipEventRecord(h->ev_join, h->stream2));
     KArgs K = kargs(h);
     if (!h->plan.sponges.empty()) {
         K.first = 0;
         launch_k_chain(K, true, h->nperms, G, st);
         launch_k_rounds(K, true, h->nperms, G, st);
     }
+    if (forked) HIPC(hipStreamWaitEvent(st, h->ev_join, 0));
     HIPC(hipGetLastError());
     return POB_OK;
 }
@@ -311,9 +354,9 @@ static int emit_to_device(pob_ctx* h, uint32_t idx) {
     HIPC(hipMemcpyAsync(h->d_emit, one, 32, hipMemcpyHostToDevice, st));   // wire 0 = 1
     GArgs A = gargs(h);
     A.emit_out = h->d_emit; A.emit_sel = idx % 64; A.emit_group = idx / 64;
-    for (const pob_ctx::Seg& sg : h->segs) {
-        A.first = sg.first; A.stage_lds = sg.lds;
-        launch_g_emit(A, sg.count, st);
+    for (const pob_ctx::Seg& sg : h->all_segs) {
+        A.first = sg.first; A.stage_lds = sg.lds == 2;
+        launch_g_emit(A, sg.lds != 0, sg.count, st);
     }
     const u64* Gp = (const u64*)h->d_bits + (uint64_t)(idx / 64) * h->plan.total.b;
     for (const SpongeDesc& s : h->plan.sponges) {
@@ -381,9 +424,9 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
         if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
         else if (which == 1) launch_k_rounds(K, true, h->nperms, G, st);
         else if (which == 2) {
-            for (const pob_ctx::Seg& sg : h->segs) {
-                A.first = sg.first; A.stage_lds = sg.lds;
-                launch_g_check(A, sg.count, G, st);
+            for (const pob_ctx::Seg& sg : h->all_segs) {
+                A.first = sg.first; A.stage_lds = sg.lds == 2;
+                launch_g_check(A, sg.lds != 0, sg.count, G, st);
             }
         } else launch_k_chain(K, false, (uint32_t)h->plan.sponges.size(), G, st);
     }

@@ -72,6 +72,8 @@ struct CountP : PolBase {
     HD bool bit(B) { return false; }
     HD void require(B, uint32_t) {}
     HD F kconst(uint32_t) { return fr_zero(); }   // Poseidon table entry (Montgomery)
+    HD F k256(uint32_t) { return fr_zero(); }     // 256^i (Montgomery)
+    HD F k256r(uint32_t) { return fr_zero(); }    // 256^i * R (so that fr_mul(plain small integer, k256r(i)) is Montgomery(small * 256^i))
     HD F input_fr(uint32_t) { return fr_zero(); }
     HD S input_sm(uint32_t) { return 0; }
     HD uint32_t lane_id() { return 0; }
@@ -85,9 +87,10 @@ struct DevMem {
     uint32_t* fr;       // this group's FR slab  [NF][8][64]
     const uint32_t* pos_tab;  // Poseidon table (Montgomery, [idx][8]) -- LDS copy when staged
     const uint32_t* inv_lut;  // canonical inverses of -4096..4096, [k+4096][8]
+    const uint32_t* pow256;   // [2][n][8]: 256^i in Montgomery form, then 256^i * R^2 mod p
     const uint8_t* in_fr;     // this group's packed inputs: FR inputs [64 lanes][nfr][32 B canonical LE]
     const int32_t* in_sm;     //                              SM inputs [64 lanes][nsm]
-    uint32_t nfr_in, nsm_in;
+    uint32_t nfr_in, nsm_in, npow256;
     uint32_t lane;
 };
 
@@ -122,6 +125,13 @@ struct DevPol : PolBase {
         for (int k = 0; k < 8; k++) v.l[k] = q[k];
         return v;
     }
+    __device__ __forceinline__ F k256(uint32_t i) {
+        F v; const uint32_t* q = m.pow256 + (size_t)i * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = q[k];
+        return v;
+    }
+    __device__ __forceinline__ F k256r(uint32_t i) { return k256(i + m.npow256); }
     __device__ __forceinline__ F input_fr(uint32_t k) {   // canonical LE bytes -> Montgomery
         const uint32_t* q = (const uint32_t*)(m.in_fr + ((size_t)m.lane * m.nfr_in + k) * 32);
         F c;
@@ -152,9 +162,11 @@ struct CheckP : DevPol {
     uint32_t status;     // first failing === site of this lane
     uint32_t bad_wire;   // lowest wire index whose stored value contradicts its definition (per lane)
     __device__ __forceinline__ void mark(bool bad, uint32_t w) { if (bad && w < bad_wire) bad_wire = w; }
-    __device__ __forceinline__ B put(BitRef r, B v) { B s = ld(r); mark(((s ^ v) >> m.lane) & 1, r.w); return s; }
-    __device__ __forceinline__ S put(SmRef r, S v) { S s = ld(r); mark(s != v, r.w); return s; }
-    __device__ __forceinline__ F put(FrRef r, const F& v) { F s = ld(r); mark(!fr_eq(s, v), r.w); return s; }
+    // put returns the EXPECTED value: if the stored wire equals it they are interchangeable, if not the witness is already
+    // flagged -- so the loads are off the dependency chain and many can be in flight.
+    __device__ __forceinline__ B put(BitRef r, B v) { B s = ld(r); mark(((s ^ v) >> m.lane) & 1, r.w); return v; }
+    __device__ __forceinline__ S put(SmRef r, S v) { S s = ld(r); mark(s != v, r.w); return v; }
+    __device__ __forceinline__ F put(FrRef r, const F& v) { F s = ld(r); mark(!fr_eq(s, v), r.w); return v; }
     __device__ __forceinline__ B hint(BitRef r, B) { return ld(r); }
     __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
