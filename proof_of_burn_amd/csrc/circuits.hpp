@@ -24,7 +24,7 @@ enum UnitKind : uint32_t {
     U_POB_INPUT = 1, U_POB_RANGE, U_POB_LAYER_ASSERT, U_POB_HDR_ASSERT, U_POB_POSEIDONS, U_BAH_PRE, U_BAH_POST,
     U_KB_HEAD, U_KB_RANGE, U_KB_SELROW, U_KB_POST, U_POB_N2B, U_PC_PRE, U_PC_POST, U_POB_LASTLAYER, U_POB_LASTLAYER_RANGE,
     U_POB_LASTLEN, U_POB_LEAF, U_POB_LAYER_POST, U_SC_M, U_SC_RANGE, U_SC_SUMS, U_POB_LASTLEAF,
-    U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE, U_LD_HEAD, U_LD_SELR, U_LD_TAIL, U_POB_INPUT_FR,
+    U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE, U_LD_HEAD, U_LD_SELR, U_LD_TAIL, U_POB_INPUT_FR, U_RL_ACC_B, U_RL_ACC_C,
     U_SP_INPUT, U_SP_HEAD
 };
 
@@ -86,6 +86,12 @@ struct LdRefs {
     Cur c_sel[4], c_eq[4], c_mand, c_end;
     SmRef src, len_src; BitRef dst;
 };
+// RlpEmptyAccount(mb) (rlp/empty_account.circom:20-134) and its RlpInteger(mb) (rlp/integer.circom:67-110), cut in three units
+struct RaRefs {
+    SmRef ea_o, ea_ol; FrRef ea_ib; SmRef pn, pnl, br, brl, nbl, sc;                          // RlpEmptyAccount own
+    SmRef ri_o, ri_ol; FrRef ri_i; SmRef by, len, be; BitRef isb, isz; SmRef frb;             // RlpInteger own
+    Cur c_cb, c_sl, c_lt, c_concat, c_end;
+};
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
 struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; };
 
@@ -102,6 +108,7 @@ struct CircuitLayout {
     struct { FrRef in; SmRef mzb, keyBytes, raBytes, becBytes, eip, hin, block, keccak; BitRef sbz; uint32_t kb; } pw;
     struct { SmRef out, arr, sel, T; Cur c_sel0; } ll;                   // SelectorArray1D(L, 136*NB) of :142
     RlRefs rl;
+    RaRefs ra;
     uint32_t kb_hdr, kb_layer0, nkb, nsc;
     KBRefs kbs[MAX_KB];
     ScRefs scs[MAX_SC];
@@ -466,6 +473,35 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
             p.put(R.s_o + i, acc);
         }
     } break;
+    case U_RL_ACC_B: {           // CountBytes(N) (integer.circom:16-49) and ShiftLeft(N) (:85) of RlpInteger
+        const RaRefs& A = L.ra;
+        const int N = prm.amountBytes;
+        p.cur = A.c_cb;
+        const S length = p.put(A.len, gCountBytes(p, N, A.by));
+        SmRef r = gShiftLeft(p, N, A.by, N - length);
+        for (int j = 0; j < N; j++) p.put(A.be + j, p.get(r + j));
+    } break;
+    case U_RL_ACC_C: {           // RlpInteger outputs (:96-109), RlpEmptyAccount prefixes + Concat(4+N, 66) (empty_account.circom:40-133)
+        const RaRefs& A = L.ra;
+        const RlRefs& R = L.rl;
+        const int N = prm.amountBytes, maxAcc = 4 + N + 66;
+        const bool sb = p.bit(p.get(A.isb)), zb = p.bit(p.get(A.isz));
+        const S first = p.get(A.frb), length = p.get(A.len);
+        p.put(A.pn + 2, 0x80);
+        p.put(A.pn + 3, p.put(A.br, p.put(A.ri_o, first + (zb ? 0x80 : 0))));
+        for (int j = 1; j < N + 1; j++) p.put(A.pn + 3 + j, p.put(A.br + j, p.put(A.ri_o + j, sb ? 0 : p.get(A.be + (j - 1)))));
+        const S blen = p.put(A.brl, p.put(A.ri_ol, (sb ? 0 : 1) + length + (zb ? 1 : 0)));
+        const S nb = p.put(A.nbl, 1 + blen);
+        const S pl = p.put(A.pnl, 2 + nb);
+        for (int j = 0; j < 66; j++) p.put(A.sc + j, (S)empty_account_tail(j));
+        p.put(A.pn, 0xf8);
+        p.put(A.pn + 1, nb + 66);
+        p.cur = A.c_concat;
+        S clen;
+        SmRef cc = gConcat(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen);
+        for (int j = 0; j < maxAcc; j++) p.put(R.acc + j, p.put(A.ea_o + j, p.get(cc + j)));
+        p.put(R.accLen, p.put(A.ea_ol, clen));
+    } break;
     case U_RL_B: {               // rest of TruncatedAddressHash (:62-90), AssertGreaterEqThan (:151), prefixes (:166-181), Concat (:183-188)
         const RlRefs& R = L.rl;
         const int ab = 32, n2 = 64, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
@@ -542,12 +578,15 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         gAssertBitsF(p, AB8, reveal);
         gAssertLessEqThanF(p, AB8, reveal, intended);
     } break;
-    case U_POB_POSEIDONS: {      // :113, :116
+    case U_POB_POSEIDONS: {      // :113 (a[0] = 0) remainingCoin = Poseidon3, :116 (a[0] = 1) nullifier = Poseidon2 -- two parallel units
         F bk = p.get(M.burnKey);
-        F in3[3] = {L.prefix[2], bk, fr_sub(p.get(M.intendedBalance), p.get(M.revealAmount))};
-        p.put(M.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
-        F in2[2] = {L.prefix[1], bk};
-        p.put(M.nullifier, gPoseidon<P, 3>(p, pos_off(3), in2));
+        if (d.a[0] == 0) {
+            F in3[3] = {L.prefix[2], bk, fr_sub(p.get(M.intendedBalance), p.get(M.revealAmount))};
+            p.put(M.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
+        } else {
+            F in2[2] = {L.prefix[1], bk};
+            p.put(M.nullifier, gPoseidon<P, 3>(p, pos_off(3), in2));
+        }
     } break;
     case U_BAH_PRE: {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
         F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
@@ -646,13 +685,30 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
             p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, p.k256(i)), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
         }
     } break;
-    case U_RL_ACC: {             // RlpEmptyAccount(AB)(balance) (rlp/empty_account.circom:20-134) + copy into the leaf's own wires (:153-155)
-        const RlRefs& R = L.rl;
-        const int maxAcc = 4 + prm.amountBytes + 66;
-        S al;
-        SmRef r = gRlpEmptyAccount(p, prm.amountBytes, p.get(M.actualBalance), al);
-        for (int i = 0; i < maxAcc; i++) p.put(R.acc + i, p.get(r + i));
-        p.put(R.accLen, al);
+    case U_RL_ACC: {             // RlpEmptyAccount/RlpInteger, field-element part: Num2BigEndianBytes(N)(balance), LessThan(8N), IsZero, Mux1
+                                 // (integer.circom:83,88-90); CountBytes/ShiftLeft and the byte assembly run as light units B and C
+        RaRefs A = L.ra;
+        const int N = prm.amountBytes;
+        A.ea_o = p.sms(70 + N); A.ea_ol = p.sms(1); A.ea_ib = p.frs(1);
+        A.pn = p.sms(4 + N); A.pnl = p.sms(1); A.br = p.sms(N + 1); A.brl = p.sms(1); A.nbl = p.sms(1); A.sc = p.sms(66);
+        F bal = p.put(A.ea_ib, p.get(M.actualBalance));
+        A.ri_o = p.sms(N + 1); A.ri_ol = p.sms(1); A.ri_i = p.frs(1); A.by = p.sms(N); A.len = p.sms(1); A.be = p.sms(N);
+        A.isb = p.bits(1); A.isz = p.bits(1); A.frb = p.sms(1);
+        F x = p.put(A.ri_i, bal);
+        SmRef r = gNum2BigEndianBytesF(p, N, x);
+        S lead = 0; bool still = true;
+        for (int j = 0; j < N; j++) { S b = p.put(A.by + j, p.get(r + j)); still = still && b == 0; lead += still; }
+        A.c_cb = p.cur;
+        { CountP q; q.cur = p.cur; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
+        p.cur = A.c_lt;
+        B single = p.put(A.isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
+        p.put(A.isz, gIsZeroF(p, x));
+        const S length = P::is_gen ? (S)N - lead : p.get(A.len);
+        p.put(A.frb, gMux1SF(p, 0x80 + length, x, single));
+        A.c_concat = p.cur;
+        { CountP q; q.cur = p.cur; S cl; gConcat(q, 4 + N, 66, A.pn, 0, A.sc, 0, cl); A.c_end = q.cur; }
+        p.cur = A.c_end;
+        if (P::is_count) L.ra = A;
     } break;
     case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
         F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
@@ -817,7 +873,8 @@ struct Plan {
         unit(U_POB_RANGE, 1);
         for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, 1, i); abs_units(1, LB, M.layers + i * LB); }
         unit(U_POB_HDR_ASSERT, 1); abs_units(1, HBy, M.blockHeader);
-        unit(U_POB_POSEIDONS, 1);
+        unit(U_POB_POSEIDONS, 1, 0);
+        unit(U_POB_POSEIDONS, 1, 1);
         {   // BurnAddressHash :119
             L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
             L.bah.kb = L.nkb++;
@@ -857,7 +914,7 @@ struct Plan {
                     record(U_ABS_RANGE, 5, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
                 record(U_SC_M, 5, start, i);
                 const uint32_t kk = LB - 31 + 1;
-                for (uint32_t lo = 0; lo < kk; lo += 128) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 128, kk));
+                for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
                 record(U_SC_SUMS, 7, sc.c_tail, i);
             }
         }
@@ -879,8 +936,17 @@ struct Plan {
             R.c_concat = q.cur;
             { S cl; gConcat(q, 2 + 1 + 33, 2 + 4 + prm.amountBytes + 66, R.pk, 0, R.val, 0, cl); }
             expect_cursor("RlpMerklePatriciaTrieLeaf", q.cur, chk.cur);
-            record(U_RL_ACC, 6, R.c_acc);
-            record(U_RL_B, 7, R.c_mux);
+            {   // RlpEmptyAccount: heavy part A (stage 6), CountBytes/ShiftLeft B (7), assembly C (8)
+                const Cur keep = p.cur;
+                p.cur = R.c_acc;
+                CountP qa; qa.cur = R.c_acc; { S al; gRlpEmptyAccount(qa, prm.amountBytes, fr_zero(), al); }
+                unit(U_RL_ACC, 6);
+                expect_cursor("RlpEmptyAccount", p.cur, qa.cur);
+                p.cur = keep;
+                record(U_RL_ACC_B, 7, L.ra.c_cb);
+                record(U_RL_ACC_C, 8, L.ra.c_concat);
+            }
+            record(U_RL_B, 9, R.c_mux);
             p.cur = chk.cur;
         }
         {   // ProofOfWorkChecker :211

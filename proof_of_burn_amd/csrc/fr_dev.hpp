@@ -112,16 +112,77 @@ HD Fr fr_from_i64(int64_t k) {
     Fr m = fr_to_mont(c);
     return k < 0 ? fr_neg(m) : m;
 }
-// x^(p-2) by square-and-multiply over the fixed exponent; 0 -> 0.
+// Field inversion, Montgomery in / Montgomery out, 0 -> 0.  Binary extended Euclid on 256-bit integers (shifts, adds,
+// compares only -- no multiplier): with x = a*R the loop finds y = x^-1 mod p, and Montgomery-multiplying y by R^3 gives
+// a^-1 * R.  Invariants  A*x = u, C*x = v (mod p); every step halves u or v, so <= 2*254 steps; lanes that are done idle
+// under predication and the wavefront leaves the loop when all 64 are done.  ~8x cheaper than the a^(p-2) ladder (380
+// Montgomery products), which matters for SubstringCheck's per-range batch inversions.
+#define FR_R3_LIMBS {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu}
+HD void fr256_shr1(uint32_t* a, uint32_t top) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+    a[7] = (a[7] >> 1) | (top << 31);
+}
+HD void fr256_halfmod(uint32_t* a) {            // a <- a/2 mod p
+    const uint32_t P[8] = FR_P_LIMBS;
+    uint32_t carry = 0;
+    if (a[0] & 1) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)a[i] + P[i]; a[i] = (uint32_t)c; c >>= 32; }
+        carry = (uint32_t)c;
+    }
+    fr256_shr1(a, carry);
+}
+HD void fr256_submod(uint32_t* a, const uint32_t* b) {   // a <- a - b mod p
+    const uint32_t P[8] = FR_P_LIMBS;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a[i] - b[i] - br; a[i] = (uint32_t)d; br = (d >> 63) & 1; }
+    if (br) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)a[i] + P[i]; a[i] = (uint32_t)c; c >>= 32; }
+    }
+}
 HDN Fr fr_inv(Fr a) {
     const uint32_t P[8] = FR_P_LIMBS;
-    Fr acc = fr_one_mont();
-    for (int i = 253; i >= 0; i--) {
-        acc = fr_sqr(acc);
-        uint32_t w = P[i >> 5];
-        if (i < 32) w -= 2;                 // exponent p-2 (low limb 0xf0000001 - 2, no borrow)
-        if ((w >> (i & 31)) & 1) acc = fr_mul(acc, a);
+    uint32_t u[8], v[8], A[8], C[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u[i] = a.l[i]; v[i] = P[i]; A[i] = i == 0; C[i] = 0; }
+    for (int it = 0; it < 1024; it++) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) nz |= u[i];
+#ifdef __HIP_DEVICE_COMPILE__
+        if (!__any(nz != 0)) break;
+#else
+        if (!nz) break;
+#endif
+        if (nz) {
+            if (!(u[0] & 1)) { fr256_shr1(u, 0); fr256_halfmod(A); }
+            else if (!(v[0] & 1)) { fr256_shr1(v, 0); fr256_halfmod(C); }
+            else {
+                bool ge = true, dec = false;          // u >= v ?
+#pragma unroll
+                for (int i = 7; i >= 0; i--) if (!dec && u[i] != v[i]) { ge = u[i] > v[i]; dec = true; }
+                if (ge) {
+                    uint64_t br = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)u[i] - v[i] - br; u[i] = (uint32_t)d; br = (d >> 63) & 1; }
+                    fr256_shr1(u, 0); fr256_submod(A, C); fr256_halfmod(A);
+                } else {
+                    uint64_t br = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)v[i] - u[i] - br; v[i] = (uint32_t)d; br = (d >> 63) & 1; }
+                    fr256_shr1(v, 0); fr256_submod(C, A); fr256_halfmod(C);
+                }
+            }
+        }
     }
-    return fr_is_zero(a) ? a : acc;
+    Fr y, r3 = {FR_R3_LIMBS};
+#pragma unroll
+    for (int i = 0; i < 8; i++) y.l[i] = C[i];
+    return fr_mul(y, r3);          // x = 0: the loop never runs, C = 0 -> 0
 }
 HD uint32_t fr_bit(const Fr& canon, int i) { return (canon.l[i >> 5] >> (i & 31)) & 1; }

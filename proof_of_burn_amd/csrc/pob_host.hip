@@ -52,7 +52,7 @@ struct pob_ctx {
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, all_segs;                   // per (stage, lds) for generation; all units at once for check/emit
-    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
     std::vector<KSeg> ksegs;
     uint32_t nperms = 0;
@@ -150,10 +150,17 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [](const SpongeDesc& a, const SpongeDesc& b) { return a.stage < b.stage; });
     std::vector<uint32_t> perm_sponge, perm_block;
     for (uint32_t s = 0; s <= pl.max_stage; s++) {
+        // a stage's heavy units go into ONE launch (with the LDS table if any of them needs it) unless there are many of them
+        uint32_t n_heavy = 0, n_lds = 0;
+        for (const UnitDesc& u : pl.units) if (u.stage == s) { n_heavy += unit_class(u.kind) != 0; n_lds += unit_class(u.kind) == 2; }
+        const bool merge = n_lds && n_heavy <= 64;
         for (uint32_t lds = 3; lds-- > 0;) {              // heavy (Fr) units first: they run on the second stream beside the light ones
             pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
-            for (uint32_t u = 0; u < pl.units.size(); u++)
-                if (pl.units[u].stage == s && unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
+            for (uint32_t u = 0; u < pl.units.size(); u++) {
+                uint32_t cls = unit_class(pl.units[u].kind);
+                if (merge && cls == 1) cls = 2;
+                if (pl.units[u].stage == s && cls == lds) h->order.push_back(u);
+            }
             sg.count = (uint32_t)h->order.size() - sg.first;
             if (sg.count) h->segs.push_back(sg);
         }
@@ -177,7 +184,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 
     HIPC(hipSetDevice(device));
     HIPC(hipStreamCreate(&h->stream));
-    HIPC(hipStreamCreate(&h->stream2));
+    HIPC(hipStreamCreate(&h->stream2)); HIPC(hipStreamCreate(&h->stream3)); HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
@@ -231,6 +238,8 @@ void pob_close(pob_handle h) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
+    if (h->stream3) hipStreamDestroy(h->stream3);
+    if (h->ev_join3) hipEventDestroy(h->ev_join3);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
@@ -294,17 +303,20 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
-    bool forked = false;
-    for (size_t k = h->all_segs.size(); k-- > 0;) {      // no dependencies between units here: one launch per class, heavy ones on stream 2
-        const pob_ctx::Seg& sg = h->all_segs[k];
+    bool forked = false, forked3 = false;
+    for (size_t k = h->all_segs.size(); k-- > 0;) {      // no dependencies between units here: one launch per class; the BN254 units
+        const pob_ctx::Seg& sg = h->all_segs[k];          // run on stream 2, the three Poseidon units (LDS table) on stream 3
         A.first = sg.first; A.stage_lds = sg.lds == 2;
         if (sg.lds) {
-            if (!forked) { HIPC(hipEventRecord(h->ev_fork, st)); HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
-            launch_g_check(A, true, sg.count, G, h->stream2);
-            forked = true;
+            if (!forked && !forked3) HIPC(hipEventRecord(h->ev_fork, st));
+            hipStream_t s2 = sg.lds == 2 ? h->stream3 : h->stream2;
+            HIPC(hipStreamWaitEvent(s2, h->ev_fork, 0));
+            launch_g_check(A, true, sg.count, G, s2);
+            if (sg.lds == 2) forked3 = true; else forked = true;
         } else launch_g_check(A, false, sg.count, G, st);
     }
     if (forked) HIPC(hipEventRecord(h->ev_join, h->stream2));
+    if (forked3) HIPC(hipEventRecord(h->ev_join3, h->stream3));
     KArgs K = kargs(h);
     if (!h->plan.sponges.empty()) {
         K.first = 0;
@@ -312,6 +324,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         launch_k_rounds(K, true, h->nperms, G, st);
     }
     if (forked) HIPC(hipStreamWaitEvent(st, h->ev_join, 0));
+    if (forked3) HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
     HIPC(hipGetLastError());
     return POB_OK;
 }
