@@ -45,13 +45,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     rank, local_rank, world = D.init()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
+    dev_index = int(os.environ.get("POB_FORCE_DEVICE", local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
+    torch.cuda.set_device(dev_index)
     B = args.batch
 
     # ---- synthetic inputs (seeded; rank r generates witnesses [r*B, (r+1)*B) of the global batch)
     t0 = time.time()
     batch = gen.synthetic_batch(B, depth=args.depth, seed=0xB0B + rank * B, distinct_keys=args.distinct_keys)
-    calc = WitnessCalculator(MAIN, max_batch=B, device=local_rank)
+    calc = WitnessCalculator(MAIN, max_batch=B, device=dev_index)
     fr, sm, forced = calc.pack(batch.inputs)
     calc.upload_packed(fr, sm, forced)                  # H2D happens here, outside the timed region
     setup_s = time.time() - t0
@@ -78,7 +79,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -101,8 +102,15 @@ def main():
     round_bytes = (102656 + 2 * 1600) * 8
     launch_bytes = info.n_perms * 24 * round_bytes * groups
     achieved = launch_bytes / (t_chk * 1e-3) / 1e9
+    traffic = None                                        # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py)
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_k_rounds.json")) as f:
+            pmc = json.load(f)
+        traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups / pmc["groups"])
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": launch_bytes, "avg_ms": round(t_chk, 4),
                 "gen_kernel": {"kernel": "k_rounds<GEN>", "achieved": round(info.n_perms * 24 * (102656 + 1600) * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)}}

@@ -62,6 +62,8 @@ struct KBRefs {
     BitRef k_out, k_in; SmRef k_blocks; BitRef k_finalState, f_out, f_in; SmRef f_blocks; BitRef f_s;
     uint32_t abs_w, abs_b;
     BitRef sel_out, sel_arrays; SmRef sel_select; BitRef sel_T;
+    Cur c_post;                       // Reshape(32,8) [out | in] then Bits2Num(8) x 32 [out | in[8]]
+    SmRef dst; uint32_t has_dst;      // the parent's copy of out[32]
     uint32_t mb, index;
 };
 // SubstringCheck instance (substring_check.circom:24-100)
@@ -93,7 +95,7 @@ struct RaRefs {
     Cur c_cb, c_sl, c_lt, c_concat, c_end;
 };
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
-struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; };
+struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; uint32_t cost; };
 
 #define MAX_KB 72
 #define MAX_SC 64
@@ -194,11 +196,26 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
     r.sel_out = p.bits(1600); r.sel_arrays = p.bits((n + 1) * 1600); r.sel_select = p.sms(1); r.sel_T = p.bits(1600 * (n + 1));
 }
 // selectors [j0, j1) of row `row` of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs
+// the hash output (first 256 selector outputs) also flows through outBits, Reshape, outBytes, Bits2Num, out[] and the parent's copy
+template <class P> GD void kb_out_bit(P& p, const KBRefs& r, uint32_t idx, B v, S& by) {
+    const BitRef rs_o = {r.c_post.w, r.c_post.b}, rs_i = {r.c_post.w + 256, r.c_post.b + 256};
+    const uint32_t i = idx >> 3, k = idx & 7;
+    const SmRef b2n_o = {r.c_post.w + 512 + 9 * i, r.c_post.s + i}; const BitRef b2n_i = {r.c_post.w + 512 + 9 * i + 1, r.c_post.b + 512 + 8 * i};
+    v = p.put(r.outBits + idx, v); v = p.put(rs_i + idx, v); v = p.put(rs_o + idx, v); v = p.put(r.outBytes + idx, v); v = p.put(b2n_i + k, v);
+    if (k == 0) by = 0;
+    by |= (S)p.bit(v) << k;
+    if (k == 7) {
+        S o = p.put(r.out + i, p.put(b2n_o, by));
+        if (r.has_dst) p.put(r.dst + i, o);
+    }
+}
 template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
     const uint32_t n1 = r.mb + 1;
     S blocks = p.get(r.numBlocks);
+    S by = 0;
     for (uint32_t j = j0; j < j1; j++) {
         const uint32_t idx = row * 64 + j;
+        B out;
         if (n1 <= 17) {          // all n1 candidate state words first (independent loads), then nothing but stores
             B v[17];
 #pragma unroll
@@ -217,40 +234,22 @@ template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32
                 acc = p.put(sum + k + 1, acc | (e & val));
             }
             p.require(any & ~multi, FAILCODE(T_SELECTOR, 43));
-            B out = p.put(o, acc);
-            out = p.put(r.sel_out + idx, out); out = p.put(r.f_out + idx, out); out = p.put(r.k_finalState + idx, out);
-            if (idx < 256) p.put(r.k_out + idx, out);
+            out = p.put(o, acc);
         } else {
             for (uint32_t k = 0; k < n1; k++) p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), p.get(r.f_s + (k * 1600 + idx))));
-            B o = gSelectorB(p, n1, r.sel_T + idx * n1, blocks);
-            o = p.put(r.sel_out + idx, o); o = p.put(r.f_out + idx, o); o = p.put(r.k_finalState + idx, o);
-            if (idx < 256) p.put(r.k_out + idx, o);
+            out = gSelectorB(p, n1, r.sel_T + idx * n1, blocks);
         }
+        out = p.put(r.sel_out + idx, out); out = p.put(r.f_out + idx, out); out = p.put(r.k_finalState + idx, out);
+        if (idx < 256) { out = p.put(r.k_out + idx, out); const Cur keep = p.cur; kb_out_bit(p, r, idx, out, by); p.cur = keep; }
     }
 }
-// part after the sponge: Keccak/Final/selector `blocks` inputs, Reshape(32,8) [out | in], Bits2Num(8) x 32 [out | in[8]] and the
-// copy into the parent's array.  Values are threaded through registers (no read-back of just-written wires).
-template <class P> GD void kb_post(P& p, const KBRefs& r, SmRef dst, bool has_dst) {
-    const int n1 = r.mb + 1;
+// after the selectors: Keccak/Final/selector `blocks` inputs; the Reshape(32,8) + Bits2Num(8) x 32 blocks that follow in wire
+// order (512 + 32*9 wires) are written by the selector-row units of rows 0..3 (kb_out_bit)
+template <class P> GD void kb_post(P& p, const KBRefs& r) {
     S nb = p.get(r.numBlocks);
     p.put(r.k_blocks, nb); p.put(r.f_blocks, nb); p.put(r.sel_select, nb);
-    BitRef rs_o = p.bits(256), rs_i = p.bits(256);
-    for (int i = 0; i < 32; i++) {
-        SmRef b2n_o = p.sms(1); BitRef b2n_i = p.bits(8);
-        S by = 0;
-        for (int k = 0; k < 8; k++) {
-            const int j = 8 * i + k;
-            B v;
-            if (P::is_gen) { v = 0; for (int q = 0; q < n1; q++) v |= p.ballot(nb == q) & p.get(r.f_s + (q * 1600 + j)); }   // s[blocks] (:348)
-            else v = p.get(r.k_out + j);
-            v = p.put(r.outBits + j, v); v = p.put(rs_i + j, v); v = p.put(rs_o + j, v); v = p.put(r.outBytes + j, v); v = p.put(b2n_i + k, v);
-            by |= (S)p.bit(v) << k;
-        }
-        by = p.put(r.out + i, p.put(b2n_o, by));
-        if (has_dst) p.put(dst + i, by);
-    }
+    p.cur = cur_add(r.c_post, Cur{512 + 32 * 9, 512 + 32 * 8, 32, 0}, 1);
 }
-
 
 // Selector(N) block at cursor c (selector.circom:21-46): [out | vals[N], select | isEq[N], sum[N+1]] || IsEqual x N
 struct SelBlk { SmRef o, vals, sel; BitRef isEq; SmRef sum; Cur kids; };
@@ -308,10 +307,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         kb_range(p, L.kbs[d.a[0]], src, d.a[3], d.a[4]);
     } break;
     case U_KB_SELROW: kb_selrow(p, L.kbs[d.a[0]], d.a[1], d.a[2], d.a[3]); break;
-    case U_KB_POST: {
-        SmRef dst = {d.a[1], d.a[2]};
-        kb_post(p, L.kbs[d.a[0]], dst, d.a[3] != 0);
-    } break;
+    case U_KB_POST: kb_post(p, L.kbs[d.a[0]]); break;
     case U_PC_PRE: {             // PublicCommitment(N) public_commitment.circom:18-36 up to the sponge
         const int N = L.pc.N;
         for (int j = 0; j < N; j++) {
@@ -779,7 +775,7 @@ struct Plan {
         if (!same(got, want)) throw std::runtime_error(std::string("layout planner: split units disagree with the monolithic template: ") + what);
     }
     void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0) {
-        UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5;
+        UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.cost = 0; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5;
         units.push_back(d);
         if (stage > max_stage) max_stage = stage;
     }
@@ -805,7 +801,13 @@ struct Plan {
         SpongeDesc s; s.n = r.mb; s.stage = range_stage + 1; s.src_b = r.inBlocks.i; s.src_w = r.inBlocks.w;
         s.kin_b = r.k_in.i; s.kin_w = r.k_in.w; s.fin_b = r.f_in.i; s.fin_w = r.f_in.w; s.fs_b = r.f_s.i; s.fs_w = r.f_s.w; s.abs_b = r.abs_b; s.abs_w = r.abs_w;
         sponges.push_back(s);
-        const uint32_t split = r.mb >= 8 ? 4 : 1;            // the selectors of a row are split when a selector is long
+        r.dst = dst; r.has_dst = has_dst ? 1 : 0;
+        {   // Reshape/Bits2Num blocks start after the 1600 selectors (all of equal footprint)
+            CountP q; q.cur = p.cur; r.c_post = Cur{0, 0, 0, 0}; r.has_dst = 0; kb_selrow(q, r, 24, 0, 1);
+            const Cur fp1 = {q.cur.w - p.cur.w, q.cur.b - p.cur.b, q.cur.s - p.cur.s, 0};
+            r.c_post = cur_add(p.cur, fp1, 1600); r.has_dst = has_dst ? 1 : 0;
+        }
+        const uint32_t split = r.mb >= 8 ? 4 : 1;            // a long row's 64 selectors are split over several wavefronts
         for (uint32_t row = 0; row < 25; row++) {
             const Cur c0 = p.cur;
             CountP q; q.cur = c0; kb_selrow(q, r, row, 0, 64);
@@ -813,7 +815,8 @@ struct Plan {
             for (uint32_t k = 0; k < split; k++) record(U_KB_SELROW, range_stage + 2, cur_add(c0, fp, k * (64 / split)), kb, row, k * (64 / split), (k + 1) * (64 / split));
             p.cur = q.cur;
         }
-        unit(U_KB_POST, range_stage + 2, kb, dst.w, dst.i, has_dst ? 1 : 0);
+        if (!same(p.cur, r.c_post)) throw std::runtime_error("layout planner: selector footprint");
+        unit(U_KB_POST, range_stage + 2, kb);
         if (range_stage + 1 > max_stage) max_stage = range_stage + 1;
     }
     void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst) {
@@ -849,6 +852,10 @@ struct Plan {
         unit(U_PC_POST, pre_stage + 4);
     }
 
+    // cost estimate (wires written, FR wires x8) of every unit, by replaying it on the counting policy
+    void estimate_costs() {
+        for (UnitDesc& d : units) { CountP q; const UnitDesc dd = d; unit_run(q, dd, L); d.cost = q.nput * (unit_is_heavy(d.kind) ? 4 : 1); }
+    }
     void plan_pob(const PobParams& prm) {
         memset(&L, 0, sizeof L);
         L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
@@ -940,13 +947,13 @@ struct Plan {
                 const Cur keep = p.cur;
                 p.cur = R.c_acc;
                 CountP qa; qa.cur = R.c_acc; { S al; gRlpEmptyAccount(qa, prm.amountBytes, fr_zero(), al); }
-                unit(U_RL_ACC, 6);
+                unit(U_RL_ACC, 1);                                  // depends on the balance input only: runs early
                 expect_cursor("RlpEmptyAccount", p.cur, qa.cur);
                 p.cur = keep;
-                record(U_RL_ACC_B, 7, L.ra.c_cb);
-                record(U_RL_ACC_C, 8, L.ra.c_concat);
+                record(U_RL_ACC_B, 2, L.ra.c_cb);
+                record(U_RL_ACC_C, 6, L.ra.c_concat);               // long serial unit: placed where it hides behind the BN254 units of stage 6
             }
-            record(U_RL_B, 9, R.c_mux);
+            record(U_RL_B, 7, R.c_mux);
             p.cur = chk.cur;
         }
         {   // ProofOfWorkChecker :211
@@ -960,6 +967,7 @@ struct Plan {
         }
         unit(U_POB_FINAL, 10);
         total = p.cur;
+        estimate_costs();
     }
     void plan_spend(const SpendParams& prm) {
         memset(&L, 0, sizeof L);
@@ -975,5 +983,6 @@ struct Plan {
         unit(U_SP_HEAD, 1);
         public_commitment(4, 2);
         total = p.cur;
+        estimate_costs();
     }
 };

@@ -4,7 +4,7 @@
 
 extern __shared__ uint32_t g_lds[];
 
-template <class P, bool HEAVY> __global__ void __launch_bounds__(64) g_units(GArgs A) {
+template <class P, bool HEAVY> __global__ void __launch_bounds__(64, HEAVY ? 1 : 8) g_units(GArgs A) {
     const uint32_t lane = threadIdx.x;
     const uint32_t g = P::is_emit ? A.emit_group : blockIdx.y;
     P p;

@@ -162,6 +162,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
                 if (pl.units[u].stage == s && cls == lds) h->order.push_back(u);
             }
             sg.count = (uint32_t)h->order.size() - sg.first;
+            std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
             if (sg.count) h->segs.push_back(sg);
         }
         pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0};
@@ -179,6 +180,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         pob_ctx::Seg sg{0, lds, (uint32_t)h->order.size(), 0};
         for (uint32_t u = 0; u < pl.units.size(); u++) if (unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
         sg.count = (uint32_t)h->order.size() - sg.first;
+        std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
         if (sg.count) h->all_segs.push_back(sg);
     }
 

@@ -57,13 +57,14 @@ struct PolBase {
 // ------------------------------------------------------------------ host-side layout planner policy
 struct CountP : PolBase {
     static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
-    HD B put(BitRef, B v) { return v; }
-    HD S put(SmRef, S v) { return v; }
-    HD F put(FrRef, const F& v) { return v; }
-    HD B hint(BitRef, B v) { return v; }
-    HD S hint(SmRef, S v) { return v; }
-    HD F hint(FrRef, const F& v) { return v; }
-    HD S hint_inv(SiRef, S v) { return v; }
+    uint32_t nput = 0;    // wires written: the planner's cost estimate of a unit (long units are dispatched first)
+    HD B put(BitRef, B v) { nput++; return v; }
+    HD S put(SmRef, S v) { nput++; return v; }
+    HD F put(FrRef, const F& v) { nput += 8; return v; }
+    HD B hint(BitRef, B v) { nput++; return v; }
+    HD S hint(SmRef, S v) { nput++; return v; }
+    HD F hint(FrRef, const F& v) { nput += 8; return v; }
+    HD S hint_inv(SiRef, S v) { nput++; return v; }
     HD B get(BitRef) { return 0; }
     HD S get(SmRef) { return 0; }
     HD F get(FrRef) { return fr_zero(); }
@@ -108,6 +109,8 @@ struct DevPol : PolBase {
         for (int k = 0; k < 8; k++) v.l[k] = q[k * 64];
         return v;
     }
+    // one lane stores the wave-uniform mask (a 64-lane same-address store costs the texture-address unit 64 lanes of work:
+    // measured 1.5x slower on the selector-row stage)
     __device__ __forceinline__ void st(BitRef r, B v) { if (m.lane == 0) m.bits[r.i] = v; }
     __device__ __forceinline__ void st(SmRef r, S v) { m.sm[(size_t)r.i * 64 + m.lane] = v; }
     __device__ __forceinline__ void st(SiRef r, S v) { m.sm[(size_t)r.i * 64 + m.lane] = v; }

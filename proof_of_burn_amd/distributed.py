@@ -20,7 +20,8 @@ def init(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("POB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -36,6 +37,8 @@ def gather_results(status: torch.Tensor, outputs: torch.Tensor):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return status, outputs
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and status.is_cuda:      # plumbing tests of the N>1 path on one GPU: gather through host memory
+        status, outputs = status.cpu(), outputs.cpu()
     st_all = torch.empty((world * status.shape[0],), dtype=status.dtype, device=status.device)
     out_all = torch.empty((world * outputs.shape[0], 32), dtype=outputs.dtype, device=outputs.device)
     dist.all_gather_into_tensor(st_all, status.contiguous())

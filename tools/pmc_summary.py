@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Extract per-launch FETCH_SIZE / WRITE_SIZE of the Keccak round kernels from rocprofv3 `--pmc` rocpd databases
+(separate passes, as MI355X_MICROARCH.md prescribes) and write profiles/<name>.json, which bench.py reads for `traffic`.
+
+gfx950 correction (MI355X_MICROARCH.md "HBM"): FETCH_SIZE counts 64 B per 128-B request of a coalesced stream, i.e. exactly
+half the bytes -> doubled here; WRITE_SIZE is used as reported (it matches the algorithmic write bytes to 0.2 %)."""
+import json
+import sqlite3
+import sys
+
+
+def per_launch(path, counter, kernel_like):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    sfx = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0].replace("rocpd_kernel_dispatch", "")
+    q = f"""select d.grid_size_x, d.grid_size_y, p.value from rocpd_pmc_event{sfx} p
+            join rocpd_kernel_dispatch{sfx} d on p.event_id = d.event_id join rocpd_info_kernel_symbol{sfx} k on d.kernel_id = k.id
+            join rocpd_info_pmc{sfx} i on p.pmc_id = i.id where k.kernel_name like ? and i.name = ? order by d.start"""
+    rows = [r for r in cur.execute(q, (kernel_like, counter)).fetchall()]
+    full = max(r[0] for r in rows)
+    vals = [r[2] for r in rows if r[0] == full]
+    return {"launches": len(vals), "grid_x_threads": full, "groups": rows[0][1], "avg_kb": sum(vals) / len(vals)}
+
+
+def main(fetch_db, write_db, out):
+    chk = per_launch(fetch_db, "FETCH_SIZE", "%k_roundsILb1%")
+    gen = per_launch(write_db, "WRITE_SIZE", "%k_roundsILb0%")
+    groups = chk["groups"]
+    perms_rounds = chk["grid_x_threads"] // 64
+    res = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --batch %d" % (groups * 64),
+        "groups": groups,
+        "k_rounds_check": {"fetch_size_kb_raw": chk["avg_kb"], "hbm_read_bytes_per_launch": chk["avg_kb"] * 1024 * 2,
+                           "algorithmic_bytes_per_launch": perms_rounds * groups * (102656 + 3200) * 8},
+        "k_rounds_gen": {"write_size_kb_raw": gen["avg_kb"], "hbm_write_bytes_per_launch": gen["avg_kb"] * 1024,
+                         "algorithmic_bytes_per_launch": (gen["grid_x_threads"] // 64) * groups * 102656 * 8},
+    }
+    for k in ("k_rounds_check", "k_rounds_gen"):
+        d = res[k]
+        d["traffic_over_algorithmic"] = round((d.get("hbm_read_bytes_per_launch") or d.get("hbm_write_bytes_per_launch")) / d["algorithmic_bytes_per_launch"], 4)
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
