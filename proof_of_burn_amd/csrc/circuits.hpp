@@ -269,6 +269,7 @@ HD bool unit_is_heavy(uint32_t k) {
     return k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_POB_N2B || k == U_PC_POST || k == U_POB_LAYER_POST ||
            k == U_SC_M || k == U_SC_RANGE || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == U_SP_HEAD;
 }
+HD bool unit_is_sc(uint32_t k) { return k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE; }
 HD bool unit_uses_lds(uint32_t k) { return k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD; }   // Poseidon table staged in LDS
 
 template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout& L) {
@@ -607,6 +608,86 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
         p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
     } break;
+    case U_RL_ACC: {             // RlpEmptyAccount/RlpInteger, field-element part: Num2BigEndianBytes(N)(balance), LessThan(8N), IsZero, Mux1
+                                 // (integer.circom:83,88-90); CountBytes/ShiftLeft and the byte assembly run as light units B and C
+        RaRefs A = L.ra;
+        const int N = prm.amountBytes;
+        A.ea_o = p.sms(70 + N); A.ea_ol = p.sms(1); A.ea_ib = p.frs(1);
+        A.pn = p.sms(4 + N); A.pnl = p.sms(1); A.br = p.sms(N + 1); A.brl = p.sms(1); A.nbl = p.sms(1); A.sc = p.sms(66);
+        F bal = p.put(A.ea_ib, p.get(M.actualBalance));
+        A.ri_o = p.sms(N + 1); A.ri_ol = p.sms(1); A.ri_i = p.frs(1); A.by = p.sms(N); A.len = p.sms(1); A.be = p.sms(N);
+        A.isb = p.bits(1); A.isz = p.bits(1); A.frb = p.sms(1);
+        F x = p.put(A.ri_i, bal);
+        SmRef r = gNum2BigEndianBytesF(p, N, x);
+        S lead = 0; bool still = true;
+        for (int j = 0; j < N; j++) { S b = p.put(A.by + j, p.get(r + j)); still = still && b == 0; lead += still; }
+        A.c_cb = p.cur;
+        { CountP q; q.cur = p.cur; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
+        p.cur = A.c_lt;
+        B single = p.put(A.isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
+        p.put(A.isz, gIsZeroF(p, x));
+        const S length = P::is_gen ? (S)N - lead : p.get(A.len);
+        p.put(A.frb, gMux1SF(p, 0x80 + length, x, single));
+        A.c_concat = p.cur;
+        { CountP q; q.cur = p.cur; S cl; gConcat(q, 4 + N, 66, A.pn, 0, A.sc, 0, cl); A.c_end = q.cur; }
+        p.cur = A.c_end;
+        if (P::is_count) L.ra = A;
+    } break;
+    case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
+        F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
+        p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
+        SmRef r = gNum2BigEndianBytesF(p, 32, bk);
+        for (int i = 0; i < 32; i++) p.put(L.pw.keyBytes + i, p.get(r + i));
+        r = gNum2BigEndianBytesF(p, 32, ra);
+        for (int i = 0; i < 32; i++) p.put(L.pw.raBytes + i, p.get(r + i));
+        r = gNum2BigEndianBytesF(p, 32, bec);
+        for (int i = 0; i < 32; i++) p.put(L.pw.becBytes + i, p.get(r + i));
+        SmRef e = p.sms(8);                              // EIP7503 :11-21  [out[8]]
+        const char tag[9] = "EIP-7503";
+        for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)tag[i]));
+        SmRef co = p.sms(104), ci = p.sms(104);          // ConcatFixed4(32,32,32,8) :28-48  [out | a,b,c,d]
+        for (int i = 0; i < 104; i++) {
+            SmRef s = i < 32 ? L.pw.keyBytes + i : i < 64 ? L.pw.raBytes + (i - 32) : i < 96 ? L.pw.becBytes + (i - 64) : L.pw.eip + (i - 96);
+            p.put(L.pw.hin + i, p.put(co + i, p.put(ci + i, p.get(s))));
+        }
+        SmRef f = gFitS(p, 104, 136, L.pw.hin);
+        for (int i = 0; i < 136; i++) p.put(L.pw.block + i, p.get(f + i));
+        KBRefs kr = L.kbs[L.pw.kb];
+        kb_head(p, 1, (S)104, kr);
+        if (P::is_count) L.kbs[L.pw.kb] = kr;
+    } break;
+    case U_SP_INPUT: {
+        p.put(L.sm.burnKey, p.input_fr(0)); p.put(L.sm.balance, p.input_fr(1));
+        p.put(L.sm.withdrawnBalance, p.input_fr(2)); p.put(L.sm.extraCommitment, p.input_fr(3));
+    } break;
+    case U_SP_HEAD: {            // spend.circom:41-49
+        F bk = p.get(L.sm.burnKey), bal = p.get(L.sm.balance), wd = p.get(L.sm.withdrawnBalance), ec = p.get(L.sm.extraCommitment);
+        gAssertGreaterEqThanF(p, L.spend.maxAmountBytes * 8, bal, wd);
+        F in3[3] = {L.prefix[2], bk, bal};
+        F coin = p.put(L.sm.coin, gPoseidon<P, 4>(p, pos_off(4), in3));
+        in3[2] = fr_sub(bal, wd);
+        F rc = p.put(L.sm.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
+        SmRef r = gNum2BigEndianBytesF(p, 32, coin);
+        for (int i = 0; i < 32; i++) p.put(L.sm.coinBytes + i, p.get(r + i));
+        r = gNum2BigEndianBytesF(p, 32, wd);
+        for (int i = 0; i < 32; i++) p.put(L.sm.withdrawnBalanceBytes + i, p.get(r + i));
+        r = gNum2BigEndianBytesF(p, 32, rc);
+        for (int i = 0; i < 32; i++) p.put(L.sm.remainingCoinBytes + i, p.get(r + i));
+        r = gNum2BigEndianBytesF(p, 32, ec);
+        for (int i = 0; i < 32; i++) p.put(L.sm.extraCommitmentBytes + i, p.get(r + i));
+    } break;
+    default: break;
+    }
+}
+// SubstringCheck's BN254 units get their own kernel: they need ~100 VGPRs, while the Poseidon / Num2Bits_strict units of the
+// general heavy kernel push it to 256 VGPRs (1 wave per SIMD)
+template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L) {
+    const PobMain& M = L.pm;
+    const PobParams& prm = L.pob;
+    const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
+    (void)M; (void)LB; (void)HBy;
+    p.cur = d.cur;
+    switch (d.kind) {
     case U_POB_LAYER_POST: {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
                                  // AssertLessEqThan x2, LittleEndianBytes2Num(sl); AssertByteString(mm) runs as U_ABS_RANGE units
         const int i = d.a[0];
@@ -681,79 +762,11 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
             p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, p.k256(i)), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
         }
     } break;
-    case U_RL_ACC: {             // RlpEmptyAccount/RlpInteger, field-element part: Num2BigEndianBytes(N)(balance), LessThan(8N), IsZero, Mux1
-                                 // (integer.circom:83,88-90); CountBytes/ShiftLeft and the byte assembly run as light units B and C
-        RaRefs A = L.ra;
-        const int N = prm.amountBytes;
-        A.ea_o = p.sms(70 + N); A.ea_ol = p.sms(1); A.ea_ib = p.frs(1);
-        A.pn = p.sms(4 + N); A.pnl = p.sms(1); A.br = p.sms(N + 1); A.brl = p.sms(1); A.nbl = p.sms(1); A.sc = p.sms(66);
-        F bal = p.put(A.ea_ib, p.get(M.actualBalance));
-        A.ri_o = p.sms(N + 1); A.ri_ol = p.sms(1); A.ri_i = p.frs(1); A.by = p.sms(N); A.len = p.sms(1); A.be = p.sms(N);
-        A.isb = p.bits(1); A.isz = p.bits(1); A.frb = p.sms(1);
-        F x = p.put(A.ri_i, bal);
-        SmRef r = gNum2BigEndianBytesF(p, N, x);
-        S lead = 0; bool still = true;
-        for (int j = 0; j < N; j++) { S b = p.put(A.by + j, p.get(r + j)); still = still && b == 0; lead += still; }
-        A.c_cb = p.cur;
-        { CountP q; q.cur = p.cur; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
-        p.cur = A.c_lt;
-        B single = p.put(A.isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
-        p.put(A.isz, gIsZeroF(p, x));
-        const S length = P::is_gen ? (S)N - lead : p.get(A.len);
-        p.put(A.frb, gMux1SF(p, 0x80 + length, x, single));
-        A.c_concat = p.cur;
-        { CountP q; q.cur = p.cur; S cl; gConcat(q, 4 + N, 66, A.pn, 0, A.sc, 0, cl); A.c_end = q.cur; }
-        p.cur = A.c_end;
-        if (P::is_count) L.ra = A;
-    } break;
-    case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
-        F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
-        p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
-        SmRef r = gNum2BigEndianBytesF(p, 32, bk);
-        for (int i = 0; i < 32; i++) p.put(L.pw.keyBytes + i, p.get(r + i));
-        r = gNum2BigEndianBytesF(p, 32, ra);
-        for (int i = 0; i < 32; i++) p.put(L.pw.raBytes + i, p.get(r + i));
-        r = gNum2BigEndianBytesF(p, 32, bec);
-        for (int i = 0; i < 32; i++) p.put(L.pw.becBytes + i, p.get(r + i));
-        SmRef e = p.sms(8);                              // EIP7503 :11-21  [out[8]]
-        const char tag[9] = "EIP-7503";
-        for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)tag[i]));
-        SmRef co = p.sms(104), ci = p.sms(104);          // ConcatFixed4(32,32,32,8) :28-48  [out | a,b,c,d]
-        for (int i = 0; i < 104; i++) {
-            SmRef s = i < 32 ? L.pw.keyBytes + i : i < 64 ? L.pw.raBytes + (i - 32) : i < 96 ? L.pw.becBytes + (i - 64) : L.pw.eip + (i - 96);
-            p.put(L.pw.hin + i, p.put(co + i, p.put(ci + i, p.get(s))));
-        }
-        SmRef f = gFitS(p, 104, 136, L.pw.hin);
-        for (int i = 0; i < 136; i++) p.put(L.pw.block + i, p.get(f + i));
-        KBRefs kr = L.kbs[L.pw.kb];
-        kb_head(p, 1, (S)104, kr);
-        if (P::is_count) L.kbs[L.pw.kb] = kr;
-    } break;
-    case U_SP_INPUT: {
-        p.put(L.sm.burnKey, p.input_fr(0)); p.put(L.sm.balance, p.input_fr(1));
-        p.put(L.sm.withdrawnBalance, p.input_fr(2)); p.put(L.sm.extraCommitment, p.input_fr(3));
-    } break;
-    case U_SP_HEAD: {            // spend.circom:41-49
-        F bk = p.get(L.sm.burnKey), bal = p.get(L.sm.balance), wd = p.get(L.sm.withdrawnBalance), ec = p.get(L.sm.extraCommitment);
-        gAssertGreaterEqThanF(p, L.spend.maxAmountBytes * 8, bal, wd);
-        F in3[3] = {L.prefix[2], bk, bal};
-        F coin = p.put(L.sm.coin, gPoseidon<P, 4>(p, pos_off(4), in3));
-        in3[2] = fr_sub(bal, wd);
-        F rc = p.put(L.sm.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
-        SmRef r = gNum2BigEndianBytesF(p, 32, coin);
-        for (int i = 0; i < 32; i++) p.put(L.sm.coinBytes + i, p.get(r + i));
-        r = gNum2BigEndianBytesF(p, 32, wd);
-        for (int i = 0; i < 32; i++) p.put(L.sm.withdrawnBalanceBytes + i, p.get(r + i));
-        r = gNum2BigEndianBytesF(p, 32, rc);
-        for (int i = 0; i < 32; i++) p.put(L.sm.remainingCoinBytes + i, p.get(r + i));
-        r = gNum2BigEndianBytesF(p, 32, ec);
-        for (int i = 0; i < 32; i++) p.put(L.sm.extraCommitmentBytes + i, p.get(r + i));
-    } break;
     default: break;
     }
 }
 template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
-    if (unit_is_heavy(d.kind)) unit_run_heavy(p, d, L); else unit_run_light(p, d, L);
+    if (unit_is_sc(d.kind)) unit_run_sc(p, d, L); else if (unit_is_heavy(d.kind)) unit_run_heavy(p, d, L); else unit_run_light(p, d, L);
 }
 
 // ---------------------------------------------------------------------------- host planner

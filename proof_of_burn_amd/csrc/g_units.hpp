@@ -4,7 +4,8 @@
 
 extern __shared__ uint32_t g_lds[];
 
-template <class P, bool HEAVY> __global__ void __launch_bounds__(64, HEAVY ? 1 : 8) g_units(GArgs A) {
+// CLS: 0 = light units (BIT/SM only), 1 = BN254 units (Poseidon, Num2Bits_strict, ...), 2 = SubstringCheck's BN254 units
+template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 : CLS == 2 ? 4 : 1) g_units(GArgs A) {
     const uint32_t lane = threadIdx.x;
     const uint32_t g = P::is_emit ? A.emit_group : blockIdx.y;
     P p;
@@ -16,7 +17,7 @@ template <class P, bool HEAVY> __global__ void __launch_bounds__(64, HEAVY ? 1 :
     p.m.in_fr = A.in_fr + (uint64_t)g * 64 * A.nfr_in * 32;
     p.m.in_sm = A.in_sm + (uint64_t)g * 64 * A.nsm_in;
     p.m.lane = lane;
-    if (HEAVY && A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
+    if (CLS == 1 && A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
         for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];
         __syncthreads();
         p.m.pos_tab = g_lds;
@@ -25,7 +26,7 @@ template <class P, bool HEAVY> __global__ void __launch_bounds__(64, HEAVY ? 1 :
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; }
     const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];
-    if constexpr (HEAVY) unit_run_heavy<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
+    if constexpr (CLS == 1) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
     if constexpr (P::is_gen) { if (p.status) atomicMin(&A.status[g * 64 + lane], p.status); }
     if constexpr (P::is_check) {
         if (p.status) atomicMin(&A.chk_status[g * 64 + lane], p.status);

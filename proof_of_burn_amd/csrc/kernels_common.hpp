@@ -30,9 +30,12 @@ struct KArgs {
 };
 
 // grid = (nunits, ngroups) wavefronts; lds = bytes of dynamic LDS (Poseidon table) or 0
-void launch_g_gen(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_check(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_emit(const GArgs& A, bool heavy, uint32_t nunits, hipStream_t st);
+// cls: 0 light, 1 BN254 (optionally with the Poseidon table in LDS), 2 SubstringCheck BN254
+void launch_g_gen(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit(const GArgs& A, int cls, uint32_t nunits, hipStream_t st);
+void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);

@@ -61,14 +61,15 @@ struct pob_ctx {
 
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
-void launch_g_gen(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (heavy) launch_g_gen_heavy(A, nunits, ngroups, st); else launch_g_gen_light(A, nunits, ngroups, st);
+void launch_g_gen(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+    if (cls == 1) launch_g_gen_heavy(A, nunits, ngroups, st); else if (cls == 2) launch_g_gen_sc(A, nunits, ngroups, st); else launch_g_gen_light(A, nunits, ngroups, st);
 }
-void launch_g_check(const GArgs& A, bool heavy, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (heavy) launch_g_check_heavy(A, nunits, ngroups, st); else launch_g_check_light(A, nunits, ngroups, st);
+void launch_g_check(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+    if (cls == 1) launch_g_check_heavy(A, nunits, ngroups, st); else if (cls == 2) launch_g_check_sc(A, nunits, ngroups, st); else launch_g_check_light(A, nunits, ngroups, st);
 }
-// unit class: 0 = light, 1 = heavy, 2 = heavy + Poseidon table in LDS
-static uint32_t unit_class(uint32_t kind) { return unit_uses_lds(kind) ? 2 : unit_is_heavy(kind) ? 1 : 0; }
+// scheduling class: 0 = light, 1 = BN254, 2 = BN254 + Poseidon table in LDS, 3 = SubstringCheck BN254
+static uint32_t unit_class(uint32_t kind) { return unit_is_sc(kind) ? 3 : unit_uses_lds(kind) ? 2 : unit_is_heavy(kind) ? 1 : 0; }
+static int kernel_class(uint32_t sched) { return sched == 3 ? 2 : sched ? 1 : 0; }
 
 static Fr limbs_to_mont(const uint64_t* l) {
     Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
@@ -154,7 +155,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         uint32_t n_heavy = 0, n_lds = 0;
         for (const UnitDesc& u : pl.units) if (u.stage == s) { n_heavy += unit_class(u.kind) != 0; n_lds += unit_class(u.kind) == 2; }
         const bool merge = n_lds && n_heavy <= 64;
-        for (uint32_t lds = 3; lds-- > 0;) {              // heavy (Fr) units first: they run on the second stream beside the light ones
+        for (uint32_t lds = 4; lds-- > 0;) {              // BN254 units first: they run on the second stream beside the light ones
             pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
             for (uint32_t u = 0; u < pl.units.size(); u++) {
                 uint32_t cls = unit_class(pl.units[u].kind);
@@ -176,7 +177,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         if (ks.sp_count) h->ksegs.push_back(ks);
     }
     h->nperms = (uint32_t)perm_sponge.size();
-    for (uint32_t lds = 0; lds < 3; lds++) {             // every unit once, grouped only by class (constraint evaluation / emission)
+    for (uint32_t lds = 0; lds < 4; lds++) {             // every unit once, grouped only by class (constraint evaluation / emission)
         pob_ctx::Seg sg{0, lds, (uint32_t)h->order.size(), 0};
         for (uint32_t u = 0; u < pl.units.size(); u++) if (unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
         sg.count = (uint32_t)h->order.size() - sg.first;
@@ -278,9 +279,9 @@ int pob_generate(pob_handle h, void* stream_) {
             A.first = h->segs[si].first; A.stage_lds = h->segs[si].lds == 2;
             if (h->segs[si].lds) {
                 if (!forked) { HIPC(hipEventRecord(h->ev_fork, st)); HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
-                launch_g_gen(A, true, h->segs[si].count, G, h->stream2);
+                launch_g_gen(A, kernel_class(h->segs[si].lds), h->segs[si].count, G, h->stream2);
                 forked = true;
-            } else launch_g_gen(A, false, h->segs[si].count, G, st);
+            } else launch_g_gen(A, 0, h->segs[si].count, G, st);
         }
         if (forked) { HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); }
         for (; ki < h->ksegs.size() && h->ksegs[ki].stage == s; ki++) {
@@ -313,9 +314,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
             if (!forked && !forked3) HIPC(hipEventRecord(h->ev_fork, st));
             hipStream_t s2 = sg.lds == 2 ? h->stream3 : h->stream2;
             HIPC(hipStreamWaitEvent(s2, h->ev_fork, 0));
-            launch_g_check(A, true, sg.count, G, s2);
+            launch_g_check(A, kernel_class(sg.lds), sg.count, G, s2);
             if (sg.lds == 2) forked3 = true; else forked = true;
-        } else launch_g_check(A, false, sg.count, G, st);
+        } else launch_g_check(A, 0, sg.count, G, st);
     }
     if (forked) HIPC(hipEventRecord(h->ev_join, h->stream2));
     if (forked3) HIPC(hipEventRecord(h->ev_join3, h->stream3));
@@ -371,7 +372,7 @@ static int emit_to_device(pob_ctx* h, uint32_t idx) {
     A.emit_out = h->d_emit; A.emit_sel = idx % 64; A.emit_group = idx / 64;
     for (const pob_ctx::Seg& sg : h->all_segs) {
         A.first = sg.first; A.stage_lds = sg.lds == 2;
-        launch_g_emit(A, sg.lds != 0, sg.count, st);
+        launch_g_emit(A, kernel_class(sg.lds), sg.count, st);
     }
     const u64* Gp = (const u64*)h->d_bits + (uint64_t)(idx / 64) * h->plan.total.b;
     for (const SpongeDesc& s : h->plan.sponges) {
@@ -441,7 +442,7 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
         else if (which == 2) {
             for (const pob_ctx::Seg& sg : h->all_segs) {
                 A.first = sg.first; A.stage_lds = sg.lds == 2;
-                launch_g_check(A, sg.lds != 0, sg.count, G, st);
+                launch_g_check(A, kernel_class(sg.lds), sg.count, G, st);
             }
         } else launch_k_chain(K, false, (uint32_t)h->plan.sponges.size(), G, st);
     }
