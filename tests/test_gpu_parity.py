@@ -128,3 +128,97 @@ def test_main_instantiation_batch(pkg):
     ref = ora.witness_numpy()
     assert np.array_equal(gpu, ref), f"first differing wire {_first_diff(gpu, ref)}"
     calc.close()
+
+
+def _mutations(base, rng):
+    """(label, mutated input) pairs covering every assert / === of proof_of_burn.circom and the loader's edge cases"""
+    import copy
+    P = O.P
+    out = [("valid", base)]
+
+    def mut(label, fn):
+        d = copy.deepcopy(base)
+        fn(d)
+        out.append((label, d))
+
+    L = len(base["layers"])
+    nl = base["numLayers"]
+    mut("intended>actual", lambda d: d.update(intendedBalance=str(int(d["actualBalance"]) + 1)))
+    mut("actual>max", lambda d: d.update(actualBalance=str(10 ** 19 + 1)))
+    mut("reveal>intended", lambda d: d.update(revealAmount=str(int(d["intendedBalance"]) + 1)))
+    mut("balance 2^248", lambda d: d.update(actualBalance=str(2 ** 248)))
+    mut("nibbles-1", lambda d: d.update(numLeafAddressNibbles=str(int(d["numLeafAddressNibbles"]) - 1)))
+    mut("nibbles+1", lambda d: d.update(numLeafAddressNibbles=str(int(d["numLeafAddressNibbles"]) + 1)))
+    mut("relax=1", lambda d: d.update(byteSecurityRelax=1))
+    mut("relax huge", lambda d: d.update(byteSecurityRelax=str((P + 1) // 2)))
+    mut("burnKey+1", lambda d: d.update(burnKey=str(int(d["burnKey"]) + 1)))
+    mut("extra+1", lambda d: d.update(burnExtraCommitment=str((int(d["burnExtraCommitment"]) + 1) % P)))
+    mut("proofExtra (valid)", lambda d: d.update(_proofExtraCommitment=str(rng.randrange(P))))
+    for k in (0, 40, base["layerLens"][0] - 1):
+        mut(f"layer0[{k}]^1", lambda d, k=k: d["layers"][0].__setitem__(k, d["layers"][0][k] ^ 1))
+    for k in (0, 5, 70):
+        mut(f"leaf[{k}]^1", lambda d, k=k: d["layers"][nl - 1].__setitem__(k, d["layers"][nl - 1][k] ^ 1))
+    mut("layer0 pad byte (valid: beyond layerLen)", lambda d: d["layers"][0].__setitem__(d["layerLens"][0] + 3, 7))
+    mut("layerLens0-1", lambda d: d["layerLens"].__setitem__(0, d["layerLens"][0] - 1))
+    mut("layerLens0+1", lambda d: d["layerLens"].__setitem__(0, d["layerLens"][0] + 1))
+    mut("numLayers-1", lambda d: d.update(numLayers=nl - 1))
+    mut("numLayers+1", lambda d: d.update(numLayers=nl + 1))
+    mut("numLayers=0", lambda d: d.update(numLayers=0))
+    mut("numLayers=L+1", lambda d: d.update(numLayers=L + 1))
+    mut("numLayers=2^40", lambda d: d.update(numLayers=2 ** 40))
+    mut("numLayers=p-1", lambda d: d.update(numLayers=str(P - 1)))
+    mut("header stateRoot^1", lambda d: d["blockHeader"].__setitem__(100, d["blockHeader"][100] ^ 1))
+    mut("header other byte (valid, new commitment)", lambda d: d["blockHeader"].__setitem__(10, d["blockHeader"][10] ^ 1))
+    mut("headerLen-1 (valid, new commitment)", lambda d: d.update(blockHeaderLen=d["blockHeaderLen"] - 1))
+    mut("headerLen=max", lambda d: d.update(blockHeaderLen=len(d["blockHeader"])))
+    mut("byte=256", lambda d: d["layers"][0].__setitem__(3, 256))
+    mut("unused layer byte=256", lambda d: d["layers"][L - 1].__setitem__(0, 256))
+    mut("unused layer byte changed (valid)", lambda d: d["layers"][L - 1].__setitem__(0, 99))
+    mut("unused layerLens=0", lambda d: d["layerLens"].__setitem__(L - 1, 0))
+    mut("unused layerLens=30", lambda d: d["layerLens"].__setitem__(L - 1, 30))
+    mut("unused layerLens=31 (valid)", lambda d: d["layerLens"].__setitem__(L - 1, 31))
+    mut("unused layerLens=543 (valid)", lambda d: d["layerLens"].__setitem__(L - 1, len(d["layers"][0]) - 1))
+    mut("unused layerLens=544", lambda d: d["layerLens"].__setitem__(L - 1, len(d["layers"][0])))
+    mut("layerLens=p-5", lambda d: d["layerLens"].__setitem__(L - 1, str(P - 5)))
+    mut("scalar as 1-element array (valid)", lambda d: d.update(numLayers=[nl]))
+    mut("hex string (valid)", lambda d: d.update(revealAmount=hex(int(d["revealAmount"]))))
+    return out
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+def test_failure_sets_match_oracle(pkg, depth):
+    """one GPU batch of ~40 mutated inputs (a failing lane must not disturb its neighbours): pass/fail and the public output
+    must equal the oracle's for every one of them -- every assert / === site of the circuit is hit by some mutation"""
+    import random
+    from proof_of_burn_amd import inputs as gen
+    params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
+    base = gen.synthetic_batch(1, depth=depth, seed=99 + depth, distinct_keys=1, params=params).inputs[0]
+    cases = _mutations(base, random.Random(5))
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
+    res = calc.calculate([c[1] for c in cases], check=True)
+    n_fail = 0
+    for (label, inp), r in zip(cases, res):
+        exp = O.run_main(POB_FIX, inp)
+        got = r.outputs if r.ok else None
+        assert got == exp, f"{label}: GPU {got} vs oracle {exp} ({r.message()})"
+        n_fail += exp is None
+        if r.ok:
+            assert r.check_status == 0 and r.bad_wire is None, label
+    assert exp is not None or n_fail > 0
+    assert 15 < n_fail < len(cases) - 5          # the mutation set really exercises both outcomes
+    calc.close()
+
+
+def test_max_depth_and_ragged_batches(pkg):
+    """BASELINE config 5 shape: 16-layer proofs (byteSecurityRelax = 1, 3-zero-byte PoW) on the production instantiation;
+    batch sizes that are not multiples of the 64-witness group; batch of one."""
+    from proof_of_burn_amd import inputs as gen
+    main = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
+    deep = gen.synthetic_batch(3, depth=16, seed=4242, distinct_keys=1)
+    shallow = gen.synthetic_batch(67, depth=8, seed=77, distinct_keys=2)
+    calc = pkg.WitnessCalculator(main, max_batch=70)
+    for batch in (deep.inputs + shallow.inputs, shallow.inputs[:1], shallow.inputs[:65]):
+        res = calc.calculate(batch)
+        exp = (deep.commitments + shallow.commitments) if len(batch) == 70 else shallow.commitments[:len(batch)]
+        assert [r.outputs for r in res] == [[c] for c in exp]
+    calc.close()
