@@ -195,54 +195,88 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
     p.skip_bits(n * ABSORB_WIRES);
     r.sel_out = p.bits(1600); r.sel_arrays = p.bits((n + 1) * 1600); r.sel_select = p.sms(1); r.sel_T = p.bits(1600 * (n + 1));
 }
-// selectors [j0, j1) of row `row` of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs
-// the hash output (first 256 selector outputs) also flows through outBits, Reshape, outBytes, Bits2Num, out[] and the parent's copy
-template <class P> GD void kb_out_bit(P& p, const KBRefs& r, uint32_t idx, B v, S& by) {
-    const BitRef rs_o = {r.c_post.w, r.c_post.b}, rs_i = {r.c_post.w + 256, r.c_post.b + 256};
-    const uint32_t i = idx >> 3, k = idx & 7;
-    const SmRef b2n_o = {r.c_post.w + 512 + 9 * i, r.c_post.s + i}; const BitRef b2n_i = {r.c_post.w + 512 + 9 * i + 1, r.c_post.b + 512 + 8 * i};
-    v = p.put(r.outBits + idx, v); v = p.put(rs_i + idx, v); v = p.put(rs_o + idx, v); v = p.put(r.outBytes + idx, v); v = p.put(b2n_i + k, v);
-    if (k == 0) by = 0;
-    by |= (S)p.bit(v) << k;
-    if (k == 7) {
-        S o = p.put(r.out + i, p.put(b2n_o, by));
-        if (r.has_dst) p.put(r.dst + i, o);
+// selectors [j0, j1) of row `row` of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs;
+// the hash output (first 256 selector outputs) also flows through outBits, Reshape, outBytes, Bits2Num, out[] and the parent's copy.
+// BIT wires are handled lane-distributed: lane k = selector j0 + k, value = that wire's 64-witness mask, so the selection itself is
+// plain bit-sliced logic (out = OR_k isEq_k & state_k) and a run of wires is one coalesced access.  The SM wires of the IsEqual
+// children (the same four per-witness rows for every selector) stay lane = witness.
+// Selector(n1) block on BIT data (selector.circom:21-46):  [out | vals[n1], select | isEq[n1], sum[n1+1]] || IsEqual x n1,
+// IsEqual (comparators.circom): [out | in[2]] || IsZero [out | in | inv]
+template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
+    const uint32_t n1 = N1 ? (uint32_t)N1 : r.mb + 1, n = j1 - j0, ln = p.lane_id();
+    const uint32_t fw = 9 * n1 + 3, fb = 5 * n1 + 2, fs = 4 * n1 + 1;       // footprint of one selector: wires, BIT, SM
+    const Cur c0 = p.cur;
+    const uint32_t idx = row * 64 + j0 + ln;
+    const S blocks = p.get(r.numBlocks);
+    p.require(p.ballot((uint32_t)blocks < n1), FAILCODE(T_SELECTOR, 43));
+    const uint32_t bw = c0.w + ln * fw, bb = c0.b + ln * fb;                // this lane's selector block
+    B acc = 0;
+    p.run_put(n, bw + 2 * n1 + 2, bb + 2 * n1 + 1, 0);                      // sum[0]
+#pragma unroll
+    for (uint32_t k = 0; k < n1; k++) {
+        const B v = p.run_get(n, r.f_s.i + k * 1600 + idx);
+        const B e = p.ballot((uint32_t)blocks == k);
+        p.run_put(n, r.sel_arrays.w + k * 1600 + idx, r.sel_arrays.i + k * 1600 + idx, v);
+        p.run_put(n, r.sel_T.w + idx * n1 + k, r.sel_T.i + idx * n1 + k, v);
+        p.run_put(n, bw + 1 + k, bb + 1 + k, v);                            // vals[k]
+        p.run_put(n, bw + n1 + 2 + k, bb + n1 + 1 + k, e);                  // isEq[k]
+        acc |= e & v;
+        p.run_put(n, bw + 2 * n1 + 3 + k, bb + 2 * n1 + 2 + k, acc);        // sum[k+1]
+        const uint32_t cw = bw + 3 * n1 + 3 + 6 * k, cb = bb + 3 * n1 + 2 + 2 * k;
+        p.run_put(n, cw, cb, e);                                            // IsEqual.out
+        p.run_put(n, cw + 3, cb + 1, e);                                    // IsZero.out
     }
-}
-template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
-    const uint32_t n1 = r.mb + 1;
-    S blocks = p.get(r.numBlocks);
-    S by = 0;
-    for (uint32_t j = j0; j < j1; j++) {
-        const uint32_t idx = row * 64 + j;
-        B out;
-        if (n1 <= 17) {          // all n1 candidate state words first (independent loads), then nothing but stores
-            B v[17];
+    p.run_put(n, bw, bb, acc);                                              // Selector.out
+    p.run_put(n, r.sel_out.w + idx, r.sel_out.i + idx, acc);
+    p.run_put(n, r.f_out.w + idx, r.f_out.i + idx, acc);
+    p.run_put(n, r.k_finalState.w + idx, r.k_finalState.i + idx, acc);
+    if (row < 4) {           // the 256 hash bits: Keccak.out, KeccakBytes.outBits, Reshape in/out, outBytes, Bits2Num(8).in
+        const uint32_t pw = r.c_post.w, pb = r.c_post.b;
+        p.run_put(n, r.k_out.w + idx, r.k_out.i + idx, acc);
+        p.run_put(n, r.outBits.w + idx, r.outBits.i + idx, acc);
+        p.run_put(n, pw + 256 + idx, pb + 256 + idx, acc);
+        p.run_put(n, pw + idx, pb + idx, acc);
+        p.run_put(n, r.outBytes.w + idx, r.outBytes.i + idx, acc);
+        p.run_put(n, pw + 512 + 9 * (idx >> 3) + 1 + (idx & 7), pb + 512 + idx, acc);
+        for (uint32_t jj = 0; jj < n; jj += 8) {                            // Bits2Num(8) outputs, per witness
+            S by = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 17; k++) v[k] = k < n1 ? p.get(r.f_s + (k * 1600 + idx)) : 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 17; k++) if (k < n1) v[k] = p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), v[k]));
-            // Selector(n1) on BIT data (selector.circom:21-46): [out | vals[n1], select | isEq[n1], sum[n1+1]] || IsEqual x n1
-            BitRef o = p.bits(1), vals = p.bits(n1); SmRef sel = p.sms(1); BitRef isEq = p.bits(n1), sum = p.bits(n1 + 1);
-            S select = p.put(sel, blocks);
-            B acc = p.put(sum, 0), any = 0, multi = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 17; k++) if (k < n1) {
-                B val = p.put(vals + k, v[k]);
-                B e = p.put(isEq + k, gIsEqualS(p, select, (S)k));
-                multi |= any & e; any |= e;
-                acc = p.put(sum + k + 1, acc | (e & val));
-            }
-            p.require(any & ~multi, FAILCODE(T_SELECTOR, 43));
-            out = p.put(o, acc);
-        } else {
-            for (uint32_t k = 0; k < n1; k++) p.put(r.sel_T + (idx * n1 + k), p.put(r.sel_arrays + (k * 1600 + idx), p.get(r.f_s + (k * 1600 + idx))));
-            out = gSelectorB(p, n1, r.sel_T + idx * n1, blocks);
+            for (uint32_t b = 0; b < 8; b++) by |= (S)p.bit(p.run_bcast(acc, jj + b)) << b;
+            const uint32_t i = (row * 64 + j0 + jj) >> 3;
+            const SmRef b2n_o = {pw + 512 + 9 * i, r.c_post.s + i};
+            const S o = p.put(r.out + i, p.put(b2n_o, by));
+            if (r.has_dst) p.put(r.dst + i, o);
         }
-        out = p.put(r.sel_out + idx, out); out = p.put(r.f_out + idx, out); out = p.put(r.k_finalState + idx, out);
-        if (idx < 256) { out = p.put(r.k_out + idx, out); const Cur keep = p.cur; kb_out_bit(p, r, idx, out, by); p.cur = keep; }
     }
+    // SM side of the n selectors: select, and per IsEqual child in[0] = select, in[1] = k, IsZero.in = k - select, IsZero.inv
+    for (uint32_t j = 0; j < n; j++) {
+        const uint32_t sw = c0.w + j * fw, ss = c0.s + j * fs;
+        p.put(SmRef{sw + n1 + 1, ss}, blocks);
+        for (uint32_t k0 = 0; k0 < n1; k0 += 4) {
+            SmRef rr[12]; S vv[12], kk[4], xx[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t k = k0 + q < n1 ? k0 + q : n1 - 1;           // a ragged tail repeats the last child
+                const uint32_t cw = sw + 3 * n1 + 3 + 6 * k, cs = ss + 1 + 4 * k;
+                xx[q] = (S)(k - (uint32_t)blocks);
+                rr[3 * q] = SmRef{cw + 1, cs}; vv[3 * q] = blocks;
+                rr[3 * q + 1] = SmRef{cw + 2, cs + 1}; vv[3 * q + 1] = (S)k;
+                rr[3 * q + 2] = SmRef{cw + 4, cs + 2}; vv[3 * q + 2] = xx[q];
+                kk[q] = p.hint_inv(SiRef{cw + 5, cs + 3}, xx[q]);
+            }
+            put_batch(p, rr, vv);
+            if constexpr (!P::is_gen) {
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    p.require(p.ballot(kk[q] == 0 || kk[q] == xx[q]), FAILCODE(T_ISZERO, 30));
+                    p.require(p.ballot(xx[q] == 0 || kk[q] != 0), FAILCODE(T_ISZERO, 31));
+                }
+            }
+        }
+    }
+    p.cur = cur_add(c0, Cur{fw, fb, fs, 0}, n);
 }
+template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) { kb_selrow_n<P, 0>(p, r, row, j0, j1); }
 // after the selectors: Keccak/Final/selector `blocks` inputs; the Reshape(32,8) + Bits2Num(8) x 32 blocks that follow in wire
 // order (512 + 32*9 wires) are written by the selector-row units of rows 0..3 (kb_out_bit)
 template <class P> GD void kb_post(P& p, const KBRefs& r) {
@@ -780,6 +814,11 @@ struct Plan {
     std::vector<SpongeDesc> sponges;
     Cur total;            // = counts (total.w = nWitness)
     uint32_t nfr_in, nsm_in, max_stage;
+    // Side tracks: stage ids TRACK_STRIDE*t + s belong to track t.  Track 0 is the main sequence; track t > 0 starts once stage
+    // track_fork[t] has completed and must have completed before stage track_join[t] starts.  A track may only be joined by a
+    // lower-numbered track (the host enqueues a stage's forked tracks highest first, each one completely).
+    enum { TRACK_STRIDE = 32, MAX_TRACKS = 4 };
+    uint32_t ntracks, track_fork[MAX_TRACKS], track_join[MAX_TRACKS];
     CountP p;
 
     static bool same(Cur a, Cur b) { return a.w == b.w && a.b == b.b && a.s == b.s && a.f == b.f; }
@@ -872,6 +911,11 @@ struct Plan {
     void plan_pob(const PobParams& prm) {
         memset(&L, 0, sizeof L);
         L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
+        // track 1 (TB): everything that hangs off the main inputs only -- range checks, Poseidons, BurnAddressHash, ProofOfWorkChecker,
+        // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before PublicCommitment
+        // (main stage 5).  track 2 (TC): RlpEmptyAccount's serial chain, joined before the leaf assembly (TB + 7).
+        const uint32_t TB = TRACK_STRIDE, TC = 2 * TRACK_STRIDE;
+        ntracks = 3; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = 0; track_join[2] = TB + 7;
         PobMain& M = L.pm;
         const int Ln = prm.L, LB = 136 * prm.NB, HBy = 136 * prm.HB;
         p.cur = Cur{1, 0, 0, 0};                      // wire 0 = constant 1
@@ -890,22 +934,22 @@ struct Plan {
         //         | 3 sponges A | 4 output selector rows, posts | 5 consumers | 6 sponge B, ... | 10 final ===
         unit(U_POB_INPUT_FR, 0);
         for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
-        unit(U_POB_RANGE, 1);
+        unit(U_POB_RANGE, TB + 1);
         for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, 1, i); abs_units(1, LB, M.layers + i * LB); }
         unit(U_POB_HDR_ASSERT, 1); abs_units(1, HBy, M.blockHeader);
-        unit(U_POB_POSEIDONS, 1, 0);
-        unit(U_POB_POSEIDONS, 1, 1);
+        unit(U_POB_POSEIDONS, TB + 1, 0);
+        unit(U_POB_POSEIDONS, TB + 1, 1);
         {   // BurnAddressHash :119
             L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
             L.bah.kb = L.nkb++;
-            unit(U_BAH_PRE, 1);
-            kb_ranges(L.bah.kb, 2, L.bah.block);
-            keccak_tail(L.bah.kb, 2, L.bah.hash, true);
-            unit(U_BAH_POST, 5);
+            unit(U_BAH_PRE, TB + 1);
+            kb_ranges(L.bah.kb, TB + 2, L.bah.block);
+            keccak_tail(L.bah.kb, TB + 2, L.bah.hash, true);      // sponge TB+3, rows/post TB+4
+            unit(U_BAH_POST, TB + 5);
         }
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 1, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122
-        for (int j = 0; j < 5; j++) unit(U_POB_N2B, 2, j);                                      // :132-136
+        for (int j = 0; j < 5; j++) unit(U_POB_N2B, TB + 2, j);                                    // :132-136
         public_commitment(6, 5);                                                                // :137  (pre 5, ranges 6, sponge 7, rows/post 8, commitment 9)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
             CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
@@ -939,12 +983,12 @@ struct Plan {
             }
         }
         leaf_detector(Ln, 2, M.lastLayer, M.lastLayerLen, M.isLastLayerLeaf);                    // :187 (lastLayer is written in stage 1)
-        {   // RlpMerklePatriciaTrieLeaf :198  (needs addressHashNibbles, written in stage 5)
+        {   // RlpMerklePatriciaTrieLeaf :198  (needs addressHashNibbles, written in stage TB+5)
             const Cur start = p.cur;
             CountP chk; chk.cur = start; { S ll; gRlpMptLeaf(chk, 32, prm.amountBytes, M.addressHashNibbles, 0, fr_zero(), ll); }
-            unit(U_RL_A, 6);
+            unit(U_RL_A, TB + 6);
             RlRefs& R = L.rl;
-            for (uint32_t i = 0; i < 64; i += 4) record(U_RL_SLROW, 6, R.c_sl_iseq, i, i + 4);
+            for (uint32_t i = 0; i < 64; i += 4) record(U_RL_SLROW, TB + 6, R.c_sl_iseq, i, i + 4);
             // after ShiftLeft: Mux1 x 63, Nibbles2Bytes(33), AssertGreaterEqThan(16), RlpEmptyAccount, Concat
             CountP q; q.cur = R.c_mux;
             for (int i = 0; i < 63; i++) gMux1S(q, 0, 0, 0);
@@ -960,23 +1004,23 @@ struct Plan {
                 const Cur keep = p.cur;
                 p.cur = R.c_acc;
                 CountP qa; qa.cur = R.c_acc; { S al; gRlpEmptyAccount(qa, prm.amountBytes, fr_zero(), al); }
-                unit(U_RL_ACC, 1);                                  // depends on the balance input only: runs early
+                unit(U_RL_ACC, TC + 1);                             // depends on the balance input only: its own track
                 expect_cursor("RlpEmptyAccount", p.cur, qa.cur);
                 p.cur = keep;
-                record(U_RL_ACC_B, 2, L.ra.c_cb);
-                record(U_RL_ACC_C, 6, L.ra.c_concat);               // long serial unit: placed where it hides behind the BN254 units of stage 6
+                record(U_RL_ACC_B, TC + 2, L.ra.c_cb);
+                record(U_RL_ACC_C, TC + 3, L.ra.c_concat);          // long serial unit
             }
-            record(U_RL_B, 7, R.c_mux);
+            record(U_RL_B, TB + 7, R.c_mux);
             p.cur = chk.cur;
         }
         {   // ProofOfWorkChecker :211
             L.pw.in = p.frs(3); L.pw.mzb = p.sms(1); L.pw.keyBytes = p.sms(32); L.pw.raBytes = p.sms(32); L.pw.becBytes = p.sms(32); L.pw.eip = p.sms(8);
             L.pw.hin = p.sms(104); L.pw.block = p.sms(136); L.pw.keccak = p.sms(32); L.pw.sbz = p.bits(32);
             L.pw.kb = L.nkb++;
-            unit(U_POW_PRE, 1);
-            kb_ranges(L.pw.kb, 2, L.pw.block);
-            keccak_tail(L.pw.kb, 2, L.pw.keccak, true);
-            unit(U_POW_POST, 5);
+            unit(U_POW_PRE, TB + 1);
+            kb_ranges(L.pw.kb, TB + 2, L.pw.block);
+            keccak_tail(L.pw.kb, TB + 2, L.pw.keccak, true);
+            unit(U_POW_POST, TB + 5);
         }
         unit(U_POB_FINAL, 10);
         total = p.cur;
@@ -984,7 +1028,7 @@ struct Plan {
     }
     void plan_spend(const SpendParams& prm) {
         memset(&L, 0, sizeof L);
-        L.circuit = 1; L.spend = prm; L.nkb = 0; max_stage = 0;
+        L.circuit = 1; L.spend = prm; L.nkb = 0; max_stage = 0; ntracks = 1;
         L.pob = PobParams{1, 1, 1, 0, prm.maxAmountBytes, 0, fr_zero(), fr_zero()};
         SpendMain& M = L.sm;
         p.cur = Cur{1, 0, 0, 0};

@@ -23,10 +23,17 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
         p.m.pos_tab = g_lds;
     } else p.m.pos_tab = A.pos_tab;
     if constexpr (P::is_gen) p.status = 0;
-    if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; }
+    if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.attribute = false; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; }
-    const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];
-    if constexpr (CLS == 1) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
+    for (int pass = 0;; pass++) {
+        const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
+        if constexpr (CLS == 1) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
+        if constexpr (P::is_check) {      // a lane-distributed run differed: replay the unit attributing wire by wire
+            p.run_flush();
+            if (pass == 0 && __ballot(p.rdiff != 0)) { p.attribute = true; continue; }
+        }
+        break;
+    }
     if constexpr (P::is_gen) { if (p.status) atomicMin(&A.status[g * 64 + lane], p.status); }
     if constexpr (P::is_check) {
         if (p.status) atomicMin(&A.chk_status[g * 64 + lane], p.status);

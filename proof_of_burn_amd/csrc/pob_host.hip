@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -52,9 +53,12 @@ struct pob_ctx {
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, all_segs;                   // per (stage, lds) for generation; all units at once for check/emit
-    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
     std::vector<KSeg> ksegs;
+    // side tracks (Plan::track_fork/track_join): own light + BN254 streams, own fork/join events, start and end events
+    struct Track { hipStream_t s_main = nullptr, s_heavy = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_end = nullptr; };
+    Track tracks[Plan::MAX_TRACKS];
     uint32_t nperms = 0;
     bool generated = false;
 };
@@ -114,7 +118,9 @@ static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_i
     info->n_witness = pl.total.w; info->n_bit = pl.total.b; info->n_sm = pl.total.s; info->n_fr = pl.total.f;
     info->n_fr_inputs = pl.nfr_in; info->n_sm_inputs = pl.nsm_in; info->n_outputs = 1;
     info->n_units = (uint32_t)pl.units.size(); info->n_sponges = (uint32_t)pl.sponges.size(); info->n_perms = nperms;
-    info->n_stages = pl.max_stage + 1; info->max_batch = max_batch;
+    { std::vector<char> used(pl.max_stage + 1, 0); for (const UnitDesc& u : pl.units) used[u.stage] = 1; for (const SpongeDesc& s : pl.sponges) used[s.stage] = 1;
+      info->n_stages = 0; for (char c : used) info->n_stages += c; }
+    info->max_batch = max_batch;
     info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;
     info->keccak_bit_wires = 0;
     for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
@@ -128,6 +134,16 @@ int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* 
     int rc;
     try { rc = make_plan(*plan, err, circuit, params, nparams); } catch (const std::exception& e) { fprintf(stderr, "%s\n", e.what()); rc = POB_E_STATE; }
     if (rc == POB_OK) { uint32_t np = 0; for (const SpongeDesc& sd : plan->sponges) np += sd.n; fill_info(*plan, np, 0, info); }
+    if (rc == POB_OK && getenv("POB_PLAN_DUMP")) {          // per (stage, unit kind): units, wires written (planner cost model)
+        std::vector<std::vector<uint64_t>> acc;
+        for (const UnitDesc& u : plan->units) {
+            if (acc.size() <= u.stage) acc.resize(u.stage + 1, std::vector<uint64_t>(2 * 64, 0));
+            acc[u.stage][2 * u.kind]++; acc[u.stage][2 * u.kind + 1] += u.cost;
+        }
+        for (size_t s = 0; s < acc.size(); s++) for (uint32_t k = 0; k < 64; k++) if (acc[s][2 * k])
+            fprintf(stderr, "stage %3zu kind %2u class %u units %5llu cost %9llu max/unit %8llu\n", s, k, unit_class(k), (unsigned long long)acc[s][2 * k],
+                    (unsigned long long)acc[s][2 * k + 1], (unsigned long long)(acc[s][2 * k + 1] / acc[s][2 * k]));
+    }
     delete plan;
     return rc;
 }
@@ -187,8 +203,15 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 
     HIPC(hipSetDevice(device));
     HIPC(hipStreamCreate(&h->stream));
-    HIPC(hipStreamCreate(&h->stream2)); HIPC(hipStreamCreate(&h->stream3)); HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
+    HIPC(hipStreamCreate(&h->stream2)); HIPC(hipStreamCreate(&h->stream3)); HIPC(hipStreamCreate(&h->stream4));
+    HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    for (uint32_t t = 1; t < pl.ntracks; t++) {
+        pob_ctx::Track& T = h->tracks[t];
+        HIPC(hipStreamCreate(&T.s_main)); HIPC(hipStreamCreate(&T.s_heavy));
+        HIPC(hipEventCreateWithFlags(&T.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_join, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&T.ev_start, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_end, hipEventDisableTiming));
+    }
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
@@ -242,6 +265,13 @@ void pob_close(pob_handle h) {
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->stream3) hipStreamDestroy(h->stream3);
+    if (h->stream4) hipStreamDestroy(h->stream4);
+    for (pob_ctx::Track& T : h->tracks) {
+        if (T.s_main) hipStreamDestroy(T.s_main);
+        if (T.s_heavy) hipStreamDestroy(T.s_heavy);
+        for (hipEvent_t e : {T.ev_fork, T.ev_join, T.ev_start, T.ev_end}) if (e) hipEventDestroy(e);
+    }
+    if (h->ev_join4) hipEventDestroy(h->ev_join4);
     if (h->ev_join3) hipEventDestroy(h->ev_join3);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -271,26 +301,40 @@ int pob_generate(pob_handle h, void* stream_) {
     HIPC(hipMemsetAsync(h->d_status_raw, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
-    size_t si = 0, ki = 0;
-    for (uint32_t s = 0; s <= h->plan.max_stage; s++) {
-        // heavy (BN254) units run on the second stream beside the stage's light units; the Poseidon ones stage their table in LDS
-        bool forked = false;
-        for (; si < h->segs.size() && h->segs[si].stage == s; si++) {
-            A.first = h->segs[si].first; A.stage_lds = h->segs[si].lds == 2;
-            if (h->segs[si].lds) {
-                if (!forked) { HIPC(hipEventRecord(h->ev_fork, st)); HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
-                launch_g_gen(A, kernel_class(h->segs[si].lds), h->segs[si].count, G, h->stream2);
-                forked = true;
-            } else launch_g_gen(A, 0, h->segs[si].count, G, st);
+    const Plan& pl = h->plan;
+    // one track: its stages in order; within a stage the BN254 units run on the track's second stream beside the light ones (the
+    // Poseidon ones stage their table in LDS), then the stage's Keccak sponges.  Tracks forked after a stage are enqueued completely
+    // (highest first) before the next stage, so every event is recorded before anything waits on it.
+    std::function<int(uint32_t)> run_track = [&](uint32_t t) -> int {
+        hipStream_t sm = t ? h->tracks[t].s_main : st, sh = t ? h->tracks[t].s_heavy : h->stream2;
+        hipEvent_t ef = t ? h->tracks[t].ev_fork : h->ev_fork, ej = t ? h->tracks[t].ev_join : h->ev_join;
+        for (uint32_t sid = t * Plan::TRACK_STRIDE; sid < (t + 1) * Plan::TRACK_STRIDE && sid <= pl.max_stage; sid++) {
+            for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) HIPC(hipStreamWaitEvent(sm, h->tracks[u].ev_end, 0));
+            bool forked = false;
+            for (const pob_ctx::Seg& sg : h->segs) if (sg.stage == sid) {
+                A.first = sg.first; A.stage_lds = sg.lds == 2;
+                if (sg.lds) {
+                    if (!forked) { HIPC(hipEventRecord(ef, sm)); HIPC(hipStreamWaitEvent(sh, ef, 0)); }
+                    launch_g_gen(A, kernel_class(sg.lds), sg.count, G, sh);
+                    forked = true;
+                } else launch_g_gen(A, 0, sg.count, G, sm);
+            }
+            if (forked) { HIPC(hipEventRecord(ej, sh)); HIPC(hipStreamWaitEvent(sm, ej, 0)); }
+            for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid) {
+                K.first = ks.sp_first;
+                launch_k_chain(K, false, ks.sp_count, G, sm);
+                K.first = ks.perm_first;
+                launch_k_rounds(K, false, ks.perm_count, G, sm);
+            }
+            for (uint32_t u = pl.ntracks; u-- > t + 1;) if (pl.track_fork[u] == sid) {
+                HIPC(hipEventRecord(h->tracks[u].ev_start, sm)); HIPC(hipStreamWaitEvent(h->tracks[u].s_main, h->tracks[u].ev_start, 0));
+                int rc = run_track(u); if (rc) return rc;
+                HIPC(hipEventRecord(h->tracks[u].ev_end, h->tracks[u].s_main));
+            }
         }
-        if (forked) { HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); }
-        for (; ki < h->ksegs.size() && h->ksegs[ki].stage == s; ki++) {
-            K.first = h->ksegs[ki].sp_first;
-            launch_k_chain(K, false, h->ksegs[ki].sp_count, G, st);
-            K.first = h->ksegs[ki].perm_first;
-            launch_k_rounds(K, false, h->ksegs[ki].perm_count, G, st);
-        }
-    }
+        return POB_OK;
+    };
+    { int rc = run_track(0); if (rc) return rc; }
     const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
     hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs, G * 64);
     HIPC(hipGetLastError());
@@ -306,28 +350,32 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
-    bool forked = false, forked3 = false;
-    for (size_t k = h->all_segs.size(); k-- > 0;) {      // no dependencies between units here: one launch per class; the BN254 units
-        const pob_ctx::Seg& sg = h->all_segs[k];          // run on stream 2, the three Poseidon units (LDS table) on stream 3
+    // The evaluation has no dependencies between launches: the HBM-streaming Keccak kernels (stream 4), the latency-bound
+    // light units (caller's stream), SubstringCheck's BN254 units (stream 2) and the Poseidon units (stream 3) overlap.
+    HIPC(hipEventRecord(h->ev_fork, st));
+    bool forked = false, forked3 = false, forked4 = false;
+    KArgs K = kargs(h);
+    if (!h->plan.sponges.empty()) {
+        HIPC(hipStreamWaitEvent(h->stream4, h->ev_fork, 0));
+        K.first = 0;
+        launch_k_rounds(K, true, h->nperms, G, h->stream4);
+        launch_k_chain(K, true, h->nperms, G, h->stream4);
+        HIPC(hipEventRecord(h->ev_join4, h->stream4));
+        forked4 = true;
+    }
+    for (size_t k = h->all_segs.size(); k-- > 0;) {
+        const pob_ctx::Seg& sg = h->all_segs[k];
         A.first = sg.first; A.stage_lds = sg.lds == 2;
         if (sg.lds) {
-            if (!forked && !forked3) HIPC(hipEventRecord(h->ev_fork, st));
             hipStream_t s2 = sg.lds == 2 ? h->stream3 : h->stream2;
             HIPC(hipStreamWaitEvent(s2, h->ev_fork, 0));
             launch_g_check(A, kernel_class(sg.lds), sg.count, G, s2);
             if (sg.lds == 2) forked3 = true; else forked = true;
         } else launch_g_check(A, 0, sg.count, G, st);
     }
-    if (forked) HIPC(hipEventRecord(h->ev_join, h->stream2));
-    if (forked3) HIPC(hipEventRecord(h->ev_join3, h->stream3));
-    KArgs K = kargs(h);
-    if (!h->plan.sponges.empty()) {
-        K.first = 0;
-        launch_k_chain(K, true, h->nperms, G, st);
-        launch_k_rounds(K, true, h->nperms, G, st);
-    }
-    if (forked) HIPC(hipStreamWaitEvent(st, h->ev_join, 0));
-    if (forked3) HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
+    if (forked) { HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); }
+    if (forked3) { HIPC(hipEventRecord(h->ev_join3, h->stream3)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
+    if (forked4) HIPC(hipStreamWaitEvent(st, h->ev_join4, 0));
     HIPC(hipGetLastError());
     return POB_OK;
 }

@@ -78,7 +78,20 @@ struct CountP : PolBase {
     HD F input_fr(uint32_t) { return fr_zero(); }
     HD S input_sm(uint32_t) { return 0; }
     HD uint32_t lane_id() { return 0; }
+    // lane-distributed BIT access (see DevPol): n wires
+    HD B run_get(uint32_t, uint32_t) { return 0; }
+    HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; }
+    HD B run_bcast(B, uint32_t) { return 0; }
 };
+
+// N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
+template <class P, class R, class V, int N> HD __attribute__((always_inline)) void put_batch(P& p, const R (&r)[N], const V (&v)[N]) {
+    if constexpr (P::is_check) p.put_batch(r, v);
+    else {
+#pragma unroll
+        for (int k = 0; k < N; k++) p.put(r[k], v[k]);
+    }
+}
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------ device policies
@@ -119,6 +132,13 @@ struct DevPol : PolBase {
 #pragma unroll
         for (int k = 0; k < 8; k++) q[k * 64] = v.l[k];
     }
+    // Lane-distributed BIT access: lane k < n owns ONE wire (its own BIT rank i, wire index w) and holds that wire's 64-witness
+    // mask, i.e. the wave works on up to 64 wires x 64 witnesses at once, bit-sliced like the Keccak kernels.  A run of consecutive
+    // wires is one coalesced 512-byte access instead of 64 single-lane ones.
+    __device__ __forceinline__ B run_get(uint32_t n, uint32_t i) { return m.lane < n ? m.bits[i] : 0; }
+    __device__ __forceinline__ B run_bcast(B x, uint32_t k) {     // lane k's value, wave-uniform
+        return ((B)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)k);
+    }
     __device__ __forceinline__ B get(BitRef r) { return ld(r); }
     __device__ __forceinline__ S get(SmRef r) { return ld(r); }
     __device__ __forceinline__ F get(FrRef r) { return ld(r); }
@@ -157,7 +177,21 @@ struct GenP : DevPol {
     __device__ __forceinline__ S hint_inv(SiRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
+    __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) { if (m.lane < n) m.bits[i] = x; }
 };
+
+// slow path of CheckP::run_put (by value: the policy object stays in registers): lane j holds the difference mask d of wire w
+__device__ __forceinline__ uint32_t check_attribute_run(B d, uint32_t w, uint32_t lane, uint32_t bad_wire) {
+    uint64_t act = __ballot(d != 0);
+    while (act) {
+        const int j = __builtin_ctzll(act); act &= act - 1;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d >> 32), j);
+        const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
+        const B dj = ((B)hi << 32) | lo;
+        if (((dj >> lane) & 1) && wj < bad_wire) bad_wire = wj;
+    }
+    return bad_wire;
+}
 
 // Constraint evaluator: `put` = "this wire must equal this expression of stored wires".
 struct CheckP : DevPol {
@@ -176,6 +210,31 @@ struct CheckP : DevPol {
     __device__ __forceinline__ S hint_inv(SiRef r, S) { return ld(r); }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
+    // lane-distributed runs: a run's difference is folded into `rdiff` when the NEXT run's load has been issued (one load is
+    // always in flight).  Only if a unit ends with rdiff != 0 (corrupted vector) it is replayed with `attribute` set, which
+    // resolves every run on the spot and finds the lowest mismatching wire of each witness.
+    B pend_s, pend_x, rdiff; bool attribute;
+    __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B x) {
+        B s = m.lane < n ? m.bits[i] : x;
+        if (attribute) { const B d = s ^ x; if (__ballot(d != 0)) bad_wire = check_attribute_run(d, w, m.lane, bad_wire); }
+        else rdiff |= s ^ x;
+    }
+    __device__ __forceinline__ void run_flush() {}
+    // N independent wires at once: all loads are issued before the first compare (one wait instead of N)
+    template <int N> __device__ __forceinline__ void put_batch(const BitRef (&r)[N], const B (&v)[N]) {
+        B s[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) s[k] = ld(r[k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) mark(((s[k] ^ v[k]) >> m.lane) & 1, r[k].w);
+    }
+    template <int N> __device__ __forceinline__ void put_batch(const SmRef (&r)[N], const S (&v)[N]) {
+        S s[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) s[k] = ld(r[k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) mark(s[k] != v[k], r[k].w);
+    }
 };
 
 // .wtns emitter for ONE witness of the group (lane `sel`): canonical 32-byte LE value at wire index.
@@ -219,5 +278,8 @@ struct EmitP : DevPol {
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B, uint32_t) {}
+    __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B) {
+        if (m.lane < n) { B s = m.bits[i]; Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); }
+    }
 };
 #endif  // __HIPCC__
