@@ -79,7 +79,8 @@ int pob_write_wtns(pob_handle h, uint32_t idx, const char* path);
 
 /* Measurement: average duration (ms, HIP events on `stream`) of `iters` back-to-back launches of one kernel over
  * the current batch.  which: 0 = Keccak round expansion (generate), 1 = Keccak round constraint evaluation,
- * 2 = G-unit constraint evaluation, 3 = sponge chain (generate).                                               */
+ * 2 = G-unit constraint evaluation, 3 = sponge chain (generate); 100 + k / 200 + k = evaluation / generation of all
+ * units of kind k (circuits.hpp UnitKind) alone on the device (tools/unit_times.py).                             */
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream, float* avg_ms);
 
 /* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */

@@ -128,9 +128,30 @@ HD PosOff pos_off(int t) {
 // ---------------------------------------------------------------------------- AssertByteString(N) in ranges (assert.circom:26-31)
 // own in[N] is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8
 template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint32_t lo, uint32_t hi) {
-    for (uint32_t i = lo; i < hi; i++) {
-        p.cur = cur_add(c0, FP_ABITS8, i);
-        gAssertBitsS(p, 8, p.put(own_in + i, p.get(src + i)));
+    // per byte i: own in[i]; AssertBits(8) [in | bits[8]] || Num2Bits(8) [out[8] | in] at c0 + i*FP_ABITS8.  The 16 BIT wires of a
+    // byte are consecutive in BIT rank (bits[8] then out[8]), so 4 bytes make one lane-distributed run of 64 wires.
+    const uint32_t ln = p.lane_id();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 8) {
+        const uint32_t cnt = hi - i0 < 8 ? hi - i0 : 8;
+        B compact = 0;                                   // lane 8t + k = bit k of byte i0 + t
+        for (uint32_t t = 0; t < cnt; t++) {
+            const uint32_t i = i0 + t;
+            const Cur c = cur_add(c0, FP_ABITS8, i);
+            const SmRef rr[3] = {own_in + i, SmRef{c.w, c.s}, SmRef{c.w + 17, c.s + 1}};
+            const SmLoaded<3> h = sm_load(p, rr);
+            const S v = p.get(src + i);
+            const S vv[3] = {v, v, v};
+            sm_commit(p, rr, h, vv);
+            p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
+        }
+        for (uint32_t h2 = 0; h2 < 2 && 4 * h2 < cnt; h2++) {       // bytes i0 + 4*h2 .. +3: 16 wires each
+            const uint32_t nb = cnt - 4 * h2 < 4 ? cnt - 4 * h2 : 4;
+            const uint32_t t = 4 * h2 + (ln >> 4), q = ln & 15, i = i0 + t;
+            const B x = p.run_perm(compact, 8 * t + (q & 7));
+            p.run_put(16 * nb, c0.w + 18 * i + 1 + q, c0.b + 16 * i + q, x);
+        }
     }
 }
 
@@ -160,30 +181,63 @@ template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
     r.c_loop = p.cur;
     p.cur = cur_add(cur_add(cur_add(p.cur, FP_ISEQ_S, 2 * m), FP_N2B8, m), Cur{16u * m, 16u * m, 0, 0}, 1);   // -> Keccak(mb)
 }
+// SM / SI wires of an IsEqual([a, b]) child at cursor c (its two BIT wires are written by the caller as part of a run):
+// rr/vv get in[0], in[1], IsZero.in; returns the IsZero.inv reference and operand
+#define ISEQ_SM_REFS(c) SmRef{(c).w + 1, (c).s}, SmRef{(c).w + 2, (c).s + 1}, SmRef{(c).w + 4, (c).s + 2}
 template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t lo, uint32_t hi) {
-    const uint32_t m = 136 * r.mb;
+    const uint32_t m = 136 * r.mb, cnt = hi - lo, ln = p.lane_id();     // cnt <= 16 bytes
     const S inLen = p.get(r.inLen), nb = p.get(r.numBlocks);
-    const Cur cF = cur_add(cur_add(r.c_loop, FP_ISEQ_S, 2 * m), FP_N2B8, m);      // Flatten(m,8): [out[8m] | in[8m]]
+    const S last = (S)((uint32_t)nb * 136u - 1u);
+    const Cur cE = r.c_loop, cL = cur_add(cE, FP_ISEQ_S, m), cN = cur_add(cL, FP_ISEQ_S, m), cF = cur_add(cN, FP_N2B8, m);
     const BitRef flat_o = {cF.w, cF.b}, flat_i = {cF.w + 8 * m, cF.b + 8 * m};
     // filter[i] = prod_{j<i}(1 - isEq[j]) = [inLen >= i] (unsigned: an out-of-range inLen never hits); the evaluator re-reads it
     B f = P::is_gen ? p.ballot((uint32_t)inLen >= lo) : p.get(r.pad_flt + lo);
-    for (uint32_t i = lo; i < hi; i++) {
-        S v = p.put(r.pad_in + i, p.put(r.in + i, p.get(src + i)));
-        p.cur = cur_add(r.c_loop, FP_ISEQ_S, i);
-        B e = p.put(r.pad_isEq + i, gIsEqualS(p, (S)i, inLen));
-        f = p.put(r.pad_flt + i + 1, f & ~e);
-        p.cur = cur_add(r.c_loop, FP_ISEQ_S, m + i);
-        B l = p.put(r.pad_isLast + i, gIsEqualS(p, (S)i, (S)(nb * 136 - 1)));
-        S pv = p.put(r.padded + i, p.put(r.pad_o + i, (p.bit(f) ? v : 0) + (S)p.bit(e) + (p.bit(l) ? 0x80 : 0)));
-        p.cur = cur_add(cur_add(r.c_loop, FP_ISEQ_S, 2 * m), FP_N2B8, i);
-        B bits[8];
-        gNum2Bits8(p, pv, bits);
+    B runE = 0, runL = 0, runF = 0, runPairE = 0, runPairL = 0, bits0 = 0, bits1 = 0;
+    for (uint32_t t = 0; t < cnt; t++) {
+        const uint32_t i = lo + t;
+        const Cur ce = cur_add(cE, FP_ISEQ_S, i), cl = cur_add(cL, FP_ISEQ_S, i);
+        const SmRef rr[11] = {r.in + i, r.pad_in + i, ISEQ_SM_REFS(ce), ISEQ_SM_REFS(cl), r.pad_o + i, r.padded + i, SmRef{cN.w + 9 * i + 8, cN.s + i}};
+        const SmLoaded<11> h = sm_load(p, rr);
+        const S v = p.get(src + i);
+        const S xe = (S)((uint32_t)inLen - i), xl = (S)((uint32_t)last - i);
+        const S ke = p.hint_inv(SiRef{ce.w + 5, ce.s + 3}, xe), kl = p.hint_inv(SiRef{cl.w + 5, cl.s + 3}, xl);
+        if constexpr (!P::is_gen) {
+            p.require(p.ballot((ke == 0 || ke == xe) && (kl == 0 || kl == xl)), FAILCODE(T_ISZERO, 30));
+            p.require(p.ballot((xe == 0 || ke != 0) && (xl == 0 || kl != 0)), FAILCODE(T_ISZERO, 31));
+        }
+        const B e = p.ballot(xe == 0), l = p.ballot(xl == 0);
+        f &= ~e;
+        const S pv = (p.bit(f) ? v : 0) + (S)p.bit(e) + (p.bit(l) ? 0x80 : 0);
+        const S vv[11] = {v, v, (S)i, inLen, xe, (S)i, last, xl, pv, pv, pv};
+        sm_commit(p, rr, h, vv);
+        p.require(p.ballot((uint32_t)pv < 256u), FAILCODE(T_NUM2BITS, 38));
+        runE = p.run_set(runE, t, e); runL = p.run_set(runL, t, l); runF = p.run_set(runF, t, f);
+        runPairE = p.run_set(p.run_set(runPairE, 2 * t, e), 2 * t + 1, e);
+        runPairL = p.run_set(p.run_set(runPairL, 2 * t, l), 2 * t + 1, l);
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t j = 8 * i + k;
-            B b = p.put(r.inBitsArray + j, bits[k]);
-            b = p.put(flat_i + j, b); b = p.put(flat_o + j, b); b = p.put(r.inBits + j, b); p.put(r.inBlocks + j, b);
+            const B b = p.ballot(((uint32_t)pv >> k) & 1);
+            if (t < 8) bits0 = p.run_set(bits0, 8 * t + k, b); else bits1 = p.run_set(bits1, 8 * (t - 8) + k, b);
         }
+    }
+    p.run_put(cnt, r.pad_isEq.w + lo + ln, r.pad_isEq.i + lo + ln, runE);
+    p.run_put(cnt, r.pad_flt.w + lo + 1 + ln, r.pad_flt.i + lo + 1 + ln, runF);
+    p.run_put(cnt, r.pad_isLast.w + lo + ln, r.pad_isLast.i + lo + ln, runL);
+    {   // the IsEqual children's [IsEqual.out, IsZero.out] pairs
+        const uint32_t i = lo + (ln >> 1), wh = ln & 1;
+        p.run_put(2 * cnt, cE.w + 6 * i + 3 * wh, cE.b + 2 * i + wh, runPairE);
+        p.run_put(2 * cnt, cL.w + 6 * i + 3 * wh, cL.b + 2 * i + wh, runPairL);
+    }
+    for (uint32_t h2 = 0; h2 < 2 && 8 * h2 < cnt; h2++) {      // Num2Bits(8).out, inBitsArray, Flatten in/out, inBits, Keccak's inBlocks
+        const uint32_t n = (cnt - 8 * h2 < 8 ? cnt - 8 * h2 : 8) * 8;
+        const B x = h2 ? bits1 : bits0;
+        const uint32_t j = 8 * (lo + 8 * h2) + ln, i = lo + 8 * h2 + (ln >> 3);
+        p.run_put(n, cN.w + 9 * i + (ln & 7), cN.b + j, x);
+        p.run_put(n, r.inBitsArray.w + j, r.inBitsArray.i + j, x);
+        p.run_put(n, flat_i.w + j, flat_i.i + j, x);
+        p.run_put(n, flat_o.w + j, flat_o.i + j, x);
+        p.run_put(n, r.inBits.w + j, r.inBits.i + j, x);
+        p.run_put(n, r.inBlocks.w + j, r.inBlocks.i + j, x);
     }
 }
 // Keccak(n) :374-385 / Final(n) :330-349 own wires + the n Absorb blocks (K kernels) + SelectorArray2D own wires.
@@ -913,9 +967,10 @@ struct Plan {
         L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
         // track 1 (TB): everything that hangs off the main inputs only -- range checks, Poseidons, BurnAddressHash, ProofOfWorkChecker,
         // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before PublicCommitment
-        // (main stage 5).  track 2 (TC): RlpEmptyAccount's serial chain, joined before the leaf assembly (TB + 7).
-        const uint32_t TB = TRACK_STRIDE, TC = 2 * TRACK_STRIDE;
-        ntracks = 3; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = 0; track_join[2] = TB + 7;
+        // (main stage 5).  track 2 (TR): the RlpMerklePatriciaTrieLeaf assembly, forked once BurnAddressHash is done (TB + 5) and
+        // joined before the final comparisons (main stage 10).  track 3 (TC): RlpEmptyAccount's serial chain, joined before TR + 2.
+        const uint32_t TB = TRACK_STRIDE, TR = 2 * TRACK_STRIDE, TC = 3 * TRACK_STRIDE;
+        ntracks = 4; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
         PobMain& M = L.pm;
         const int Ln = prm.L, LB = 136 * prm.NB, HBy = 136 * prm.HB;
         p.cur = Cur{1, 0, 0, 0};                      // wire 0 = constant 1
@@ -986,9 +1041,9 @@ struct Plan {
         {   // RlpMerklePatriciaTrieLeaf :198  (needs addressHashNibbles, written in stage TB+5)
             const Cur start = p.cur;
             CountP chk; chk.cur = start; { S ll; gRlpMptLeaf(chk, 32, prm.amountBytes, M.addressHashNibbles, 0, fr_zero(), ll); }
-            unit(U_RL_A, TB + 6);
+            unit(U_RL_A, TR + 1);
             RlRefs& R = L.rl;
-            for (uint32_t i = 0; i < 64; i += 4) record(U_RL_SLROW, TB + 6, R.c_sl_iseq, i, i + 4);
+            for (uint32_t i = 0; i < 64; i += 4) record(U_RL_SLROW, TR + 1, R.c_sl_iseq, i, i + 4);
             // after ShiftLeft: Mux1 x 63, Nibbles2Bytes(33), AssertGreaterEqThan(16), RlpEmptyAccount, Concat
             CountP q; q.cur = R.c_mux;
             for (int i = 0; i < 63; i++) gMux1S(q, 0, 0, 0);
@@ -1010,7 +1065,7 @@ struct Plan {
                 record(U_RL_ACC_B, TC + 2, L.ra.c_cb);
                 record(U_RL_ACC_C, TC + 3, L.ra.c_concat);          // long serial unit
             }
-            record(U_RL_B, TB + 7, R.c_mux);
+            record(U_RL_B, TR + 2, R.c_mux);
             p.cur = chk.cur;
         }
         {   // ProofOfWorkChecker :211

@@ -53,10 +53,13 @@ struct pob_ctx {
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, all_segs;                   // per (stage, lds) for generation; all units at once for check/emit
-    hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr; bool own_stream3 = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
     std::vector<KSeg> ksegs;
     // side tracks (Plan::track_fork/track_join): own light + BN254 streams, own fork/join events, start and end events
+    // (ROCm multiplexes streams onto 4 hardware queues by default: the handle keeps to the caller's stream + 3 of its own --
+    //  stream2, trackB (track 1), trackC (tracks 2 and 3, which run one after the other anyway); a track's BN254 and light
+    //  launches of one stage share its stream)
     struct Track { hipStream_t s_main = nullptr, s_heavy = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_end = nullptr; };
     Track tracks[Plan::MAX_TRACKS];
     uint32_t nperms = 0;
@@ -203,15 +206,17 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 
     HIPC(hipSetDevice(device));
     HIPC(hipStreamCreate(&h->stream));
-    HIPC(hipStreamCreate(&h->stream2)); HIPC(hipStreamCreate(&h->stream3)); HIPC(hipStreamCreate(&h->stream4));
+    HIPC(hipStreamCreate(&h->stream2));
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < pl.ntracks; t++) {
         pob_ctx::Track& T = h->tracks[t];
-        HIPC(hipStreamCreate(&T.s_main)); HIPC(hipStreamCreate(&T.s_heavy));
+        if (t <= 2) HIPC(hipStreamCreate(&T.s_main)); else T.s_main = h->tracks[2].s_main;
+        T.s_heavy = T.s_main;
         HIPC(hipEventCreateWithFlags(&T.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_join, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&T.ev_start, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_end, hipEventDisableTiming));
     }
+    if (pl.ntracks > 1) h->stream3 = h->tracks[1].s_main; else { HIPC(hipStreamCreate(&h->stream3)); h->own_stream3 = true; }
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
@@ -264,11 +269,9 @@ void pob_close(pob_handle h) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
-    if (h->stream3) hipStreamDestroy(h->stream3);
-    if (h->stream4) hipStreamDestroy(h->stream4);
+    if (h->own_stream3 && h->stream3) hipStreamDestroy(h->stream3);
     for (pob_ctx::Track& T : h->tracks) {
-        if (T.s_main) hipStreamDestroy(T.s_main);
-        if (T.s_heavy) hipStreamDestroy(T.s_heavy);
+        if (T.s_main && &T <= &h->tracks[2]) hipStreamDestroy(T.s_main);
         for (hipEvent_t e : {T.ev_fork, T.ev_join, T.ev_start, T.ev_end}) if (e) hipEventDestroy(e);
     }
     if (h->ev_join4) hipEventDestroy(h->ev_join4);
@@ -350,19 +353,11 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
-    // The evaluation has no dependencies between launches: the HBM-streaming Keccak kernels (stream 4), the latency-bound
-    // light units (caller's stream), SubstringCheck's BN254 units (stream 2) and the Poseidon units (stream 3) overlap.
+    // The evaluation has no dependencies between launches.  The latency-bound G kernels overlap each other (light units on the
+    // caller's stream, SubstringCheck's BN254 units on stream 2, the Poseidon units on stream 3); the HBM-streaming Keccak kernels
+    // follow the light units on the caller's stream -- run beside them they saturate HBM and stretch every serial unit ~3x.
     HIPC(hipEventRecord(h->ev_fork, st));
-    bool forked = false, forked3 = false, forked4 = false;
-    KArgs K = kargs(h);
-    if (!h->plan.sponges.empty()) {
-        HIPC(hipStreamWaitEvent(h->stream4, h->ev_fork, 0));
-        K.first = 0;
-        launch_k_rounds(K, true, h->nperms, G, h->stream4);
-        launch_k_chain(K, true, h->nperms, G, h->stream4);
-        HIPC(hipEventRecord(h->ev_join4, h->stream4));
-        forked4 = true;
-    }
+    bool forked = false, forked3 = false;
     for (size_t k = h->all_segs.size(); k-- > 0;) {
         const pob_ctx::Seg& sg = h->all_segs[k];
         A.first = sg.first; A.stage_lds = sg.lds == 2;
@@ -373,9 +368,14 @@ int pob_constraint_check(pob_handle h, void* stream_) {
             if (sg.lds == 2) forked3 = true; else forked = true;
         } else launch_g_check(A, 0, sg.count, G, st);
     }
+    if (!h->plan.sponges.empty()) {
+        KArgs K = kargs(h);
+        K.first = 0;
+        launch_k_rounds(K, true, h->nperms, G, st);
+        launch_k_chain(K, true, h->nperms, G, st);
+    }
     if (forked) { HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); }
     if (forked3) { HIPC(hipEventRecord(h->ev_join3, h->stream3)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
-    if (forked4) HIPC(hipStreamWaitEvent(st, h->ev_join4, 0));
     HIPC(hipGetLastError());
     return POB_OK;
 }
@@ -483,9 +483,21 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     KArgs K = kargs(h); K.first = 0;
     GArgs A = gargs(h);
+    uint32_t* d_sel = nullptr; uint32_t nsel = 0, sel_cls = 0;
+    if (which >= 100) {          // 100 + kind: evaluation, 200 + kind: generation of all units of one kind, alone on the device
+        const uint32_t kind = (uint32_t)which % 100;
+        std::vector<uint32_t> sel;
+        for (uint32_t u = 0; u < h->plan.units.size(); u++) if (h->plan.units[u].kind == kind) sel.push_back(u);
+        if (sel.empty()) { *avg_ms = 0; hipEventDestroy(e0); hipEventDestroy(e1); return POB_OK; }
+        nsel = (uint32_t)sel.size(); sel_cls = unit_class(kind);
+        HIPC(hipMalloc(&d_sel, nsel * 4)); HIPC(hipMemcpy(d_sel, sel.data(), nsel * 4, hipMemcpyHostToDevice));
+        A.order = d_sel; A.first = 0; A.stage_lds = sel_cls == 2;
+    }
     HIPC(hipEventRecord(e0, st));
     for (int it = 0; it < iters; it++) {
-        if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
+        if (which >= 200) launch_g_gen(A, kernel_class(sel_cls), nsel, G, st);
+        else if (which >= 100) launch_g_check(A, kernel_class(sel_cls), nsel, G, st);
+        else if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
         else if (which == 1) launch_k_rounds(K, true, h->nperms, G, st);
         else if (which == 2) {
             for (const pob_ctx::Seg& sg : h->all_segs) {
@@ -499,6 +511,7 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
     float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (d_sel) hipFree(d_sel);
     return POB_OK;
 }
 

@@ -82,8 +82,33 @@ struct CountP : PolBase {
     HD B run_get(uint32_t, uint32_t) { return 0; }
     HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; }
     HD B run_bcast(B, uint32_t) { return 0; }
+    HD B run_set(B run, uint32_t, B) { return run; }
+    HD B run_perm(B run, uint32_t) { return run; }
 };
 
+// Two-phase SM batch: sm_load issues the evaluator's loads of N wires BEFORE their expected values are computed, sm_commit
+// writes (generation) / compares (evaluation) them.
+template <int N> struct SmLoaded { S s[N]; };
+template <class P, int N> HD __attribute__((always_inline)) SmLoaded<N> sm_load(P& p, const SmRef (&r)[N]) {
+    SmLoaded<N> h;
+    if constexpr (P::is_check) {
+#pragma unroll
+        for (int k = 0; k < N; k++) h.s[k] = p.get(r[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) h.s[k] = 0;
+    }
+    return h;
+}
+template <class P, int N> HD __attribute__((always_inline)) void sm_commit(P& p, const SmRef (&r)[N], const SmLoaded<N>& h, const S (&v)[N]) {
+    if constexpr (P::is_check) {
+#pragma unroll
+        for (int k = 0; k < N; k++) p.mark(h.s[k] != v[k], r[k].w);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) p.put(r[k], v[k]);
+    }
+}
 // N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
 template <class P, class R, class V, int N> HD __attribute__((always_inline)) void put_batch(P& p, const R (&r)[N], const V (&v)[N]) {
     if constexpr (P::is_check) p.put_batch(r, v);
@@ -138,6 +163,12 @@ struct DevPol : PolBase {
     __device__ __forceinline__ B run_get(uint32_t n, uint32_t i) { return m.lane < n ? m.bits[i] : 0; }
     __device__ __forceinline__ B run_bcast(B x, uint32_t k) {     // lane k's value, wave-uniform
         return ((B)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)k);
+    }
+    __device__ __forceinline__ B run_set(B run, uint32_t k, B mask) { return m.lane == k ? mask : run; }   // lane k of the run := wave-uniform mask
+    __device__ __forceinline__ B run_perm(B run, uint32_t src_lane) {   // this lane := lane src_lane's value
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)run);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)(run >> 32));
+        return ((B)hi << 32) | lo;
     }
     __device__ __forceinline__ B get(BitRef r) { return ld(r); }
     __device__ __forceinline__ S get(SmRef r) { return ld(r); }

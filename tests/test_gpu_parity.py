@@ -109,6 +109,37 @@ def test_constraint_evaluator_detects_corruption(pkg):
     calc.close()
 
 
+@pytest.mark.parametrize("which", ["spend", "pob"])
+def test_constraint_evaluator_corruption_sweep(pkg, which):
+    """flip one stored BIT wire of witness 1 at many positions (uniform over the BIT ranks, plus a dense sweep of the first
+    ranks, which are G-unit wires): every flip must flag witness 1 and only witness 1.  Covers the lane-distributed run
+    evaluation (selector rows, Pad/Num2Bits ranges, AssertByteString) and its per-wire attribution replay."""
+    if which == "spend":
+        s = _suite("test_spend"); main = "Spend(31)"
+    else:
+        s = _suite("test_proof_of_burn"); main = POB_FIX
+    inp = [s["cases"][0]["input"]] * 3
+    calc = pkg.WitnessCalculator(main, max_batch=3)
+    res = calc.calculate(inp, check=True)
+    assert all(r.ok and r.bad_wire is None and r.check_status == 0 for r in res)
+    nbit = int(calc.info.n_bit)
+    rng = np.random.default_rng(7)
+    idxs = sorted(set(rng.integers(0, nbit, 600).tolist()) | set(range(0, min(nbit, 40000), 97)) | set(range(max(0, nbit - 30000), nbit, 61)))
+    missed = []
+    for bit_index in idxs:
+        calc.lib.pob_debug_xor_bits(calc.h, 0, bit_index, 1 << 1)
+        calc.constraint_check()
+        r = calc.results(with_check=True)
+        calc.lib.pob_debug_xor_bits(calc.h, 0, bit_index, 1 << 1)
+        flagged = [x.bad_wire is not None or x.check_status != 0 for x in r]
+        if flagged != [False, True, False]:
+            missed.append((bit_index, flagged, r[1].bad_wire, r[1].check_status))
+    calc.constraint_check()
+    assert all(r.bad_wire is None and r.check_status == 0 for r in calc.results(with_check=True))
+    calc.close()
+    assert not missed, f"{len(missed)} of {len(idxs)} corruptions mis-detected, first: {missed[:5]}"
+
+
 def test_main_instantiation_batch(pkg):
     """production parameters ProofOfBurn(16,4,16,50,31,2,1e19,1e20) (circuits/main_proof_of_burn.circom:27) on synthetic
     10-layer proofs: all valid, commitments equal the host-side formula, constraint evaluator clean, one .wtns vs oracle."""
