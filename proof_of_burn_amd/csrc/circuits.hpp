@@ -302,31 +302,16 @@ template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t r
             if (r.has_dst) p.put(r.dst + i, o);
         }
     }
-    // SM side of the n selectors: select, and per IsEqual child in[0] = select, in[1] = k, IsZero.in = k - select, IsZero.inv
-    for (uint32_t j = 0; j < n; j++) {
-        const uint32_t sw = c0.w + j * fw, ss = c0.s + j * fs;
-        p.put(SmRef{sw + n1 + 1, ss}, blocks);
-        for (uint32_t k0 = 0; k0 < n1; k0 += 4) {
-            SmRef rr[12]; S vv[12], kk[4], xx[4];
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-                const uint32_t k = k0 + q < n1 ? k0 + q : n1 - 1;           // a ragged tail repeats the last child
-                const uint32_t cw = sw + 3 * n1 + 3 + 6 * k, cs = ss + 1 + 4 * k;
-                xx[q] = (S)(k - (uint32_t)blocks);
-                rr[3 * q] = SmRef{cw + 1, cs}; vv[3 * q] = blocks;
-                rr[3 * q + 1] = SmRef{cw + 2, cs + 1}; vv[3 * q + 1] = (S)k;
-                rr[3 * q + 2] = SmRef{cw + 4, cs + 2}; vv[3 * q + 2] = xx[q];
-                kk[q] = p.hint_inv(SiRef{cw + 5, cs + 3}, xx[q]);
-            }
-            put_batch(p, rr, vv);
-            if constexpr (!P::is_gen) {
-#pragma unroll
-                for (uint32_t q = 0; q < 4; q++) {
-                    p.require(p.ballot(kk[q] == 0 || kk[q] == xx[q]), FAILCODE(T_ISZERO, 30));
-                    p.require(p.ballot(xx[q] == 0 || kk[q] != 0), FAILCODE(T_ISZERO, 31));
-                }
-            }
-        }
+    // SM side of the n selectors: select, and per IsEqual child in[0] = select, in[1] = k, IsZero.in = k - select, IsZero.inv.
+    // Every selector carries the same rows, so each kind of wire is swept over the selectors with many loads in flight.
+    sm_rows_same<P, 16>(p, c0.w + n1 + 1, c0.s, fw, fs, n, blocks);
+    for (uint32_t k = 0; k < n1; k++) {
+        const uint32_t cw = c0.w + 3 * n1 + 3 + 6 * k, cs = c0.s + 1 + 4 * k;
+        const S x = (S)(k - (uint32_t)blocks);
+        sm_rows_same<P, 16>(p, cw + 1, cs, fw, fs, n, blocks);
+        sm_rows_same<P, 16>(p, cw + 2, cs + 1, fw, fs, n, (S)k);
+        sm_rows_same<P, 16>(p, cw + 4, cs + 2, fw, fs, n, x);
+        si_rows_same<P, 16>(p, cw + 5, cs + 3, fw, fs, n, x);
     }
     p.cur = cur_add(c0, Cur{fw, fb, fs, 0}, n);
 }
@@ -492,7 +477,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         const SelBlk sb = sel_blk(R.c_sel[which], N);
         const S select = 2 + p.get(R.keyLen) + (S)which;
         S acc;
-        if (P::is_gen) { const uint32_t us = (uint32_t)select; acc = us < lo ? p.get(R.src + us) : 0; }
+        if (P::is_gen) { const uint32_t us = (uint32_t)select; acc = us < lo ? p.get_lane(R.src, us) : 0; }
         else acc = p.get(sb.sum + lo);
         for (uint32_t i = lo; i < hi; i++) {
             const S v = p.put(sb.vals + i, p.get(R.src + i));

@@ -4,8 +4,14 @@
 
 extern __shared__ uint32_t g_lds[];
 
+#ifndef POB_HEAVY_WAVES
+#define POB_HEAVY_WAVES 1      // waves per SIMD the BN254 kernels are compiled for (VGPR budget 512 / POB_HEAVY_WAVES)
+#endif
+
 // CLS: 0 = light units (BIT/SM only), 1 = BN254 units (Poseidon, Num2Bits_strict, ...), 2 = SubstringCheck's BN254 units
-template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 : CLS == 2 ? 4 : 1) g_units(GArgs A) {
+template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 : CLS == 2 ? 4 : POB_HEAVY_WAVES) g_units(GArgs A) {
+    // the few long BN254 chains share their SIMDs with thousands of short light / Keccak waves: let the arbiter favour them
+    if constexpr (CLS != 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
     const uint32_t g = P::is_emit ? A.emit_group : blockIdx.y;
     P p;
@@ -16,20 +22,28 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
     p.m.nfr_in = A.nfr_in; p.m.nsm_in = A.nsm_in;
     p.m.in_fr = A.in_fr + (uint64_t)g * 64 * A.nfr_in * 32;
     p.m.in_sm = A.in_sm + (uint64_t)g * 64 * A.nsm_in;
-    p.m.lane = lane;
+    p.m.lane = lane; p.m.lane4 = lane * 4;
+    {   // raw buffer resources (gfx9 word3: 32-bit data format); BIT ranks index 8-byte words: i << 3 < 2^32 needs bits_stride < 2^29
+        const uint64_t nb = A.bits_stride * 8, ns = A.sm_stride * 4, nf = A.fr_stride * 4;
+        p.m.rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.m.bits, 0, (int)(nb > 0xFFFFFFFFull ? 0xFFFFFFFFull : nb), 0x00020000);
+        p.m.rs_sm = __builtin_amdgcn_make_buffer_rsrc(p.m.sm, 0, (int)(ns > 0xFFFFFFFFull ? 0xFFFFFFFFull : ns), 0x00020000);
+        p.m.rs_fr = __builtin_amdgcn_make_buffer_rsrc(p.m.fr, 0, (int)(nf > 0xFFFFFFFFull ? 0xFFFFFFFFull : nf), 0x00020000);
+    }
     if (CLS == 1 && A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
         for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];
         __syncthreads();
         p.m.pos_tab = g_lds;
     } else p.m.pos_tab = A.pos_tab;
     if constexpr (P::is_gen) p.status = 0;
-    if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.attribute = false; }
+    if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false;
+                                 p.pend_bs = p.pend_bv = 0; p.pend_ss = p.pend_sv = 0; p.pend_fs = p.pend_fv = fr_zero(); p.pend_bw = p.pend_sw = p.pend_fw = 0xFFFFFFFFu; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; }
     for (int pass = 0;; pass++) {
         const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
+        if constexpr (CLS == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
         if constexpr (CLS == 1) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
         if constexpr (P::is_check) {      // a lane-distributed run differed: replay the unit attributing wire by wire
-            p.run_flush();
+            p.run_flush(); p.put_flush();
             if (pass == 0 && __ballot(p.rdiff != 0)) { p.attribute = true; continue; }
         }
         break;

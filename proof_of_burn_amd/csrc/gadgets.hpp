@@ -52,22 +52,27 @@ template <class P> HD void gNum2Bits8(P& p, S in, B* outv) {
     }
     p.require(p.ballot((uint32_t)x == acc), FAILCODE(T_NUM2BITS, 38));
 }
-// field-element flavour (n <= 254)
-template <class P> GD BitRef gNum2BitsF(P& p, int n, const F& in) {
+// field-element flavour (n <= 254): the bits are produced lane-distributed (BV) from the canonical value; callers that need a bit
+// of their own witness read it from the canonical value (cout), callers that copy the bits reuse the vector (vout).
+// Evaluation: out[k] must equal the bits of the canonical `in` (unique below 2^254 < 2p: an aliased decomposition is a mismatch)
+// and `in` must fit n bits (the `lc1 === in` of bitify.circom:38).
+template <class P> GD BitRef gNum2BitsF(P& p, int n, const F& in, BV* vout = nullptr, F* cout = nullptr) {
     BitRef o = p.bits(n); FrRef i = p.frs(1);
     F x = p.put(i, in);
-    F c = fr_from_mont(x), acc = fr_zero();
+    F c = fr_from_mont(x);
+    const BV v = bv_from_canon(p, c, n);
+    bv_put(p, o, n, v);
+    bool ok = true;
+    if (n < 254) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint32_t w = 0;
-        for (int k = 0; k < 32; k++) {
-            int idx = 32 * j + k;
-            if (idx < n) { B b = p.hint(o + idx, p.ballot((c.l[j] >> k) & 1)); w |= (uint32_t)p.bit(b) << k; }
+        for (int j = 0; j < 8; j++) {
+            if (32 * j >= n) ok = ok && c.l[j] == 0;
+            else if (32 * j + 32 > n) ok = ok && (c.l[j] >> (n - 32 * j)) == 0;
         }
-        acc.l[j] = w;
     }
-    bool ok = fr_eq(acc, c) || (n >= 254 && fr_geq_p(acc) && fr_eq(fr_sub_p(acc), c));   // sum === in (mod p)
     p.require(p.ballot(ok), FAILCODE(T_NUM2BITS, 38));
+    if (vout) *vout = v;
+    if (cout) *cout = c;
     return o;
 }
 // Bits2Num(8)  [out | in[8]]
@@ -127,8 +132,9 @@ template <class P> GD B gLessThanF(P& p, int n, const F& a, const F& b) {
     BitRef o = p.bits(1); FrRef in = p.frs(2);
     F x = p.put(in, a), y = p.put(in + 1, b);
     Fr e = fr_zero(); e.l[n >> 5] = 1u << (n & 31);       // 2^n canonical (n <= 252)
-    BitRef nb = gNum2BitsF(p, n + 1, fr_sub(fr_add(x, fr_to_mont(e)), y));
-    return p.put(o, ~p.get(nb + n));
+    F c;
+    gNum2BitsF(p, n + 1, fr_sub(fr_add(x, fr_to_mont(e)), y), nullptr, &c);
+    return p.put(o, ~p.ballot(canon_bit(c, n)));
 }
 // LessEqThan(n) [out | in[2]] || LessThan(n)(in0, in1+1);  GreaterEqThan(n) || LessThan(n)(in1, in0+1)
 template <class P> GD B gLessEqThanS(P& p, int n, S a, S b) {
@@ -196,44 +202,53 @@ template <class P> GD S gMux1SF(P& p, S c0, const F& c1, B s) {
 
 // ============================================================================ circomlib: compconstant / aliascheck / Num2Bits_strict
 // CompConstant(ct = p-1)  [out | in[254] | parts[127], sout] || Num2Bits(135)
-template <class P> GD B gCompConstantPm1(P& p, BitRef src) {
+template <class P> GD B gCompConstantPm1(P& p, const BV& v, const F& c) {      // v / c: the 254 input bits / their canonical value
     BitRef o = p.bits(1); BitRef in = p.bits(254); FrRef parts = p.frs(127); FrRef sout = p.frs(1);
     const uint32_t PM1[8] = {0xf0000000u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    for (int k = 0; k < 254; k++) p.put(in + k, p.get(src + k));
+    bv_put(p, in, 254, v);
     // a, b, e as canonical 256-bit integers kept in Montgomery form
     Fr bc = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0}};
     F b = fr_to_mont(bc), a = fr_one_mont(), e = fr_one_mont(), sum = fr_zero();
-    for (int i = 0; i < 127; i++) {
-        uint32_t clsb = (PM1[(2 * i) >> 5] >> ((2 * i) & 31)) & 1, cmsb = (PM1[(2 * i + 1) >> 5] >> ((2 * i + 1) & 31)) & 1;
-        bool sl = p.bit(p.get(in + 2 * i)), sm = p.bit(p.get(in + 2 * i + 1));
-        F v;
-        if (!cmsb && !clsb) v = (sm && sl) ? b : ((sm || sl) ? b : fr_zero());          // -b*sm*sl + b*sm + b*sl
-        else if (!cmsb && clsb) {                                                         // a*sm*sl - a*sl + b*sm - a*sm + a
-            v = a; if (sm && sl) v = fr_add(v, a); if (sl) v = fr_sub(v, a); if (sm) { v = fr_add(v, b); v = fr_sub(v, a); }
-        } else if (cmsb && !clsb) {                                                       // b*sm*sl - a*sm + a
-            v = a; if (sm && sl) v = fr_add(v, b); if (sm) v = fr_sub(v, a);
-        } else v = (sm && sl) ? fr_zero() : a;                                            // -a*sm*sl + a
-        sum = fr_add(sum, p.put(parts + i, v));
-        b = fr_sub(b, e); a = fr_add(a, e); e = fr_add(e, e);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        for (int t = 0; t < 16; t++) {
+            const int i = 16 * j + t;
+            if (i < 127) {
+                const uint32_t clsb = (PM1[j] >> (2 * t)) & 1, cmsb = (PM1[j] >> (2 * t + 1)) & 1;
+                const bool sl = (c.l[j] >> (2 * t)) & 1, sm = (c.l[j] >> (2 * t + 1)) & 1;
+                F pv;
+                if (!cmsb && !clsb) pv = (sm || sl) ? b : fr_zero();                                    // -b*sm*sl + b*sm + b*sl
+                else if (!cmsb && clsb) {                                                                // a*sm*sl - a*sl + b*sm - a*sm + a
+                    pv = a; if (sm && sl) pv = fr_add(pv, a); if (sl) pv = fr_sub(pv, a); if (sm) { pv = fr_add(pv, b); pv = fr_sub(pv, a); }
+                } else if (cmsb && !clsb) {                                                              // b*sm*sl - a*sm + a
+                    pv = a; if (sm && sl) pv = fr_add(pv, b); if (sm) pv = fr_sub(pv, a);
+                } else pv = (sm && sl) ? fr_zero() : a;                                                  // -a*sm*sl + a
+                sum = fr_add(sum, p.put(parts + i, pv));
+                b = fr_sub(b, e); a = fr_add(a, e); e = fr_add(e, e);
+            }
+        }
     }
-    F so = p.put(sout, sum);
-    BitRef nb = gNum2BitsF(p, 135, so);
-    return p.put(o, p.get(nb + 127));
+    F so = p.put(sout, sum), sc;
+    gNum2BitsF(p, 135, so, nullptr, &sc);
+    return p.put(o, p.ballot(canon_bit(sc, 127)));
 }
 // AliasCheck [ | in[254]] || CompConstant(-1);  out === 0
-template <class P> GD void gAliasCheck(P& p, BitRef src) {
+template <class P> GD void gAliasCheck(P& p, const BV& v, const F& c) {
     BitRef in = p.bits(254);
-    for (int k = 0; k < 254; k++) p.put(in + k, p.get(src + k));
-    B gt = gCompConstantPm1(p, in);
+    bv_put(p, in, 254, v);
+    B gt = gCompConstantPm1(p, v, c);
     p.require(~gt, FAILCODE(T_ALIASCHECK, 31));
 }
 // Num2Bits_strict [out[254] | in] || Num2Bits(254), AliasCheck   (initialisation order, see oracle header)
-template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in) {
+template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in, BV* vout = nullptr, F* cout = nullptr) {
     BitRef o = p.bits(254); FrRef i = p.frs(1);
     F x = p.put(i, in);
-    BitRef nb = gNum2BitsF(p, 254, x);
-    for (int k = 0; k < 254; k++) p.put(o + k, p.get(nb + k));
-    gAliasCheck(p, o);
+    BV v; F c;
+    gNum2BitsF(p, 254, x, &v, &c);
+    bv_put(p, o, 254, v);
+    gAliasCheck(p, v, c);
+    if (vout) *vout = v;
+    if (cout) *cout = c;
     return o;
 }
 
@@ -330,8 +345,9 @@ template <class P> GD void gAssertBitsS(P& p, int nb, S in) {
 template <class P> GD void gAssertBitsF(P& p, int nb, const F& in) {
     FrRef i = p.frs(1); BitRef bits = p.bits(nb);
     F x = p.put(i, in);
-    BitRef c = gNum2BitsF(p, nb, x);
-    for (int k = 0; k < nb; k++) p.put(bits + k, p.get(c + k));
+    BV v;
+    gNum2BitsF(p, nb, x, &v);
+    bv_put(p, bits, nb, v);
 }
 // AssertByteString(N) :26-31  [ | in[N]] || AssertBits(8) x N
 template <class P> GD void gAssertByteString(P& p, int N, SmRef src) {
@@ -562,41 +578,62 @@ template <class P> GD F gBigEndianBytes2NumF(P& p, int N, SmRef src) {
     return p.put(o, gLittleEndianBytes2NumF(p, N, rev));
 }
 // Num2BitsSafe(N) :46-56
-template <class P> GD BitRef gNum2BitsSafeF(P& p, int N, const F& in) {
-    if (N >= 254) {   // [out[N] | in | bitsStrict[254]] || Num2Bits_strict, Fit(254, N)
+template <class P> GD BitRef gNum2BitsSafeF(P& p, int N, const F& in, BV* vout = nullptr, F* cout = nullptr) {
+    BV v; F c;
+    if (N >= 254) {   // [out[N] | in | bitsStrict[254]] || Num2Bits_strict, Fit(254, N) [out[N] | in[254]]
         BitRef o = p.bits(N); FrRef i = p.frs(1); BitRef bs = p.bits(254);
         F x = p.put(i, in);
-        BitRef s = gNum2BitsStrict(p, x);
-        for (int k = 0; k < 254; k++) p.put(bs + k, p.get(s + k));
-        BitRef f = gFitB(p, 254, N, bs);
-        for (int k = 0; k < N; k++) p.put(o + k, p.get(f + k));
+        gNum2BitsStrict(p, x, &v, &c);
+        bv_put(p, bs, 254, v);
+        BitRef fo = p.bits(N), fi = p.bits(254);
+        bv_put(p, fi, 254, v);
+        bv_put(p, fo, N, v);                 // bits 254.. of v are zero
+        bv_put(p, o, N, v);
+        if (vout) *vout = v;
+        if (cout) *cout = c;
         return o;
     }
     BitRef o = p.bits(N); FrRef i = p.frs(1);   // [out[N] | in] || Num2Bits(N)
     F x = p.put(i, in);
-    BitRef nb = gNum2BitsF(p, N, x);
-    for (int k = 0; k < N; k++) p.put(o + k, p.get(nb + k));
+    gNum2BitsF(p, N, x, &v, &c);
+    bv_put(p, o, N, v);
+    if (vout) *vout = v;
+    if (cout) *cout = c;
     return o;
 }
 // Num2LittleEndianBytes(N) :69-83  [out[N] | in | bits[8N], byteArrays[N][8]] || Num2BitsSafe(8N), Reshape(N,8), Bits2Num(8) x N
-template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in) {
+// (Reshape [out[8N] | in[8N]] is the identity on row-major data; Bits2Num(8) [out | in[8]])
+template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in, F* cout = nullptr) {
     SmRef o = p.sms(N); FrRef i = p.frs(1); BitRef bits = p.bits(8 * N), ba = p.bits(8 * N);
     F x = p.put(i, in);
-    BitRef s = gNum2BitsSafeF(p, 8 * N, x);
-    for (int k = 0; k < 8 * N; k++) p.put(bits + k, p.get(s + k));
-    BitRef r = gFlattenB(p, 8 * N, bits);
-    for (int k = 0; k < 8 * N; k++) p.put(ba + k, p.get(r + k));
-    for (int j = 0; j < N; j++) p.put(o + j, gBits2Num8(p, ba + 8 * j));
+    BV v; F c;
+    gNum2BitsSafeF(p, 8 * N, x, &v, &c);
+    bv_put(p, bits, 8 * N, v);
+    BitRef ro = p.bits(8 * N), ri = p.bits(8 * N);
+    bv_put(p, ri, 8 * N, v);
+    bv_put(p, ro, 8 * N, v);
+    bv_put(p, ba, 8 * N, v);
+    const Cur kids = p.cur;                                  // N x Bits2Num(8)
+    bv_put_children(p, kids.w, kids.b, 9, 1, 8, 8 * N, v);
+    for (int j = 0; j < N; j++) {
+        const S by = canon_byte(c, j);
+        p.put(o + j, p.put(SmRef{kids.w + 9 * j, kids.s + j}, by));
+    }
+    p.cur = Cur{kids.w + 9u * N, kids.b + 8u * N, kids.s + (uint32_t)N, kids.f};
+    if (cout) *cout = c;
     return o;
 }
-// Num2BigEndianBytes(N) :90-96  [out[N] | in | littleEndian[N]] || Num2LittleEndianBytes(N), Reverse(N)
+// Num2BigEndianBytes(N) :90-96  [out[N] | in | littleEndian[N]] || Num2LittleEndianBytes(N), Reverse(N) [out[N] | in[N]]
 template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in) {
     SmRef o = p.sms(N); FrRef i = p.frs(1); SmRef le = p.sms(N);
     F x = p.put(i, in);
-    SmRef l = gNum2LittleEndianBytesF(p, N, x);
-    for (int j = 0; j < N; j++) p.put(le + j, p.get(l + j));
-    SmRef r = gReverseS(p, N, le);
-    for (int j = 0; j < N; j++) p.put(o + j, p.get(r + j));
+    F c;
+    gNum2LittleEndianBytesF(p, N, x, &c);
+    SmRef ro, ri;
+    for (int j = 0; j < N; j++) p.put(le + j, canon_byte(c, j));
+    ro = p.sms(N); ri = p.sms(N);
+    for (int j = 0; j < N; j++) { const S by = canon_byte(c, j); p.put(ri + j, by); p.put(ro + (N - 1 - j), by); }
+    for (int j = 0; j < N; j++) p.put(o + j, canon_byte(c, N - 1 - j));
     return o;
 }
 // Bytes2Nibbles(N) :103-121  [out[2N] | in[N] | inDecomposed[N][8]] || Num2Bits(8) x N

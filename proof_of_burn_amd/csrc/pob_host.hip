@@ -143,6 +143,11 @@ int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* 
             if (acc.size() <= u.stage) acc.resize(u.stage + 1, std::vector<uint64_t>(2 * 64, 0));
             acc[u.stage][2 * u.kind]++; acc[u.stage][2 * u.kind + 1] += u.cost;
         }
+        if (const char* wq = getenv("POB_PLAN_FIND")) {      // which units start closest below wire index wq
+            const uint32_t w = (uint32_t)strtoul(wq, nullptr, 10);
+            for (const UnitDesc& u : plan->units) if (u.cur.w <= w && w - u.cur.w < 200000)
+                fprintf(stderr, "unit kind %u stage %u cur.w %u (+%u) b %u s %u a = %u %u %u %u %u %u\n", u.kind, u.stage, u.cur.w, w - u.cur.w, u.cur.b, u.cur.s, u.a[0], u.a[1], u.a[2], u.a[3], u.a[4], u.a[5]);
+        }
         for (size_t s = 0; s < acc.size(); s++) for (uint32_t k = 0; k < 64; k++) if (acc[s][2 * k])
             fprintf(stderr, "stage %3zu kind %2u class %u units %5llu cost %9llu max/unit %8llu\n", s, k, unit_class(k), (unsigned long long)acc[s][2 * k],
                     (unsigned long long)acc[s][2 * k + 1], (unsigned long long)(acc[s][2 * k + 1] / acc[s][2 * k]));

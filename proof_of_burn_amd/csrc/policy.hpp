@@ -67,6 +67,7 @@ struct CountP : PolBase {
     HD S hint_inv(SiRef, S v) { nput++; return v; }
     HD B get(BitRef) { return 0; }
     HD S get(SmRef) { return 0; }
+    HD S get_lane(SmRef, uint32_t) { return 0; }
     HD F get(FrRef) { return fr_zero(); }
     HD void raw_put(FrRef, const F&) {}
     HD B ballot(bool) { return 0; }
@@ -109,6 +110,91 @@ template <class P, int N> HD __attribute__((always_inline)) void sm_commit(P& p,
         for (int k = 0; k < N; k++) p.put(r[k], v[k]);
     }
 }
+// n SM wires (w0 + t*dw, s0 + t*ds), t < n, that all carry the same per-witness value v: BATCH evaluator loads in flight
+template <class P, int BATCH> HD __attribute__((always_inline)) void sm_rows_same(P& p, uint32_t w0, uint32_t s0, uint32_t dw, uint32_t ds, uint32_t n, S v) {
+    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
+        SmRef rr[BATCH]; S vv[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const uint32_t t = t0 + q < n ? t0 + q : n - 1;          // a ragged tail repeats the last wire
+            rr[q] = SmRef{w0 + t * dw, s0 + t * ds}; vv[q] = v;
+        }
+        const SmLoaded<BATCH> h = sm_load(p, rr);
+        sm_commit(p, rr, h, vv);
+    }
+}
+// same for IsZero.inv wires of operand x (comparators.circom:30-31 on the stored code)
+template <class P, int BATCH> HD __attribute__((always_inline)) void si_rows_same(P& p, uint32_t w0, uint32_t s0, uint32_t dw, uint32_t ds, uint32_t n, S x) {
+    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
+        S kk[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const uint32_t t = t0 + q < n ? t0 + q : n - 1;
+            kk[q] = p.hint_inv(SiRef{w0 + t * dw, s0 + t * ds}, x);
+        }
+        if constexpr (!P::is_gen) {
+            bool ok30 = true, ok31 = true;
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) { ok30 = ok30 && (kk[q] == 0 || kk[q] == x); ok31 = ok31 && (x == 0 || kk[q] != 0); }
+            p.require(p.ballot(ok30), FAILCODE(T_ISZERO, 30));
+            p.require(p.ballot(ok31), FAILCODE(T_ISZERO, 31));
+        }
+    }
+}
+// Lane-distributed bit vector of up to 256 BIT wires: bit 64q + k lives in lane k of r[q] as that wire's 64-witness mask.  A
+// decomposition (Num2Bits and everything copied from it) is built ONCE from the witnesses' canonical values and then written /
+// verified as runs -- no wire of it is ever read back.
+struct BV { B r[4]; };
+template <class P> HD __attribute__((always_inline)) BV bv_from_canon(P& p, const F& c, int n) {
+    BV v; v.r[0] = v.r[1] = v.r[2] = v.r[3] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        for (int k = 0; k < 32; k++) {
+            const int idx = 32 * j + k;
+            if (idx < n) v.r[j >> 1] = p.run_set(v.r[j >> 1], (uint32_t)(idx & 63), p.ballot((c.l[j] >> k) & 1));
+        }
+    }
+    return v;
+}
+// wires dst + 0 .. n-1 := bits 0 .. n-1
+template <class P> HD __attribute__((always_inline)) void bv_put(P& p, BitRef dst, int n, const BV& v) {
+    const uint32_t ln = p.lane_id();
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (64 * q < n) p.run_put((uint32_t)(n - 64 * q < 64 ? n - 64 * q : 64), dst.w + 64 * q + ln, dst.i + 64 * q + ln, v.r[q]);
+}
+// the same bits as the BIT wires of n/per consecutive child components (each: `per` bits at wire offset `off`, `cw` wires in all)
+template <class P> HD __attribute__((always_inline)) void bv_put_children(P& p, uint32_t w0, uint32_t b0, uint32_t cw, uint32_t off, uint32_t per, int n, const BV& v) {
+    const uint32_t ln = p.lane_id();
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (64 * q < n) {
+        const uint32_t idx = 64 * q + ln;
+        p.run_put((uint32_t)(n - 64 * q < 64 ? n - 64 * q : 64), w0 + (idx / per) * cw + off + idx % per, b0 + idx, v.r[q]);
+    }
+}
+HD bool canon_bit(const F& c, int k) {          // bit k of a canonical value (k compile-time or uniform)
+    bool b = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((k >> 5) == j) b = (c.l[j] >> (k & 31)) & 1;
+    return b;
+}
+HD S canon_byte(const F& c, int i) {            // little-endian byte i
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((i >> 2) == j) w = c.l[j];
+    return (S)((w >> (8 * (i & 3))) & 0xffu);
+}
+// dst[i] = src[i], i < n, BATCH loads ahead of the stores / compares (a copy loop otherwise pays one memory round trip per wire)
+template <class P, int BATCH> HD __attribute__((always_inline)) void sm_copy(P& p, SmRef dst, SmRef src, int n) {
+    for (int i0 = 0; i0 < n; i0 += BATCH) {
+        SmRef rr[BATCH]; S vv[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) rr[q] = dst + (uint32_t)(i0 + q < n ? i0 + q : n - 1);
+        const SmLoaded<BATCH> h = sm_load(p, rr);
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) vv[q] = p.get(src + (uint32_t)(i0 + q < n ? i0 + q : n - 1));
+        sm_commit(p, rr, h, vv);
+    }
+}
 // N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
 template <class P, class R, class V, int N> HD __attribute__((always_inline)) void put_batch(P& p, const R (&r)[N], const V (&v)[N]) {
     if constexpr (P::is_check) p.put_batch(r, v);
@@ -131,7 +217,13 @@ struct DevMem {
     const int32_t* in_sm;     //                              SM inputs [64 lanes][nsm]
     uint32_t nfr_in, nsm_in, npow256;
     uint32_t lane;
+    // buffer resources over the three slabs: a wire access is `buffer_load/store v, v_lane_offset, s[rsrc], s_wire_offset offen`
+    // -- the per-wire part of the address stays scalar, no 64-bit per-lane address arithmetic (or registers) per access
+    __amdgpu_buffer_rsrc_t rs_bits, rs_sm, rs_fr;
+    uint32_t lane4;     // lane * 4
 };
+typedef int pob_v2i __attribute__((ext_vector_type(2)));
+#define POB_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))      // wire indices are wave-uniform by construction (get_lane is the exception)
 
 struct DevPol : PolBase {
     DevMem m;
@@ -139,28 +231,35 @@ struct DevPol : PolBase {
     __device__ __forceinline__ bool bit(B v) { return (v >> m.lane) & 1; }
     __device__ __forceinline__ uint32_t lane_id() { return m.lane; }
     __device__ __forceinline__ B ld(BitRef r) { return m.bits[r.i]; }
-    __device__ __forceinline__ S ld(SmRef r) { return m.sm[(size_t)r.i * 64 + m.lane]; }
-    __device__ __forceinline__ S ld(SiRef r) { return m.sm[(size_t)r.i * 64 + m.lane]; }
+    __device__ __forceinline__ S ld(SmRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
+    __device__ __forceinline__ S ld(SiRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ F ld(FrRef r) {
-        F v; const uint32_t* q = m.fr + (size_t)r.i * 512 + m.lane;
+        F v; const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
-        for (int k = 0; k < 8; k++) v.l[k] = q[k * 64];
+        for (int k = 0; k < 8; k++) v.l[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(m.rs_fr, (int)(m.lane4 + 256u * k), (int)so, 0);
         return v;
     }
     // one lane stores the wave-uniform mask (a 64-lane same-address store costs the texture-address unit 64 lanes of work:
     // measured 1.5x slower on the selector-row stage)
     __device__ __forceinline__ void st(BitRef r, B v) { if (m.lane == 0) m.bits[r.i] = v; }
-    __device__ __forceinline__ void st(SmRef r, S v) { m.sm[(size_t)r.i * 64 + m.lane] = v; }
-    __device__ __forceinline__ void st(SiRef r, S v) { m.sm[(size_t)r.i * 64 + m.lane] = v; }
+    __device__ __forceinline__ void st(SmRef r, S v) { __builtin_amdgcn_raw_buffer_store_b32(v, m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
+    __device__ __forceinline__ void st(SiRef r, S v) { __builtin_amdgcn_raw_buffer_store_b32(v, m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void st(FrRef r, const F& v) {
-        uint32_t* q = m.fr + (size_t)r.i * 512 + m.lane;
+        const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
-        for (int k = 0; k < 8; k++) q[k * 64] = v.l[k];
+        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b32((int)v.l[k], m.rs_fr, (int)(m.lane4 + 256u * k), (int)so, 0);
     }
     // Lane-distributed BIT access: lane k < n owns ONE wire (its own BIT rank i, wire index w) and holds that wire's 64-witness
     // mask, i.e. the wave works on up to 64 wires x 64 witnesses at once, bit-sliced like the Keccak kernels.  A run of consecutive
     // wires is one coalesced 512-byte access instead of 64 single-lane ones.
-    __device__ __forceinline__ B run_get(uint32_t n, uint32_t i) { return m.lane < n ? m.bits[i] : 0; }
+    // inactive lanes (>= n) address past the end of the slab: a raw-buffer load there returns 0 and a store is dropped, so the
+    // access needs no exec-mask branch
+    __device__ __forceinline__ uint32_t run_off(uint32_t n, uint32_t i) { return m.lane < n ? (i << 3) : 0xFFFFFFF8u; }
+    __device__ __forceinline__ B run_ld_off(uint32_t off) {
+        const pob_v2i q = __builtin_amdgcn_raw_buffer_load_b64(m.rs_bits, (int)off, 0, 0);
+        return ((B)(uint32_t)q.y << 32) | (uint32_t)q.x;
+    }
+    __device__ __forceinline__ B run_get(uint32_t n, uint32_t i) { return run_ld_off(run_off(n, i)); }
     __device__ __forceinline__ B run_bcast(B x, uint32_t k) {     // lane k's value, wave-uniform
         return ((B)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)k);
     }
@@ -172,6 +271,8 @@ struct DevPol : PolBase {
     }
     __device__ __forceinline__ B get(BitRef r) { return ld(r); }
     __device__ __forceinline__ S get(SmRef r) { return ld(r); }
+    // SM wire base + k with a PER-WITNESS k (generation shortcuts that index by a witness value)
+    __device__ __forceinline__ S get_lane(SmRef base, uint32_t k) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)(m.lane4 + ((base.i + k) << 8)), 0, 0); }
     __device__ __forceinline__ F get(FrRef r) { return ld(r); }
     __device__ __forceinline__ F kconst(uint32_t idx) {
         F v; const uint32_t* q = m.pos_tab + (size_t)idx * 8;
@@ -208,7 +309,10 @@ struct GenP : DevPol {
     __device__ __forceinline__ S hint_inv(SiRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
-    __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) { if (m.lane < n) m.bits[i] = x; }
+    __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
+        pob_v2i q; q.x = (int)(uint32_t)x; q.y = (int)(uint32_t)(x >> 32);
+        __builtin_amdgcn_raw_buffer_store_b64(q, m.rs_bits, (int)run_off(n, i), 0, 0);
+    }
 };
 
 // slow path of CheckP::run_put (by value: the policy object stays in registers): lane j holds the difference mask d of wire w
@@ -232,9 +336,36 @@ struct CheckP : DevPol {
     __device__ __forceinline__ void mark(bool bad, uint32_t w) { if (bad && w < bad_wire) bad_wire = w; }
     // put returns the EXPECTED value: if the stored wire equals it they are interchangeable, if not the witness is already
     // flagged -- so the loads are off the dependency chain and many can be in flight.
-    __device__ __forceinline__ B put(BitRef r, B v) { B s = ld(r); mark(((s ^ v) >> m.lane) & 1, r.w); return v; }
-    __device__ __forceinline__ S put(SmRef r, S v) { S s = ld(r); mark(s != v, r.w); return v; }
-    __device__ __forceinline__ F put(FrRef r, const F& v) { F s = ld(r); mark(!fr_eq(s, v), r.w); return v; }
+    // The compare of a wire is resolved one `put` later, after the NEXT wire's load has been issued (sched_barrier keeps that
+    // order), so a chain of puts always has two memory round trips overlapped instead of one exposed per wire.
+    B pend_bs, pend_bv; uint32_t pend_bw;            // BIT (wave-uniform)
+    S pend_ss, pend_sv; uint32_t pend_sw;            // SM
+    F pend_fs, pend_fv; uint32_t pend_fw;            // FR
+    __device__ __forceinline__ B put(BitRef r, B v) {
+        const B s = ld(r);
+        __builtin_amdgcn_sched_barrier(0);
+        mark(((pend_bs ^ pend_bv) >> m.lane) & 1, pend_bw);
+        pend_bs = s; pend_bv = v; pend_bw = r.w;
+        return v;
+    }
+    __device__ __forceinline__ S put(SmRef r, S v) {
+        const S s = ld(r);
+        __builtin_amdgcn_sched_barrier(0);
+        mark(pend_ss != pend_sv, pend_sw);
+        pend_ss = s; pend_sv = v; pend_sw = r.w;
+        return v;
+    }
+    __device__ __forceinline__ F put(FrRef r, const F& v) {
+        const F s = ld(r);
+        __builtin_amdgcn_sched_barrier(0);
+        mark(!fr_eq(pend_fs, pend_fv), pend_fw);
+        pend_fs = s; pend_fv = v; pend_fw = r.w;
+        return v;
+    }
+    __device__ __forceinline__ void put_flush() {
+        mark(((pend_bs ^ pend_bv) >> m.lane) & 1, pend_bw); mark(pend_ss != pend_sv, pend_sw); mark(!fr_eq(pend_fs, pend_fv), pend_fw);
+        pend_bs = pend_bv = 0; pend_ss = pend_sv = 0; pend_fs = pend_fv = fr_zero();
+    }
     __device__ __forceinline__ B hint(BitRef r, B) { return ld(r); }
     __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
@@ -244,13 +375,19 @@ struct CheckP : DevPol {
     // lane-distributed runs: a run's difference is folded into `rdiff` when the NEXT run's load has been issued (one load is
     // always in flight).  Only if a unit ends with rdiff != 0 (corrupted vector) it is replayed with `attribute` set, which
     // resolves every run on the spot and finds the lowest mismatching wire of each witness.
-    B pend_s, pend_x, rdiff; bool attribute;
-    __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B x) {
-        B s = m.lane < n ? m.bits[i] : x;
-        if (attribute) { const B d = s ^ x; if (__ballot(d != 0)) bad_wire = check_attribute_run(d, w, m.lane, bad_wire); }
-        else rdiff |= s ^ x;
+    B pend_s, pend_x, rdiff; uint32_t pend_w; bool attribute;
+    __device__ __forceinline__ void run_resolve() {
+        const B d = pend_s ^ pend_x;
+        rdiff |= d;
+        if (attribute) { if (__ballot(d != 0)) bad_wire = check_attribute_run(d, pend_w, m.lane, bad_wire); }
     }
-    __device__ __forceinline__ void run_flush() {}
+    __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B x) {
+        const B s = run_ld_off(run_off(n, i));          // inactive lanes read 0 ...
+        __builtin_amdgcn_sched_barrier(0);              // keep the issue of this load ahead of the wait on the previous one
+        run_resolve();                                  // (the previous run: its load has had this one's issue to complete)
+        pend_s = s; pend_x = m.lane < n ? x : 0; pend_w = w;   // ... and expect 0
+    }
+    __device__ __forceinline__ void run_flush() { run_resolve(); pend_s = pend_x = 0; }
     // N independent wires at once: all loads are issued before the first compare (one wait instead of N)
     template <int N> __device__ __forceinline__ void put_batch(const BitRef (&r)[N], const B (&v)[N]) {
         B s[N];
@@ -310,7 +447,7 @@ struct EmitP : DevPol {
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B, uint32_t) {}
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B) {
-        if (m.lane < n) { B s = m.bits[i]; Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); }
+        if (m.lane < n) { B s = run_ld_off(i << 3); Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); }
     }
 };
 #endif  // __HIPCC__
