@@ -32,10 +32,8 @@ struct PobParams { int L, NB, HB, minNib, amountBytes, powZero; Fr maxIntended, 
 struct SpendParams { int maxAmountBytes; };
 
 // footprints {wires, BIT, SM, FR} of fixed-size components
-HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k}; return r; }
 #define FP_ISEQ_S (Cur{6, 2, 4, 0})          // IsEqual [out | in[2]] + IsZero [out | in | inv]
 #define FP_ISEQ_F (Cur{6, 2, 0, 4})
-#define FP_ABITS8 (Cur{18, 16, 2, 0})        // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]
 #define FP_N2B8 (Cur{9, 8, 1, 0})
 
 // references to main's own wires (proof_of_burn.circom:41-72 in/out, :113-200 intermediates)
@@ -123,36 +121,6 @@ HD PosOff pos_off(int t) {
     else if (t == 4) { k.C = POS_OFF_C_4; k.S = POS_OFF_S_4; k.M = POS_OFF_M_4; k.Pm = POS_OFF_P_4; k.rp = POS_RP_4; }
     else { k.C = POS_OFF_C_5; k.S = POS_OFF_S_5; k.M = POS_OFF_M_5; k.Pm = POS_OFF_P_5; k.rp = POS_RP_5; }
     return k;
-}
-
-// ---------------------------------------------------------------------------- AssertByteString(N) in ranges (assert.circom:26-31)
-// own in[N] is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8
-template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint32_t lo, uint32_t hi) {
-    // per byte i: own in[i]; AssertBits(8) [in | bits[8]] || Num2Bits(8) [out[8] | in] at c0 + i*FP_ABITS8.  The 16 BIT wires of a
-    // byte are consecutive in BIT rank (bits[8] then out[8]), so 4 bytes make one lane-distributed run of 64 wires.
-    const uint32_t ln = p.lane_id();
-    for (uint32_t i0 = lo; i0 < hi; i0 += 8) {
-        const uint32_t cnt = hi - i0 < 8 ? hi - i0 : 8;
-        B compact = 0;                                   // lane 8t + k = bit k of byte i0 + t
-        for (uint32_t t = 0; t < cnt; t++) {
-            const uint32_t i = i0 + t;
-            const Cur c = cur_add(c0, FP_ABITS8, i);
-            const SmRef rr[3] = {own_in + i, SmRef{c.w, c.s}, SmRef{c.w + 17, c.s + 1}};
-            const SmLoaded<3> h = sm_load(p, rr);
-            const S v = p.get(src + i);
-            const S vv[3] = {v, v, v};
-            sm_commit(p, rr, h, vv);
-            p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
-        }
-        for (uint32_t h2 = 0; h2 < 2 && 4 * h2 < cnt; h2++) {       // bytes i0 + 4*h2 .. +3: 16 wires each
-            const uint32_t nb = cnt - 4 * h2 < 4 ? cnt - 4 * h2 : 4;
-            const uint32_t t = 4 * h2 + (ln >> 4), q = ln & 15, i = i0 + t;
-            const B x = p.run_perm(compact, 8 * t + (q & 7));
-            p.run_put(16 * nb, c0.w + 18 * i + 1 + q, c0.b + 16 * i + q, x);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------- keccak.circom: Pad / KeccakBytes
@@ -368,7 +336,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
     } break;
     case U_BAH_POST: {           // :82 Bytes2Nibbles(32) + main.addressHashNibbles (:119)
         SmRef nb = gBytes2Nibbles(p, 32, L.bah.hash);
-        for (int i = 0; i < 64; i++) p.put(M.addressHashNibbles + i, p.put(L.bah.nibbles + i, p.get(nb + i)));
+        { copy_n(p, L.bah.nibbles, nb, (int)(64)); copy_n(p, M.addressHashNibbles, nb, (int)(64)); }
     } break;
     case U_KB_HEAD: {            // a[0] = kb index, a[1..2] = inLen ref
         SmRef len = {d.a[1], d.a[2]};
@@ -392,9 +360,9 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         }
         for (int j = 0; j < N; j++) gAssertByteString(p, 32, L.pc.in + 32 * j);
         SmRef f = gFlattenS(p, 32 * N, L.pc.in);
-        for (int i = 0; i < 32 * N; i++) p.put(L.pc.flat + i, p.get(f + i));
+        copy_n(p, L.pc.flat, f, (int)(32 * N));
         f = gFitS(p, 32 * N, 136 * L.pc.nb, L.pc.flat);
-        for (int i = 0; i < 136 * L.pc.nb; i++) p.put(L.pc.block + i, p.get(f + i));
+        copy_n(p, L.pc.block, f, (int)(136 * L.pc.nb));
         KBRefs r = L.kbs[L.pc.kb];
         kb_head(p, L.pc.nb, (S)(32 * N), r);
         if (P::is_count) L.kbs[L.pc.kb] = r;
@@ -417,7 +385,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         S nl = p.get(M.numLayers);
         p.put(M.lastLayerLen, gSelectorS(p, prm.L, M.layerLens, nl - 1));
         BitRef f = gFilter(p, prm.L, nl);
-        for (int i = 0; i < prm.L; i++) p.put(M.layerExists + i, p.get(f + i));
+        copy_n(p, M.layerExists, f, (int)(prm.L));
     } break;
     case U_POB_LEAF: {           // :159
         const int i = d.a[0];
@@ -446,7 +414,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         R.keyPrefixIsValid = p.bits(1); R.keyIsMultiByte = p.bits(1); R.keyExtraLen = p.sms(1); R.keyLen = p.sms(1); R.valueWrapperPrefix = p.sms(1);
         R.valueWrapperPrefixIsB8 = p.bits(1); R.valueWrapperLen = p.sms(1); R.valuePrefix = p.sms(1); R.valuePrefixIsF8 = p.bits(1);
         R.valueLen = p.sms(1); R.isValueWrapperLenConsistent = p.bits(1); R.isKeyValueLenEqualWithLayerLen = p.bits(1);
-        for (uint32_t i = 0; i < N; i++) p.put(R.layer + i, p.get(R.src + i));
+        copy_n(p, R.layer, R.src, (int)(N));
         const S layerLen = p.put(R.ll, p.get(R.len_src));
         gAssertLessEqThanS(p, 16, layerLen, (S)N);
         p.put(R.leafPrefixIsF8, gIsEqualS(p, p.get(R.src), (S)0xf8));
@@ -508,12 +476,12 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         const int ab = 32, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
         R.o = p.sms(maxOut); R.ol = p.sms(1); R.in = p.sms(2 * ab); R.inl = p.sms(1); R.bal = p.frs(1);
         R.key = p.sms(maxKey); R.keyLen = p.sms(1); R.acc = p.sms(maxAcc); R.accLen = p.sms(1); R.pk = p.sms(maxPK); R.pkLen = p.sms(1); R.val = p.sms(maxVal); R.valLen = p.sms(1);
-        for (int i = 0; i < 2 * ab; i++) p.put(R.in + i, p.get(M.addressHashNibbles + i));
+        copy_n(p, R.in, M.addressHashNibbles, (int)(2 * ab));
         S nibLen = p.put(R.inl, p.get(M.numLeafAddressNibbles));
         p.put(R.bal, p.get(M.actualBalance));
         const int n2 = 2 * ab;
         R.t_o = p.sms(ab + 1); R.t_ol = p.sms(1); R.t_in = p.sms(n2); R.t_il = p.sms(1); R.t_dv = p.sms(1); R.t_rm = p.sms(1); R.t_shf = p.sms(n2); R.t_on = p.sms(n2 + 2); R.t_tmp = p.sms(n2 - 1);
-        for (int i = 0; i < n2; i++) p.put(R.t_in + i, p.get(M.addressHashNibbles + i));
+        copy_n(p, R.t_in, M.addressHashNibbles, (int)(n2));
         nibLen = p.put(R.t_il, nibLen);
         for (int i = 0; i < n2 - 1; i++) p.put(R.t_tmp + i, 0);
         gAssertLessEqThanS(p, 7, nibLen, (S)n2);
@@ -521,7 +489,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         gDivide(p, 7, nibLen, (S)2, q, r);
         p.put(R.t_dv, q); p.put(R.t_rm, r);
         R.s_o = p.sms(n2); R.s_in = p.sms(n2); R.s_cn = p.sms(1); R.s_isEq = p.bits(n2 * n2); R.s_temp = p.sms(n2 * n2);
-        for (int i = 0; i < n2; i++) p.put(R.s_in + i, p.get(M.addressHashNibbles + i));
+        copy_n(p, R.s_in, M.addressHashNibbles, (int)(n2));
         S count = p.put(R.s_cn, n2 - nibLen);
         gAssertLessEqThanS(p, 16, count, (S)n2);
         R.c_sl_iseq = p.cur;
@@ -549,7 +517,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         p.cur = A.c_cb;
         const S length = p.put(A.len, gCountBytes(p, N, A.by));
         SmRef r = gShiftLeft(p, N, A.by, N - length);
-        for (int j = 0; j < N; j++) p.put(A.be + j, p.get(r + j));
+        copy_n(p, A.be, r, (int)(N));
     } break;
     case U_RL_ACC_C: {           // RlpInteger outputs (:96-109), RlpEmptyAccount prefixes + Concat(4+N, 66) (empty_account.circom:40-133)
         const RaRefs& A = L.ra;
@@ -569,13 +537,13 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         p.cur = A.c_concat;
         S clen;
         SmRef cc = gConcat(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen);
-        for (int j = 0; j < maxAcc; j++) p.put(R.acc + j, p.put(A.ea_o + j, p.get(cc + j)));
+        { copy_n(p, A.ea_o, cc, (int)(maxAcc)); copy_n(p, R.acc, cc, (int)(maxAcc)); }
         p.put(R.accLen, p.put(A.ea_ol, clen));
     } break;
     case U_RL_B: {               // rest of TruncatedAddressHash (:62-90), AssertGreaterEqThan (:151), prefixes (:166-181), Concat (:183-188)
         const RlRefs& R = L.rl;
         const int ab = 32, n2 = 64, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
-        for (int i = 0; i < n2; i++) p.put(R.t_shf + i, p.get(R.s_o + i));
+        copy_n(p, R.t_shf, R.s_o, (int)(n2));
         const S r = p.get(R.t_rm), q = p.get(R.t_dv);
         p.put(R.t_on, 2 + r);
         p.put(R.t_on + 1, r * p.get(R.t_shf));
@@ -586,7 +554,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
             else p.put(R.t_on + i + 2, (1 - r) * p.get(R.t_shf + i));
         }
         SmRef by = gNibbles2Bytes(p, ab + 1, R.t_on);
-        for (int i = 0; i < ab + 1; i++) p.put(R.key + i, p.put(R.t_o + i, p.get(by + i)));
+        { copy_n(p, R.t_o, by, (int)(ab + 1)); copy_n(p, R.key, by, (int)(ab + 1)); }
         const S kl = p.put(R.keyLen, p.put(R.t_ol, 1 + q));
         gAssertGreaterEqThanS(p, 16, kl, (S)2);
         const S al = p.get(R.accLen);
@@ -599,7 +567,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         p.cur = R.c_concat;
         S cl;
         SmRef c = gConcat(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl);
-        for (int i = 0; i < maxOut; i++) p.put(M.leaf + i, p.put(R.o + i, p.get(c + i)));
+        { copy_n(p, R.o, c, (int)(maxOut)); copy_n(p, M.leaf, c, (int)(maxOut)); }
         p.put(M.leafLen, p.put(R.ol, cl));
     } break;
     case U_POW_POST: {           // :73-79
@@ -661,9 +629,9 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
     case U_BAH_PRE: {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
         F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
         SmRef ab = gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec);
-        for (int i = 0; i < 20; i++) p.put(L.bah.addressBytes + i, p.get(ab + i));
+        copy_n(p, L.bah.addressBytes, ab, (int)(20));
         SmRef f = gFitS(p, 20, 136, L.bah.addressBytes);
-        for (int i = 0; i < 136; i++) p.put(L.bah.block + i, p.get(f + i));
+        copy_n(p, L.bah.block, f, (int)(136));
         KBRefs r = L.kbs[L.bah.kb];
         kb_head(p, 1, (S)20, r);
         if (P::is_count) L.kbs[L.bah.kb] = r;
@@ -673,11 +641,11 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         FrRef src = j == 0 ? M.nullifier : j == 1 ? M.remainingCoin : j == 2 ? M.revealAmount : j == 3 ? M.burnExtraCommitment : M.proofExtraCommitment;
         SmRef dst = j == 0 ? M.nullifierBytes : j == 1 ? M.remainingCoinBytes : j == 2 ? M.revealAmountBytes : j == 3 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
         SmRef r = gNum2BigEndianBytesF(p, 32, p.get(src));
-        for (int i = 0; i < 32; i++) p.put(dst + i, p.get(r + i));
+        copy_n(p, dst, r, (int)(32));
     } break;
     case U_PC_POST: {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
         SmRef f = gFitS(p, 32, 31, L.pc.hash);
-        for (int i = 0; i < 31; i++) p.put(L.pc.reduced + i, p.get(f + i));
+        copy_n(p, L.pc.reduced, f, (int)(31));
         F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
         p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
     } break;
@@ -710,11 +678,11 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
         p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
         SmRef r = gNum2BigEndianBytesF(p, 32, bk);
-        for (int i = 0; i < 32; i++) p.put(L.pw.keyBytes + i, p.get(r + i));
+        copy_n(p, L.pw.keyBytes, r, (int)(32));
         r = gNum2BigEndianBytesF(p, 32, ra);
-        for (int i = 0; i < 32; i++) p.put(L.pw.raBytes + i, p.get(r + i));
+        copy_n(p, L.pw.raBytes, r, (int)(32));
         r = gNum2BigEndianBytesF(p, 32, bec);
-        for (int i = 0; i < 32; i++) p.put(L.pw.becBytes + i, p.get(r + i));
+        copy_n(p, L.pw.becBytes, r, (int)(32));
         SmRef e = p.sms(8);                              // EIP7503 :11-21  [out[8]]
         const char tag[9] = "EIP-7503";
         for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)tag[i]));
@@ -724,7 +692,7 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
             p.put(L.pw.hin + i, p.put(co + i, p.put(ci + i, p.get(s))));
         }
         SmRef f = gFitS(p, 104, 136, L.pw.hin);
-        for (int i = 0; i < 136; i++) p.put(L.pw.block + i, p.get(f + i));
+        copy_n(p, L.pw.block, f, (int)(136));
         KBRefs kr = L.kbs[L.pw.kb];
         kb_head(p, 1, (S)104, kr);
         if (P::is_count) L.kbs[L.pw.kb] = kr;
@@ -741,13 +709,13 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         in3[2] = fr_sub(bal, wd);
         F rc = p.put(L.sm.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
         SmRef r = gNum2BigEndianBytesF(p, 32, coin);
-        for (int i = 0; i < 32; i++) p.put(L.sm.coinBytes + i, p.get(r + i));
+        copy_n(p, L.sm.coinBytes, r, (int)(32));
         r = gNum2BigEndianBytesF(p, 32, wd);
-        for (int i = 0; i < 32; i++) p.put(L.sm.withdrawnBalanceBytes + i, p.get(r + i));
+        copy_n(p, L.sm.withdrawnBalanceBytes, r, (int)(32));
         r = gNum2BigEndianBytesF(p, 32, rc);
-        for (int i = 0; i < 32; i++) p.put(L.sm.remainingCoinBytes + i, p.get(r + i));
+        copy_n(p, L.sm.remainingCoinBytes, r, (int)(32));
         r = gNum2BigEndianBytesF(p, 32, ec);
-        for (int i = 0; i < 32; i++) p.put(L.sm.extraCommitmentBytes + i, p.get(r + i));
+        copy_n(p, L.sm.extraCommitmentBytes, r, (int)(32));
     } break;
     default: break;
     }
@@ -790,13 +758,36 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
             if (P::is_count) L.scs[i] = sc;
         }
     } break;
-    case U_SC_M: {               // M[i+1] <== mainInput[i]*256^i + M[i]  (substring_check.circom:45-49); reads the source bytes;
-                                 // 256^i comes from a table in "double Montgomery" form so that byte * 256^i is ONE Montgomery product
+    case U_SC_M: {               // M[k+1] <== mainInput[k]*256^k + M[k]  (substring_check.circom:45-49) for k in [a1, a2); reads the source
+                                 // bytes; 256^k comes from a table in "double Montgomery" form so that byte * 256^k is ONE Montgomery
+                                 // product.  The prefix M[a1] is rebuilt from the bytes below a1, 31 at a time (31 bytes packed into limbs
+                                 // are one canonical value: one product per 31 bytes), so the 17 ranges of a layer run side by side.
         const ScRefs& sc = L.scs[d.a[0]];
-        F acc = p.put(sc.M, fr_zero());
-        for (int k = 0; k < LB; k++) {
-            Fr b = {{(uint32_t)p.get(M.layers + ((d.a[0] - 1) * LB + k)), 0, 0, 0, 0, 0, 0, 0}};
-            acc = p.put(sc.M + k + 1, fr_add(fr_mul(b, p.k256r(k)), acc));
+        const uint32_t lo = d.a[1], hi = d.a[2];
+        const SmRef src = M.layers + ((d.a[0] - 1) * LB);
+        F acc = fr_zero();
+        for (uint32_t c0 = 0; c0 < lo; c0 += 31) {
+            const uint32_t n = lo - c0 < 31 ? lo - c0 : 31;
+            S by[31];
+#pragma unroll
+            for (uint32_t q = 0; q < 31; q++) by[q] = p.get(src + (c0 + (q < n ? q : 0)));
+            bool small = true;
+            Fr v = fr_zero();
+#pragma unroll
+            for (uint32_t q = 0; q < 31; q++) if (q < n) { small = small && (uint32_t)by[q] < 256u; v.l[q >> 2] |= ((uint32_t)by[q] & 0xffu) << (8 * (q & 3)); }
+            if (p.ballot(!small) == 0) acc = fr_add(acc, fr_mul(v, p.k256r(c0)));
+            else {               // some witness carries a non-byte here (it fails AssertByteString): keep the per-byte definition exact
+#pragma unroll 1
+                for (uint32_t q = 0; q < n; q++) {
+                    Fr b1 = {{(uint32_t)p.get(src + (c0 + q)), 0, 0, 0, 0, 0, 0, 0}};
+                    acc = fr_add(fr_mul(b1, p.k256r(c0 + q)), acc);
+                }
+            }
+        }
+        if (lo == 0) p.put(sc.M, fr_zero());
+        for (uint32_t k = lo; k < hi; k++) {
+            Fr b1 = {{(uint32_t)p.get(src + k), 0, 0, 0, 0, 0, 0, 0}};
+            acc = p.put(sc.M + k + 1, fr_add(fr_mul(b1, p.k256r(k)), acc));
         }
     } break;
     case U_SC_RANGE: {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
@@ -1016,9 +1007,9 @@ struct Plan {
                 const SmRef src = M.layers + (i - 1) * LB;
                 for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32)
                     record(U_ABS_RANGE, 5, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
-                record(U_SC_M, 5, start, i);
+                for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) record(U_SC_M, 5, start, i, lo, std::min<uint32_t>(lo + 32, LB));
                 const uint32_t kk = LB - 31 + 1;
-                for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
+                for (uint32_t lo = 0; lo < kk; lo += 64) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 64, kk));
                 record(U_SC_SUMS, 7, sc.c_tail, i);
             }
         }

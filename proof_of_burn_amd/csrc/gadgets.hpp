@@ -349,10 +349,43 @@ template <class P> GD void gAssertBitsF(P& p, int nb, const F& in) {
     gNum2BitsF(p, nb, x, &v);
     bv_put(p, bits, nb, v);
 }
+#define FP_ABITS8 (Cur{18, 16, 2, 0})        // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]
+// ---------------------------------------------------------------------------- AssertByteString(N) in ranges (assert.circom:26-31)
+// own in[N] is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8
+template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint32_t lo, uint32_t hi) {
+    // per byte i: own in[i]; AssertBits(8) [in | bits[8]] || Num2Bits(8) [out[8] | in] at c0 + i*FP_ABITS8.  The 16 BIT wires of a
+    // byte are consecutive in BIT rank (bits[8] then out[8]), so 4 bytes make one lane-distributed run of 64 wires.
+    const uint32_t ln = p.lane_id();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 8) {
+        const uint32_t cnt = hi - i0 < 8 ? hi - i0 : 8;
+        B compact = 0;                                   // lane 8t + k = bit k of byte i0 + t
+        for (uint32_t t = 0; t < cnt; t++) {
+            const uint32_t i = i0 + t;
+            const Cur c = cur_add(c0, FP_ABITS8, i);
+            const SmRef rr[3] = {own_in + i, SmRef{c.w, c.s}, SmRef{c.w + 17, c.s + 1}};
+            const SmLoaded<3> h = sm_load(p, rr);
+            const S v = p.get(src + i);
+            const S vv[3] = {v, v, v};
+            sm_commit(p, rr, h, vv);
+            p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
+        }
+        for (uint32_t h2 = 0; h2 < 2 && 4 * h2 < cnt; h2++) {       // bytes i0 + 4*h2 .. +3: 16 wires each
+            const uint32_t nb = cnt - 4 * h2 < 4 ? cnt - 4 * h2 : 4;
+            const uint32_t t = 4 * h2 + (ln >> 4), q = ln & 15, i = i0 + t;
+            const B x = p.run_perm(compact, 8 * t + (q & 7));
+            p.run_put(16 * nb, c0.w + 18 * i + 1 + q, c0.b + 16 * i + q, x);
+        }
+    }
+}
+
 // AssertByteString(N) :26-31  [ | in[N]] || AssertBits(8) x N
 template <class P> GD void gAssertByteString(P& p, int N, SmRef src) {
     SmRef in = p.sms(N);
-    for (int i = 0; i < N; i++) gAssertBitsS(p, 8, p.put(in + i, p.get(src + i)));
+    const Cur c0 = p.cur;
+    abs_range(p, c0, in, src, 0, (uint32_t)N);
+    p.cur = Cur{c0.w + 18u * N, c0.b + 16u * N, c0.s + 2u * N, c0.f};
 }
 // AssertLessThan(B) :40-47 / AssertLessEqThan :56-63 / AssertGreaterEqThan :72-79   [ | a, b | out]; out === 1
 template <class P> GD void gAssertLessThanS(P& p, int nb, S a, S b) {
@@ -401,31 +434,31 @@ template <class P> GD BitRef gFilter(P& p, int N, S in) {
 // Fit(M,N) :47-57  [out[N] | in[M]]
 template <class P> GD SmRef gFitS(P& p, int M, int N, SmRef src) {
     SmRef o = p.sms(N), in = p.sms(M);
-    for (int i = 0; i < M; i++) { S v = p.put(in + i, p.get(src + i)); if (i < N) p.put(o + i, v); }
+    copy_n(p, in, src, M); copy_n(p, o, src, M < N ? M : N);
     for (int i = M; i < N; i++) p.put(o + i, 0);
     return o;
 }
 template <class P> GD BitRef gFitB(P& p, int M, int N, BitRef src) {
     BitRef o = p.bits(N), in = p.bits(M);
-    for (int i = 0; i < M; i++) { B v = p.put(in + i, p.get(src + i)); if (i < N) p.put(o + i, v); }
+    copy_n(p, in, src, M); copy_n(p, o, src, M < N ? M : N);
     for (int i = M; i < N; i++) p.put(o + i, 0);
     return o;
 }
 // Flatten(M,N) :64-72 and Reshape(M,N) :79-87 are the identity on row-major data  [out[MN] | in[MN]]
 template <class P> GD SmRef gFlattenS(P& p, int n, SmRef src) {
     SmRef o = p.sms(n), in = p.sms(n);
-    for (int i = 0; i < n; i++) p.put(o + i, p.put(in + i, p.get(src + i)));
+    { copy_n(p, in, src, (int)(n)); copy_n(p, o, src, (int)(n)); }
     return o;
 }
 template <class P> GD BitRef gFlattenB(P& p, int n, BitRef src) {
     BitRef o = p.bits(n), in = p.bits(n);
-    for (int i = 0; i < n; i++) p.put(o + i, p.put(in + i, p.get(src + i)));
+    { copy_n(p, in, src, (int)(n)); copy_n(p, o, src, (int)(n)); }
     return o;
 }
 // Reverse(N) :94-100  [out[N] | in[N]]
 template <class P> GD SmRef gReverseS(P& p, int N, SmRef src) {
     SmRef o = p.sms(N), in = p.sms(N);
-    for (int i = 0; i < N; i++) p.put(o + (N - 1 - i), p.put(in + i, p.get(src + i)));
+    copy_n(p, in, src, N); sm_copy<P, 8>(p, o, src, N, true);
     return o;
 }
 
@@ -486,7 +519,7 @@ template <class P> GD SmRef gSelectorArray1D(P& p, int n, int q, SmRef src, S se
 template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count) {
     SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(n * n); SmRef temp = p.sms(n * n);
     count = p.put(cn, count);
-    for (int j = 0; j < n; j++) p.put(in + j, p.get(src + j));
+    copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)n);
     for (int i = 0; i < n; i++) {
         S acc = 0;
@@ -502,7 +535,7 @@ template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count) {
 template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count) {
     SmRef o = p.sms(n + ms), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(ms + 1); SmRef temps = p.sms((ms + 1) * n);
     count = p.put(cn, count);
-    for (int j = 0; j < n; j++) p.put(in + j, p.get(src + j));
+    copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)ms);
     for (int i = 0; i <= ms; i++) {
         B e = p.put(isEq + i, gIsEqualS(p, (S)i, count));
@@ -536,16 +569,16 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
 template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef b, S bLen, S& outLen) {
     SmRef o = p.sms(La + Lb), ol = p.sms(1), ia = p.sms(La), ial = p.sms(1), ib = p.sms(Lb), ibl = p.sms(1);
     SmRef mA = p.sms(La), mB = p.sms(Lb), sB = p.sms(La + Lb);
-    for (int i = 0; i < La; i++) p.put(ia + i, p.get(a + i));
+    copy_n(p, ia, a, (int)(La));
     aLen = p.put(ial, aLen);
-    for (int i = 0; i < Lb; i++) p.put(ib + i, p.get(b + i));
+    copy_n(p, ib, b, (int)(Lb));
     bLen = p.put(ibl, bLen);
     gAssertLessEqThanS(p, 16, aLen, (S)La);
     gAssertLessEqThanS(p, 16, bLen, (S)Lb);
     SmRef x = gMask(p, La, ia, aLen);
-    for (int i = 0; i < La; i++) p.put(mA + i, p.get(x + i));
+    copy_n(p, mA, x, (int)(La));
     x = gMask(p, Lb, ib, bLen);
-    for (int i = 0; i < Lb; i++) p.put(mB + i, p.get(x + i));
+    copy_n(p, mB, x, (int)(Lb));
     x = gShiftRight(p, Lb, La, mB, aLen);
     for (int i = 0; i < La + Lb; i++) {
         S s = p.put(sB + i, p.get(x + i));
@@ -572,9 +605,9 @@ template <class P> GD F gLittleEndianBytes2NumF(P& p, int N, SmRef src) {
 // BigEndianBytes2Num(N) :33-39  [out | in[N] | inReversed[N]] || Reverse(N), LittleEndianBytes2Num(N)
 template <class P> GD F gBigEndianBytes2NumF(P& p, int N, SmRef src) {
     FrRef o = p.frs(1); SmRef in = p.sms(N), rev = p.sms(N);
-    for (int i = 0; i < N; i++) p.put(in + i, p.get(src + i));
+    copy_n(p, in, src, (int)(N));
     SmRef r = gReverseS(p, N, in);
-    for (int i = 0; i < N; i++) p.put(rev + i, p.get(r + i));
+    copy_n(p, rev, r, (int)(N));
     return p.put(o, gLittleEndianBytes2NumF(p, N, rev));
 }
 // Num2BitsSafe(N) :46-56
@@ -656,7 +689,7 @@ template <class P> GD SmRef gBytes2Nibbles(P& p, int N, SmRef src) {
 // Nibbles2Bytes(n) :132-141  [bytes[n] | nibbles[2n]] || AssertBits(4) x 2n
 template <class P> GD SmRef gNibbles2Bytes(P& p, int n, SmRef src) {
     SmRef o = p.sms(n), nib = p.sms(2 * n);
-    for (int i = 0; i < 2 * n; i++) p.put(nib + i, p.get(src + i));
+    copy_n(p, nib, src, (int)(2 * n));
     for (int i = 0; i < n; i++) {
         S a = p.get(nib + 2 * i), b = p.get(nib + 2 * i + 1);
         gAssertBitsS(p, 4, a); gAssertBitsS(p, 4, b);
@@ -673,9 +706,9 @@ template <class P> GD B gSubstringCheck(P& p, int mm, int sl, SmRef mainSrc, S m
     const int k = mm - sl + 1;
     BitRef o = p.bits(1); SmRef mi = p.sms(mm), ml = p.sms(1), si = p.sms(sl);
     FrRef num = p.frs(1), M = p.frs(mm + 1); BitRef ex = p.bits(k), isl = p.bits(k), alw = p.bits(k + 1); SmRef sums = p.sms(k + 1); BitRef dne = p.bits(1);
-    for (int i = 0; i < mm; i++) p.put(mi + i, p.get(mainSrc + i));
+    copy_n(p, mi, mainSrc, (int)(mm));
     mainLen = p.put(ml, mainLen);
-    for (int i = 0; i < sl; i++) p.put(si + i, p.get(subSrc + i));
+    copy_n(p, si, subSrc, (int)(sl));
     gAssertByteString(p, sl, si);
     gAssertByteString(p, mm, mi);
     gAssertLessEqThanS(p, 16, mainLen, (S)mm);
@@ -742,10 +775,10 @@ template <class P> GD SmRef gRlpInteger(P& p, int N, const F& in, S& outLen) {
     BitRef isb = p.bits(1), isz = p.bits(1); SmRef frb = p.sms(1);
     F x = p.put(i, in);
     SmRef r = gNum2BigEndianBytesF(p, N, x);
-    for (int j = 0; j < N; j++) p.put(by + j, p.get(r + j));
+    copy_n(p, by, r, (int)(N));
     S length = p.put(len, gCountBytes(p, N, by));
     r = gShiftLeft(p, N, by, N - length);
-    for (int j = 0; j < N; j++) p.put(be + j, p.get(r + j));
+    copy_n(p, be, r, (int)(N));
     B single = p.put(isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
     B zero = p.put(isz, gIsZeroF(p, x));
     S first = p.put(frb, gMux1SF(p, 0x80 + length, x, single));
@@ -780,7 +813,7 @@ template <class P> GD SmRef gRlpEmptyAccount(P& p, int mb, const F& balance, S& 
     p.put(pn + 1, nb + 66);
     S clen;
     SmRef c = gConcat(p, 4 + mb, 66, pn, pl, sc, (S)66, clen);
-    for (int j = 0; j < 70 + mb; j++) p.put(o + j, p.get(c + j));
+    copy_n(p, o, c, (int)(70 + mb));
     outLen = p.put(ol, clen);
     return o;
 }
@@ -792,7 +825,7 @@ template <class P> GD SmRef gRlpEmptyAccount(P& p, int mb, const F& balance, S& 
 template <class P> GD SmRef gTruncatedAddressHash(P& p, int b, SmRef src, S len, S& outLen) {
     const int n2 = 2 * b;
     SmRef o = p.sms(b + 1), ol = p.sms(1), in = p.sms(n2), il = p.sms(1), dv = p.sms(1), rm = p.sms(1), shf = p.sms(n2), on = p.sms(n2 + 2), tmp = p.sms(n2 - 1);
-    for (int i = 0; i < n2; i++) p.put(in + i, p.get(src + i));
+    copy_n(p, in, src, (int)(n2));
     len = p.put(il, len);
     for (int i = 0; i < n2 - 1; i++) p.put(tmp + i, 0);
     gAssertLessEqThanS(p, 7, len, (S)n2);
@@ -800,7 +833,7 @@ template <class P> GD SmRef gTruncatedAddressHash(P& p, int b, SmRef src, S len,
     gDivide(p, 7, len, (S)2, q, r);
     q = p.put(dv, q); r = p.put(rm, r);
     SmRef s = gShiftLeft(p, n2, in, n2 - len);
-    for (int i = 0; i < n2; i++) p.put(shf + i, p.get(s + i));
+    copy_n(p, shf, s, (int)(n2));
     p.put(on, 2 + r);
     p.put(on + 1, r * p.get(shf));
     B rbit = p.ballot(r & 1);
@@ -809,7 +842,7 @@ template <class P> GD SmRef gTruncatedAddressHash(P& p, int b, SmRef src, S len,
         else p.put(on + i + 2, (1 - r) * p.get(shf + i));
     }
     SmRef by = gNibbles2Bytes(p, b + 1, on);
-    for (int i = 0; i < b + 1; i++) p.put(o + i, p.get(by + i));
+    copy_n(p, o, by, (int)(b + 1));
     outLen = p.put(ol, 1 + q);
     return o;
 }
@@ -818,17 +851,17 @@ template <class P> GD SmRef gRlpMptLeaf(P& p, int ab, int bb, SmRef nibSrc, S ni
     const int maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
     SmRef o = p.sms(maxOut), ol = p.sms(1), in = p.sms(2 * ab), inl = p.sms(1); FrRef ib = p.frs(1);
     SmRef key = p.sms(maxKey), keyLen = p.sms(1), acc = p.sms(maxAcc), accLen = p.sms(1), pk = p.sms(maxPK), pkLen = p.sms(1), val = p.sms(maxVal), valLen = p.sms(1);
-    for (int i = 0; i < 2 * ab; i++) p.put(in + i, p.get(nibSrc + i));
+    copy_n(p, in, nibSrc, (int)(2 * ab));
     nibLen = p.put(inl, nibLen);
     F bal = p.put(ib, balance);
     S kl;
     SmRef r = gTruncatedAddressHash(p, ab, in, nibLen, kl);
-    for (int i = 0; i < maxKey; i++) p.put(key + i, p.get(r + i));
+    copy_n(p, key, r, (int)(maxKey));
     kl = p.put(keyLen, kl);
     gAssertGreaterEqThanS(p, 16, kl, (S)2);                                   // :151
     S al;
     r = gRlpEmptyAccount(p, bb, bal, al);
-    for (int i = 0; i < maxAcc; i++) p.put(acc + i, p.get(r + i));
+    copy_n(p, acc, r, (int)(maxAcc));
     al = p.put(accLen, al);
     p.put(val, 0xb8); p.put(val + 1, al);
     for (int i = 0; i < maxAcc; i++) p.put(val + 2 + i, p.get(acc + i));
@@ -838,7 +871,7 @@ template <class P> GD SmRef gRlpMptLeaf(P& p, int ab, int bb, SmRef nibSrc, S ni
     S pl = p.put(pkLen, 3 + kl);
     S cl;
     SmRef c = gConcat(p, maxPK, maxVal, pk, pl, val, vl, cl);
-    for (int i = 0; i < maxOut; i++) p.put(o + i, p.get(c + i));
+    copy_n(p, o, c, (int)(maxOut));
     outLen = p.put(ol, cl);
     return o;
 }
@@ -859,7 +892,7 @@ template <class P> GD B gLeafDetector(P& p, int N, SmRef src, S layerLen) {
     BitRef keyPrefixIsValid = p.bits(1), keyIsMultiByte = p.bits(1); SmRef keyExtraLen = p.sms(1), keyLen = p.sms(1), valueWrapperPrefix = p.sms(1);
     BitRef valueWrapperPrefixIsB8 = p.bits(1); SmRef valueWrapperLen = p.sms(1), valuePrefix = p.sms(1); BitRef valuePrefixIsF8 = p.bits(1);
     SmRef valueLen = p.sms(1); BitRef isValueWrapperLenConsistent = p.bits(1), isKeyValueLenEqualWithLayerLen = p.bits(1);
-    for (int i = 0; i < N; i++) p.put(layer + i, p.get(src + i));
+    copy_n(p, layer, src, (int)(N));
     layerLen = p.put(ll, layerLen);
     gAssertLessEqThanS(p, 16, layerLen, (S)N);
     B m[7];
@@ -889,8 +922,8 @@ template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix
     F pin[4]; pin[0] = prefix0; pin[1] = p.put(in, bk); pin[2] = p.put(in + 1, ra); pin[3] = p.put(in + 2, bec);
     F hash = p.put(h, gPoseidon<P, 5>(p, k5, pin));
     SmRef r = gNum2BigEndianBytesF(p, 32, hash);
-    for (int i = 0; i < 32; i++) p.put(hb + i, p.get(r + i));
+    copy_n(p, hb, r, (int)(32));
     r = gFitS(p, 32, 20, hb);
-    for (int i = 0; i < 20; i++) p.put(o + i, p.get(r + i));
+    copy_n(p, o, r, (int)(20));
     return o;
 }

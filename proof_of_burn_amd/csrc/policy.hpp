@@ -33,6 +33,7 @@ typedef int32_t S;    // SM value of this lane's witness
 typedef Fr F;         // FR value (Montgomery) of this lane's witness
 
 struct Cur { uint32_t w, b, s, f; };   // next free: wire index, BIT rank, SM rank, FR rank
+HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k}; return r; }
 struct BitRef { uint32_t w, i; HD BitRef operator+(uint32_t k) const { BitRef r = {w + k, i + k}; return r; } };
 struct SmRef  { uint32_t w, i; HD SmRef  operator+(uint32_t k) const { SmRef  r = {w + k, i + k}; return r; } };
 struct SiRef  { uint32_t w, i; HD SiRef  operator+(uint32_t k) const { SiRef  r = {w + k, i + k}; return r; } };
@@ -184,15 +185,25 @@ HD S canon_byte(const F& c, int i) {            // little-endian byte i
     return (S)((w >> (8 * (i & 3))) & 0xffu);
 }
 // dst[i] = src[i], i < n, BATCH loads ahead of the stores / compares (a copy loop otherwise pays one memory round trip per wire)
-template <class P, int BATCH> HD __attribute__((always_inline)) void sm_copy(P& p, SmRef dst, SmRef src, int n) {
+template <class P, int BATCH> HD __attribute__((always_inline)) void sm_copy(P& p, SmRef dst, SmRef src, int n, bool rev = false) {   // rev: dst[n-1-i] = src[i]
     for (int i0 = 0; i0 < n; i0 += BATCH) {
         SmRef rr[BATCH]; S vv[BATCH];
 #pragma unroll
-        for (int q = 0; q < BATCH; q++) rr[q] = dst + (uint32_t)(i0 + q < n ? i0 + q : n - 1);
+        for (int q = 0; q < BATCH; q++) { const int i = i0 + q < n ? i0 + q : n - 1; rr[q] = dst + (uint32_t)(rev ? n - 1 - i : i); }
         const SmLoaded<BATCH> h = sm_load(p, rr);
 #pragma unroll
         for (int q = 0; q < BATCH; q++) vv[q] = p.get(src + (uint32_t)(i0 + q < n ? i0 + q : n - 1));
         sm_commit(p, rr, h, vv);
+    }
+}
+// dst[i] = src[i], i < n: SM wires in batches of 16, BIT wires as lane-distributed runs of 64
+template <class P> HD __attribute__((always_inline)) void copy_n(P& p, SmRef dst, SmRef src, int n) { sm_copy<P, 8>(p, dst, src, n); }
+template <class P> HD __attribute__((always_inline)) void copy_n(P& p, BitRef dst, BitRef src, int n) {
+    const uint32_t ln = p.lane_id();
+    for (int q = 0; q < n; q += 64) {
+        const uint32_t m = (uint32_t)(n - q < 64 ? n - q : 64);
+        const B v = p.run_get(m, src.i + q + ln);
+        p.run_put(m, dst.w + q + ln, dst.i + q + ln, v);
     }
 }
 // N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
