@@ -801,29 +801,46 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
             FrRef r = {c.w + 1 + which + (which >= 2 ? 1u : 0u), c.f + which};
             return r;
         };
-        if (P::is_gen) {         // Montgomery batch inversion over this range, scratch = the witness' own isz.in / isz.inv slots
-            F run = fr_one_mont();
-            for (uint32_t i = lo; i < hi; i++) {
-                F dd = fr_sub(fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), fr_mul(subNum, p.k256(i)));
-                p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
-                if (!fr_is_zero(dd)) run = fr_mul(run, dd);
-            }
-            F inv = fr_inv(run);
-            for (uint32_t i = hi; i-- > lo;) {
-                F dd = p.get(fref(i, 2)), pre = p.get(fref(i, 3));
-                const bool z = fr_is_zero(dd);
-                p.raw_put(fref(i, 3), z ? fr_zero() : fr_mul(inv, pre));
-                if (!z) inv = fr_mul(inv, dd);
-            }
-        }
         // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
         const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
         B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
-        for (uint32_t i = lo; i < hi; i++) {
-            p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
-            B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
-            allowed = p.put(sc.alw + i + 1, allowed & ~last);
-            p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, p.k256(i)), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
+        if constexpr (P::is_gen) {
+            // One forward pass writes IsEqual(exists).in[0..1] and IsZero.in for good and leaves the running product of the non-zero
+            // operands in the IsZero.inv slot; one inversion (Montgomery's trick); one backward pass turns the slots into inverses.
+            F run = fr_one_mont();
+            B exm = 0;                                   // bit i - lo (per witness): operand i is zero  (hi - lo <= 64)
+            for (uint32_t i = lo; i < hi; i++) {
+                const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), dd = fr_sub(t2, t1);
+                p.raw_put(fref(i, 0), t1); p.raw_put(fref(i, 1), t2); p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
+                const bool z = fr_is_zero(dd);
+                if (z) exm |= (B)1 << (i - lo); else run = fr_mul(run, dd);
+            }
+#ifdef POB_EXP_NOINV
+            F inv = run;
+#else
+            F inv = fr_inv(run);
+#endif
+            for (uint32_t i = hi; i-- > lo;) {
+                const bool z = (exm >> (i - lo)) & 1;
+                const F pre = p.get(fref(i, 3));
+                p.raw_put(fref(i, 3), z ? fr_zero() : fr_mul(inv, pre));
+                if (!z) inv = fr_mul(inv, p.get(fref(i, 2)));
+            }
+            for (uint32_t i = lo; i < hi; i++) {         // the BIT / SM wires: IsEqual(isLastIndex), allowed, exists and the two IsEqual(exists) outputs
+                p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
+                B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
+                allowed = p.put(sc.alw + i + 1, allowed & ~last);
+                const B e = p.ballot((exm >> (i - lo)) & 1);
+                BitRef eo = p.bits(1); p.frs(2); BitRef zo = p.bits(1); p.frs(2);
+                p.put(sc.ex + i, p.put(eo, p.put(zo, e)));
+            }
+        } else {
+            for (uint32_t i = lo; i < hi; i++) {
+                p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
+                B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
+                allowed = p.put(sc.alw + i + 1, allowed & ~last);
+                p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, p.k256(i)), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
+            }
         }
     } break;
     default: break;

@@ -179,6 +179,96 @@ HD void fr256_submod(uint32_t* a, const uint32_t* b) {   // a <- a - b mod p
         for (int i = 0; i < 8; i++) { c += (uint64_t)a[i] + P[i]; a[i] = (uint32_t)c; c >>= 32; }
     }
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device: Kaliski's almost-inverse with batched shifts, branch-free per step.  Phase 1 works on plain 256-bit integers --
+// (u, v) start as (p, x), the coefficients (r, s) are only added and shifted LEFT (no modular halving), k counts the shifts --
+// and ends with r = -x^-1 * 2^k mod p, 254 <= k <= 508.  Every step subtracts the smaller of the two odd values from the larger
+// and strips ALL trailing zeros of the difference at once (ctz), so ~190 steps of ~120 instructions replace the ~360 steps of
+// the classic loop whose four divergent paths a wavefront executes one after the other.  Phase 2 is one Montgomery product with
+// 2^(768-k) from a table: (x = a*R)  x^-1 * 2^k * 2^(768-k) * 2^-256 = a^-1 * R.
+#include "fr_pow2_table.h"
+static __device__ const uint32_t FR_POW2_TAB[FR_POW2_TAB_LEN * 8] = FR_POW2_TAB_INIT;
+HDN Fr fr_inv(Fr a) {
+    const uint32_t P[8] = FR_P_LIMBS;
+    uint32_t u[8], v[8], r[8], s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u[i] = P[i]; v[i] = a.l[i]; r[i] = 0; s[i] = i == 0; }
+    uint32_t k = 0;
+    bool active = !fr_is_zero(a);
+    for (int it = 0; it < 1100; it++) {
+        if (!__any(active)) break;
+        const bool eu = active && !(u[0] & 1), ev = active && !(v[0] & 1);
+        if (__any(eu || ev)) {              // only before the first step (x even) and after a difference with > 31 trailing zeros
+            const bool wu = eu;             // shift u (and s) or v (and r)
+            const uint32_t w0 = wu ? u[0] : v[0];
+            const uint32_t t = (eu || ev) ? (w0 ? (uint32_t)__builtin_ctz(w0) : 31u) : 0u;     // 0: this lane has nothing to fix
+            const uint32_t tt = t > 31u ? 31u : t;
+            uint32_t x[8], c[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { x[i] = wu ? u[i] : v[i]; c[i] = wu ? s[i] : r[i]; }
+            uint32_t xs[8], cs[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t hi_ = i < 7 ? x[i + 1] : 0u, lo_ = i > 0 ? c[i - 1] : 0u;
+                xs[i] = tt ? (x[i] >> tt) | (hi_ << (32 - tt)) : x[i];
+                cs[i] = tt ? (c[i] << tt) | (lo_ >> (32 - tt)) : c[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (wu) { u[i] = xs[i]; s[i] = cs[i]; } else { v[i] = xs[i]; r[i] = cs[i]; }
+            }
+            k += tt;
+            continue;
+        }
+        // both odd: d = |u - v|, sum = r + s
+        uint32_t d[8], sum[8];
+        uint32_t bw = 0, cy = 0, nzd = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t df = (uint64_t)u[i] - v[i] - bw; d[i] = (uint32_t)df; bw = (uint32_t)(df >> 63);
+            const uint64_t sm = (uint64_t)r[i] + s[i] + cy; sum[i] = (uint32_t)sm; cy = (uint32_t)(sm >> 32);
+        }
+        if (bw) {                            // u < v: d = -d
+            uint32_t c1 = 1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const uint64_t ng = (uint64_t)(~d[i]) + c1; d[i] = (uint32_t)ng; c1 = (uint32_t)(ng >> 32); }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) nzd |= d[i];
+        const bool gt = !bw && nzd != 0;     // u > v: u <- d >> t, r <- r + s, s <<= t;  otherwise v <- d >> t, s <- r + s, r <<= t
+        const uint32_t t = nzd ? (d[0] ? (uint32_t)__builtin_ctz(d[0]) : 31u) : 1u;
+        const uint32_t tt = t > 31u ? 31u : t;                   // >= 1: the difference of two odd values is even
+        uint32_t dsh[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t hi_ = i < 7 ? d[i + 1] : 0u;
+            dsh[i] = (d[i] >> tt) | (hi_ << (32 - tt));
+            const uint32_t ci = gt ? s[i] : r[i], cl = i > 0 ? (gt ? s[i - 1] : r[i - 1]) : 0u;
+            sh[i] = (ci << tt) | (cl >> (32 - tt));
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (gt) { u[i] = dsh[i]; r[i] = sum[i]; s[i] = sh[i]; } else { v[i] = dsh[i]; s[i] = sum[i]; r[i] = sh[i]; }
+            }
+            k += tt;
+            if (nzd == 0) active = false;    // u == v (== gcd = 1): v is now 0, done
+        }
+    }
+    // r < 2p; almost-inverse = p - (r mod p)
+    Fr rr;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rr.l[i] = r[i];
+    if (fr_geq_p(rr)) rr = fr_sub_p(rr);
+    Fr res = fr_sub(fr_zero(), rr);
+    Fr c;
+    const uint32_t kk = k < FR_POW2_TAB_LEN ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c.l[i] = FR_POW2_TAB[kk * 8 + i];
+    Fr y = fr_mul(res, c);
+    return fr_is_zero(a) ? fr_zero() : y;
+}
+#else
 HDN Fr fr_inv(Fr a) {
     const uint32_t P[8] = FR_P_LIMBS;
     uint32_t u[8], v[8], A[8], C[8];
@@ -219,4 +309,5 @@ HDN Fr fr_inv(Fr a) {
     for (int i = 0; i < 8; i++) y.l[i] = C[i];
     return fr_mul(y, r3);          // x = 0: the loop never runs, C = 0 -> 0
 }
+#endif
 HD uint32_t fr_bit(const Fr& canon, int i) { return (canon.l[i >> 5] >> (i & 31)) & 1; }
