@@ -640,8 +640,7 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         const int j = d.a[0];
         FrRef src = j == 0 ? M.nullifier : j == 1 ? M.remainingCoin : j == 2 ? M.revealAmount : j == 3 ? M.burnExtraCommitment : M.proofExtraCommitment;
         SmRef dst = j == 0 ? M.nullifierBytes : j == 1 ? M.remainingCoinBytes : j == 2 ? M.revealAmountBytes : j == 3 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
-        SmRef r = gNum2BigEndianBytesF(p, 32, p.get(src));
-        copy_n(p, dst, r, (int)(32));
+        gNum2BigEndianBytesF(p, 32, p.get(src), &dst);
     } break;
     case U_PC_POST: {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
         SmRef f = gFitS(p, 32, 31, L.pc.hash);
@@ -677,12 +676,9 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
     case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
         F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
         p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
-        SmRef r = gNum2BigEndianBytesF(p, 32, bk);
-        copy_n(p, L.pw.keyBytes, r, (int)(32));
-        r = gNum2BigEndianBytesF(p, 32, ra);
-        copy_n(p, L.pw.raBytes, r, (int)(32));
-        r = gNum2BigEndianBytesF(p, 32, bec);
-        copy_n(p, L.pw.becBytes, r, (int)(32));
+        gNum2BigEndianBytesF(p, 32, bk, &L.pw.keyBytes);
+        gNum2BigEndianBytesF(p, 32, ra, &L.pw.raBytes);
+        gNum2BigEndianBytesF(p, 32, bec, &L.pw.becBytes);
         SmRef e = p.sms(8);                              // EIP7503 :11-21  [out[8]]
         const char tag[9] = "EIP-7503";
         for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)tag[i]));
@@ -708,14 +704,10 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         F coin = p.put(L.sm.coin, gPoseidon<P, 4>(p, pos_off(4), in3));
         in3[2] = fr_sub(bal, wd);
         F rc = p.put(L.sm.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
-        SmRef r = gNum2BigEndianBytesF(p, 32, coin);
-        copy_n(p, L.sm.coinBytes, r, (int)(32));
-        r = gNum2BigEndianBytesF(p, 32, wd);
-        copy_n(p, L.sm.withdrawnBalanceBytes, r, (int)(32));
-        r = gNum2BigEndianBytesF(p, 32, rc);
-        copy_n(p, L.sm.remainingCoinBytes, r, (int)(32));
-        r = gNum2BigEndianBytesF(p, 32, ec);
-        copy_n(p, L.sm.extraCommitmentBytes, r, (int)(32));
+        gNum2BigEndianBytesF(p, 32, coin, &L.sm.coinBytes);
+        gNum2BigEndianBytesF(p, 32, wd, &L.sm.withdrawnBalanceBytes);
+        gNum2BigEndianBytesF(p, 32, rc, &L.sm.remainingCoinBytes);
+        gNum2BigEndianBytesF(p, 32, ec, &L.sm.extraCommitmentBytes);
     } break;
     default: break;
     }
@@ -864,7 +856,7 @@ struct Plan {
     // Side tracks: stage ids TRACK_STRIDE*t + s belong to track t.  Track 0 is the main sequence; track t > 0 starts once stage
     // track_fork[t] has completed and must have completed before stage track_join[t] starts.  A track may only be joined by a
     // lower-numbered track (the host enqueues a stage's forked tracks highest first, each one completely).
-    enum { TRACK_STRIDE = 32, MAX_TRACKS = 4 };
+    enum { TRACK_STRIDE = 32, MAX_TRACKS = 5 };
     uint32_t ntracks, track_fork[MAX_TRACKS], track_join[MAX_TRACKS];
     CountP p;
 
@@ -962,8 +954,11 @@ struct Plan {
         // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before PublicCommitment
         // (main stage 5).  track 2 (TR): the RlpMerklePatriciaTrieLeaf assembly, forked once BurnAddressHash is done (TB + 5) and
         // joined before the final comparisons (main stage 10).  track 3 (TC): RlpEmptyAccount's serial chain, joined before TR + 2.
-        const uint32_t TB = TRACK_STRIDE, TR = 2 * TRACK_STRIDE, TC = 3 * TRACK_STRIDE;
-        ntracks = 4; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
+        // track 4 (TN): the five Num2BigEndianBytes of PublicCommitment's inputs, forked once the Poseidons are done (TB + 1), joined
+        // before PublicCommitment (main stage 5); it runs on the main track's BN254 stream, which is idle until then.
+        const uint32_t TB = TRACK_STRIDE, TR = 2 * TRACK_STRIDE, TC = 3 * TRACK_STRIDE, TN = 4 * TRACK_STRIDE;
+        ntracks = 5; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
+        track_fork[4] = TB + 1; track_join[4] = 5;
         PobMain& M = L.pm;
         const int Ln = prm.L, LB = 136 * prm.NB, HBy = 136 * prm.HB;
         p.cur = Cur{1, 0, 0, 0};                      // wire 0 = constant 1
@@ -997,7 +992,7 @@ struct Plan {
         }
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 1, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122
-        for (int j = 0; j < 5; j++) unit(U_POB_N2B, TB + 2, j);                                    // :132-136
+        for (int j = 0; j < 5; j++) unit(U_POB_N2B, TN + 1, j);                                    // :132-136
         public_commitment(6, 5);                                                                // :137  (pre 5, ranges 6, sponge 7, rows/post 8, commitment 9)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
             CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
@@ -1026,7 +1021,7 @@ struct Plan {
                     record(U_ABS_RANGE, 5, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
                 for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) record(U_SC_M, 5, start, i, lo, std::min<uint32_t>(lo + 32, LB));
                 const uint32_t kk = LB - 31 + 1;
-                for (uint32_t lo = 0; lo < kk; lo += 64) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 64, kk));
+                for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
                 record(U_SC_SUMS, 7, sc.c_tail, i);
             }
         }

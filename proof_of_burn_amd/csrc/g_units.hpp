@@ -8,8 +8,9 @@ extern __shared__ uint32_t g_lds[];
 #define POB_HEAVY_WAVES 1      // waves per SIMD the BN254 kernels are compiled for (VGPR budget 512 / POB_HEAVY_WAVES)
 #endif
 
-// CLS: 0 = light units (BIT/SM only), 1 = BN254 units (Poseidon, Num2Bits_strict, ...), 2 = SubstringCheck's BN254 units
-template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 : CLS == 2 ? 4 : POB_HEAVY_WAVES) g_units(GArgs A) {
+// CLS: 0 = light units (BIT/SM only), 1 = BN254 units (Poseidon, Num2Bits_strict, ...), 2 = SubstringCheck's BN254 units,
+//      3 = the BN254 units again at <= 128 VGPRs (generation, launches without a Poseidon unit)
+template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 : CLS >= 2 ? 4 : POB_HEAVY_WAVES) g_units(GArgs A) {
     // the few long BN254 chains share their SIMDs with thousands of short light / Keccak waves: let the arbiter favour them
     if constexpr (CLS != 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
@@ -41,7 +42,7 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
     for (int pass = 0;; pass++) {
         const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
         if constexpr (CLS == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
-        if constexpr (CLS == 1) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
+        if constexpr (CLS == 1 || CLS == 3) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
         if constexpr (P::is_check) {      // a lane-distributed run differed: replay the unit attributing wire by wire
             p.run_flush(); p.put_flush();
             if (pass == 0 && __ballot(p.rdiff != 0)) { p.attribute = true; continue; }

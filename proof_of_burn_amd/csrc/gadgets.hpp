@@ -537,21 +537,34 @@ template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count)
     count = p.put(cn, count);
     copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)ms);
-    for (int i = 0; i <= ms; i++) {
-        B e = p.put(isEq + i, gIsEqualS(p, (S)i, count));
-        bool hit = p.bit(e);
-        for (int j = 0; j < n; j++) p.put(temps + (i * n + j), hit ? p.get(in + j) : 0);
+    for (int i = 0; i <= ms; i++) p.put(isEq + i, gIsEqualS(p, (S)i, count));      // isEq[i] = [i == count]
+    // temps[i][j] = isEq[i] * in[j]: each in[j] is read once (not once per i), the column is written without reading anything back
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        S v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = p.get(src + (uint32_t)(j0 + q < n ? j0 + q : n - 1));
+        for (int i = 0; i <= ms; i++) {
+            const bool hit = (uint32_t)i == (uint32_t)count;
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (j0 + q < n) p.put(temps + (uint32_t)(i * n + j0 + q), hit ? v[q] : 0);
+        }
     }
-    for (int t = 0; t < n + ms; t++) {           // out[t] = sum_{i+j=t} temps[i][j]
-        S acc = 0;
-        int i0 = t - (n - 1) > 0 ? t - (n - 1) : 0, i1 = t < ms ? t : ms;
-        for (int i = i0; i <= i1; i++) acc += p.get(temps + (i * n + (t - i)));
-        p.put(o + t, acc);
+    // out[t] = sum_{i+j=t} temps[i][j] = in[t - count] when 0 <= t - count < n (exactly one isEq is set), read per witness
+    const uint32_t cnt = (uint32_t)count;
+    for (int t0 = 0; t0 < n + ms; t0 += 8) {
+        S v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t t = (uint32_t)(t0 + q < n + ms ? t0 + q : n + ms - 1);
+            const bool inside = cnt <= (uint32_t)ms && t >= cnt && t - cnt < (uint32_t)n;
+            v[q] = p.get_lane(src, inside ? t - cnt : 0u);
+            if (!inside) v[q] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (t0 + q < n + ms) p.put(o + (uint32_t)(t0 + q), v[q]);
     }
     return o;
 }
-
-// ============================================================================ circuits/utils/concat.circom
 // Mask(n) :18-30  [out[n] | in[n], count | filter[n]] || Filter(n)
 template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef flt = p.bits(n);
@@ -657,7 +670,8 @@ template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in, F*
     return o;
 }
 // Num2BigEndianBytes(N) :90-96  [out[N] | in | littleEndian[N]] || Num2LittleEndianBytes(N), Reverse(N) [out[N] | in[N]]
-template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in) {
+// `also`: a caller's copy of out[] (written from the same per-witness bytes, not read back)
+template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const SmRef* also = nullptr) {
     SmRef o = p.sms(N); FrRef i = p.frs(1); SmRef le = p.sms(N);
     F x = p.put(i, in);
     F c;
@@ -666,7 +680,7 @@ template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in) {
     for (int j = 0; j < N; j++) p.put(le + j, canon_byte(c, j));
     ro = p.sms(N); ri = p.sms(N);
     for (int j = 0; j < N; j++) { const S by = canon_byte(c, j); p.put(ri + j, by); p.put(ro + (N - 1 - j), by); }
-    for (int j = 0; j < N; j++) p.put(o + j, canon_byte(c, N - 1 - j));
+    for (int j = 0; j < N; j++) { const S by = canon_byte(c, N - 1 - j); p.put(o + j, by); if (also) p.put(*also + j, by); }
     return o;
 }
 // Bytes2Nibbles(N) :103-121  [out[2N] | in[N] | inDecomposed[N][8]] || Num2Bits(8) x N

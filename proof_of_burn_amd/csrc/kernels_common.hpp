@@ -38,6 +38,7 @@ void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStrea
 void launch_g_check_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_gen_heavy_small(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);

@@ -69,7 +69,8 @@ struct pob_ctx {
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
 void launch_g_gen(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (cls == 1) launch_g_gen_heavy(A, nunits, ngroups, st); else if (cls == 2) launch_g_gen_sc(A, nunits, ngroups, st); else launch_g_gen_light(A, nunits, ngroups, st);
+    if (cls == 1) { if (A.stage_lds) launch_g_gen_heavy(A, nunits, ngroups, st); else launch_g_gen_heavy_small(A, nunits, ngroups, st); }
+    else if (cls == 2) launch_g_gen_sc(A, nunits, ngroups, st); else launch_g_gen_light(A, nunits, ngroups, st);
 }
 void launch_g_check(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
     if (cls == 1) launch_g_check_heavy(A, nunits, ngroups, st); else if (cls == 2) launch_g_check_sc(A, nunits, ngroups, st); else launch_g_check_light(A, nunits, ngroups, st);
@@ -211,17 +212,21 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 
     HIPC(hipSetDevice(device));
     HIPC(hipStreamCreate(&h->stream));
-    HIPC(hipStreamCreate(&h->stream2));
+    // the side-track streams get dispatch priority: their few workgroups take the next free slots instead of queueing behind the
+    // 30k workgroups of a Keccak expansion running on the caller's stream
+    int prio_lo = 0, prio_hi = 0;
+    HIPC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < pl.ntracks; t++) {
         pob_ctx::Track& T = h->tracks[t];
-        if (t <= 2) HIPC(hipStreamCreate(&T.s_main)); else T.s_main = h->tracks[2].s_main;
+        if (t <= 2) HIPC(hipStreamCreateWithPriority(&T.s_main, hipStreamNonBlocking, prio_hi)); else T.s_main = t == 3 ? h->tracks[2].s_main : h->stream2;
         T.s_heavy = T.s_main;
         HIPC(hipEventCreateWithFlags(&T.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_join, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&T.ev_start, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_end, hipEventDisableTiming));
     }
-    if (pl.ntracks > 1) h->stream3 = h->tracks[1].s_main; else { HIPC(hipStreamCreate(&h->stream3)); h->own_stream3 = true; }
+    if (pl.ntracks > 1) h->stream3 = h->tracks[1].s_main; else { HIPC(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi)); h->own_stream3 = true; }
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
