@@ -801,8 +801,14 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
             // operands in the IsZero.inv slot; one inversion (Montgomery's trick); one backward pass turns the slots into inverses.
             F run = fr_one_mont();
             B exm = 0;                                   // bit i - lo (per witness): operand i is zero  (hi - lo <= 64)
+            F ma = p.get(sc.M + lo + sl), mb = p.get(sc.M + lo);
             for (uint32_t i = lo; i < hi; i++) {
-                const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), dd = fr_sub(t2, t1);
+                // the next position's M operands are requested BEFORE this position's stores are issued: a load queued behind stores
+                // completes only after them (one in-order counter), which would put a store round trip into every iteration
+                const uint32_t in = i + 1 < hi ? i + 1 : i;
+                const F na = p.get(sc.M + in + sl), nb = p.get(sc.M + in);
+                const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_sub(ma, mb), dd = fr_sub(t2, t1);
+                ma = na; mb = nb;
                 p.raw_put(fref(i, 0), t1); p.raw_put(fref(i, 1), t2); p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
                 const bool z = fr_is_zero(dd);
                 if (z) exm |= (B)1 << (i - lo); else run = fr_mul(run, dd);
