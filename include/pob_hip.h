@@ -92,6 +92,10 @@ void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]);
  * with keccak256(key | postfix)[0:zero_bytes] == 0; returns the number of increments or -1.                      */
 int64_t pob_pow_search(const uint8_t start_key[32], const uint8_t* postfix, uint32_t postfix_len, uint32_t zero_bytes,
                        uint64_t max_tries, uint8_t out_key[32]);
+/* The same search as a HIP kernel on `device` (one candidate key per thread, Keccak-f on 64-bit lanes, windows of 2^24 keys,
+ * smallest offset of the first window with a hit): identical result, -2 on a HIP error.                          */
+int64_t pob_pow_search_gpu(int device, const uint8_t start_key[32], const uint8_t* postfix, uint32_t postfix_len,
+                           uint32_t zero_bytes, uint64_t max_tries, uint8_t out_key[32]);
 
 #ifdef __cplusplus
 }

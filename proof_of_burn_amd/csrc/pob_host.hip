@@ -34,6 +34,51 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 
+// ---- proof-of-work search (input producer, reference tests/main.py:47-56): thread t hashes key = start + t
+__device__ __forceinline__ uint64_t pow_rotl(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+__global__ void __launch_bounds__(256) k_pow_search(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3,       // start key, big-endian words
+                                                     const uint64_t* __restrict__ tail,                       // lanes 4..16 of the padded block
+                                                     uint64_t base, uint64_t count, uint64_t mask, unsigned long long* found) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t off = base + t;
+    uint64_t w3 = k3 + off, c = w3 < k3, w2 = k2 + c; c = w2 < c; uint64_t w1 = k1 + c; c = w1 < c; const uint64_t w0 = k0 + c;
+    uint64_t a[25];
+    a[0] = __builtin_bswap64(w0); a[1] = __builtin_bswap64(w1); a[2] = __builtin_bswap64(w2); a[3] = __builtin_bswap64(w3);
+#pragma unroll
+    for (int i = 4; i < 17; i++) a[i] = tail[i - 4];
+#pragma unroll
+    for (int i = 17; i < 25; i++) a[i] = 0;
+    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+                             0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+                             0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+                             0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        uint64_t cc[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; x++) cc[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            const uint64_t d = cc[(x + 4) % 5] ^ pow_rotl(cc[(x + 1) % 5], 1);
+#pragma unroll
+            for (int y = 0; y < 25; y += 5) a[y + x] ^= d;
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++)
+#pragma unroll
+            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = pow_rotl(a[x + 5 * y], ROT[x + 5 * y]);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5)
+#pragma unroll
+            for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+        a[0] ^= RC[r];
+    }
+    if ((a[0] & mask) == 0) atomicMin(found, (unsigned long long)off);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct pob_ctx {
     int device = 0, circuit = 0;
@@ -585,6 +630,45 @@ int64_t pob_pow_search(const uint8_t start_key[32], const uint8_t* postfix, uint
         for (int i = 31; i >= 0; i--) if (++msg[i]) break;      // big-endian increment
     }
     return -1;
+}
+
+// The same search on the GPU: windows of 2^24 candidate keys, first window with a hit wins and its smallest offset is returned,
+// so the result equals the sequential search's.  Returns the number of increments or -1 (exhausted / bad arguments), -2 on a HIP error.
+int64_t pob_pow_search_gpu(int device, const uint8_t start_key[32], const uint8_t* postfix, uint32_t postfix_len, uint32_t zero_bytes,
+                           uint64_t max_tries, uint8_t out_key[32]) {
+    if (postfix_len > 100 || zero_bytes > 8 || zero_bytes == 0) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    uint8_t blk[136]; memset(blk, 0, 136);
+    memcpy(blk + 32, postfix, postfix_len);
+    const uint32_t len = 32 + postfix_len;
+    blk[len] ^= 0x01; blk[135] ^= 0x80;
+    uint64_t tail[13];
+    for (int i = 0; i < 13; i++) memcpy(&tail[i], blk + 32 + 8 * i, 8);
+    uint64_t kw[4];
+    for (int i = 0; i < 4; i++) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = (v << 8) | start_key[8 * i + j]; kw[i] = v; }
+    uint64_t* d_tail = nullptr; unsigned long long* d_found = nullptr;
+    if (hipMalloc(&d_tail, sizeof tail) != hipSuccess || hipMalloc(&d_found, 8) != hipSuccess) return -2;
+    hipMemcpy(d_tail, tail, sizeof tail, hipMemcpyHostToDevice);
+    const uint64_t mask = zero_bytes == 8 ? ~0ULL : ((1ULL << (8 * zero_bytes)) - 1);
+    const uint64_t WIN = 1ULL << 24;
+    int64_t result = -1;
+    for (uint64_t base = 0; base < max_tries; base += WIN) {
+        const uint64_t cnt = max_tries - base < WIN ? max_tries - base : WIN;
+        unsigned long long init = ~0ULL;
+        hipMemcpy(d_found, &init, 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_pow_search, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, 0, kw[0], kw[1], kw[2], kw[3], d_tail, base, cnt, mask, d_found);
+        unsigned long long got = ~0ULL;
+        if (hipMemcpy(&got, d_found, 8, hipMemcpyDeviceToHost) != hipSuccess) { result = -2; break; }
+        if (got != ~0ULL) { result = (int64_t)got; break; }
+    }
+    hipFree(d_tail); hipFree(d_found);
+    if (result >= 0) {           // key = start + result (256-bit big-endian)
+        uint64_t w[4] = {kw[0], kw[1], kw[2], kw[3]};
+        uint64_t add = (uint64_t)result;
+        for (int i = 3; i >= 0 && add; i--) { const uint64_t o = w[i]; w[i] += add; add = w[i] < o; }
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out_key[8 * i + j] = (uint8_t)(w[i] >> (56 - 8 * j));
+    }
+    return result;
 }
 
 }  // extern "C"

@@ -75,10 +75,16 @@ def hex_prefix_leaf(nibbles) -> bytes:
     return bytes(out)
 
 
-def pow_search(start_key: int, reveal: int, extra: int, zero_bytes: int, max_tries: int = 1 << 28) -> int:
+def pow_search(start_key: int, reveal: int, extra: int, zero_bytes: int, max_tries: int = 1 << 28, device: int | None = None) -> int:
+    """first burn key >= start_key whose keccak(key | reveal | extra | "EIP-7503") starts with zero_bytes zero bytes
+    (reference tests/main.py:47-56); device = GPU ordinal runs the search as a HIP kernel (same result)"""
     postfix = reveal.to_bytes(32, "big") + extra.to_bytes(32, "big") + b"EIP-7503"
     out = ctypes.create_string_buffer(32)
-    tries = load_library().pob_pow_search(start_key.to_bytes(32, "big"), postfix, len(postfix), zero_bytes, max_tries, out)
+    lib = load_library()
+    if device is None:
+        tries = lib.pob_pow_search(start_key.to_bytes(32, "big"), postfix, len(postfix), zero_bytes, max_tries, out)
+    else:
+        tries = lib.pob_pow_search_gpu(device, start_key.to_bytes(32, "big"), postfix, len(postfix), zero_bytes, max_tries, out)
     if tries < 0:
         raise RuntimeError("proof-of-work search exhausted")
     return int.from_bytes(out.raw, "big")

@@ -79,13 +79,15 @@ def load_library() -> ctypes.CDLL:
     lib.pob_keccak256.restype = None
     lib.pob_pow_search.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
     lib.pob_pow_search.restype = ctypes.c_int64
+    lib.pob_pow_search_gpu.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
+    lib.pob_pow_search_gpu.restype = ctypes.c_int64
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_results", "pob_results_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_time_kernel", "pob_debug_xor_bits", "pob_keccak256", "pob_pow_search"]
+                    "pob_write_wtns", "pob_time_kernel", "pob_debug_xor_bits", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:

@@ -253,3 +253,22 @@ def test_max_depth_and_ragged_batches(pkg):
         exp = (deep.commitments + shallow.commitments) if len(batch) == 70 else shallow.commitments[:len(batch)]
         assert [r.outputs for r in res] == [[c] for c in exp]
     calc.close()
+
+
+def test_pow_search_gpu_matches_host(pkg):
+    """row f1: the input producer's proof-of-work (tests/main.py:47-56) as a HIP kernel returns the same first key as the
+    sequential host search, for 1..3 zero bytes, including a start key whose low 64 bits wrap."""
+    import ctypes
+    lib = pkg.load_library()
+    from proof_of_burn_amd import inputs as gen
+    cases = [(12345, 10**18, 7, 1), (2**200 + 99, 5 * 10**17, 2**100 + 3, 2), ((1 << 64) - 1000, 10**18, 0, 2), (2**255 - 5, 1, 2**250, 3)]
+    for start, reveal, extra, zb in cases:
+        postfix = reveal.to_bytes(32, "big") + extra.to_bytes(32, "big") + b"EIP-7503"
+        o1, o2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        t1 = lib.pob_pow_search(start.to_bytes(32, "big"), postfix, len(postfix), zb, 1 << 28, o1)
+        t2 = lib.pob_pow_search_gpu(0, start.to_bytes(32, "big"), postfix, len(postfix), zb, 1 << 28, o2)
+        assert t1 >= 0 and t1 == t2 and o1.raw == o2.raw, (start, zb, t1, t2)
+        key = int.from_bytes(o2.raw, "big")
+        assert key == start + t1
+        assert pkg.keccak256(o2.raw + postfix)[:zb] == bytes(zb)
+        assert gen.pow_search(start, reveal, extra, zb, device=0) == key
