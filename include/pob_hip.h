@@ -29,6 +29,7 @@ typedef struct {
     uint32_t n_units, n_sponges, n_perms, n_stages, max_batch;
     uint64_t group_bytes;        /* HBM-resident bytes of the compact witness vector per 64 witnesses           */
     uint64_t keccak_bit_wires;   /* wires handled by the bit-sliced Keccak kernels                              */
+    uint64_t n_sb;               /* wires of the int8 class (operands of the Keccak output selectors' IsEqual gadgets) */
 } pob_info_t;
 
 /* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference

@@ -226,7 +226,7 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
 // IsEqual (comparators.circom): [out | in[2]] || IsZero [out | in | inv]
 template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
     const uint32_t n1 = N1 ? (uint32_t)N1 : r.mb + 1, n = j1 - j0, ln = p.lane_id();
-    const uint32_t fw = 9 * n1 + 3, fb = 5 * n1 + 2, fs = 4 * n1 + 1;       // footprint of one selector: wires, BIT, SM
+    const uint32_t fw = 9 * n1 + 3, fb = 5 * n1 + 2, fq = 4 * n1 + 1;       // footprint of one selector: wires, BIT, SB (no SM)
     const Cur c0 = p.cur;
     const uint32_t idx = row * 64 + j0 + ln;
     const S blocks = p.get(r.numBlocks);
@@ -272,16 +272,16 @@ template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t r
     }
     // SM side of the n selectors: select, and per IsEqual child in[0] = select, in[1] = k, IsZero.in = k - select, IsZero.inv.
     // Every selector carries the same rows, so each kind of wire is swept over the selectors with many loads in flight.
-    sm_rows_same<P, 16>(p, c0.w + n1 + 1, c0.s, fw, fs, n, blocks);
+    sb_rows_same<P, 16>(p, c0.w + n1 + 1, c0.q, fw, fq, n, blocks);
     for (uint32_t k = 0; k < n1; k++) {
-        const uint32_t cw = c0.w + 3 * n1 + 3 + 6 * k, cs = c0.s + 1 + 4 * k;
+        const uint32_t cw = c0.w + 3 * n1 + 3 + 6 * k, cq = c0.q + 1 + 4 * k;
         const S x = (S)(k - (uint32_t)blocks);
-        sm_rows_same<P, 16>(p, cw + 1, cs, fw, fs, n, blocks);
-        sm_rows_same<P, 16>(p, cw + 2, cs + 1, fw, fs, n, (S)k);
-        sm_rows_same<P, 16>(p, cw + 4, cs + 2, fw, fs, n, x);
-        si_rows_same<P, 16>(p, cw + 5, cs + 3, fw, fs, n, x);
+        sb_rows_same<P, 16>(p, cw + 1, cq, fw, fq, n, blocks);
+        sb_rows_same<P, 16>(p, cw + 2, cq + 1, fw, fq, n, (S)k);
+        sb_rows_same<P, 16>(p, cw + 4, cq + 2, fw, fq, n, x);
+        sbi_rows_same<P, 16>(p, cw + 5, cq + 3, fw, fq, n, x);
     }
-    p.cur = cur_add(c0, Cur{fw, fb, fs, 0}, n);
+    p.cur = cur_add(c0, Cur{fw, fb, 0, 0, fq}, n);
 }
 template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) { kb_selrow_n<P, 0>(p, r, row, j0, j1); }
 // after the selectors: Keccak/Final/selector `blocks` inputs; the Reshape(32,8) + Bits2Num(8) x 32 blocks that follow in wire
@@ -298,7 +298,7 @@ HD SelBlk sel_blk(Cur c, uint32_t N) {
     SelBlk s;
     s.o = SmRef{c.w, c.s}; s.vals = SmRef{c.w + 1, c.s + 1}; s.sel = SmRef{c.w + 1 + N, c.s + 1 + N};
     s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum = SmRef{c.w + 2 + 2 * N, c.s + 2 + N};
-    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f};
+    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f, c.q};
     return s;
 }
 HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; }
@@ -866,7 +866,7 @@ struct Plan {
     uint32_t ntracks, track_fork[MAX_TRACKS], track_join[MAX_TRACKS];
     CountP p;
 
-    static bool same(Cur a, Cur b) { return a.w == b.w && a.b == b.b && a.s == b.s && a.f == b.f; }
+    static bool same(Cur a, Cur b) { return a.w == b.w && a.b == b.b && a.s == b.s && a.f == b.f && a.q == b.q; }
     // the monolithic template (gadgets.hpp) walked by CountP must end where the split units say it ends
     void expect_cursor(const char* what, Cur got, Cur want) {
         if (!same(got, want)) throw std::runtime_error(std::string("layout planner: split units disagree with the monolithic template: ") + what);
@@ -901,14 +901,14 @@ struct Plan {
         r.dst = dst; r.has_dst = has_dst ? 1 : 0;
         {   // Reshape/Bits2Num blocks start after the 1600 selectors (all of equal footprint)
             CountP q; q.cur = p.cur; r.c_post = Cur{0, 0, 0, 0}; r.has_dst = 0; kb_selrow(q, r, 24, 0, 1);
-            const Cur fp1 = {q.cur.w - p.cur.w, q.cur.b - p.cur.b, q.cur.s - p.cur.s, 0};
+            const Cur fp1 = {q.cur.w - p.cur.w, q.cur.b - p.cur.b, q.cur.s - p.cur.s, 0, q.cur.q - p.cur.q};
             r.c_post = cur_add(p.cur, fp1, 1600); r.has_dst = has_dst ? 1 : 0;
         }
-        const uint32_t split = r.mb >= 8 ? 4 : 1;            // a long row's 64 selectors are split over several wavefronts
+        const uint32_t split = r.mb >= 8 ? 4 : r.mb >= 3 ? 2 : 1;            // a row's 64 selectors are split over several wavefronts
         for (uint32_t row = 0; row < 25; row++) {
             const Cur c0 = p.cur;
             CountP q; q.cur = c0; kb_selrow(q, r, row, 0, 64);
-            const Cur fp = {(q.cur.w - c0.w) / 64, (q.cur.b - c0.b) / 64, (q.cur.s - c0.s) / 64, 0};
+            const Cur fp = {(q.cur.w - c0.w) / 64, (q.cur.b - c0.b) / 64, (q.cur.s - c0.s) / 64, 0, (q.cur.q - c0.q) / 64};
             for (uint32_t k = 0; k < split; k++) record(U_KB_SELROW, range_stage + 2, cur_add(c0, fp, k * (64 / split)), kb, row, k * (64 / split), (k + 1) * (64 / split));
             p.cur = q.cur;
         }

@@ -19,6 +19,7 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
     p.m.bits = A.bits + (uint64_t)g * A.bits_stride;
     p.m.sm = A.sm + (uint64_t)g * A.sm_stride;
     p.m.fr = A.fr + (uint64_t)g * A.fr_stride;
+    int8_t* sbp = A.sb + (uint64_t)g * A.sb_stride;
     p.m.inv_lut = A.inv_lut; p.m.pow256 = A.pow256; p.m.npow256 = A.npow256;
     p.m.nfr_in = A.nfr_in; p.m.nsm_in = A.nsm_in;
     p.m.in_fr = A.in_fr + (uint64_t)g * 64 * A.nfr_in * 32;
@@ -29,6 +30,7 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
         p.m.rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.m.bits, 0, (int)(nb > 0xFFFFFFFFull ? 0xFFFFFFFFull : nb), 0x00020000);
         p.m.rs_sm = __builtin_amdgcn_make_buffer_rsrc(p.m.sm, 0, (int)(ns > 0xFFFFFFFFull ? 0xFFFFFFFFull : ns), 0x00020000);
         p.m.rs_fr = __builtin_amdgcn_make_buffer_rsrc(p.m.fr, 0, (int)(nf > 0xFFFFFFFFull ? 0xFFFFFFFFull : nf), 0x00020000);
+        p.m.rs_sb = __builtin_amdgcn_make_buffer_rsrc(sbp, 0, (int)(A.sb_stride > 0xFFFFFFFFull ? 0xFFFFFFFFull : A.sb_stride), 0x00020000);
     }
     if (CLS == 1 && A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
         for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];

@@ -385,7 +385,7 @@ template <class P> GD void gAssertByteString(P& p, int N, SmRef src) {
     SmRef in = p.sms(N);
     const Cur c0 = p.cur;
     abs_range(p, c0, in, src, 0, (uint32_t)N);
-    p.cur = Cur{c0.w + 18u * N, c0.b + 16u * N, c0.s + 2u * N, c0.f};
+    p.cur = Cur{c0.w + 18u * N, c0.b + 16u * N, c0.s + 2u * N, c0.f, c0.q};
 }
 // AssertLessThan(B) :40-47 / AssertLessEqThan :56-63 / AssertGreaterEqThan :72-79   [ | a, b | out]; out === 1
 template <class P> GD void gAssertLessThanS(P& p, int nb, S a, S b) {
@@ -665,7 +665,7 @@ template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in, F*
         const S by = canon_byte(c, j);
         p.put(o + j, p.put(SmRef{kids.w + 9 * j, kids.s + j}, by));
     }
-    p.cur = Cur{kids.w + 9u * N, kids.b + 8u * N, kids.s + (uint32_t)N, kids.f};
+    p.cur = Cur{kids.w + 9u * N, kids.b + 8u * N, kids.s + (uint32_t)N, kids.f, kids.q};
     if (cout) *cout = c;
     return o;
 }

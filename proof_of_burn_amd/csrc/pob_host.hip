@@ -87,7 +87,7 @@ struct pob_ctx {
     std::string err;
     hipStream_t stream = nullptr;
     // device memory
-    uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr;
+    uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr; int8_t* d_sb = nullptr;
     UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
@@ -134,6 +134,7 @@ static GArgs gargs(pob_ctx* h) {
     A.units = h->d_units; A.order = h->d_order; A.L = h->d_L;
     A.bits = h->d_bits; A.sm = h->d_sm; A.fr = h->d_fr;
     A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
+    A.sb = h->d_sb; A.sb_stride = (uint64_t)h->plan.total.q * 64;
     A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr; A.in_sm = h->d_in_sm;
     A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
     A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
@@ -170,7 +171,8 @@ static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_i
     { std::vector<char> used(pl.max_stage + 1, 0); for (const UnitDesc& u : pl.units) used[u.stage] = 1; for (const SpongeDesc& s : pl.sponges) used[s.stage] = 1;
       info->n_stages = 0; for (char c : used) info->n_stages += c; }
     info->max_batch = max_batch;
-    info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;
+    info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048 + (uint64_t)pl.total.q * 64;
+    info->n_sb = pl.total.q;
     info->keccak_bit_wires = 0;
     for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
 }
@@ -276,6 +278,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
     HIPC(hipMalloc(&h->d_fr, G * (uint64_t)pl.total.f * 2048));
+    HIPC(hipMalloc(&h->d_sb, std::max<uint64_t>(G * (uint64_t)pl.total.q * 64, 64)));
     HIPC(hipMalloc(&h->d_units, pl.units.size() * sizeof(UnitDesc)));
     HIPC(hipMalloc(&h->d_order, h->order.size() * sizeof(uint32_t)));
     HIPC(hipMalloc(&h->d_L, sizeof(CircuitLayout)));
@@ -319,7 +322,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
-    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
+    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
                     h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_emit};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);

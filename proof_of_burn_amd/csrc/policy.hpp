@@ -12,6 +12,8 @@
 //   SI   wires (IsZero.inv of an SM operand): stored in the SM array as the operand k itself; the
 //        wire's value is k^-1 mod p (0 for k = 0), decoded through a table when a .wtns is emitted.
 //   FR   wires (genuine field elements): 8 x uint32 limb planes [wire][limb][64 lanes], Montgomery form.
+//   SB   wires (operands of the Keccak output selectors' IsEqual gadgets: |value| <= 33 in a valid witness, half of all
+//        non-BIT wires): int8 [wire][64 lanes] (64 B rows); IsZero.inv among them is stored as its operand like SI.
 //
 // Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
 // run of same-class wires (e.g. a whole Keccak-f block, 2 506 944 BIT wires) is contiguous in HBM.
@@ -32,12 +34,13 @@ typedef uint64_t B;   // BIT value: lane mask over the 64 witnesses of the group
 typedef int32_t S;    // SM value of this lane's witness
 typedef Fr F;         // FR value (Montgomery) of this lane's witness
 
-struct Cur { uint32_t w, b, s, f; };   // next free: wire index, BIT rank, SM rank, FR rank
-HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k}; return r; }
+struct Cur { uint32_t w, b, s, f, q; };   // next free: wire index, BIT rank, SM rank, FR rank, SB rank
+HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k, a.q + d.q * k}; return r; }
 struct BitRef { uint32_t w, i; HD BitRef operator+(uint32_t k) const { BitRef r = {w + k, i + k}; return r; } };
 struct SmRef  { uint32_t w, i; HD SmRef  operator+(uint32_t k) const { SmRef  r = {w + k, i + k}; return r; } };
 struct SiRef  { uint32_t w, i; HD SiRef  operator+(uint32_t k) const { SiRef  r = {w + k, i + k}; return r; } };
 struct FrRef  { uint32_t w, i; HD FrRef  operator+(uint32_t k) const { FrRef  r = {w + k, i + k}; return r; } };
+struct SbRef  { uint32_t w, i; HD SbRef  operator+(uint32_t k) const { SbRef  r = {w + k, i + k}; return r; } };   // SB class (int8 rows)
 
 // failure codes: (template id << 12) | source line of the failing assert / === in the reference circuits
 enum : uint32_t {
@@ -52,6 +55,7 @@ struct PolBase {
     HD SmRef sms(uint32_t n) { SmRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
     HD SiRef sis(uint32_t n) { SiRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
     HD FrRef frs(uint32_t n) { FrRef r = {cur.w, cur.f}; cur.w += n; cur.f += n; return r; }
+    HD SbRef sbs(uint32_t n) { SbRef r = {cur.w, cur.q}; cur.w += n; cur.q += n; return r; }
     HD void skip_bits(uint32_t n) { cur.w += n; cur.b += n; }
 };
 
@@ -69,6 +73,9 @@ struct CountP : PolBase {
     HD B get(BitRef) { return 0; }
     HD S get(SmRef) { return 0; }
     HD S get_lane(SmRef, uint32_t) { return 0; }
+    HD S get(SbRef) { return 0; }
+    HD S put(SbRef, S v) { nput++; return v; }
+    HD S hint_inv(SbRef, S v) { nput++; return v; }
     HD F get(FrRef) { return fr_zero(); }
     HD void raw_put(FrRef, const F&) {}
     HD B ballot(bool) { return 0; }
@@ -206,6 +213,39 @@ template <class P> HD __attribute__((always_inline)) void copy_n(P& p, BitRef ds
         p.run_put(m, dst.w + q + ln, dst.i + q + ln, v);
     }
 }
+// the SB-class versions of sm_rows_same / si_rows_same
+template <class P, int BATCH> HD __attribute__((always_inline)) void sb_rows_same(P& p, uint32_t w0, uint32_t q0, uint32_t dw, uint32_t dq, uint32_t n, S v) {
+    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
+        S got[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const uint32_t t = t0 + q < n ? t0 + q : n - 1;
+            const SbRef r = {w0 + t * dw, q0 + t * dq};
+            if constexpr (P::is_check) got[q] = p.get(r); else got[q] = p.put(r, v);
+        }
+        if constexpr (P::is_check) {
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) { const uint32_t t = t0 + q < n ? t0 + q : n - 1; p.mark(got[q] != v, w0 + t * dw); }
+        }
+    }
+}
+template <class P, int BATCH> HD __attribute__((always_inline)) void sbi_rows_same(P& p, uint32_t w0, uint32_t q0, uint32_t dw, uint32_t dq, uint32_t n, S x) {
+    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
+        S kk[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const uint32_t t = t0 + q < n ? t0 + q : n - 1;
+            kk[q] = p.hint_inv(SbRef{w0 + t * dw, q0 + t * dq}, x);
+        }
+        if constexpr (!P::is_gen) {
+            bool ok30 = true, ok31 = true;
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) { ok30 = ok30 && (kk[q] == 0 || kk[q] == x); ok31 = ok31 && (x == 0 || kk[q] != 0); }
+            p.require(p.ballot(ok30), FAILCODE(T_ISZERO, 30));
+            p.require(p.ballot(ok31), FAILCODE(T_ISZERO, 31));
+        }
+    }
+}
 // N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
 template <class P, class R, class V, int N> HD __attribute__((always_inline)) void put_batch(P& p, const R (&r)[N], const V (&v)[N]) {
     if constexpr (P::is_check) p.put_batch(r, v);
@@ -230,7 +270,7 @@ struct DevMem {
     uint32_t lane;
     // buffer resources over the three slabs: a wire access is `buffer_load/store v, v_lane_offset, s[rsrc], s_wire_offset offen`
     // -- the per-wire part of the address stays scalar, no 64-bit per-lane address arithmetic (or registers) per access
-    __amdgpu_buffer_rsrc_t rs_bits, rs_sm, rs_fr;
+    __amdgpu_buffer_rsrc_t rs_bits, rs_sm, rs_fr, rs_sb;
     uint32_t lane4;     // lane * 4
 };
 typedef int pob_v2i __attribute__((ext_vector_type(2)));
@@ -244,6 +284,9 @@ struct DevPol : PolBase {
     __device__ __forceinline__ B ld(BitRef r) { return m.bits[r.i]; }
     __device__ __forceinline__ S ld(SmRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ S ld(SiRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
+    __device__ __forceinline__ S ld(SbRef r) { return (S)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(m.rs_sb, (int)m.lane, (int)(POB_UNI(r.i) << 6), 0); }
+    __device__ __forceinline__ void st(SbRef r, S v) { __builtin_amdgcn_raw_buffer_store_b8((char)v, m.rs_sb, (int)m.lane, (int)(POB_UNI(r.i) << 6), 0); }
+    __device__ __forceinline__ S get(SbRef r) { return ld(r); }
     __device__ __forceinline__ F ld(FrRef r) {
         F v; const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
@@ -318,6 +361,8 @@ struct GenP : DevPol {
     __device__ __forceinline__ S hint(SmRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ F hint(FrRef r, const F& v) { st(r, v); return v; }
     __device__ __forceinline__ S hint_inv(SiRef r, S v) { st(r, v); return v; }
+    __device__ __forceinline__ S put(SbRef r, S v) { st(r, v); return v; }
+    __device__ __forceinline__ S hint_inv(SbRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
@@ -381,6 +426,8 @@ struct CheckP : DevPol {
     __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
     __device__ __forceinline__ S hint_inv(SiRef r, S) { return ld(r); }
+    __device__ __forceinline__ S put(SbRef r, S v) { mark(ld(r) != v, r.w); return v; }
+    __device__ __forceinline__ S hint_inv(SbRef r, S) { return ld(r); }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     // lane-distributed runs: a run's difference is folded into `rdiff` when the NEXT run's load has been issued (one load is
@@ -440,8 +487,10 @@ struct EmitP : DevPol {
     __device__ __forceinline__ B hint(BitRef r, B v) { return put(r, v); }
     __device__ __forceinline__ S hint(SmRef r, S v) { return put(r, v); }
     __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
-    __device__ __forceinline__ S hint_inv(SiRef r, S) {
-        S k = ld(r);
+    __device__ __forceinline__ S put(SbRef r, S) { S s = ld(r); if (m.lane == sel) w32(r.w, small(s)); return s; }
+    __device__ __forceinline__ S hint_inv(SbRef r, S) { S k = ld(r); emit_inv(r.w, k); return k; }
+    __device__ __forceinline__ S hint_inv(SiRef r, S) { S k = ld(r); emit_inv(r.w, k); return k; }
+    __device__ __forceinline__ void emit_inv(uint32_t w, S k) {
         if (m.lane == sel) {
             F c;
             if (k >= -4096 && k <= 4096) {
@@ -451,9 +500,8 @@ struct EmitP : DevPol {
             } else {
                 c = fr_from_mont(fr_inv(fr_from_i64(k)));
             }
-            w32(r.w, c);
+            w32(w, c);
         }
-        return k;
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B, uint32_t) {}
