@@ -628,10 +628,15 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
     } break;
     case U_BAH_PRE: {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
         F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
-        SmRef ab = gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec);
-        copy_n(p, L.bah.addressBytes, ab, (int)(20));
-        SmRef f = gFitS(p, 20, 136, L.bah.addressBytes);
-        copy_n(p, L.bah.block, f, (int)(136));
+        F hc;
+        gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec, &hc);
+        // addressBytes, Fit(20, 136) [out[136] | in[20]] and the Keccak block: the 20 bytes again, written per witness (nothing read back)
+        SmRef fo = p.sms(136), fi = p.sms(20);
+        for (int i = 0; i < 136; i++) {
+            const S by = i < 20 ? canon_byte(hc, 31 - i) : 0;
+            if (i < 20) { p.put(L.bah.addressBytes + i, by); p.put(fi + i, by); }
+            p.put(fo + i, by); p.put(L.bah.block + i, by);
+        }
         KBRefs r = L.kbs[L.bah.kb];
         kb_head(p, 1, (S)20, r);
         if (P::is_count) L.kbs[L.bah.kb] = r;

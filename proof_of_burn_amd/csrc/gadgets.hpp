@@ -257,40 +257,56 @@ template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in, BV* vout = nullp
 struct PosOff { uint32_t C, S, M, Pm; int rp; };
 template <class P> HD F gSigma(P& p, const F& in) {   // [out | in | in2, in4]
     FrRef o = p.frs(1), i = p.frs(1), m = p.frs(2);
-    F x = p.put(i, in);
-    F x2 = p.put(m, fr_sqr(x)), x4 = p.put(m + 1, fr_sqr(x2));
-    return p.put(o, fr_mul(x4, x));
+    const FrRef rr[4] = {i, m, m + 1, o};
+    const FrLoaded<4> h = fr_load(p, rr);
+    const F x2 = fr_sqr(in), x4 = fr_sqr(x2), out = fr_mul(x4, in);
+    const F vv[4] = {in, x2, x4, out};
+    fr_commit(p, rr, h, vv);
+    return out;
 }
 template <class P, int T> GD void gArk(P& p, const PosOff& k, int r, F* st) {   // [out[t] | in[t]]
     FrRef o = p.frs(T), i = p.frs(T);
+    FrRef rr[2 * T]; F vv[2 * T];
 #pragma unroll
-    for (int j = 0; j < T; j++) { F x = p.put(i + j, st[j]); st[j] = p.put(o + j, fr_add(x, p.kconst(k.C + r + j))); }
+    for (int j = 0; j < T; j++) { rr[j] = i + j; rr[T + j] = o + j; }
+    const FrLoaded<2 * T> h = fr_load(p, rr);
+#pragma unroll
+    for (int j = 0; j < T; j++) { vv[j] = st[j]; st[j] = vv[T + j] = fr_add(st[j], p.kconst(k.C + r + j)); }
+    fr_commit(p, rr, h, vv);
 }
 template <class P, int T> GD void gMix(P& p, uint32_t mat, F* st) {             // out[i] = sum_j A[i][j] in[j]
     FrRef o = p.frs(T), i = p.frs(T);
-    F x[T];
+    FrRef rr[2 * T]; F vv[2 * T];
 #pragma unroll
-    for (int j = 0; j < T; j++) x[j] = p.put(i + j, st[j]);
+    for (int j = 0; j < T; j++) { rr[j] = i + j; rr[T + j] = o + j; vv[j] = st[j]; }
+    const FrLoaded<2 * T> h = fr_load(p, rr);
 #pragma unroll
     for (int a = 0; a < T; a++) {
         F acc = fr_zero();
 #pragma unroll
-        for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(mat + a * T + j), x[j]));
-        st[a] = p.put(o + a, acc);
+        for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(mat + a * T + j), vv[j]));
+        vv[T + a] = acc;
     }
+#pragma unroll
+    for (int a = 0; a < T; a++) st[a] = vv[T + a];
+    fr_commit(p, rr, h, vv);
 }
 template <class P, int T> GD void gMixS(P& p, const PosOff& k, int r, F* st) {
     FrRef o = p.frs(T), i = p.frs(T);
-    F x[T];
+    FrRef rr[2 * T]; F vv[2 * T];
 #pragma unroll
-    for (int j = 0; j < T; j++) x[j] = p.put(i + j, st[j]);
+    for (int j = 0; j < T; j++) { rr[j] = i + j; rr[T + j] = o + j; vv[j] = st[j]; }
+    const FrLoaded<2 * T> h = fr_load(p, rr);
     uint32_t base = k.S + (2 * T - 1) * r;
     F acc = fr_zero();
 #pragma unroll
-    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(base + j), x[j]));
-    st[0] = p.put(o, acc);
+    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(base + j), vv[j]));
+    vv[T] = acc;
 #pragma unroll
-    for (int j = 1; j < T; j++) st[j] = p.put(o + j, fr_add(x[j], fr_mul(x[0], p.kconst(base + T + j - 1))));
+    for (int j = 1; j < T; j++) vv[T + j] = fr_add(vv[j], fr_mul(vv[0], p.kconst(base + T + j - 1)));
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = vv[T + j];
+    fr_commit(p, rr, h, vv);
 }
 // Poseidon(T-1) [out | inputs[T-1]] || PoseidonEx [out[1] | inputs[T-1], initialState] || ark0; 3x{T Sigma, ark, mix(M)};
 // T Sigma, ark4, mix(P); RP x {sigmaP, mixS}; 3x{T Sigma, ark, mix(M)}; T Sigma; mixLast [out | in[T]]
@@ -671,7 +687,7 @@ template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in, F*
 }
 // Num2BigEndianBytes(N) :90-96  [out[N] | in | littleEndian[N]] || Num2LittleEndianBytes(N), Reverse(N) [out[N] | in[N]]
 // `also`: a caller's copy of out[] (written from the same per-witness bytes, not read back)
-template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const SmRef* also = nullptr) {
+template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const SmRef* also = nullptr, F* cout = nullptr) {
     SmRef o = p.sms(N); FrRef i = p.frs(1); SmRef le = p.sms(N);
     F x = p.put(i, in);
     F c;
@@ -681,6 +697,7 @@ template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const
     ro = p.sms(N); ri = p.sms(N);
     for (int j = 0; j < N; j++) { const S by = canon_byte(c, j); p.put(ri + j, by); p.put(ro + (N - 1 - j), by); }
     for (int j = 0; j < N; j++) { const S by = canon_byte(c, N - 1 - j); p.put(o + j, by); if (also) p.put(*also + j, by); }
+    if (cout) *cout = c;
     return o;
 }
 // Bytes2Nibbles(N) :103-121  [out[2N] | in[N] | inDecomposed[N][8]] || Num2Bits(8) x N
@@ -931,13 +948,14 @@ template <class P> GD B gLeafDetector(P& p, int N, SmRef src, S layerLen) {
 
 // ============================================================================ circuits/utils/burn_address.circom:47-58
 // BurnAddress  [addressBytes[20] | burnKey, revealAmount, burnExtraCommitment | hash, hashBytes[32]] || Poseidon(4), Num2BigEndianBytes(32), Fit(32,20)
-template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec) {
+template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec, F* hash_canon = nullptr) {
     SmRef o = p.sms(20); FrRef in = p.frs(3), h = p.frs(1); SmRef hb = p.sms(32);
     F pin[4]; pin[0] = prefix0; pin[1] = p.put(in, bk); pin[2] = p.put(in + 1, ra); pin[3] = p.put(in + 2, bec);
     F hash = p.put(h, gPoseidon<P, 5>(p, k5, pin));
-    SmRef r = gNum2BigEndianBytesF(p, 32, hash);
-    copy_n(p, hb, r, (int)(32));
-    r = gFitS(p, 32, 20, hb);
-    copy_n(p, o, r, (int)(20));
+    F c;
+    gNum2BigEndianBytesF(p, 32, hash, &hb, &c);          // hashBytes[i] = big-endian byte i = little-endian byte 31 - i, written per witness
+    SmRef fo = p.sms(20), fi = p.sms(32);                // Fit(32, 20)  [out[20] | in[32]]
+    for (int i = 0; i < 32; i++) { const S by = canon_byte(c, 31 - i); p.put(fi + i, by); if (i < 20) { p.put(fo + i, by); p.put(o + i, by); } }
+    if (hash_canon) *hash_canon = c;
     return o;
 }

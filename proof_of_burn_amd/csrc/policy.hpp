@@ -213,6 +213,29 @@ template <class P> HD __attribute__((always_inline)) void copy_n(P& p, BitRef ds
         p.run_put(m, dst.w + q + ln, dst.i + q + ln, v);
     }
 }
+// Two-phase FR batch (Poseidon rounds): the evaluator requests all N stored elements (8 N loads) before the expected values --
+// N Montgomery products deep -- are computed, then compares; generation stores.
+template <int N> struct FrLoaded { F s[N]; };
+template <class P, int N> HD __attribute__((always_inline)) FrLoaded<N> fr_load(P& p, const FrRef (&r)[N]) {
+    FrLoaded<N> h;
+    if constexpr (P::is_check) {
+#pragma unroll
+        for (int k = 0; k < N; k++) h.s[k] = p.get(r[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) h.s[k] = fr_zero();
+    }
+    return h;
+}
+template <class P, int N> HD __attribute__((always_inline)) void fr_commit(P& p, const FrRef (&r)[N], const FrLoaded<N>& h, const F (&v)[N]) {
+    if constexpr (P::is_check) {
+#pragma unroll
+        for (int k = 0; k < N; k++) p.mark(!fr_eq(h.s[k], v[k]), r[k].w);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) p.put(r[k], v[k]);
+    }
+}
 // the SB-class versions of sm_rows_same / si_rows_same
 template <class P, int BATCH> HD __attribute__((always_inline)) void sb_rows_same(P& p, uint32_t w0, uint32_t q0, uint32_t dw, uint32_t dq, uint32_t n, S v) {
     for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
