@@ -941,7 +941,7 @@ struct Plan {
         L.lds[inst].src = src; L.lds[inst].len_src = len; L.lds[inst].dst = dst;
         unit(U_LD_HEAD, stage, inst);
         expect_cursor("LeafDetector", p.cur, chk.cur);
-        for (uint32_t k = 0; k < 4; k++) for (uint32_t lo = 0; lo < N; lo += 136) record(U_LD_SELR, stage + 1, p.cur, inst, k, lo, std::min(lo + 136, N));
+        for (uint32_t k = 0; k < 4; k++) for (uint32_t lo = 0; lo < N; lo += 34) record(U_LD_SELR, stage + 1, p.cur, inst, k, lo, std::min(lo + 34, N));
         record(U_LD_TAIL, stage + 2, p.cur, inst);
     }
     void public_commitment(int N, uint32_t pre_stage) {   // public_commitment.circom:18-42
@@ -1011,7 +1011,7 @@ struct Plan {
             unit(U_POB_LASTLAYER, 1);
             L.ll.c_sel0 = p.cur;
             const Cur fp = {9u * Ln + 3, 3u * Ln, 6u * Ln + 3, 0};
-            for (uint32_t j = 0; j < (uint32_t)LB; j += 16) record(U_POB_LASTLAYER_RANGE, 1, p.cur, j, std::min<uint32_t>(j + 16, LB));
+            for (uint32_t j = 0; j < (uint32_t)LB; j += 4) record(U_POB_LASTLAYER_RANGE, 1, p.cur, j, std::min<uint32_t>(j + 4, LB));
             p.cur = cur_add(p.cur, fp, LB);
             expect_cursor("SelectorArray1D", p.cur, chk.cur);
         }
