@@ -818,11 +818,7 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
                 const bool z = fr_is_zero(dd);
                 if (z) exm |= (B)1 << (i - lo); else run = fr_mul(run, dd);
             }
-#ifdef POB_EXP_NOINV
-            F inv = run;
-#else
             F inv = fr_inv(run);
-#endif
             for (uint32_t i = hi; i-- > lo;) {
                 const bool z = (exm >> (i - lo)) & 1;
                 const F pre = p.get(fref(i, 3));
