@@ -341,7 +341,10 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
     case U_KB_HEAD: {            // a[0] = kb index, a[1..2] = inLen ref
         SmRef len = {d.a[1], d.a[2]};
         KBRefs r = L.kbs[d.a[0]];
-        kb_head(p, r.mb, p.get(len), r);
+        // a[3] = 1 + index of the length among the packed SM inputs: generation then reads the input buffer, so the head can run in
+        // stage 0 beside the input units that write the wire (the evaluator reads the wire)
+        const S inLen = (P::is_gen && d.a[3]) ? p.input_sm(d.a[3] - 1) : p.get(len);
+        kb_head(p, r.mb, inLen, r);
         if (P::is_count) L.kbs[d.a[0]] = r;
     } break;
     case U_KB_RANGE: {           // a[0] = kb index, a[1..2] = src ref, a[3..4] = byte range
@@ -863,7 +866,7 @@ struct Plan {
     // Side tracks: stage ids TRACK_STRIDE*t + s belong to track t.  Track 0 is the main sequence; track t > 0 starts once stage
     // track_fork[t] has completed and must have completed before stage track_join[t] starts.  A track may only be joined by a
     // lower-numbered track (the host enqueues a stage's forked tracks highest first, each one completely).
-    enum { TRACK_STRIDE = 32, MAX_TRACKS = 5 };
+    enum { TRACK_STRIDE = 32, MAX_TRACKS = 6 };
     uint32_t ntracks, track_fork[MAX_TRACKS], track_join[MAX_TRACKS];
     CountP p;
 
@@ -917,10 +920,10 @@ struct Plan {
         unit(U_KB_POST, range_stage + 2, kb);
         if (range_stage + 1 > max_stage) max_stage = range_stage + 1;
     }
-    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst) {
+    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst, uint32_t len_input = 0) {
         L.kbs[kb].mb = mb;
         const Cur start = p.cur;
-        unit(U_KB_HEAD, stage, kb, len.w, len.i);
+        unit(U_KB_HEAD, stage, kb, len.w, len.i, len_input);
         const uint32_t m = 136 * mb;
         for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage + 1, start, kb, src.w, src.i, lo, std::min(lo + 16, m));
         keccak_tail(kb, stage + 1, dst, true);
@@ -964,8 +967,13 @@ struct Plan {
         // track 4 (TN): the five Num2BigEndianBytes of PublicCommitment's inputs, forked once the Poseidons are done (TB + 1), joined
         // before PublicCommitment (main stage 5); it runs on the main track's BN254 stream, which is idle until then.
         const uint32_t TB = TRACK_STRIDE, TR = 2 * TRACK_STRIDE, TC = 3 * TRACK_STRIDE, TN = 4 * TRACK_STRIDE;
-        ntracks = 5; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
+        ntracks = 6; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
         track_fork[4] = TB + 1; track_join[4] = 5;
+        // track 5 (TP): everything of the layers / header that is NOT on the way to their Keccak sponges -- byte asserts, SelectorArray1D,
+        // leaf detectors -- so that the main track is only inputs + KeccakBytes heads (0), byte ranges (1), sponges A (2), rows (3)
+        // and the round expansion starts 0.5 ms earlier; joined before main stage 5.
+        const uint32_t TP = 5 * TRACK_STRIDE;
+        track_fork[5] = 0; track_join[5] = 5;
         PobMain& M = L.pm;
         const int Ln = prm.L, LB = 136 * prm.NB, HBy = 136 * prm.HB;
         p.cur = Cur{1, 0, 0, 0};                      // wire 0 = constant 1
@@ -979,14 +987,15 @@ struct Plan {
         M.substringCheckers = p.bits(Ln - 1); M.layerKeccaks = p.sms(32 * Ln); M.reducedLayerKeccaks = p.sms(31 * Ln); M.isLeaf = p.bits(Ln);
         M.isLastLayerLeaf = p.bits(1); M.leaf = p.sms(139); M.leafLen = p.sms(1);
         nfr_in = 6; nsm_in = 1 + Ln * LB + Ln + 1 + HBy + 2;
+        const uint32_t in0 = M.numLeafAddressNibbles.i;      // SM inputs are contiguous SM ranks from here (U_POB_INPUT)
 
         // stages: 0 inputs | 1 heads, byte asserts, selectors, leaf detectors | 2 KeccakBytes byte ranges, embedded pre parts
         //         | 3 sponges A | 4 output selector rows, posts | 5 consumers | 6 sponge B, ... | 10 final ===
         unit(U_POB_INPUT_FR, 0);
         for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
         unit(U_POB_RANGE, TB + 1);
-        for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, 1, i); abs_units(1, LB, M.layers + i * LB); }
-        unit(U_POB_HDR_ASSERT, 1); abs_units(1, HBy, M.blockHeader);
+        for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, TP + 1, i); abs_units(TP + 1, LB, M.layers + i * LB); }
+        unit(U_POB_HDR_ASSERT, TP + 1); abs_units(TP + 1, HBy, M.blockHeader);
         unit(U_POB_POSEIDONS, TB + 1, 0);
         unit(U_POB_POSEIDONS, TB + 1, 1);
         {   // BurnAddressHash :119
@@ -998,25 +1007,25 @@ struct Plan {
             unit(U_BAH_POST, TB + 5);
         }
         L.kb_hdr = L.nkb++;
-        keccak_bytes(L.kb_hdr, prm.HB, 1, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122
+        keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot, M.blockHeaderLen.i - in0 + 1);       // :122
         for (int j = 0; j < 5; j++) unit(U_POB_N2B, TN + 1, j);                                    // :132-136
         public_commitment(6, 5);                                                                // :137  (pre 5, ranges 6, sponge 7, rows/post 8, commitment 9)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
             CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
             L.ll.out = p.sms(LB); L.ll.arr = p.sms(Ln * LB); L.ll.sel = p.sms(1); L.ll.T = p.sms(LB * Ln);
-            unit(U_POB_LASTLAYER, 1);
+            unit(U_POB_LASTLAYER, TP + 1);
             L.ll.c_sel0 = p.cur;
             const Cur fp = {9u * Ln + 3, 3u * Ln, 6u * Ln + 3, 0};
-            for (uint32_t j = 0; j < (uint32_t)LB; j += 4) record(U_POB_LASTLAYER_RANGE, 1, p.cur, j, std::min<uint32_t>(j + 4, LB));
+            for (uint32_t j = 0; j < (uint32_t)LB; j += 4) record(U_POB_LASTLAYER_RANGE, TP + 1, p.cur, j, std::min<uint32_t>(j + 4, LB));
             p.cur = cur_add(p.cur, fp, LB);
             expect_cursor("SelectorArray1D", p.cur, chk.cur);
         }
-        unit(U_POB_LASTLEN, 1);
+        unit(U_POB_LASTLEN, TP + 1);
         L.kb_layer0 = L.nkb; L.nkb += Ln;
         L.nsc = Ln;
         for (int i = 0; i < Ln; i++) {                                                          // :157-181
-            leaf_detector(i, 1, M.layers + i * LB, M.layerLens + i, M.isLeaf + i);
-            keccak_bytes(L.kb_layer0 + i, prm.NB, 1, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i);
+            leaf_detector(i, TP + 1, M.layers + i * LB, M.layerLens + i, M.isLeaf + i);
+            keccak_bytes(L.kb_layer0 + i, prm.NB, 0, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i, (M.layerLens + i).i - in0 + 1);
             const Cur start = p.cur;
             unit(U_POB_LAYER_POST, 5, i);
             if (i > 0) {
@@ -1032,7 +1041,7 @@ struct Plan {
                 record(U_SC_SUMS, 7, sc.c_tail, i);
             }
         }
-        leaf_detector(Ln, 2, M.lastLayer, M.lastLayerLen, M.isLastLayerLeaf);                    // :187 (lastLayer is written in stage 1)
+        leaf_detector(Ln, TP + 2, M.lastLayer, M.lastLayerLen, M.isLastLayerLeaf);                    // :187 (lastLayer is written in stage 1)
         {   // RlpMerklePatriciaTrieLeaf :198  (needs addressHashNibbles, written in stage TB+5)
             const Cur start = p.cur;
             CountP chk; chk.cur = start; { S ll; gRlpMptLeaf(chk, 32, prm.amountBytes, M.addressHashNibbles, 0, fr_zero(), ll); }
