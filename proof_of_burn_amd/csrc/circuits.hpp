@@ -989,8 +989,8 @@ struct Plan {
         nfr_in = 6; nsm_in = 1 + Ln * LB + Ln + 1 + HBy + 2;
         const uint32_t in0 = M.numLeafAddressNibbles.i;      // SM inputs are contiguous SM ranks from here (U_POB_INPUT)
 
-        // stages: 0 inputs | 1 heads, byte asserts, selectors, leaf detectors | 2 KeccakBytes byte ranges, embedded pre parts
-        //         | 3 sponges A | 4 output selector rows, posts | 5 consumers | 6 sponge B, ... | 10 final ===
+        // main track: 0 inputs + KeccakBytes heads | 1 KeccakBytes byte ranges | 2 sponges A | 3 output selector rows, posts
+        //             | 5 consumers (SubstringCheck, PublicCommitment) | 6 ... | 10 final ===          (side tracks: see above)
         unit(U_POB_INPUT_FR, 0);
         for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
         unit(U_POB_RANGE, TB + 1);
