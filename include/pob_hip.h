@@ -80,12 +80,19 @@ int pob_write_wtns(pob_handle h, uint32_t idx, const char* path);
 
 /* Measurement: average duration (ms, HIP events on `stream`) of `iters` back-to-back launches of one kernel over
  * the current batch.  which: 0 = Keccak round expansion (generate), 1 = Keccak round constraint evaluation,
- * 2 = G-unit constraint evaluation, 3 = sponge chain (generate); 100 + k / 200 + k = evaluation / generation of all
- * units of kind k (circuits.hpp UnitKind) alone on the device (tools/unit_times.py).                             */
+ * 2 = G-unit constraint evaluation (every family, back to back), 3 = sponge chain (generate); 100 + k / 200 + k = evaluation /
+ * generation of all units of kind k (circuits.hpp UnitKind) alone on the device; 300 + f = the evaluation kernel of family f
+ * (circuits.hpp Fam) alone (tools/unit_times.py).                                                                */
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream, float* avg_ms);
 
 /* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
+/* Test hook for the constraint evaluator: corrupt ONE stored value of ONE witness (lane `lane` of group `group`) of storage class
+ * `cls` at storage index `index` (the wire's rank within its class): BIT: flips the bit if xor_mask & 1; SM: int32 ^= xor_mask;
+ * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask; SB: int8 ^= xor_mask.  IsZero.inv wires live in the SM / SB slabs as their
+ * operand code, so poking those indices pokes the hint.                                                                          */
+enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2, POB_CLASS_SB = 3 };
+int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
 
 /* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */
 void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]);

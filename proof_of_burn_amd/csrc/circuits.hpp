@@ -25,8 +25,31 @@ enum UnitKind : uint32_t {
     U_KB_HEAD, U_KB_RANGE, U_KB_SELROW, U_KB_POST, U_POB_N2B, U_PC_PRE, U_PC_POST, U_POB_LASTLAYER, U_POB_LASTLAYER_RANGE,
     U_POB_LASTLEN, U_POB_LEAF, U_POB_LAYER_POST, U_SC_M, U_SC_RANGE, U_SC_SUMS, U_POB_LASTLEAF,
     U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE, U_LD_HEAD, U_LD_SELR, U_LD_TAIL, U_POB_INPUT_FR, U_RL_ACC_B, U_RL_ACC_C,
-    U_SP_INPUT, U_SP_HEAD
+    U_SP_INPUT, U_SP_HEAD,
+    // evaluator-only units (UNIT_CHECK): sub-blocks of composite units run as wavefronts of their own, from STORED wires
+    CK_POS_SEG,          // a0 = T, a1 = segment (>= 1) of the Poseidon block at cur (gadgets.hpp gPoseidonSegStored)
+    CK_N2BE,             // Num2BigEndianBytes(a0) at cur; a1,a2 = source FR wire; a3,a4,a5 = caller's copy of out[] (w, i, present)
+    U_KIND_COUNT
 };
+enum : uint32_t { UNIT_GEN = 1, UNIT_CHECK = 2 };      // UnitDesc.flags: generation + emission / constraint evaluation
+// Kernel FAMILIES: every family is compiled as a kernel of its own (own register allocation -- one kernel over every unit kind
+// spilled ~1.9 k VGPRs in the evaluator); generation merges families into the classes of its stage scheduler.
+enum Fam : uint32_t { F_MISC = 0, F_RANGE, F_SELROW, F_LD, F_RL, F_SC, F_POS, F_N2B, F_COUNT };
+#define FAM_BIT(f) (1u << (f))
+#define FAM_LIGHT (FAM_BIT(F_MISC) | FAM_BIT(F_RANGE) | FAM_BIT(F_SELROW) | FAM_BIT(F_LD) | FAM_BIT(F_RL))
+#define FAM_HEAVY (FAM_BIT(F_POS) | FAM_BIT(F_N2B))
+#define FAM_ALL ((1u << F_COUNT) - 1)
+HD constexpr uint32_t fam_of(uint32_t k) {
+    return (k == U_KB_RANGE || k == U_ABS_RANGE) ? F_RANGE
+         : k == U_KB_SELROW ? F_SELROW
+         : (k == U_LD_HEAD || k == U_LD_SELR || k == U_LD_TAIL || k == U_POB_LASTLAYER_RANGE || k == U_SC_SUMS) ? F_LD
+         : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B) ? F_RL
+         : (k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE) ? F_SC
+         : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG) ? F_POS
+         : (k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_N2B || k == U_PC_POST || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == CK_N2BE) ? F_N2B
+         : F_MISC;
+}
+#define UCASE(K) case K: if constexpr (((MASK) >> fam_of(K)) & 1u)
 
 struct PobParams { int L, NB, HB, minNib, amountBytes, powZero; Fr maxIntended, maxActual; };   // Montgomery
 struct SpendParams { int maxAmountBytes; };
@@ -93,7 +116,7 @@ struct RaRefs {
     Cur c_cb, c_sl, c_lt, c_concat, c_end;
 };
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
-struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; uint32_t cost; };
+struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; uint32_t cost, flags; };
 
 #define MAX_KB 72
 #define MAX_SC 64
@@ -110,6 +133,7 @@ struct CircuitLayout {
     RlRefs rl;
     RaRefs ra;
     uint32_t kb_hdr, kb_layer0, nkb, nsc;
+    Cur fp_n2be32, fp_n2beN;       // footprints of Num2BigEndianBytes(32) / (amountBytes): the evaluator's composite units step over these blocks
     KBRefs kbs[MAX_KB];
     ScRefs scs[MAX_SC];
     LdRefs lds[MAX_SC + 1];
@@ -304,41 +328,39 @@ HD SelBlk sel_blk(Cur c, uint32_t N) {
 HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; }
 
 // ---------------------------------------------------------------------------- unit bodies
-// Units are split in two kernels by register appetite: LIGHT units touch only BIT/SM wires (few VGPRs -> high occupancy,
-// which is what hides the store/load latency of this lane-per-witness code); HEAVY units do BN254 arithmetic.
-HD bool unit_is_heavy(uint32_t k) {
-    return k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_POB_N2B || k == U_PC_POST || k == U_POB_LAYER_POST ||
-           k == U_SC_M || k == U_SC_RANGE || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == U_SP_HEAD;
-}
-HD bool unit_is_sc(uint32_t k) { return k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE; }
-HD bool unit_uses_lds(uint32_t k) { return k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD; }   // Poseidon table staged in LDS
+// ONE switch over every unit kind; a kernel instantiates it with the MASK of the families it serves and the other cases
+// compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
+// this lane-per-witness code); F_SC / F_POS / F_N2B do BN254 arithmetic.
+HD bool unit_is_heavy(uint32_t k) { return fam_of(k) >= F_SC; }
+HD bool unit_uses_lds(uint32_t k) { return k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD; }   // generation: Poseidon table staged in LDS
 
-template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout& L) {
+template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
+
     const PobMain& M = L.pm;
     const PobParams& prm = L.pob;
     const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
     (void)M; (void)LB; (void)HBy;
     p.cur = d.cur;
     switch (d.kind) {
-    case U_POB_INPUT:     // SM main inputs [a0, a1) from the packed batch buffer (declaration order = contiguous SM ranks)
+    UCASE(U_POB_INPUT) {   // SM main inputs [a0, a1) from the packed batch buffer (declaration order = contiguous SM ranks)
         for (uint32_t k = d.a[0]; k < d.a[1]; k++) { SmRef r = {M.numLeafAddressNibbles.w + k, M.numLeafAddressNibbles.i + k}; p.put(r, p.input_sm(k)); }
-        break;
-    case U_POB_LAYER_ASSERT:     // :101 (the AssertByteString of :102 runs as U_ABS_RANGE units)
+    } break;
+    UCASE(U_POB_LAYER_ASSERT) {   // :101 (the AssertByteString of :102 runs as U_ABS_RANGE units)
         gAssertLessThanS(p, 16, p.get(M.layerLens + d.a[0]), (S)(LB * 8));
-        break;
-    case U_POB_HDR_ASSERT:       // :105, stateRoot copy :125-129
+    } break;
+    UCASE(U_POB_HDR_ASSERT) {     // :105, stateRoot copy :125-129
         gAssertLessThanS(p, 16, p.get(M.blockHeaderLen), (S)(HBy * 8));
         for (int i = 0; i < 32; i++) p.put(M.stateRoot + i, p.get(M.blockHeader + 91 + i));
-        break;
-    case U_ABS_RANGE: {          // cur = first AssertBits(8) child; a = own_in (w,i), src (w,i), lo, hi
+    } break;
+    UCASE(U_ABS_RANGE) {          // cur = first AssertBits(8) child; a = own_in (w,i), src (w,i), lo, hi
         SmRef own = {d.a[0], d.a[1]}, src = {d.a[2], d.a[3]};
         abs_range(p, d.cur, own, src, d.a[4], d.a[5]);
     } break;
-    case U_BAH_POST: {           // :82 Bytes2Nibbles(32) + main.addressHashNibbles (:119)
+    UCASE(U_BAH_POST) {           // :82 Bytes2Nibbles(32) + main.addressHashNibbles (:119)
         SmRef nb = gBytes2Nibbles(p, 32, L.bah.hash);
         { copy_n(p, L.bah.nibbles, nb, (int)(64)); copy_n(p, M.addressHashNibbles, nb, (int)(64)); }
     } break;
-    case U_KB_HEAD: {            // a[0] = kb index, a[1..2] = inLen ref
+    UCASE(U_KB_HEAD) {            // a[0] = kb index, a[1..2] = inLen ref
         SmRef len = {d.a[1], d.a[2]};
         KBRefs r = L.kbs[d.a[0]];
         // a[3] = 1 + index of the length among the packed SM inputs: generation then reads the input buffer, so the head can run in
@@ -347,13 +369,13 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         kb_head(p, r.mb, inLen, r);
         if (P::is_count) L.kbs[d.a[0]] = r;
     } break;
-    case U_KB_RANGE: {           // a[0] = kb index, a[1..2] = src ref, a[3..4] = byte range
+    UCASE(U_KB_RANGE) {           // a[0] = kb index, a[1..2] = src ref, a[3..4] = byte range
         SmRef src = {d.a[1], d.a[2]};
         kb_range(p, L.kbs[d.a[0]], src, d.a[3], d.a[4]);
     } break;
-    case U_KB_SELROW: kb_selrow(p, L.kbs[d.a[0]], d.a[1], d.a[2], d.a[3]); break;
-    case U_KB_POST: kb_post(p, L.kbs[d.a[0]]); break;
-    case U_PC_PRE: {             // PublicCommitment(N) public_commitment.circom:18-36 up to the sponge
+    UCASE(U_KB_SELROW) { kb_selrow(p, L.kbs[d.a[0]], d.a[1], d.a[2], d.a[3]); } break;
+    UCASE(U_KB_POST) { kb_post(p, L.kbs[d.a[0]]); } break;
+    UCASE(U_PC_PRE) {             // PublicCommitment(N) public_commitment.circom:18-36 up to the sponge
         const int N = L.pc.N;
         for (int j = 0; j < N; j++) {
             SmRef src;
@@ -370,10 +392,10 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         kb_head(p, L.pc.nb, (S)(32 * N), r);
         if (P::is_count) L.kbs[L.pc.kb] = r;
     } break;
-    case U_POB_LASTLAYER:        // :142-143 SelectorArray1D(L, LB): the select input; selectors run as range units
+    UCASE(U_POB_LASTLAYER) {      // :142-143 SelectorArray1D(L, LB): the select input; selectors run as range units
         p.put(L.ll.sel, p.get(M.numLayers) - 1);
-        break;
-    case U_POB_LASTLAYER_RANGE: {   // selectors [a0, a1) of SelectorArray1D (selector.circom:62-77); Selector(n) footprint {9n+3, 3n, 6n+3, 0}
+    } break;
+    UCASE(U_POB_LASTLAYER_RANGE) {   // selectors [a0, a1) of SelectorArray1D (selector.circom:62-77); Selector(n) footprint {9n+3, 3n, 6n+3, 0}
         const uint32_t n = prm.L, q = LB;
         const Cur fp = {9 * n + 3, 3 * n, 6 * n + 3, 0};
         S select = p.get(M.numLayers) - 1;
@@ -384,17 +406,13 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
             p.put(M.lastLayer + j, v);
         }
     } break;
-    case U_POB_LASTLEN: {        // :146, :150
+    UCASE(U_POB_LASTLEN) {        // :146, :150
         S nl = p.get(M.numLayers);
         p.put(M.lastLayerLen, gSelectorS(p, prm.L, M.layerLens, nl - 1));
         BitRef f = gFilter(p, prm.L, nl);
         copy_n(p, M.layerExists, f, (int)(prm.L));
     } break;
-    case U_POB_LEAF: {           // :159
-        const int i = d.a[0];
-        p.put(M.isLeaf + i, gLeafDetector(p, LB, M.layers + i * LB, p.get(M.layerLens + i)));
-    } break;
-    case U_SC_SUMS: {            // sums[] (:94), doesNotExist, out (:98-99), substringCheckers[i-1] and the constraint of proof_of_burn.circom:179
+    UCASE(U_SC_SUMS) {            // sums[] (:94), doesNotExist, out (:98-99), substringCheckers[i-1] and the constraint of proof_of_burn.circom:179
         const uint32_t i = d.a[0];
         const ScRefs& sc = L.scs[i];
         const uint32_t kk = LB - 31 + 1;
@@ -406,10 +424,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         B out = p.put(M.substringCheckers + (i - 1), p.put(sc.out, ~none));
         p.require(out | ~p.get(M.layerExists + i), FAILCODE(T_POB, 179));
     } break;
-    case U_POB_LASTLEAF:         // :187
-        p.put(M.isLastLayerLeaf, gLeafDetector(p, LB, M.lastLayer, p.get(M.lastLayerLen)));
-        break;
-    case U_LD_HEAD: {            // LeafDetector(N) :247-278 up to keyLen; selector heads (select input, sum[0], range check)
+    UCASE(U_LD_HEAD) {            // LeafDetector(N) :247-278 up to keyLen; selector heads (select input, sum[0], range check)
         LdRefs R = L.lds[d.a[0]];
         const uint32_t N = LB;
         R.isLeaf = p.bits(1); R.layer = p.sms(N); R.ll = p.sms(1);
@@ -442,7 +457,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         p.cur = R.c_end;
         if (P::is_count) L.lds[d.a[0]] = R;
     } break;
-    case U_LD_SELR: {            // entries [a2, a3) of selector a1 of LeafDetector a0; sum[i] = [select < i] * vals[select]
+    UCASE(U_LD_SELR) {            // entries [a2, a3) of selector a1 of LeafDetector a0; sum[i] = [select < i] * vals[select]
         const LdRefs& R = L.lds[d.a[0]];
         const uint32_t N = LB, which = d.a[1], lo = d.a[2], hi = d.a[3];
         const SelBlk sb = sel_blk(R.c_sel[which], N);
@@ -461,7 +476,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
             p.put(dst, p.put(sb.o, acc));
         }
     } break;
-    case U_LD_TAIL: {            // :280-293 the four IsEquals after the selectors, MultiAND(7), isLeaf
+    UCASE(U_LD_TAIL) {            // :280-293 the four IsEquals after the selectors, MultiAND(7), isLeaf
         const LdRefs& R = L.lds[d.a[0]];
         const S kl = p.get(R.keyLen), ll = p.get(R.ll), vwp = p.get(R.valueWrapperPrefix), vwl = p.get(R.valueWrapperLen), vp = p.get(R.valuePrefix), vl = p.get(R.valueLen);
         B m[7];
@@ -473,7 +488,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         p.cur = R.c_mand;
         p.put(R.dst, p.put(R.isLeaf, MultiANDg<P, 7>::run(p, m)));
     } break;
-    case U_RL_A: {               // RlpMerklePatriciaTrieLeaf(32, AB) :102-189, part 1: own inputs, TruncatedAddressHash(32) :50-90 head
+    UCASE(U_RL_A) {               // RlpMerklePatriciaTrieLeaf(32, AB) :102-189, part 1: own inputs, TruncatedAddressHash(32) :50-90 head
                                  // (AssertLessEqThan(7), Divide(7)) and ShiftLeft(64) head (shift.circom:17-24)
         RlRefs R = L.rl;
         const int ab = 32, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
@@ -500,7 +515,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         R.c_mux = p.cur;
         if (P::is_count) { Cur a = L.rl.c_age, b = L.rl.c_acc, c = L.rl.c_concat; L.rl = R; L.rl.c_age = a; L.rl.c_acc = b; L.rl.c_concat = c; }
     } break;
-    case U_RL_SLROW: {           // rows [a0, a1) of ShiftLeft(64) (shift.circom:27-36): out[i] = sum_j in[j]*(i == j - count)
+    UCASE(U_RL_SLROW) {           // rows [a0, a1) of ShiftLeft(64) (shift.circom:27-36): out[i] = sum_j in[j]*(i == j - count)
         const RlRefs& R = L.rl;
         const uint32_t n = 64;
         const S count = (S)n - p.get(M.numLeafAddressNibbles);
@@ -514,7 +529,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
             p.put(R.s_o + i, acc);
         }
     } break;
-    case U_RL_ACC_B: {           // CountBytes(N) (integer.circom:16-49) and ShiftLeft(N) (:85) of RlpInteger
+    UCASE(U_RL_ACC_B) {           // CountBytes(N) (integer.circom:16-49) and ShiftLeft(N) (:85) of RlpInteger
         const RaRefs& A = L.ra;
         const int N = prm.amountBytes;
         p.cur = A.c_cb;
@@ -522,7 +537,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         SmRef r = gShiftLeft(p, N, A.by, N - length);
         copy_n(p, A.be, r, (int)(N));
     } break;
-    case U_RL_ACC_C: {           // RlpInteger outputs (:96-109), RlpEmptyAccount prefixes + Concat(4+N, 66) (empty_account.circom:40-133)
+    UCASE(U_RL_ACC_C) {           // RlpInteger outputs (:96-109), RlpEmptyAccount prefixes + Concat(4+N, 66) (empty_account.circom:40-133)
         const RaRefs& A = L.ra;
         const RlRefs& R = L.rl;
         const int N = prm.amountBytes, maxAcc = 4 + N + 66;
@@ -543,7 +558,7 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         { copy_n(p, A.ea_o, cc, (int)(maxAcc)); copy_n(p, R.acc, cc, (int)(maxAcc)); }
         p.put(R.accLen, p.put(A.ea_ol, clen));
     } break;
-    case U_RL_B: {               // rest of TruncatedAddressHash (:62-90), AssertGreaterEqThan (:151), prefixes (:166-181), Concat (:183-188)
+    UCASE(U_RL_B) {               // rest of TruncatedAddressHash (:62-90), AssertGreaterEqThan (:151), prefixes (:166-181), Concat (:183-188)
         const RlRefs& R = L.rl;
         const int ab = 32, n2 = 64, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
         copy_n(p, R.t_shf, R.s_o, (int)(n2));
@@ -573,14 +588,14 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         { copy_n(p, R.o, c, (int)(maxOut)); copy_n(p, M.leaf, c, (int)(maxOut)); }
         p.put(M.leafLen, p.put(R.ol, cl));
     } break;
-    case U_POW_POST: {           // :73-79
+    UCASE(U_POW_POST) {           // :73-79
         BitRef f = gFilter(p, 32, p.get(L.pw.mzb));
         for (int i = 0; i < 32; i++) {
             B z = p.put(L.pw.sbz + i, p.get(f + i));
             p.require(p.ballot(p.get(L.pw.keccak + i) == 0) | ~z, FAILCODE(T_POW, 79));
         }
     } break;
-    case U_POB_FINAL: {          // :186, :188, :191-193, :203-206
+    UCASE(U_POB_FINAL) {          // :186, :188, :191-193, :203-206
         S cnt = 0;
         for (int i = 0; i < prm.L; i++) cnt += (S)p.bit(p.get(M.isLeaf + i));
         p.require(p.ballot(cnt == 1), FAILCODE(T_POB, 186));
@@ -593,21 +608,11 @@ template <class P> GD void unit_run_light(P& p, const UnitDesc& d, CircuitLayout
         p.require(p.ballot(ok), FAILCODE(T_POB, 204));
         p.require(p.ballot(p.get(M.leafLen) == p.get(M.lastLayerLen)), FAILCODE(T_POB, 206));
     } break;
-    default: break;
-    }
-}
-template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout& L) {
-    const PobMain& M = L.pm;
-    const PobParams& prm = L.pob;
-    const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
-    (void)M; (void)LB; (void)HBy;
-    p.cur = d.cur;
-    switch (d.kind) {
-    case U_POB_INPUT_FR:  // FR main inputs (canonical LE -> Montgomery)
+    UCASE(U_POB_INPUT_FR) {  // FR main inputs (canonical LE -> Montgomery)
         p.put(M.burnKey, p.input_fr(0)); p.put(M.actualBalance, p.input_fr(1)); p.put(M.intendedBalance, p.input_fr(2));
         p.put(M.revealAmount, p.input_fr(3)); p.put(M.burnExtraCommitment, p.input_fr(4)); p.put(M.proofExtraCommitment, p.input_fr(5));
-        break;
-    case U_POB_RANGE: {   // proof_of_burn.circom:84-97
+    } break;
+    UCASE(U_POB_RANGE) {   // proof_of_burn.circom:84-97
         const int AB8 = prm.amountBytes * 8;
         F intended = p.get(M.intendedBalance), actual = p.get(M.actualBalance), reveal = p.get(M.revealAmount);
         gAssertLessEqThanF(p, AB8, intended, prm.maxIntended);
@@ -619,20 +624,20 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         gAssertBitsF(p, AB8, reveal);
         gAssertLessEqThanF(p, AB8, reveal, intended);
     } break;
-    case U_POB_POSEIDONS: {      // :113 (a[0] = 0) remainingCoin = Poseidon3, :116 (a[0] = 1) nullifier = Poseidon2 -- two parallel units
+    UCASE(U_POB_POSEIDONS) {      // :113 (a[0] = 0) remainingCoin = Poseidon3, :116 (a[0] = 1) nullifier = Poseidon2 -- two parallel units
         F bk = p.get(M.burnKey);
         if (d.a[0] == 0) {
             F in3[3] = {L.prefix[2], bk, fr_sub(p.get(M.intendedBalance), p.get(M.revealAmount))};
-            p.put(M.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
+            p.put(M.remainingCoin, gPoseidonU<P, 4>(p, pos_off(4), in3));
         } else {
             F in2[2] = {L.prefix[1], bk};
-            p.put(M.nullifier, gPoseidon<P, 3>(p, pos_off(3), in2));
+            p.put(M.nullifier, gPoseidonU<P, 3>(p, pos_off(3), in2));
         }
     } break;
-    case U_BAH_PRE: {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
+    UCASE(U_BAH_PRE) {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
         F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
         F hc;
-        gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec, &hc);
+        gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec, L.fp_n2be32, &hc);
         // addressBytes, Fit(20, 136) [out[136] | in[20]] and the Keccak block: the 20 bytes again, written per witness (nothing read back)
         SmRef fo = p.sms(136), fi = p.sms(20);
         for (int i = 0; i < 136; i++) {
@@ -644,19 +649,19 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         kb_head(p, 1, (S)20, r);
         if (P::is_count) L.kbs[L.bah.kb] = r;
     } break;
-    case U_POB_N2B: {            // :132-136  Num2BigEndianBytes(32) of nullifier, remainingCoin, revealAmount, burnExtraCommitment, _proofExtraCommitment
+    UCASE(U_POB_N2B) {            // :132-136  Num2BigEndianBytes(32) of nullifier, remainingCoin, revealAmount, burnExtraCommitment, _proofExtraCommitment
         const int j = d.a[0];
         FrRef src = j == 0 ? M.nullifier : j == 1 ? M.remainingCoin : j == 2 ? M.revealAmount : j == 3 ? M.burnExtraCommitment : M.proofExtraCommitment;
         SmRef dst = j == 0 ? M.nullifierBytes : j == 1 ? M.remainingCoinBytes : j == 2 ? M.revealAmountBytes : j == 3 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
         gNum2BigEndianBytesF(p, 32, p.get(src), &dst);
     } break;
-    case U_PC_POST: {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
+    UCASE(U_PC_POST) {            // :40-41 Fit(32,31), BigEndianBytes2Num(31); commitment (proof_of_burn.circom:137 / spend.circom:50)
         SmRef f = gFitS(p, 32, 31, L.pc.hash);
         copy_n(p, L.pc.reduced, f, (int)(31));
         F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
         p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
     } break;
-    case U_RL_ACC: {             // RlpEmptyAccount/RlpInteger, field-element part: Num2BigEndianBytes(N)(balance), LessThan(8N), IsZero, Mux1
+    UCASE(U_RL_ACC) {             // RlpEmptyAccount/RlpInteger, field-element part: Num2BigEndianBytes(N)(balance), LessThan(8N), IsZero, Mux1
                                  // (integer.circom:83,88-90); CountBytes/ShiftLeft and the byte assembly run as light units B and C
         RaRefs A = L.ra;
         const int N = prm.amountBytes;
@@ -666,7 +671,8 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         A.ri_o = p.sms(N + 1); A.ri_ol = p.sms(1); A.ri_i = p.frs(1); A.by = p.sms(N); A.len = p.sms(1); A.be = p.sms(N);
         A.isb = p.bits(1); A.isz = p.bits(1); A.frb = p.sms(1);
         F x = p.put(A.ri_i, bal);
-        SmRef r = gNum2BigEndianBytesF(p, N, x);
+        const SmRef r = {p.cur.w, p.cur.s};                 // Num2BigEndianBytes.out[N] = the block's first wires
+        gNum2BigEndianBytesFU(p, N, A.ri_i, x, L.fp_n2beN);
         S lead = 0; bool still = true;
         for (int j = 0; j < N; j++) { S b = p.put(A.by + j, p.get(r + j)); still = still && b == 0; lead += still; }
         A.c_cb = p.cur;
@@ -681,15 +687,15 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         p.cur = A.c_end;
         if (P::is_count) L.ra = A;
     } break;
-    case U_POW_PRE: {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
+    UCASE(U_POW_PRE) {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
         F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
         p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
-        gNum2BigEndianBytesF(p, 32, bk, &L.pw.keyBytes);
-        gNum2BigEndianBytesF(p, 32, ra, &L.pw.raBytes);
-        gNum2BigEndianBytesF(p, 32, bec, &L.pw.becBytes);
+        gNum2BigEndianBytesFU(p, 32, L.pw.in, bk, L.fp_n2be32, &L.pw.keyBytes);
+        gNum2BigEndianBytesFU(p, 32, L.pw.in + 1, ra, L.fp_n2be32, &L.pw.raBytes);
+        gNum2BigEndianBytesFU(p, 32, L.pw.in + 2, bec, L.fp_n2be32, &L.pw.becBytes);
         SmRef e = p.sms(8);                              // EIP7503 :11-21  [out[8]]
-        const char tag[9] = "EIP-7503";
-        for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)tag[i]));
+        const uint64_t tag = 0x333035372D504945ULL;      // "EIP-7503", first character in the low byte
+        for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)((tag >> (8 * i)) & 0xff)));
         SmRef co = p.sms(104), ci = p.sms(104);          // ConcatFixed4(32,32,32,8) :28-48  [out | a,b,c,d]
         for (int i = 0; i < 104; i++) {
             SmRef s = i < 32 ? L.pw.keyBytes + i : i < 64 ? L.pw.raBytes + (i - 32) : i < 96 ? L.pw.becBytes + (i - 64) : L.pw.eip + (i - 96);
@@ -701,35 +707,23 @@ template <class P> GD void unit_run_heavy(P& p, const UnitDesc& d, CircuitLayout
         kb_head(p, 1, (S)104, kr);
         if (P::is_count) L.kbs[L.pw.kb] = kr;
     } break;
-    case U_SP_INPUT: {
+    UCASE(U_SP_INPUT) {
         p.put(L.sm.burnKey, p.input_fr(0)); p.put(L.sm.balance, p.input_fr(1));
         p.put(L.sm.withdrawnBalance, p.input_fr(2)); p.put(L.sm.extraCommitment, p.input_fr(3));
     } break;
-    case U_SP_HEAD: {            // spend.circom:41-49
+    UCASE(U_SP_HEAD) {            // spend.circom:41-49
         F bk = p.get(L.sm.burnKey), bal = p.get(L.sm.balance), wd = p.get(L.sm.withdrawnBalance), ec = p.get(L.sm.extraCommitment);
         gAssertGreaterEqThanF(p, L.spend.maxAmountBytes * 8, bal, wd);
         F in3[3] = {L.prefix[2], bk, bal};
-        F coin = p.put(L.sm.coin, gPoseidon<P, 4>(p, pos_off(4), in3));
+        F coin = p.put(L.sm.coin, gPoseidonU<P, 4>(p, pos_off(4), in3));
         in3[2] = fr_sub(bal, wd);
-        F rc = p.put(L.sm.remainingCoin, gPoseidon<P, 4>(p, pos_off(4), in3));
-        gNum2BigEndianBytesF(p, 32, coin, &L.sm.coinBytes);
-        gNum2BigEndianBytesF(p, 32, wd, &L.sm.withdrawnBalanceBytes);
-        gNum2BigEndianBytesF(p, 32, rc, &L.sm.remainingCoinBytes);
-        gNum2BigEndianBytesF(p, 32, ec, &L.sm.extraCommitmentBytes);
+        F rc = p.put(L.sm.remainingCoin, gPoseidonU<P, 4>(p, pos_off(4), in3));
+        gNum2BigEndianBytesFU(p, 32, L.sm.coin, coin, L.fp_n2be32, &L.sm.coinBytes);
+        gNum2BigEndianBytesFU(p, 32, L.sm.withdrawnBalance, wd, L.fp_n2be32, &L.sm.withdrawnBalanceBytes);
+        gNum2BigEndianBytesFU(p, 32, L.sm.remainingCoin, rc, L.fp_n2be32, &L.sm.remainingCoinBytes);
+        gNum2BigEndianBytesFU(p, 32, L.sm.extraCommitment, ec, L.fp_n2be32, &L.sm.extraCommitmentBytes);
     } break;
-    default: break;
-    }
-}
-// SubstringCheck's BN254 units get their own kernel: they need ~100 VGPRs, while the Poseidon / Num2Bits_strict units of the
-// general heavy kernel push it to 256 VGPRs (1 wave per SIMD)
-template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L) {
-    const PobMain& M = L.pm;
-    const PobParams& prm = L.pob;
-    const int LB = 136 * prm.NB, HBy = 136 * prm.HB;
-    (void)M; (void)LB; (void)HBy;
-    p.cur = d.cur;
-    switch (d.kind) {
-    case U_POB_LAYER_POST: {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
+    UCASE(U_POB_LAYER_POST) {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
                                  // AssertLessEqThan x2, LittleEndianBytes2Num(sl); AssertByteString(mm) runs as U_ABS_RANGE units
         const int i = d.a[0];
         SmRef f = gFitS(p, 32, 31, M.layerKeccaks + 32 * i);
@@ -758,7 +752,7 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
             if (P::is_count) L.scs[i] = sc;
         }
     } break;
-    case U_SC_M: {               // M[k+1] <== mainInput[k]*256^k + M[k]  (substring_check.circom:45-49) for k in [a1, a2); reads the source
+    UCASE(U_SC_M) {               // M[k+1] <== mainInput[k]*256^k + M[k]  (substring_check.circom:45-49) for k in [a1, a2); reads the source
                                  // bytes; 256^k comes from a table in "double Montgomery" form so that byte * 256^k is ONE Montgomery
                                  // product.  The prefix M[a1] is rebuilt from the bytes below a1, 31 at a time (31 bytes packed into limbs
                                  // are one canonical value: one product per 31 bytes), so the 17 ranges of a layer run side by side.
@@ -790,7 +784,7 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
             acc = p.put(sc.M + k + 1, fr_add(fr_mul(b1, p.k256r(k)), acc));
         }
     } break;
-    case U_SC_RANGE: {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
+    UCASE(U_SC_RANGE) {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
         const ScRefs& sc = L.scs[d.a[0]];
         const uint32_t lo = d.a[1], hi = d.a[2], sl = 31;
         const S mainLen = p.get(sc.ml);
@@ -821,7 +815,7 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
                 const bool z = fr_is_zero(dd);
                 if (z) exm |= (B)1 << (i - lo); else run = fr_mul(run, dd);
             }
-            F inv = fr_inv(run);
+            F inv = fr_inv_inl(run);
             for (uint32_t i = hi; i-- > lo;) {
                 const bool z = (exm >> (i - lo)) & 1;
                 const F pre = p.get(fref(i, 3));
@@ -845,12 +839,23 @@ template <class P> GD void unit_run_sc(P& p, const UnitDesc& d, CircuitLayout& L
             }
         }
     } break;
+    UCASE(CK_POS_SEG) {          // segment a1 of the Poseidon(a0 - 1) block at cur, from the stored state wires before it
+        if constexpr (!(P::is_check || P::is_count)) { (void)d; }
+        else if (d.a[0] == 3) gPoseidonSegStored<P, 3>(p, pos_off(3), d.cur, d.a[1]);
+        else if (d.a[0] == 4) gPoseidonSegStored<P, 4>(p, pos_off(4), d.cur, d.a[1]);
+        else gPoseidonSegStored<P, 5>(p, pos_off(5), d.cur, d.a[1]);
+    } break;
+    UCASE(CK_N2BE) {             // Num2BigEndianBytes(a0) at cur of the stored FR wire (a1, a2), caller's copy of out[] at (a3, a4) if a5
+        if constexpr (P::is_check || P::is_count) {
+            const FrRef src = {d.a[1], d.a[2]}; const SmRef also = {d.a[3], d.a[4]};
+            gNum2BigEndianBytesFv(p, (int)d.a[0], p.get(src), also, d.a[5] != 0);
+        }
+    } break;
     default: break;
     }
 }
-template <class P> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
-    if (unit_is_sc(d.kind)) unit_run_sc(p, d, L); else if (unit_is_heavy(d.kind)) unit_run_heavy(p, d, L); else unit_run_light(p, d, L);
-}
+// (host planner: every family)
+template <class P> GD void unit_run_all(P& p, const UnitDesc& d, CircuitLayout& L) { unit_run<P, FAM_ALL>(p, d, L); }
 
 // ---------------------------------------------------------------------------- host planner
 #include <algorithm>
@@ -877,13 +882,24 @@ struct Plan {
     }
     void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0) {
         UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.cost = 0; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5;
+        d.flags = (kind == CK_POS_SEG || kind == CK_N2BE) ? UNIT_CHECK : (UNIT_GEN | UNIT_CHECK);
         units.push_back(d);
         if (stage > max_stage) max_stage = stage;
     }
     void unit(uint32_t kind, uint32_t stage, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0) {
         record(kind, stage, p.cur, a0, a1, a2, a3, a4);
         const UnitDesc d = units.back();
-        unit_run(p, d, L);                 // CountP: advances p.cur over the unit's wires, fills the reference tables
+        p.nnotes = 0;
+        unit_run_all(p, d, L);             // CountP: advances p.cur over the unit's wires, fills the reference tables
+        // sub-blocks the evaluator runs as wavefronts of their own (they start from stored wires): Poseidon segments 1.., byte conversions
+        for (uint32_t k = 0; k < p.nnotes; k++) {
+            const PlanNote& nt = p.notes[k];
+            if (nt.what == NOTE_POSEIDON) {
+                const uint32_t ns = pos_nseg(pos_off((int)nt.n).rp);
+                for (uint32_t seg = 1; seg < ns; seg++) record(CK_POS_SEG, stage, nt.cur, nt.n, seg);
+            } else if (nt.what == NOTE_N2BE) record(CK_N2BE, stage, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4]);
+        }
+        p.nnotes = 0;
     }
     // AssertByteString(N)(src) as range units; p.cur = start of the AssertByteString block
     void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32) {
@@ -955,11 +971,12 @@ struct Plan {
 
     // cost estimate (wires written, FR wires x8) of every unit, by replaying it on the counting policy
     void estimate_costs() {
-        for (UnitDesc& d : units) { CountP q; const UnitDesc dd = d; unit_run(q, dd, L); d.cost = q.nput * (unit_is_heavy(d.kind) ? 4 : 1); }
+        for (UnitDesc& d : units) { CountP q; const UnitDesc dd = d; unit_run_all(q, dd, L); d.cost = q.nput * (unit_is_heavy(d.kind) ? 4 : 1); }
     }
     void plan_pob(const PobParams& prm) {
         memset(&L, 0, sizeof L);
         L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
+        L.fp_n2be32 = n2be_footprint(32); L.fp_n2beN = n2be_footprint(prm.amountBytes);
         // track 1 (TB): everything that hangs off the main inputs only -- range checks, Poseidons, BurnAddressHash, ProofOfWorkChecker,
         // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before PublicCommitment
         // (main stage 5).  track 2 (TR): the RlpMerklePatriciaTrieLeaf assembly, forked once BurnAddressHash is done (TB + 5) and
@@ -1088,6 +1105,7 @@ struct Plan {
     void plan_spend(const SpendParams& prm) {
         memset(&L, 0, sizeof L);
         L.circuit = 1; L.spend = prm; L.nkb = 0; max_stage = 0; ntracks = 1;
+        L.fp_n2be32 = n2be_footprint(32); L.fp_n2beN = n2be_footprint(prm.maxAmountBytes);
         L.pob = PobParams{1, 1, 1, 0, prm.maxAmountBytes, 0, fr_zero(), fr_zero()};
         SpendMain& M = L.sm;
         p.cur = Cur{1, 0, 0, 0};

@@ -17,6 +17,12 @@
 #endif
 
 struct Fr { uint32_t l[8]; };
+// opaque use of a VGPR value: a point the compiler cannot move the computation of x across (tests/hostsim builds for x86)
+#ifdef POB_HOSTSIM
+#define POB_OPAQUE(x) asm volatile("" : "+r"(x))
+#else
+#define POB_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 
 // p, R = 2^256 mod p (Montgomery 1), R2 = 2^512 mod p, -p^-1 mod 2^32
 #define FR_P_LIMBS   {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}
@@ -188,7 +194,9 @@ HD void fr256_submod(uint32_t* a, const uint32_t* b) {   // a <- a - b mod p
 // 2^(768-k) from a table: (x = a*R)  x^-1 * 2^k * 2^(768-k) * 2^-256 = a^-1 * R.
 #include "fr_pow2_table.h"
 static __device__ const uint32_t FR_POW2_TAB[FR_POW2_TAB_LEN * 8] = FR_POW2_TAB_INIT;
-HDN Fr fr_inv(Fr a) {
+// fr_inv_inl: inlined into its (few) generation call sites -- as a called function it needs more VGPRs than the caller-saved set
+// and saves callee-saved ones on the stack, which is the only scratch those kernels would have; fr_inv: the called form.
+HD Fr fr_inv_inl(Fr a) {
     const uint32_t P[8] = FR_P_LIMBS;
     uint32_t u[8], v[8], r[8], s[8];
 #pragma unroll
@@ -268,6 +276,20 @@ HDN Fr fr_inv(Fr a) {
     Fr y = fr_mul(res, c);
     return fr_is_zero(a) ? fr_zero() : y;
 }
+HDN Fr fr_inv(Fr a) { return fr_inv_inl(a); }
+// a^(p-2) by square-and-multiply over fr_mul calls only (no stack): the emitter's rare path (IsZero operands beyond the table)
+HD Fr fr_inv_fermat(const Fr& a) {
+    const uint32_t E[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};   // p - 2
+    Fr r = fr_one_mont();
+    for (int i = 253; i >= 0; i--) {
+        r = fr_mul(r, r);
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if ((i >> 5) == j) w = E[j];
+        if ((w >> (i & 31)) & 1) r = fr_mul(r, a);
+    }
+    return r;
+}
 #else
 HDN Fr fr_inv(Fr a) {
     const uint32_t P[8] = FR_P_LIMBS;
@@ -309,5 +331,7 @@ HDN Fr fr_inv(Fr a) {
     for (int i = 0; i < 8; i++) y.l[i] = C[i];
     return fr_mul(y, r3);          // x = 0: the loop never runs, C = 0 -> 0
 }
+HD Fr fr_inv_inl(const Fr& a) { return fr_inv(a); }
+HD Fr fr_inv_fermat(const Fr& a) { return fr_inv(a); }
 #endif
 HD uint32_t fr_bit(const Fr& canon, int i) { return (canon.l[i >> 5] >> (i & 31)) & 1; }

@@ -1,4 +1,2 @@
 #include "g_units.hpp"
-void launch_g_check_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    hipLaunchKernelGGL((g_units<CheckP, 2>), dim3(nunits, ngroups), dim3(64), A.stage_lds ? sizeof(POS_TABLE_MONT) : 0, st, A);
-}
+POB_DEFINE_G_LAUNCH(launch_g_check_sc, CheckP, FAM_BIT(F_SC), 4, false)

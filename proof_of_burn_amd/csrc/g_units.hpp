@@ -1,18 +1,14 @@
-// The G-unit kernel: one wavefront = one unit (circuits.hpp) for one group of 64 witnesses, lane = witness.
+// The G-unit kernels: one wavefront = one unit (circuits.hpp) for one group of 64 witnesses, lane = witness.
 #pragma once
 #include "kernels_common.hpp"
 
 extern __shared__ uint32_t g_lds[];
 
-#ifndef POB_HEAVY_WAVES
-#define POB_HEAVY_WAVES 1      // waves per SIMD the BN254 kernels are compiled for (VGPR budget 512 / POB_HEAVY_WAVES)
-#endif
-
-// CLS: 0 = light units (BIT/SM only), 1 = BN254 units (Poseidon, Num2Bits_strict, ...), 2 = SubstringCheck's BN254 units,
-//      3 = the BN254 units again at <= 128 VGPRs (generation, launches without a Poseidon unit)
-template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 : CLS >= 2 ? 4 : POB_HEAVY_WAVES) g_units(GArgs A) {
+// MASK = families (circuits.hpp Fam) this kernel serves; WAVES = waves per SIMD it is compiled for (VGPR budget 512 / WAVES);
+// LDS = may stage the Poseidon table in LDS (generation's Poseidon kernel)
+template <class P, uint32_t MASK, int WAVES, bool LDS> __global__ void __launch_bounds__(64, WAVES) g_units(GArgs A) {
     // the few long BN254 chains share their SIMDs with thousands of short light / Keccak waves: let the arbiter favour them
-    if constexpr (CLS != 0) __builtin_amdgcn_s_setprio(3);
+    if constexpr ((MASK & ~FAM_LIGHT) != 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
     const uint32_t g = P::is_emit ? A.emit_group : blockIdx.y;
     P p;
@@ -32,21 +28,23 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
         p.m.rs_fr = __builtin_amdgcn_make_buffer_rsrc(p.m.fr, 0, (int)(nf > 0xFFFFFFFFull ? 0xFFFFFFFFull : nf), 0x00020000);
         p.m.rs_sb = __builtin_amdgcn_make_buffer_rsrc(sbp, 0, (int)(A.sb_stride > 0xFFFFFFFFull ? 0xFFFFFFFFull : A.sb_stride), 0x00020000);
     }
-    if (CLS == 1 && A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
-        for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];
-        __syncthreads();
-        p.m.pos_tab = g_lds;
-    } else p.m.pos_tab = A.pos_tab;
+    p.m.pos_tab = A.pos_tab;
+    if constexpr (LDS) {
+        if (A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
+            for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];
+            __syncthreads();
+            p.m.pos_tab = g_lds;
+        }
+    }
     if constexpr (P::is_gen) p.status = 0;
-    if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false;
-                                 p.pend_bs = p.pend_bv = 0; p.pend_ss = p.pend_sv = 0; p.pend_fs = p.pend_fv = fr_zero(); p.pend_bw = p.pend_sw = p.pend_fw = 0xFFFFFFFFu; }
+    if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; }
     for (int pass = 0;; pass++) {
         const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
-        if constexpr (CLS == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
-        if constexpr (CLS == 1 || CLS == 3) unit_run_heavy<P>(p, d, *A.L); else if constexpr (CLS == 2) unit_run_sc<P>(p, d, *A.L); else unit_run_light<P>(p, d, *A.L);
+        if constexpr ((MASK & ~FAM_LIGHT) == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
+        unit_run<P, MASK>(p, d, *A.L);
         if constexpr (P::is_check) {      // a lane-distributed run differed: replay the unit attributing wire by wire
-            p.run_flush(); p.put_flush();
+            p.run_flush();
             if (pass == 0 && __ballot(p.rdiff != 0)) { p.attribute = true; continue; }
         }
         break;
@@ -57,3 +55,8 @@ template <class P, int CLS> __global__ void __launch_bounds__(64, CLS == 0 ? 8 :
         if (p.bad_wire != 0xFFFFFFFFu) atomicMin(&A.bad_wire[g * 64 + lane], p.bad_wire);
     }
 }
+// one launcher per kernel (each in its own translation unit, compiled in parallel)
+#define POB_DEFINE_G_LAUNCH(name, POL, MASK, WAVES, LDS)                                                                       \
+    void name(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st) {                                             \
+        hipLaunchKernelGGL((g_units<POL, (MASK), WAVES, LDS>), dim3(nunits, ngroups), dim3(64), (LDS && A.stage_lds) ? sizeof(POS_TABLE_MONT) : 0, st, A); \
+    }

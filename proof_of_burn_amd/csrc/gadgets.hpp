@@ -10,6 +10,7 @@
 //     `[out | in | mid] || children` and the reference file:line.
 //   * `<==`  -> p.put(ref, expr)   `<--` -> p.hint(ref, value)   `===`/assert -> p.require(mask, code)
 #pragma once
+#include <type_traits>
 #include "policy.hpp"
 
 #ifdef __HIPCC__
@@ -99,7 +100,7 @@ template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) 
     BitRef o = p.bits(1); FrRef i = p.frs(1); FrRef v = p.frs(1);
     F x = p.put(i, in);
     F iv;
-    if (P::is_gen && !inv_is_stored) iv = p.hint(v, fr_inv(x));
+    if (P::is_gen && !inv_is_stored) iv = p.hint(v, fr_inv_inl(x));
     else if (P::is_gen) iv = p.get(v);                    // pre-computed by a batched inversion
     else iv = p.hint(v, x);
     F t = fr_mul(x, iv);                                  // in*inv (Montgomery)
@@ -131,7 +132,9 @@ template <class P> GD B gLessThanS(P& p, int n, S a, S b) {
 template <class P> GD B gLessThanF(P& p, int n, const F& a, const F& b) {
     BitRef o = p.bits(1); FrRef in = p.frs(2);
     F x = p.put(in, a), y = p.put(in + 1, b);
-    Fr e = fr_zero(); e.l[n >> 5] = 1u << (n & 31);       // 2^n canonical (n <= 252)
+    Fr e;                                                 // 2^n canonical (n <= 252); no dynamically indexed store: that would put e in scratch
+#pragma unroll
+    for (int j = 0; j < 8; j++) e.l[j] = (n >> 5) == j ? 1u << (n & 31) : 0u;
     F c;
     gNum2BitsF(p, n + 1, fr_sub(fr_add(x, fr_to_mont(e)), y), nullptr, &c);
     return p.put(o, ~p.ballot(canon_bit(c, n)));
@@ -254,101 +257,155 @@ template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in, BV* vout = nullp
 
 // ============================================================================ circomlib: poseidon.circom (optimised schedule)
 // table offsets: tools/gen_poseidon.py -> poseidon_consts.h (C | S | M | P per t, Montgomery)
+// Poseidon(T-1) [out | inputs[T-1]] || PoseidonEx [out[1] | inputs[T-1], initialState] || ark0; 3x{T Sigma, ark, mix(M)};
+// T Sigma, ark4, mix(P); RP x {sigmaP, mixS}; 3x{T Sigma, ark, mix(M)}; T Sigma; mixLast [out | in[T]]
+// Every wire is an FR wire, so the block is cut into SEGMENTS at closed-form offsets: head (own + PoseidonEx inputs + ark0),
+// 4 + 3 full rounds, the partial rounds in chunks of POS_PCH, and the tail (last S-boxes, mixLast, outputs).  The generator runs
+// the segments in sequence with the state in registers; the evaluator runs EACH segment as its own wavefront from the STORED
+// output wires of the block before it (every relation of a round is local given stored wires).
 struct PosOff { uint32_t C, S, M, Pm; int rp; };
-template <class P> HD F gSigma(P& p, const F& in) {   // [out | in | in2, in4]
+#define POS_PCH 4                                                   // partial rounds per evaluator segment
+HD uint32_t pos_nchunks(int rp) { return (uint32_t)(rp + POS_PCH - 1) / POS_PCH; }
+HD uint32_t pos_nseg(int rp) { return 1 + 4 + pos_nchunks(rp) + 3 + 1; }
+HD uint32_t pos_wires(int T, int rp) { return (4 * T + 1) + 7 * 8 * T + (uint32_t)rp * (4 + 2 * T) + (5 * T + 1); }
+// FR-wire offset of segment `seg` inside the Poseidon block
+HD uint32_t pos_seg_off(int T, int rp, uint32_t seg) {
+    const uint32_t nch = pos_nchunks(rp), head = 4 * T + 1, full = 8 * T, part = 4 + 2 * T;
+    if (seg == 0) return 0;
+    if (seg <= 5) return head + (seg - 1) * full;                                   // seg 5 = first partial chunk
+    if (seg < 5 + nch) return head + 4 * full + (seg - 5) * POS_PCH * part;
+    return head + 4 * full + (uint32_t)rp * part + (seg - 5 - nch) * full;             // second-half full rounds, then the tail
+}
+// A state element is a VALUE for generation / counting / emission.  The evaluator never holds the state in registers: there a state
+// element is a STORED WIRE (+ an optional round constant still to be added) that is loaded where a relation uses it, so a segment
+// needs a dozen live VGPRs besides the Montgomery multiplier's own (holding T elements across the multiplier calls spilled).
+struct PosLazy { FrRef r; uint32_t c; };                 // stored[r] + (c != ~0u ? kconst(c) : 0)
+template <class P> struct PosSt { typedef typename std::conditional<P::is_check, PosLazy, F>::type type; };
+template <class P> HD F pv_get(P&, const F& v) { return v; }
+template <class P> HD F pv_get(P& p, const PosLazy& v) { const F x = p.get(v.r); return v.c != 0xFFFFFFFFu ? fr_add(x, p.kconst(v.c)) : x; }
+template <class P> HD typename PosSt<P>::type pv_at(P&, FrRef r, const F& val) {      // the wire r, whose value is val
+    if constexpr (P::is_check) { (void)val; return PosLazy{r, 0xFFFFFFFFu}; } else { (void)r; return val; }
+}
+template <class P> HD typename PosSt<P>::type pv_addc(P& p, const typename PosSt<P>::type& v, uint32_t cidx) {
+    if constexpr (P::is_check) { (void)p; return PosLazy{v.r, cidx}; } else return fr_add(v, p.kconst(cidx));
+}
+template <class P> HD typename PosSt<P>::type gSigma(P& p, const typename PosSt<P>::type& in) {   // [out | in | in2, in4]
     FrRef o = p.frs(1), i = p.frs(1), m = p.frs(2);
-    const FrRef rr[4] = {i, m, m + 1, o};
-    const FrLoaded<4> h = fr_load(p, rr);
-    const F x2 = fr_sqr(in), x4 = fr_sqr(x2), out = fr_mul(x4, in);
-    const F vv[4] = {in, x2, x4, out};
-    fr_commit(p, rr, h, vv);
-    return out;
+    const F x = p.put(i, pv_get(p, in));
+    const F x2 = p.put(m, fr_sqr(x));
+    const F x4 = p.put(m + 1, fr_sqr(x2));
+    return pv_at(p, o, p.put(o, fr_mul(x4, x)));
 }
-template <class P, int T> GD void gArk(P& p, const PosOff& k, int r, F* st) {   // [out[t] | in[t]]
+template <class P, int T> GD void gArk(P& p, const PosOff& k, int r, typename PosSt<P>::type* st) {   // [out[t] | in[t]]
     FrRef o = p.frs(T), i = p.frs(T);
-    FrRef rr[2 * T]; F vv[2 * T];
 #pragma unroll
-    for (int j = 0; j < T; j++) { rr[j] = i + j; rr[T + j] = o + j; }
-    const FrLoaded<2 * T> h = fr_load(p, rr);
-#pragma unroll
-    for (int j = 0; j < T; j++) { vv[j] = st[j]; st[j] = vv[T + j] = fr_add(st[j], p.kconst(k.C + r + j)); }
-    fr_commit(p, rr, h, vv);
+    for (int j = 0; j < T; j++) {
+        const F x = p.put(i + j, pv_get(p, st[j]));
+        st[j] = pv_at(p, o + j, p.put(o + j, fr_add(x, p.kconst(k.C + r + j))));
+    }
 }
-template <class P, int T> GD void gMix(P& p, uint32_t mat, F* st) {             // out[i] = sum_j A[i][j] in[j]
+template <class P, int T> GD void gMix(P& p, uint32_t mat, typename PosSt<P>::type* st) {             // out[i] = sum_j A[i][j] in[j]
     FrRef o = p.frs(T), i = p.frs(T);
-    FrRef rr[2 * T]; F vv[2 * T];
+    typename PosSt<P>::type in[T];
 #pragma unroll
-    for (int j = 0; j < T; j++) { rr[j] = i + j; rr[T + j] = o + j; vv[j] = st[j]; }
-    const FrLoaded<2 * T> h = fr_load(p, rr);
+    for (int j = 0; j < T; j++) in[j] = pv_at(p, i + j, p.put(i + j, pv_get(p, st[j])));
 #pragma unroll
     for (int a = 0; a < T; a++) {
         F acc = fr_zero();
 #pragma unroll
-        for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(mat + a * T + j), vv[j]));
-        vv[T + a] = acc;
+        for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(mat + a * T + j), pv_get(p, in[j])));
+        st[a] = pv_at(p, o + a, p.put(o + a, acc));
     }
-#pragma unroll
-    for (int a = 0; a < T; a++) st[a] = vv[T + a];
-    fr_commit(p, rr, h, vv);
 }
-template <class P, int T> GD void gMixS(P& p, const PosOff& k, int r, F* st) {
+template <class P, int T> GD void gMixS(P& p, const PosOff& k, int r, typename PosSt<P>::type* st) {
     FrRef o = p.frs(T), i = p.frs(T);
-    FrRef rr[2 * T]; F vv[2 * T];
+    typename PosSt<P>::type in[T];
 #pragma unroll
-    for (int j = 0; j < T; j++) { rr[j] = i + j; rr[T + j] = o + j; vv[j] = st[j]; }
-    const FrLoaded<2 * T> h = fr_load(p, rr);
-    uint32_t base = k.S + (2 * T - 1) * r;
+    for (int j = 0; j < T; j++) in[j] = pv_at(p, i + j, p.put(i + j, pv_get(p, st[j])));
+    const uint32_t base = k.S + (2 * T - 1) * r;
     F acc = fr_zero();
 #pragma unroll
-    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(base + j), vv[j]));
-    vv[T] = acc;
+    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(base + j), pv_get(p, in[j])));
+    st[0] = pv_at(p, o, p.put(o, acc));
 #pragma unroll
-    for (int j = 1; j < T; j++) vv[T + j] = fr_add(vv[j], fr_mul(vv[0], p.kconst(base + T + j - 1)));
-#pragma unroll
-    for (int j = 0; j < T; j++) st[j] = vv[T + j];
-    fr_commit(p, rr, h, vv);
+    for (int j = 1; j < T; j++) st[j] = pv_at(p, o + j, p.put(o + j, fr_add(pv_get(p, in[j]), fr_mul(pv_get(p, in[0]), p.kconst(base + T + j - 1)))));
 }
-// Poseidon(T-1) [out | inputs[T-1]] || PoseidonEx [out[1] | inputs[T-1], initialState] || ark0; 3x{T Sigma, ark, mix(M)};
-// T Sigma, ark4, mix(P); RP x {sigmaP, mixS}; 3x{T Sigma, ark, mix(M)}; T Sigma; mixLast [out | in[T]]
-template <class P, int T> GD F gPoseidon(P& p, const PosOff& k, const F* inputs) {
-    FrRef o = p.frs(1), in = p.frs(T - 1);
-    F st[T];
-    st[0] = fr_zero();
+// one full round: T Sigma, ark (constants at C + cr), mix with matrix `mat`
+template <class P, int T> GD void gPosFull(P& p, const PosOff& k, int cr, uint32_t mat, typename PosSt<P>::type* st) {
 #pragma unroll
-    for (int j = 1; j < T; j++) st[j] = p.put(in + (j - 1), inputs[j - 1]);
-    FrRef eo = p.frs(1), ein = p.frs(T - 1), einit = p.frs(1);
+    for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
+    gArk<P, T>(p, k, cr, st);
+    gMix<P, T>(p, mat, st);
+}
+template <class P, int T> GD void gPosPartial(P& p, const PosOff& k, int r, typename PosSt<P>::type* st) {
+    st[0] = pv_addc(p, gSigma(p, st[0]), k.C + 5 * T + r);
+    gMixS<P, T>(p, k, r, st);
+}
+// segment `seg` of the Poseidon block at `base` (p.cur must stand at the segment's first wire); st = the state entering it
+// (seg 0: st[1..T-1] = the caller's inputs, as values)
+template <class P, int T> GD void gPoseidonSeg0(P& p, const PosOff& k, const F* inputs, typename PosSt<P>::type* st) {
+    FrRef in = p.frs(T - 1);                                       // (own `out`: declared by the caller, written / checked by the tail)
+    p.frs(1);                                                      // PoseidonEx.out
+    FrRef ein = p.frs(T - 1), einit = p.frs(1);
 #pragma unroll
-    for (int j = 1; j < T; j++) st[j] = p.put(ein + (j - 1), st[j]);
-    st[0] = p.put(einit, st[0]);
+    for (int j = 1; j < T; j++) { const F x = p.put(in + (j - 1), inputs[j - 1]); st[j] = pv_at(p, ein + (j - 1), p.put(ein + (j - 1), x)); }
+    st[0] = pv_at(p, einit, p.put(einit, fr_zero()));
     gArk<P, T>(p, k, 0, st);
-    for (int r = 0; r < 3; r++) {
+}
+template <class P, int T> GD void gPoseidonSeg(P& p, const PosOff& k, Cur base, uint32_t seg, typename PosSt<P>::type* st) {
+    const uint32_t nch = pos_nchunks(k.rp);
+    if (seg <= 3) gPosFull<P, T>(p, k, (int)seg * T, k.M, st);
+    else if (seg == 4) gPosFull<P, T>(p, k, 4 * T, k.Pm, st);
+    else if (seg < 5 + nch) {
+        const int r0 = (int)(seg - 5) * POS_PCH, r1 = r0 + POS_PCH < k.rp ? r0 + POS_PCH : k.rp;
+        for (int r = r0; r < r1; r++) gPosPartial<P, T>(p, k, r, st);
+    } else if (seg < 5 + nch + 3) gPosFull<P, T>(p, k, 5 * T + k.rp + (int)(seg - 5 - nch) * T, k.M, st);
+    else {
 #pragma unroll
         for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
-        gArk<P, T>(p, k, (r + 1) * T, st);
-        gMix<P, T>(p, k.M, st);
+        FrRef lo = p.frs(1), li = p.frs(T);
+        F acc = fr_zero();
+#pragma unroll
+        for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(k.M + j), p.put(li + j, pv_get(p, st[j]))));
+        const F h = p.put(lo, acc);
+        const FrRef o = {base.w, base.f}, eo = {base.w + (uint32_t)T, base.f + (uint32_t)T};
+        st[0] = pv_at(p, o, p.put(o, p.put(eo, h)));
     }
+}
+template <class P, int T> GD F gPoseidon(P& p, const PosOff& k, const F* inputs) {
+    const Cur base = p.cur;
+    const FrRef o = p.frs(1);                                      // out
+    typename PosSt<P>::type st[T];
+    gPoseidonSeg0<P, T>(p, k, inputs, st);
+    const uint32_t ns = pos_nseg(k.rp);
+    for (uint32_t seg = 1; seg < ns; seg++) gPoseidonSeg<P, T>(p, k, base, seg, st);
+    (void)o;
+    return pv_get(p, st[0]);
+}
+// the evaluator's segment unit: the state entering segment seg >= 1 is the stored out[T] of the block before it
+// (ark0 / mix / mixS, all [out[T] | in[T]]: the T wires at cursor - 2T)
+template <class P, int T> GD void gPoseidonSegStored(P& p, const PosOff& k, Cur base, uint32_t seg) {
+    const uint32_t off = pos_seg_off(T, k.rp, seg);
+    p.cur = Cur{base.w + off, base.b, base.s, base.f + off, base.q};
+    typename PosSt<P>::type st[T];
 #pragma unroll
-    for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
-    gArk<P, T>(p, k, 4 * T, st);
-    gMix<P, T>(p, k.Pm, st);
-    for (int r = 0; r < k.rp; r++) {
-        st[0] = fr_add(gSigma(p, st[0]), p.kconst(k.C + 5 * T + r));
-        gMixS<P, T>(p, k, r, st);
-    }
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
-        gArk<P, T>(p, k, 5 * T + k.rp + r * T, st);
-        gMix<P, T>(p, k.M, st);
-    }
-#pragma unroll
-    for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
-    FrRef lo = p.frs(1), li = p.frs(T);
-    F acc = fr_zero();
-#pragma unroll
-    for (int j = 0; j < T; j++) acc = fr_add(acc, fr_mul(p.kconst(k.M + j), p.put(li + j, st[j])));
-    F h = p.put(lo, acc);
-    return p.put(o, p.put(eo, h));
+    for (int j = 0; j < T; j++) { const FrRef r = {p.cur.w - 2 * T + j, p.cur.f - 2 * T + j}; st[j] = pv_at(p, r, p.get(r)); }
+    gPoseidonSeg<P, T>(p, k, base, seg, st);
+}
+
+// Poseidon as a composite unit sees it: generation / counting / emission run the whole block; the evaluator checks the head
+// (the inputs) here, leaves segments 1.. to CK_POS_SEG units and continues from the block's STORED output wire.
+template <class P, int T> GD F gPoseidonU(P& p, const PosOff& k, const F* inputs) {
+    if constexpr (P::is_count) p.note(NOTE_POSEIDON, (uint32_t)T, p.cur);
+    if constexpr (P::is_check) {
+        const Cur base = p.cur;
+        p.frs(1);
+        typename PosSt<P>::type st[T];
+        gPoseidonSeg0<P, T>(p, k, inputs, st);
+        const uint32_t n = pos_wires(T, k.rp);
+        p.cur = Cur{base.w + n, base.b, base.s, base.f + n, base.q};
+        return p.get(FrRef{base.w, base.f});
+    } else return gPoseidon<P, T>(p, k, inputs);
 }
 
 // ============================================================================ circuits/utils/assert.circom
@@ -687,7 +744,9 @@ template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in, F*
 }
 // Num2BigEndianBytes(N) :90-96  [out[N] | in | littleEndian[N]] || Num2LittleEndianBytes(N), Reverse(N) [out[N] | in[N]]
 // `also`: a caller's copy of out[] (written from the same per-witness bytes, not read back)
-template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const SmRef* also = nullptr, F* cout = nullptr) {
+// (the caller's copy travels by value + flag: a pointer to a local SmRef chosen at run time put the SmRef in scratch)
+template <class P> GD SmRef gNum2BigEndianBytesFv(P& p, int N, const F& in, SmRef also_ref, bool has_also, F* cout = nullptr) {
+    const SmRef* also = has_also ? &also_ref : nullptr;
     SmRef o = p.sms(N); FrRef i = p.frs(1); SmRef le = p.sms(N);
     F x = p.put(i, in);
     F c;
@@ -696,9 +755,24 @@ template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const
     for (int j = 0; j < N; j++) p.put(le + j, canon_byte(c, j));
     ro = p.sms(N); ri = p.sms(N);
     for (int j = 0; j < N; j++) { const S by = canon_byte(c, j); p.put(ri + j, by); p.put(ro + (N - 1 - j), by); }
-    for (int j = 0; j < N; j++) { const S by = canon_byte(c, N - 1 - j); p.put(o + j, by); if (also) p.put(*also + j, by); }
+    for (int j = 0; j < N; j++) { const S by = canon_byte(c, N - 1 - j); p.put(o + j, by); if (has_also) p.put(also_ref + j, by); }
     if (cout) *cout = c;
+    (void)also;
     return o;
+}
+template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const SmRef* also = nullptr, F* cout = nullptr) {
+    return gNum2BigEndianBytesFv(p, N, in, also ? *also : SmRef{0, 0}, also != nullptr, cout);
+}
+// footprint of Num2BigEndianBytes(N) (every wire count is a function of N only)
+HD Cur n2be_footprint(int N) { CountP q; q.cur = Cur{0, 0, 0, 0, 0}; gNum2BigEndianBytesF(q, N, fr_zero()); return q.cur; }
+// Num2BigEndianBytes as a composite unit sees it: `src` = the caller's stored wire that feeds it.  The evaluator runs the block
+// as a CK_N2BE unit of its own (from the stored `src`) and the composite only steps over it; *cout = canonical value of x.
+template <class P> GD void gNum2BigEndianBytesFU(P& p, int N, FrRef src, const F& x, Cur fp, const SmRef* also = nullptr, F* cout = nullptr) {
+    if constexpr (P::is_count) p.note(NOTE_N2BE, (uint32_t)N, p.cur, src.w, src.i, also ? also->w : 0u, also ? also->i : 0u, also ? 1u : 0u);
+    if constexpr (P::is_check) {
+        p.cur = cur_add(p.cur, fp, 1);
+        if (cout) *cout = fr_from_mont(x);
+    } else gNum2BigEndianBytesF(p, N, x, also, cout);
 }
 // Bytes2Nibbles(N) :103-121  [out[2N] | in[N] | inDecomposed[N][8]] || Num2Bits(8) x N
 template <class P> GD SmRef gBytes2Nibbles(P& p, int N, SmRef src) {
@@ -948,12 +1022,12 @@ template <class P> GD B gLeafDetector(P& p, int N, SmRef src, S layerLen) {
 
 // ============================================================================ circuits/utils/burn_address.circom:47-58
 // BurnAddress  [addressBytes[20] | burnKey, revealAmount, burnExtraCommitment | hash, hashBytes[32]] || Poseidon(4), Num2BigEndianBytes(32), Fit(32,20)
-template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec, F* hash_canon = nullptr) {
+template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec, Cur fp_n2be32, F* hash_canon = nullptr) {
     SmRef o = p.sms(20); FrRef in = p.frs(3), h = p.frs(1); SmRef hb = p.sms(32);
     F pin[4]; pin[0] = prefix0; pin[1] = p.put(in, bk); pin[2] = p.put(in + 1, ra); pin[3] = p.put(in + 2, bec);
-    F hash = p.put(h, gPoseidon<P, 5>(p, k5, pin));
+    F hash = p.put(h, gPoseidonU<P, 5>(p, k5, pin));
     F c;
-    gNum2BigEndianBytesF(p, 32, hash, &hb, &c);          // hashBytes[i] = big-endian byte i = little-endian byte 31 - i, written per witness
+    gNum2BigEndianBytesFU(p, 32, h, hash, fp_n2be32, &hb, &c);   // hashBytes[i] = big-endian byte i = little-endian byte 31 - i, written per witness
     SmRef fo = p.sms(20), fi = p.sms(32);                // Fit(32, 20)  [out[20] | in[32]]
     for (int i = 0; i < 32; i++) { const S by = canon_byte(c, 31 - i); p.put(fi + i, by); if (i < 20) { p.put(fo + i, by); p.put(o + i, by); } }
     if (hash_canon) *hash_canon = c;

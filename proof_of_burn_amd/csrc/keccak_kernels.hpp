@@ -43,7 +43,7 @@ struct CheckIO {
     __device__ __forceinline__ void arr(uint32_t off, u64 v) { bad |= base[off + lane] ^ v; }
     __device__ __forceinline__ void gate(uint32_t off, u64 o, u64 a, u64 b) {
         const u64* q = base + off + 3 * lane; bad |= (q[0] ^ o) | (q[1] ^ a) | (q[2] ^ b);
-        asm volatile("" : "+v"(bad));        // opaque point: stops LLVM from reassociating one 4800-term OR tree (compile time)
+        POB_OPAQUE(bad);                     // opaque point: stops LLVM from reassociating one 4800-term OR tree (compile time)
     }
 };
 

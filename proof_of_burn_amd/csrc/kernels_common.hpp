@@ -30,18 +30,24 @@ struct KArgs {
     uint32_t first, count;
 };
 
-// grid = (nunits, ngroups) wavefronts; lds = bytes of dynamic LDS (Poseidon table) or 0
-// cls: 0 light, 1 BN254 (optionally with the Poseidon table in LDS), 2 SubstringCheck BN254
-void launch_g_gen(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_check(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_emit(const GArgs& A, int cls, uint32_t nunits, hipStream_t st);
-void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_check_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+// grid = (nunits, ngroups) wavefronts.  Generation: one kernel per scheduling class (light | SubstringCheck BN254 | Poseidon with the
+// table in LDS, serving every BN254 family | the non-Poseidon BN254 units at <= 128 VGPRs); constraint evaluation: one kernel per
+// family (circuits.hpp Fam); emission: light | BN254 | SubstringCheck.
 void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_gen_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_gen_heavy_small(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_check_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_check_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_gen_pos(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_gen_n2b(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_misc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_range(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_selrow(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_ld(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_rl(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_pos(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_n2b(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);

@@ -33,6 +33,8 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
     status[w] = s == 0xFFFFFFFFu ? 0 : s;
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
+__global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
+__global__ void k_xor_u8(uint8_t* p, uint8_t mask) { *p ^= mask; }
 
 // ---- proof-of-work search (input producer, reference tests/main.py:47-56): thread t hashes key = start + t
 __device__ __forceinline__ uint64_t pow_rotl(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
@@ -97,7 +99,7 @@ struct pob_ctx {
     // schedule
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
-    std::vector<Seg> segs, all_segs;                   // per (stage, lds) for generation; all units at once for check/emit
+    std::vector<Seg> segs, emit_segs, chk_segs;        // per (stage, class) for generation; per class for emission; per FAMILY for evaluation
     hipStream_t stream2 = nullptr, stream3 = nullptr; bool own_stream3 = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
     std::vector<KSeg> ksegs;
@@ -113,16 +115,29 @@ struct pob_ctx {
 
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
-void launch_g_gen(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (cls == 1) { if (A.stage_lds) launch_g_gen_heavy(A, nunits, ngroups, st); else launch_g_gen_heavy_small(A, nunits, ngroups, st); }
-    else if (cls == 2) launch_g_gen_sc(A, nunits, ngroups, st); else launch_g_gen_light(A, nunits, ngroups, st);
+// generation scheduling class: 0 = light, 1 = BN254 (no Poseidon), 2 = BN254 + Poseidon table in LDS, 3 = SubstringCheck BN254
+static uint32_t unit_class(uint32_t kind) { return fam_of(kind) == F_SC ? 3 : unit_uses_lds(kind) ? 2 : unit_is_heavy(kind) ? 1 : 0; }
+static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+    if (cls == 3) launch_g_gen_sc(A, nunits, ngroups, st);
+    else if (cls == 2 || (cls == 1 && A.stage_lds)) launch_g_gen_pos(A, nunits, ngroups, st);
+    else if (cls == 1) launch_g_gen_n2b(A, nunits, ngroups, st);
+    else launch_g_gen_light(A, nunits, ngroups, st);
 }
-void launch_g_check(const GArgs& A, int cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (cls == 1) launch_g_check_heavy(A, nunits, ngroups, st); else if (cls == 2) launch_g_check_sc(A, nunits, ngroups, st); else launch_g_check_light(A, nunits, ngroups, st);
+static void launch_g_check(const GArgs& A, uint32_t fam, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+    switch (fam) {
+    case F_MISC: launch_g_check_misc(A, nunits, ngroups, st); break;
+    case F_RANGE: launch_g_check_range(A, nunits, ngroups, st); break;
+    case F_SELROW: launch_g_check_selrow(A, nunits, ngroups, st); break;
+    case F_LD: launch_g_check_ld(A, nunits, ngroups, st); break;
+    case F_RL: launch_g_check_rl(A, nunits, ngroups, st); break;
+    case F_SC: launch_g_check_sc(A, nunits, ngroups, st); break;
+    case F_POS: launch_g_check_pos(A, nunits, ngroups, st); break;
+    default: launch_g_check_n2b(A, nunits, ngroups, st); break;
+    }
 }
-// scheduling class: 0 = light, 1 = BN254, 2 = BN254 + Poseidon table in LDS, 3 = SubstringCheck BN254
-static uint32_t unit_class(uint32_t kind) { return unit_is_sc(kind) ? 3 : unit_uses_lds(kind) ? 2 : unit_is_heavy(kind) ? 1 : 0; }
-static int kernel_class(uint32_t sched) { return sched == 3 ? 2 : sched ? 1 : 0; }
+static void launch_g_emit(const GArgs& A, uint32_t cls, uint32_t nunits, hipStream_t st) {
+    if (cls == 3) launch_g_emit_sc(A, nunits, 1, st); else if (cls) launch_g_emit_heavy(A, nunits, 1, st); else launch_g_emit_light(A, nunits, 1, st);
+}
 
 static Fr limbs_to_mont(const uint64_t* l) {
     Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
@@ -147,28 +162,53 @@ static KArgs kargs(pob_ctx* h) {
     return K;
 }
 
+// a small template parameter: 4 x 64-bit limbs whose upper limbs must be zero
+static bool small_param(const uint64_t* l, uint64_t lo, uint64_t hi, int* out) {
+    if (l[1] | l[2] | l[3]) return false;
+    if (l[0] < lo || l[0] > hi) return false;
+    *out = (int)l[0];
+    return true;
+}
+// a field-valued template parameter (the two balance bounds): reduced mod p, Montgomery
+static Fr field_param(const uint64_t* l) {
+    Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+    for (int k = 0; k < 6 && fr_geq_p(c); k++) c = fr_sub_p(c);        // 2^256 / p < 6
+    return fr_to_mont(c);
+}
 static int make_plan(Plan& plan, std::string& err, int circuit, const uint64_t* params, int nparams) {
     if (circuit == POB_CIRCUIT_PROOF_OF_BURN) {
         if (nparams != 8) { err = "ProofOfBurn takes 8 template parameters"; return POB_E_ARG; }
         PobParams prm;
-        prm.L = (int)params[0]; prm.NB = (int)params[4]; prm.HB = (int)params[8]; prm.minNib = (int)params[12];
-        prm.amountBytes = (int)params[16]; prm.powZero = (int)params[20];
-        prm.maxIntended = limbs_to_mont(params + 24); prm.maxActual = limbs_to_mont(params + 28);
-        if (prm.L < 2 || prm.L > 64 || prm.NB < 1 || prm.NB > 16 || prm.HB < 1 || prm.HB > 32 || prm.amountBytes < 1 || prm.amountBytes > 31 ||
-            4 + prm.L > MAX_KB || prm.L > MAX_SC) { err = "unsupported ProofOfBurn parameters"; return POB_E_ARG; }
+        if (!small_param(params + 0, 2, 64, &prm.L) || !small_param(params + 4, 1, 16, &prm.NB) || !small_param(params + 8, 1, 32, &prm.HB) ||
+            !small_param(params + 12, 0, 64, &prm.minNib) || !small_param(params + 16, 1, 31, &prm.amountBytes) || !small_param(params + 20, 0, 32, &prm.powZero) ||
+            4 + prm.L > MAX_KB || prm.L > MAX_SC) {
+            err = "unsupported ProofOfBurn parameters (maxNumLayers 2..64, maxNodeBlocks 1..16, maxHeaderBlocks 1..32, minLeafAddressNibbles 0..64, "
+                  "amountBytes 1..31, powMinimumZeroBytes 0..32)";
+            return POB_E_ARG;
+        }
+        prm.maxIntended = field_param(params + 24); prm.maxActual = field_param(params + 28);
+        // The layout uses 32-bit wire indices and class ranks with 32-bit byte offsets (BIT rank << 3, SM << 8, FR << 11, SB << 6):
+        // reject instantiations that cannot fit BEFORE the cursors could wrap (2.6 M wires per Keccak-f permutation dominate).
+        const uint64_t perms = (uint64_t)prm.L * prm.NB + prm.HB + 2 + 1 + 1;
+        if (perms * 2600000ull >= (1ull << 29)) { err = "instantiation too large for the 32-bit layout offsets (more than 206 Keccak-f permutations)"; return POB_E_ARG; }
         plan.plan_pob(prm);
     } else if (circuit == POB_CIRCUIT_SPEND) {
-        if (nparams != 1 || params[0] < 1 || params[0] > 31) { err = "Spend takes maxAmountBytes in 1..31"; return POB_E_ARG; }
-        SpendParams sp; sp.maxAmountBytes = (int)params[0];
+        int mab = 0;
+        if (nparams != 1 || !small_param(params, 1, 31, &mab)) { err = "Spend takes maxAmountBytes in 1..31"; return POB_E_ARG; }
+        SpendParams sp; sp.maxAmountBytes = mab;
         plan.plan_spend(sp);
     } else { err = "unknown circuit"; return POB_E_ARG; }
+    const Cur t = plan.total;
+    if (t.b >= (1u << 29) || t.s >= (1u << 24) || t.f >= (1u << 21) || t.q >= (1u << 26)) {
+        err = "instantiation exceeds the layout's offset limits (BIT < 2^29, SM < 2^24, FR < 2^21, SB < 2^26 wires)"; return POB_E_ARG;
+    }
     return POB_OK;
 }
 static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_info_t* info) {
     info->n_witness = pl.total.w; info->n_bit = pl.total.b; info->n_sm = pl.total.s; info->n_fr = pl.total.f;
     info->n_fr_inputs = pl.nfr_in; info->n_sm_inputs = pl.nsm_in; info->n_outputs = 1;
     info->n_units = (uint32_t)pl.units.size(); info->n_sponges = (uint32_t)pl.sponges.size(); info->n_perms = nperms;
-    { std::vector<char> used(pl.max_stage + 1, 0); for (const UnitDesc& u : pl.units) used[u.stage] = 1; for (const SpongeDesc& s : pl.sponges) used[s.stage] = 1;
+    { std::vector<char> used(pl.max_stage + 1, 0); for (const UnitDesc& u : pl.units) if (u.flags & UNIT_GEN) used[u.stage] = 1; for (const SpongeDesc& s : pl.sponges) used[s.stage] = 1;
       info->n_stages = 0; for (char c : used) info->n_stages += c; }
     info->max_batch = max_batch;
     info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048 + (uint64_t)pl.total.q * 64;
@@ -225,11 +265,12 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     for (uint32_t s = 0; s <= pl.max_stage; s++) {
         // a stage's heavy units go into ONE launch (with the LDS table if any of them needs it) unless there are many of them
         uint32_t n_heavy = 0, n_lds = 0;
-        for (const UnitDesc& u : pl.units) if (u.stage == s) { n_heavy += unit_class(u.kind) != 0; n_lds += unit_class(u.kind) == 2; }
+        for (const UnitDesc& u : pl.units) if (u.stage == s && (u.flags & UNIT_GEN)) { n_heavy += unit_class(u.kind) != 0; n_lds += unit_class(u.kind) == 2; }
         const bool merge = n_lds && n_heavy <= 64;
         for (uint32_t lds = 4; lds-- > 0;) {              // BN254 units first: they run on the second stream beside the light ones
             pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
             for (uint32_t u = 0; u < pl.units.size(); u++) {
+                if (!(pl.units[u].flags & UNIT_GEN)) continue;
                 uint32_t cls = unit_class(pl.units[u].kind);
                 if (merge && cls == 1) cls = 2;
                 if (pl.units[u].stage == s && cls == lds) h->order.push_back(u);
@@ -249,12 +290,18 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         if (ks.sp_count) h->ksegs.push_back(ks);
     }
     h->nperms = (uint32_t)perm_sponge.size();
-    for (uint32_t lds = 0; lds < 4; lds++) {             // every unit once, grouped only by class (constraint evaluation / emission)
-        pob_ctx::Seg sg{0, lds, (uint32_t)h->order.size(), 0};
-        for (uint32_t u = 0; u < pl.units.size(); u++) if (unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
+    for (uint32_t cls = 0; cls < 4; cls++) {             // emission: every generation unit once, grouped by class
+        pob_ctx::Seg sg{0, cls, (uint32_t)h->order.size(), 0};
+        for (uint32_t u = 0; u < pl.units.size(); u++) if ((pl.units[u].flags & UNIT_GEN) && unit_class(pl.units[u].kind) == cls) h->order.push_back(u);
+        sg.count = (uint32_t)h->order.size() - sg.first;
+        if (sg.count) h->emit_segs.push_back(sg);
+    }
+    for (uint32_t fam = 0; fam < F_COUNT; fam++) {       // constraint evaluation: every evaluator unit once, one launch per family, long units first
+        pob_ctx::Seg sg{0, fam, (uint32_t)h->order.size(), 0};
+        for (uint32_t u = 0; u < pl.units.size(); u++) if ((pl.units[u].flags & UNIT_CHECK) && fam_of(pl.units[u].kind) == fam) h->order.push_back(u);
         sg.count = (uint32_t)h->order.size() - sg.first;
         std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
-        if (sg.count) h->all_segs.push_back(sg);
+        if (sg.count) h->chk_segs.push_back(sg);
     }
 
     HIPC(hipSetDevice(device));
@@ -376,7 +423,7 @@ int pob_generate(pob_handle h, void* stream_) {
                 A.first = sg.first; A.stage_lds = sg.lds == 2;
                 if (sg.lds) {
                     if (!forked) { HIPC(hipEventRecord(ef, sm)); HIPC(hipStreamWaitEvent(sh, ef, 0)); }
-                    launch_g_gen(A, kernel_class(sg.lds), sg.count, G, sh);
+                    launch_g_gen(A, sg.lds, sg.count, G, sh);
                     forked = true;
                 } else launch_g_gen(A, 0, sg.count, G, sm);
             }
@@ -411,29 +458,38 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
-    // The evaluation has no dependencies between launches.  The latency-bound G kernels overlap each other (light units on the
-    // caller's stream, SubstringCheck's BN254 units on stream 2, the Poseidon units on stream 3); the HBM-streaming Keccak kernels
-    // follow the light units on the caller's stream -- run beside them they saturate HBM and stretch every serial unit ~3x.
+    // The evaluation has no dependencies between launches: one kernel per family, spread over the caller's stream and the handle's
+    // two side streams so that the families' long units start together.  The HBM-streaming Keccak kernels follow on the caller's
+    // stream once every G family is done -- run beside them they saturate HBM and stretch every latency-bound unit ~3x
+    // (POB_CHECK_OVERLAP=1: do not wait for the side streams first).
+    static const int overlap = getenv("POB_CHECK_OVERLAP") ? atoi(getenv("POB_CHECK_OVERLAP")) : 0;
     HIPC(hipEventRecord(h->ev_fork, st));
-    bool forked = false, forked3 = false;
-    for (size_t k = h->all_segs.size(); k-- > 0;) {
-        const pob_ctx::Seg& sg = h->all_segs[k];
-        A.first = sg.first; A.stage_lds = sg.lds == 2;
-        if (sg.lds) {
-            hipStream_t s2 = sg.lds == 2 ? h->stream3 : h->stream2;
-            HIPC(hipStreamWaitEvent(s2, h->ev_fork, 0));
-            launch_g_check(A, kernel_class(sg.lds), sg.count, G, s2);
-            if (sg.lds == 2) forked3 = true; else forked = true;
-        } else launch_g_check(A, 0, sg.count, G, st);
-    }
+    HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    HIPC(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+    // stream of each family: RL (longest serial units) and the BN254 families on the side streams, the wide light families on st
+    auto stream_of = [&](uint32_t fam) -> hipStream_t {
+        switch (fam) {
+        case F_RL: case F_POS: case F_MISC: return h->stream3;
+        case F_N2B: case F_SC: case F_LD: return h->stream2;
+        default: return st;
+        }
+    };
+    for (int pass = 0; pass < 2; pass++)                // the side streams' first launches are their long poles: RL, N2B
+        for (const pob_ctx::Seg& sg : h->chk_segs) {
+            const bool first = sg.lds == F_RL || sg.lds == F_N2B;
+            if (first != (pass == 0)) continue;
+            A.first = sg.first; A.stage_lds = 0;
+            launch_g_check(A, sg.lds, sg.count, G, stream_of(sg.lds));
+        }
+    HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipEventRecord(h->ev_join3, h->stream3));
+    if (!overlap) { HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
     if (!h->plan.sponges.empty()) {
         KArgs K = kargs(h);
         K.first = 0;
         launch_k_rounds(K, true, h->nperms, G, st);
         launch_k_chain(K, true, h->nperms, G, st);
     }
-    if (forked) { HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); }
-    if (forked3) { HIPC(hipEventRecord(h->ev_join3, h->stream3)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
+    if (overlap) { HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
     HIPC(hipGetLastError());
     return POB_OK;
 }
@@ -467,6 +523,12 @@ int pob_results_device(pob_handle h, void** d_status, void** d_outputs) {
 static int emit_to_device(pob_ctx* h, uint32_t idx) {
     if (!h->generated || idx >= h->n) return POB_E_STATE;
     HIPC(hipSetDevice(h->device));
+    {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
+        uint32_t st_w = 0;
+        HIPC(hipDeviceSynchronize());
+        HIPC(hipMemcpy(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost));
+        if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; return POB_E_STATE; }
+    }
     const uint64_t bytes = (uint64_t)h->plan.total.w * 32;
     if (!h->d_emit) HIPC(hipMalloc(&h->d_emit, bytes));
     hipStream_t st = h->stream;
@@ -476,9 +538,9 @@ static int emit_to_device(pob_ctx* h, uint32_t idx) {
     HIPC(hipMemcpyAsync(h->d_emit, one, 32, hipMemcpyHostToDevice, st));   // wire 0 = 1
     GArgs A = gargs(h);
     A.emit_out = h->d_emit; A.emit_sel = idx % 64; A.emit_group = idx / 64;
-    for (const pob_ctx::Seg& sg : h->all_segs) {
-        A.first = sg.first; A.stage_lds = sg.lds == 2;
-        launch_g_emit(A, kernel_class(sg.lds), sg.count, st);
+    for (const pob_ctx::Seg& sg : h->emit_segs) {
+        A.first = sg.first; A.stage_lds = 0;
+        launch_g_emit(A, sg.lds, sg.count, st);
     }
     const u64* Gp = (const u64*)h->d_bits + (uint64_t)(idx / 64) * h->plan.total.b;
     for (const SpongeDesc& s : h->plan.sponges) {
@@ -541,26 +603,28 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     KArgs K = kargs(h); K.first = 0;
     GArgs A = gargs(h);
-    uint32_t* d_sel = nullptr; uint32_t nsel = 0, sel_cls = 0;
-    if (which >= 100) {          // 100 + kind: evaluation, 200 + kind: generation of all units of one kind, alone on the device
-        const uint32_t kind = (uint32_t)which % 100;
+    uint32_t* d_sel = nullptr; uint32_t nsel = 0, sel_cls = 0, sel_fam = 0;
+    if (which >= 100 && which < 300) {   // 100 + kind: evaluation, 200 + kind: generation of all units of one kind, alone on the device
+        const uint32_t kind = (uint32_t)which % 100, need = which >= 200 ? UNIT_GEN : UNIT_CHECK;
         std::vector<uint32_t> sel;
-        for (uint32_t u = 0; u < h->plan.units.size(); u++) if (h->plan.units[u].kind == kind) sel.push_back(u);
+        for (uint32_t u = 0; u < h->plan.units.size(); u++) if (h->plan.units[u].kind == kind && (h->plan.units[u].flags & need)) sel.push_back(u);
         if (sel.empty()) { *avg_ms = 0; hipEventDestroy(e0); hipEventDestroy(e1); return POB_OK; }
-        nsel = (uint32_t)sel.size(); sel_cls = unit_class(kind);
+        nsel = (uint32_t)sel.size(); sel_cls = unit_class(kind); sel_fam = fam_of(kind);
         HIPC(hipMalloc(&d_sel, nsel * 4)); HIPC(hipMemcpy(d_sel, sel.data(), nsel * 4, hipMemcpyHostToDevice));
-        A.order = d_sel; A.first = 0; A.stage_lds = sel_cls == 2;
+        A.order = d_sel; A.first = 0; A.stage_lds = which >= 200 && sel_cls == 2;
     }
     HIPC(hipEventRecord(e0, st));
     for (int it = 0; it < iters; it++) {
-        if (which >= 200) launch_g_gen(A, kernel_class(sel_cls), nsel, G, st);
-        else if (which >= 100) launch_g_check(A, kernel_class(sel_cls), nsel, G, st);
+        if (which >= 300) {          // 300 + family: that family's evaluation kernel alone
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == (uint32_t)which - 300) { A.first = sg.first; A.stage_lds = 0; launch_g_check(A, sg.lds, sg.count, G, st); }
+        } else if (which >= 200) launch_g_gen(A, sel_cls, nsel, G, st);
+        else if (which >= 100) launch_g_check(A, sel_fam, nsel, G, st);
         else if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
         else if (which == 1) launch_k_rounds(K, true, h->nperms, G, st);
         else if (which == 2) {
-            for (const pob_ctx::Seg& sg : h->all_segs) {
-                A.first = sg.first; A.stage_lds = sg.lds == 2;
-                launch_g_check(A, kernel_class(sg.lds), sg.count, G, st);
+            for (const pob_ctx::Seg& sg : h->chk_segs) {
+                A.first = sg.first; A.stage_lds = 0;
+                launch_g_check(A, sg.lds, sg.count, G, st);
             }
         } else launch_k_chain(K, false, (uint32_t)h->plan.sponges.size(), G, st);
     }
@@ -577,6 +641,27 @@ int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_
     if (!h || group >= h->groups || bit_index >= h->plan.total.b) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, h->stream, h->d_bits + (uint64_t)group * h->plan.total.b + bit_index, mask);
+    HIPC(hipStreamSynchronize(h->stream));
+    return POB_OK;
+}
+
+int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask) {
+    if (!h || group >= h->groups || lane >= 64) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    const Cur t = h->plan.total;
+    if (cls == POB_CLASS_BIT) {
+        if (index >= t.b) return POB_E_ARG;
+        hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, h->stream, h->d_bits + (uint64_t)group * t.b + index, (uint64_t)(xor_mask & 1u) << lane);
+    } else if (cls == POB_CLASS_SM) {
+        if (index >= t.s) return POB_E_ARG;
+        hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, h->stream, (uint32_t*)h->d_sm + ((uint64_t)group * t.s + index) * 64 + lane, xor_mask);
+    } else if (cls == POB_CLASS_FR) {
+        if (index >= t.f || sub >= 8) return POB_E_ARG;
+        hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, h->stream, h->d_fr + ((uint64_t)group * t.f + index) * 512 + sub * 64 + lane, xor_mask);
+    } else if (cls == POB_CLASS_SB) {
+        if (index >= t.q) return POB_E_ARG;
+        hipLaunchKernelGGL(k_xor_u8, dim3(1), dim3(1), 0, h->stream, (uint8_t*)h->d_sb + ((uint64_t)group * t.q + index) * 64 + lane, (uint8_t)xor_mask);
+    } else return POB_E_ARG;
     HIPC(hipStreamSynchronize(h->stream));
     return POB_OK;
 }

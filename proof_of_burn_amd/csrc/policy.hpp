@@ -60,9 +60,17 @@ struct PolBase {
 };
 
 // ------------------------------------------------------------------ host-side layout planner policy
+// sub-blocks of a composite unit that the constraint evaluator runs as wavefronts of their own (circuits.hpp CK_* units);
+// the counting policy notes them while the planner walks the composite
+enum : uint32_t { NOTE_POSEIDON = 1, NOTE_N2BE = 2 };
+struct PlanNote { uint32_t what, n; Cur cur; uint32_t a[5]; };
 struct CountP : PolBase {
     static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
     uint32_t nput = 0;    // wires written: the planner's cost estimate of a unit (long units are dispatched first)
+    PlanNote notes[8]; uint32_t nnotes = 0;
+    HD void note(uint32_t what, uint32_t n, Cur c, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0) {
+        if (nnotes < 8) { PlanNote& x = notes[nnotes++]; x.what = what; x.n = n; x.cur = c; x.a[0] = a0; x.a[1] = a1; x.a[2] = a2; x.a[3] = a3; x.a[4] = a4; }
+    }
     HD B put(BitRef, B v) { nput++; return v; }
     HD S put(SmRef, S v) { nput++; return v; }
     HD F put(FrRef, const F& v) { nput += 8; return v; }
@@ -113,6 +121,7 @@ template <class P, int N> HD __attribute__((always_inline)) void sm_commit(P& p,
     if constexpr (P::is_check) {
 #pragma unroll
         for (int k = 0; k < N; k++) p.mark(h.s[k] != v[k], r[k].w);
+        p.pin();
     } else {
 #pragma unroll
         for (int k = 0; k < N; k++) p.put(r[k], v[k]);
@@ -230,7 +239,7 @@ template <class P, int N> HD __attribute__((always_inline)) FrLoaded<N> fr_load(
 template <class P, int N> HD __attribute__((always_inline)) void fr_commit(P& p, const FrRef (&r)[N], const FrLoaded<N>& h, const F (&v)[N]) {
     if constexpr (P::is_check) {
 #pragma unroll
-        for (int k = 0; k < N; k++) p.mark(!fr_eq(h.s[k], v[k]), r[k].w);
+        for (int k = 0; k < N; k++) { p.mark(!fr_eq(h.s[k], v[k]), r[k].w); p.pin(); }
     } else {
 #pragma unroll
         for (int k = 0; k < N; k++) p.put(r[k], v[k]);
@@ -407,49 +416,28 @@ __device__ __forceinline__ uint32_t check_attribute_run(B d, uint32_t w, uint32_
     return bad_wire;
 }
 
-// Constraint evaluator: `put` = "this wire must equal this expression of stored wires".
+// Constraint evaluator: `put(w, e)` = "the STORED wire w must equal the expression e", and it returns the STORED value of w, so
+// every later expression is evaluated on stored operands: each `<==` / `===` is checked as a relation between stored wires,
+// locally -- a wrong wire flags its own definition and the relations of its direct consumers, nothing downstream is re-derived
+// from it.  That locality is what lets the evaluator cut the generator's serial chains (Poseidon rounds, byte conversions) into
+// independent units that start from stored wires (circuits.hpp CK_* units).
 struct CheckP : DevPol {
     static constexpr bool is_gen = false, is_check = true, is_emit = false, is_count = false;
     uint32_t status;     // first failing === site of this lane
     uint32_t bad_wire;   // lowest wire index whose stored value contradicts its definition (per lane)
     __device__ __forceinline__ void mark(bool bad, uint32_t w) { if (bad && w < bad_wire) bad_wire = w; }
-    // put returns the EXPECTED value: if the stored wire equals it they are interchangeable, if not the witness is already
-    // flagged -- so the loads are off the dependency chain and many can be in flight.
-    // The compare of a wire is resolved one `put` later, after the NEXT wire's load has been issued (sched_barrier keeps that
-    // order), so a chain of puts always has two memory round trips overlapped instead of one exposed per wire.
-    B pend_bs, pend_bv; uint32_t pend_bw;            // BIT (wave-uniform)
-    S pend_ss, pend_sv; uint32_t pend_sw;            // SM
-    F pend_fs, pend_fv; uint32_t pend_fw;            // FR
-    __device__ __forceinline__ B put(BitRef r, B v) {
-        const B s = ld(r);
-        __builtin_amdgcn_sched_barrier(0);
-        mark(((pend_bs ^ pend_bv) >> m.lane) & 1, pend_bw);
-        pend_bs = s; pend_bv = v; pend_bw = r.w;
-        return v;
-    }
-    __device__ __forceinline__ S put(SmRef r, S v) {
-        const S s = ld(r);
-        __builtin_amdgcn_sched_barrier(0);
-        mark(pend_ss != pend_sv, pend_sw);
-        pend_ss = s; pend_sv = v; pend_sw = r.w;
-        return v;
-    }
-    __device__ __forceinline__ F put(FrRef r, const F& v) {
-        const F s = ld(r);
-        __builtin_amdgcn_sched_barrier(0);
-        mark(!fr_eq(pend_fs, pend_fv), pend_fw);
-        pend_fs = s; pend_fv = v; pend_fw = r.w;
-        return v;
-    }
-    __device__ __forceinline__ void put_flush() {
-        mark(((pend_bs ^ pend_bv) >> m.lane) & 1, pend_bw); mark(pend_ss != pend_sv, pend_sw); mark(!fr_eq(pend_fs, pend_fv), pend_fw);
-        pend_bs = pend_bv = 0; pend_ss = pend_sv = 0; pend_fs = pend_fv = fr_zero();
-    }
+    __device__ __forceinline__ void pin() { POB_OPAQUE(bad_wire); }      // the compares so far are resolved HERE (see put(FrRef))
+    __device__ __forceinline__ B put(BitRef r, B v) { const B s = ld(r); mark(((s ^ v) >> m.lane) & 1, r.w); return s; }
+    __device__ __forceinline__ S put(SmRef r, S v) { const S s = ld(r); mark(s != v, r.w); return s; }
+    // (the opaque asm pins the compare HERE: left alone, LLVM sinks every compare to the end of the kernel -- bad_wire is only used
+    //  there -- and keeps both 8-limb operands of every relation alive until then: thousands of spilled VGPRs)
+    __device__ __forceinline__ F put(FrRef r, const F& v) { const F s = ld(r); mark(!fr_eq(s, v), r.w); POB_OPAQUE(bad_wire); return s; }
+    __device__ __forceinline__ void put_flush() {}
     __device__ __forceinline__ B hint(BitRef r, B) { return ld(r); }
     __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
     __device__ __forceinline__ S hint_inv(SiRef r, S) { return ld(r); }
-    __device__ __forceinline__ S put(SbRef r, S v) { mark(ld(r) != v, r.w); return v; }
+    __device__ __forceinline__ S put(SbRef r, S v) { const S s = ld(r); mark(s != v, r.w); return s; }
     __device__ __forceinline__ S hint_inv(SbRef r, S) { return ld(r); }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
@@ -521,7 +509,7 @@ struct EmitP : DevPol {
 #pragma unroll
                 for (int j = 0; j < 8; j++) c.l[j] = q[j];
             } else {
-                c = fr_from_mont(fr_inv(fr_from_i64(k)));
+                c = fr_from_mont(fr_inv_fermat(fr_from_i64(k)));
             }
             w32(w, c);
         }
