@@ -71,12 +71,26 @@ int pob_sync(pob_handle h);
 int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* check_status, uint32_t* bad_wire);
 /* Device-resident results for the RCCL gather: status u32[max_batch_padded], outputs u8[max_batch_padded][32]. */
 int pob_results_device(pob_handle h, void** d_status, void** d_outputs);
+/* The same results as ONE packed record per witness, {u32 status, u8 commitment[32]} = 36 bytes, device-resident
+ * (u8[max_batch_padded][36]): what a rank contributes to the single all-gather of the multi-GPU path.          */
+#define POB_RECORD_BYTES 36
+int pob_results_records_device(pob_handle h, void** d_records);
 
 /* Replaces writeBinWitness (patch point `fclose(write_ptr)` at reference tests/test.py:36): expands witness `idx`
  * of the batch to canonical 32-byte LE values.  pob_emit_witness: payload only (32*W bytes) into host memory;
  * pob_write_wtns: full iden3 .wtns file.                                                                         */
 int pob_emit_witness(pob_handle h, uint32_t idx, uint8_t* dst, uint64_t cap);
 int pob_write_wtns(pob_handle h, uint32_t idx, const char* path);
+/* The streaming form underneath both: the canonical payload is expanded from the compact resident vector in WINDOWS of
+ * `window_wires` wires (0 = 8 Mi wires = 256 MiB), double-buffered on the device and in pinned host memory, so that expanding window
+ * k+1, copying it D2H and the caller's consumption of window k overlap, and a whole 32*W-byte device buffer never exists.
+ * pob_emit_next hands out the next window (pinned host memory owned by the handle, valid until the following call) with its first
+ * wire and wire count; n_wires = 0 ends the witness.  The buffers are kept for the next witness.  A witness whose status is non-zero
+ * is refused (POB_E_STATE): like the reference binary, a failed input produces no witness (reference tests/test.py:65-68).         */
+int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires);
+int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires);
+/* Measurement: `count` witnesses from `first_idx` on, back to back through the window pipeline into pinned host memory.          */
+int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes);
 
 /* Measurement: average duration (ms, HIP events on `stream`) of `iters` back-to-back launches of one kernel over
  * the current batch.  which: 0 = Keccak round expansion (generate), 1 = Keccak round constraint evaluation,
@@ -93,6 +107,10 @@ int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_
  * operand code, so poking those indices pokes the hint.                                                                          */
 enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2, POB_CLASS_SB = 3 };
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
+/* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the
+ * first Poseidon block); "pad.div.out" / "pad.div.rem" / "pad.iseq.inv" of KeccakBytes instance k (the Divide hint of
+ * divide.circom:23-24 and an IsZero.inv hint); ProofOfBurn only: "sc.M" / "sc.exists" / "sc.isz.inv" [k] of layer 1's SubstringCheck. */
+int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire);
 
 /* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */
 void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]);

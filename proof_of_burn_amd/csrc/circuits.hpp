@@ -80,6 +80,7 @@ struct KBRefs {
     SmRef out, in, inLen, padded, numBlocks; BitRef inBitsArray, inBits, inBlocks, outBits, outBytes;
     SmRef pad_o, pad_nb, pad_in, pad_il, pad_dv, pad_rm; BitRef pad_flt, pad_isEq, pad_isLast;
     Cur c_loop;                       // first IsEqual of Pad's isEq loop; then m isLast IsEquals, m Num2Bits(8), Flatten(m,8)
+    Cur c_div;                        // Pad's Divide(16) block: [out, rem | a, b] ...  (divide.circom:17-33)
     BitRef k_out, k_in; SmRef k_blocks; BitRef k_finalState, f_out, f_in; SmRef f_blocks; BitRef f_s;
     uint32_t abs_w, abs_b;
     BitRef sel_out, sel_arrays; SmRef sel_select; BitRef sel_T;
@@ -164,6 +165,7 @@ template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
     r.pad_flt = p.bits(m + 1); r.pad_isEq = p.bits(m); r.pad_isLast = p.bits(m);
     inLen = p.put(r.pad_il, inLen);
     S q, rem;
+    r.c_div = p.cur;
     gDivide(p, 16, inLen, (S)136, q, rem);
     q = p.put(r.pad_dv, q); p.put(r.pad_rm, rem);
     S nb = p.put(r.pad_nb, q + 1);

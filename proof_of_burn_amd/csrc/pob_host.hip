@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <functional>
 #include <string>
@@ -21,7 +22,8 @@ __global__ void k_init_invlut(uint32_t* lut) {   // canonical inverses of -4096.
     for (int j = 0; j < 8; j++) lut[t * 8 + j] = c.l[j];
 }
 // status/outputs of the batch: commitment FR (Montgomery) -> canonical LE; 0xFFFFFFFF -> 0 (ok)
-__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, const uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t n) {
+// and the same as ONE record per witness {u32 status, u8 commitment[32]} (36 B): the payload of the multi-GPU result gather
+__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, const uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t* records, uint32_t n) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
     const uint32_t g = w / 64, lane = w % 64;
@@ -30,7 +32,11 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
     Fr c = fr_from_mont(m);
     for (int k = 0; k < 8; k++) ((uint32_t*)(outputs + (uint64_t)w * 32))[k] = c.l[k];
     uint32_t s = status_raw[w];
-    status[w] = s == 0xFFFFFFFFu ? 0 : s;
+    s = s == 0xFFFFFFFFu ? 0 : s;
+    status[w] = s;
+    uint32_t* rec = records + (uint64_t)w * 9;
+    rec[0] = s;
+    for (int k = 0; k < 8; k++) rec[1 + k] = c.l[k];
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
@@ -94,8 +100,16 @@ struct pob_ctx {
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
     uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
-    uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr; uint8_t* d_outputs = nullptr;
-    uint8_t* d_emit = nullptr;
+    uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
+    // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
+    // consumes window k (pob_emit_begin / pob_emit_next)
+    struct Emit {
+        uint8_t* d_win[2] = {nullptr, nullptr}; uint8_t* h_pin[2] = {nullptr, nullptr};
+        hipStream_t s_copy = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+        uint64_t win_wires = 0, alloc_wires = 0, next_make = 0, next_take = 0, nwin = 0; uint32_t idx = 0; bool active = false;
+        struct Run { uint32_t w, b, n; };
+        std::vector<Run> runs;                          // the Keccak-owned BIT runs (wire index, BIT rank, count), sorted by wire index
+    } em;
     // schedule
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
@@ -348,6 +362,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_status_raw, npad * 4)); HIPC(hipMalloc(&h->d_status, npad * 4));
     HIPC(hipMalloc(&h->d_chk, npad * 4)); HIPC(hipMalloc(&h->d_bad, npad * 4));
     HIPC(hipMalloc(&h->d_outputs, npad * 32));
+    HIPC(hipMalloc(&h->d_records, npad * 36));
     HIPC(hipMemcpy(h->d_units, pl.units.data(), pl.units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_order, h->order.data(), h->order.size() * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_L, &pl.L, sizeof(CircuitLayout), hipMemcpyHostToDevice));
@@ -370,8 +385,13 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_emit};
+                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1]};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (int k = 0; k < 2; k++) {
+        if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
+        for (hipEvent_t e : {h->em.ev_made[k], h->em.ev_copied[k], h->em.ev_free[k]}) if (e) hipEventDestroy(e);
+    }
+    if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->own_stream3 && h->stream3) hipStreamDestroy(h->stream3);
@@ -444,7 +464,7 @@ int pob_generate(pob_handle h, void* stream_) {
     };
     { int rc = run_track(0); if (rc) return rc; }
     const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
-    hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs, G * 64);
+    hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs, h->d_records, G * 64);
     HIPC(hipGetLastError());
     h->generated = true;
     return POB_OK;
@@ -520,37 +540,97 @@ int pob_results_device(pob_handle h, void** d_status, void** d_outputs) {
     return POB_OK;
 }
 
-static int emit_to_device(pob_ctx* h, uint32_t idx) {
-    if (!h->generated || idx >= h->n) return POB_E_STATE;
-    HIPC(hipSetDevice(h->device));
-    {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
-        uint32_t st_w = 0;
-        HIPC(hipDeviceSynchronize());
-        HIPC(hipMemcpy(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost));
-        if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; return POB_E_STATE; }
-    }
-    const uint64_t bytes = (uint64_t)h->plan.total.w * 32;
-    if (!h->d_emit) HIPC(hipMalloc(&h->d_emit, bytes));
+int pob_results_records_device(pob_handle h, void** d_records) {
+    if (!h || !d_records) return POB_E_ARG;
+    *d_records = h->d_records;
+    return POB_OK;
+}
+
+// ---- streaming emission (reference: writeBinWitness, patch point tests/test.py:36).  The canonical payload (32 B per wire: 6.9 GB for
+// the production instantiation) never exists on the device as a whole: it is expanded window by window from the compact resident
+// vector, each window goes D2H into pinned memory on a copy stream while the next one is being expanded and the caller consumes
+// the previous one.
+static int emit_make_window(pob_ctx* h, uint64_t k) {
+    pob_ctx::Emit& E = h->em;
+    const int slot = (int)(k & 1);
+    const uint64_t W = h->plan.total.w, w0 = k * E.win_wires, wn = std::min(E.win_wires, W - w0);
     hipStream_t st = h->stream;
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemsetAsync(h->d_emit, 0xEE, bytes, st));              // any wire nobody owns stays 0xEE.. (not a field element)
-    const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-    HIPC(hipMemcpyAsync(h->d_emit, one, 32, hipMemcpyHostToDevice, st));   // wire 0 = 1
+    HIPC(hipStreamWaitEvent(st, E.ev_free[slot], 0));                       // the copy of the window that used this slot before is done
+    HIPC(hipMemsetAsync(E.d_win[slot], 0xEE, wn * 32, st));                 // any wire nobody owns stays 0xEE.. (not a field element)
+    if (w0 == 0) { const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(E.d_win[slot], one, 32, hipMemcpyHostToDevice, st)); }   // wire 0 = 1
     GArgs A = gargs(h);
-    A.emit_out = h->d_emit; A.emit_sel = idx % 64; A.emit_group = idx / 64;
+    A.emit_out = E.d_win[slot]; A.emit_sel = E.idx % 64; A.emit_group = E.idx / 64; A.emit_w0 = (uint32_t)w0; A.emit_wn = (uint32_t)wn;
     for (const pob_ctx::Seg& sg : h->emit_segs) {
         A.first = sg.first; A.stage_lds = 0;
         launch_g_emit(A, sg.lds, sg.count, st);
     }
-    const u64* Gp = (const u64*)h->d_bits + (uint64_t)(idx / 64) * h->plan.total.b;
-    for (const SpongeDesc& s : h->plan.sponges) {
-        const uint32_t rng[4][3] = {{s.kin_w, s.kin_b, s.n * 1088}, {s.fin_w, s.fin_b, s.n * 1088}, {s.fs_w, s.fs_b, (s.n + 1) * 1600}, {s.abs_w, s.abs_b, s.n * ABSORB_WIRES}};
-        for (int k = 0; k < 4; k++) {
-            launch_k_emit_bits(Gp, h->d_emit, rng[k][0], rng[k][1], rng[k][2], idx % 64, st);
-        }
+    const u64* Gp = (const u64*)h->d_bits + (uint64_t)(E.idx / 64) * h->plan.total.b;
+    for (const pob_ctx::Emit::Run& r : E.runs) {                            // the Keccak kernels' wires: contiguous BIT runs cut to the window
+        const uint64_t lo = std::max<uint64_t>(r.w, w0), hi = std::min<uint64_t>((uint64_t)r.w + r.n, w0 + wn);
+        if (lo >= hi) continue;
+        launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), E.idx % 64, st);
     }
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(st));
+    HIPC(hipEventRecord(E.ev_made[slot], st));
+    HIPC(hipStreamWaitEvent(E.s_copy, E.ev_made[slot], 0));
+    HIPC(hipMemcpyAsync(E.h_pin[slot], E.d_win[slot], wn * 32, hipMemcpyDeviceToHost, E.s_copy));
+    HIPC(hipEventRecord(E.ev_copied[slot], E.s_copy));
+    HIPC(hipEventRecord(E.ev_free[slot], E.s_copy));
+    return POB_OK;
+}
+
+int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
+    if (!h) return POB_E_ARG;
+    if (!h->generated || idx >= h->n) { h->err = "nothing generated / witness index out of range"; return POB_E_STATE; }
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipDeviceSynchronize());
+    {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
+        uint32_t st_w = 0;
+        HIPC(hipMemcpy(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost));
+        if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; return POB_E_STATE; }
+    }
+    pob_ctx::Emit& E = h->em;
+    const uint64_t W = h->plan.total.w;
+    if (window_wires == 0) window_wires = 8ull << 20;                       // 8 Mi wires = 256 MiB windows
+    window_wires = std::min<uint64_t>(window_wires, W);
+    if (!E.s_copy) {
+        HIPC(hipStreamCreateWithPriority(&E.s_copy, hipStreamNonBlocking, 0));
+        for (int k = 0; k < 2; k++) {
+            HIPC(hipEventCreateWithFlags(&E.ev_made[k], hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
+            HIPC(hipEventCreateWithFlags(&E.ev_free[k], hipEventDisableTiming));
+        }
+        for (const SpongeDesc& sp : h->plan.sponges) {
+            E.runs.push_back({sp.kin_w, sp.kin_b, sp.n * 1088}); E.runs.push_back({sp.fin_w, sp.fin_b, sp.n * 1088});
+            E.runs.push_back({sp.fs_w, sp.fs_b, (sp.n + 1) * 1600}); E.runs.push_back({sp.abs_w, sp.abs_b, sp.n * ABSORB_WIRES});
+        }
+        std::sort(E.runs.begin(), E.runs.end(), [](const pob_ctx::Emit::Run& a, const pob_ctx::Emit::Run& b) { return a.w < b.w; });
+    }
+    if (E.alloc_wires < window_wires) {                                     // (re)allocated only when a larger window is asked for: K witnesses reuse the buffers
+        for (int k = 0; k < 2; k++) {
+            if (E.d_win[k]) { HIPC(hipFree(E.d_win[k])); E.d_win[k] = nullptr; }
+            if (E.h_pin[k]) { HIPC(hipHostFree(E.h_pin[k])); E.h_pin[k] = nullptr; }
+            HIPC(hipMalloc(&E.d_win[k], window_wires * 32));
+            HIPC(hipHostMalloc((void**)&E.h_pin[k], window_wires * 32, hipHostMallocDefault));
+        }
+        E.alloc_wires = window_wires;
+    }
+    for (int k = 0; k < 2; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
+    E.win_wires = window_wires; E.nwin = (W + window_wires - 1) / window_wires; E.idx = idx; E.next_make = 0; E.next_take = 0; E.active = true;
+    for (; E.next_make < std::min<uint64_t>(1, E.nwin); E.next_make++) { int rc = emit_make_window(h, E.next_make); if (rc) return rc; }
+    return POB_OK;
+}
+
+int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires) {
+    if (!h || !data || !first_wire || !n_wires) return POB_E_ARG;
+    pob_ctx::Emit& E = h->em;
+    if (!E.active) { h->err = "pob_emit_next without pob_emit_begin"; return POB_E_STATE; }
+    if (E.next_take == E.nwin) { E.active = false; *data = nullptr; *first_wire = h->plan.total.w; *n_wires = 0; return POB_OK; }
+    HIPC(hipSetDevice(h->device));
+    // the window handed out by the previous call is released now: its slot takes the window after the one returned here
+    if (E.next_make < E.nwin && E.next_make <= E.next_take + 1) { int rc = emit_make_window(h, E.next_make); if (rc) return rc; E.next_make++; }
+    const uint64_t k = E.next_take++;
+    HIPC(hipEventSynchronize(E.ev_copied[k & 1]));
+    *data = E.h_pin[k & 1]; *first_wire = k * E.win_wires; *n_wires = std::min(E.win_wires, h->plan.total.w - k * E.win_wires);
     return POB_OK;
 }
 
@@ -558,19 +638,25 @@ int pob_emit_witness(pob_handle h, uint32_t idx, uint8_t* dst, uint64_t cap) {
     if (!h || !dst) return POB_E_ARG;
     const uint64_t bytes = (uint64_t)h->plan.total.w * 32;
     if (cap < bytes) { h->err = "destination too small"; return POB_E_ARG; }
-    int rc = emit_to_device(h, idx);
+    int rc = pob_emit_begin(h, idx, 0);
     if (rc) return rc;
-    HIPC(hipMemcpy(dst, h->d_emit, bytes, hipMemcpyDeviceToHost));
+    for (;;) {
+        const uint8_t* p; uint64_t w0, wn;
+        rc = pob_emit_next(h, &p, &w0, &wn);
+        if (rc) return rc;
+        if (!wn) break;
+        memcpy(dst + w0 * 32, p, wn * 32);
+    }
     return POB_OK;
 }
 
 int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
     if (!h || !path) return POB_E_ARG;
-    int rc = emit_to_device(h, idx);
+    int rc = pob_emit_begin(h, idx, 0);
     if (rc) return rc;
     const uint64_t W = h->plan.total.w, bytes = W * 32;
     FILE* f = fopen(path, "wb");
-    if (!f) { h->err = std::string("cannot open ") + path; return POB_E_IO; }
+    if (!f) { h->err = std::string("cannot open ") + path; h->em.active = false; return POB_E_IO; }
     // iden3 .wtns container: "wtns" v2, 2 sections: (1) n8=32, prime, nWitness  (2) values
     uint8_t hdr[76];
     const uint64_t P64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
@@ -580,17 +666,38 @@ int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
     u32 = 32; memcpy(hdr + 24, &u32, 4); memcpy(hdr + 28, P64, 32); u32 = (uint32_t)W; memcpy(hdr + 60, &u32, 4);
     u32 = 2; memcpy(hdr + 64, &u32, 4); u64v = bytes; memcpy(hdr + 68, &u64v, 8);
     bool ok = fwrite(hdr, 1, 76, f) == 76;
-    const uint64_t CH = 256ull << 20;
-    uint8_t* stage = nullptr;
-    if (hipHostMalloc((void**)&stage, CH, hipHostMallocDefault) != hipSuccess) { fclose(f); h->err = "hipHostMalloc failed"; return POB_E_NOMEM; }
-    for (uint64_t off = 0; ok && off < bytes; off += CH) {
-        uint64_t n = std::min(CH, bytes - off);
-        if (hipMemcpy(stage, h->d_emit + off, n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-        ok = fwrite(stage, 1, n, f) == n;
+    for (;;) {
+        const uint8_t* p; uint64_t w0, wn;
+        rc = pob_emit_next(h, &p, &w0, &wn);
+        if (rc) { fclose(f); remove(path); return rc; }
+        if (!wn) break;
+        if (ok) ok = fwrite(p, 1, wn * 32, f) == wn * 32;
     }
-    hipHostFree(stage);
     fclose(f);
-    if (!ok) { h->err = "write failed"; return POB_E_IO; }
+    if (!ok) { remove(path); h->err = "write failed"; return POB_E_IO; }
+    return POB_OK;
+}
+
+// emission throughput: K witnesses back to back through the window pipeline, the windows only touched (first + last cache line)
+int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes) {
+    if (!h || !seconds || !bytes || count == 0) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipDeviceSynchronize());
+    uint64_t total = 0; volatile uint8_t sink = 0;
+    timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t i = 0; i < count; i++) {
+        int rc = pob_emit_begin(h, first_idx + i, window_wires);
+        if (rc) return rc;
+        for (;;) {
+            const uint8_t* p; uint64_t w0, wn;
+            rc = pob_emit_next(h, &p, &w0, &wn);
+            if (rc) return rc;
+            if (!wn) break;
+            sink = sink ^ p[0] ^ p[wn * 32 - 1]; total += wn * 32;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec); *bytes = total;
     return POB_OK;
 }
 
@@ -664,6 +771,40 @@ int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32
     } else return POB_E_ARG;
     HIPC(hipStreamSynchronize(h->stream));
     return POB_OK;
+}
+
+// where a few named wires live (test hook for the evaluator's corruption tests): storage class, rank within the class, wire index
+int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire) {
+    if (!h || !name || !cls || !index || !wire) return POB_E_ARG;
+    const Plan& pl = h->plan; const CircuitLayout& L = pl.L;
+    const std::string n = name;
+    auto set = [&](int c, uint64_t i, uint64_t w) { *cls = c; *index = i; *wire = w; return POB_OK; };
+    if (n == "poseidon") {            // k-th wire of the first Poseidon block (every wire of it is an FR wire)
+        for (const UnitDesc& u : pl.units) if (u.kind == CK_POS_SEG) {
+            if (k >= pos_wires((int)u.a[0], pos_off((int)u.a[0]).rp)) return POB_E_ARG;
+            return set(POB_CLASS_FR, u.cur.f + k, u.cur.w + k);
+        }
+        return POB_E_ARG;
+    }
+    if (n == "commitment") { const FrRef r = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? L.pm.commitment : L.sm.commitment; return set(POB_CLASS_FR, r.i, r.w); }
+    if (n == "pad.div.out" || n == "pad.div.rem" || n == "pad.iseq.inv") {       // of KeccakBytes instance k
+        if (k >= L.nkb) return POB_E_ARG;
+        const KBRefs& r = L.kbs[k];
+        if (n == "pad.iseq.inv") return set(POB_CLASS_SM, r.c_loop.s + 3, r.c_loop.w + 5);      // IsEqual([0, inLen]).IsZero.inv (stored as its operand)
+        const uint32_t o = n == "pad.div.rem" ? 1 : 0;
+        return set(POB_CLASS_SM, r.c_div.s + o, r.c_div.w + o);
+    }
+    if (h->circuit == POB_CIRCUIT_PROOF_OF_BURN && L.nsc > 1) {                  // SubstringCheck of layer 1 (substring_check.circom:45-49, :91)
+        const ScRefs& sc = L.scs[1];
+        const uint32_t mm = 136u * (uint32_t)L.pob.NB, kk = mm - 31 + 1;
+        if (n == "sc.M" && k <= mm) return set(POB_CLASS_FR, sc.M.i + k, sc.M.w + k);
+        if (n == "sc.exists" && k < kk) return set(POB_CLASS_BIT, sc.ex.i + k, sc.ex.w + k);
+        if (n == "sc.isz.inv" && k < kk) {   // IsEqual(exists[k]).IsZero.inv: FR wires of position k are in0, in1, isz.in, isz.inv
+            const Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, k + 1), FP_ISEQ_F, k);
+            return set(POB_CLASS_FR, c.f + 3, c.w + 5);
+        }
+    }
+    return POB_E_ARG;
 }
 
 // ---- host Keccak-256 (FIPS-202 permutation, original 0x01 padding) for input producers

@@ -288,6 +288,14 @@ template <class P, class R, class V, int N> HD __attribute__((always_inline)) vo
 }
 
 #ifdef __HIPCC__
+// A BIT wire is shared by the 64 lanes of its wavefront (one lane stores the mask, every lane may load it later).  On the GPU the
+// wavefront executes in lockstep, so a later load sees the store; the CPU test shim (tests/hostsim) runs the lanes as independent
+// fibers and needs a meeting point after such a store.  Nothing on the GPU.
+#ifdef POB_HOSTSIM
+#define POB_WAVE_FENCE() __syncthreads()
+#else
+#define POB_WAVE_FENCE() ((void)0)
+#endif
 // ------------------------------------------------------------------ device policies
 struct DevMem {
     uint64_t* bits;     // this group's BIT slab
@@ -327,7 +335,7 @@ struct DevPol : PolBase {
     }
     // one lane stores the wave-uniform mask (a 64-lane same-address store costs the texture-address unit 64 lanes of work:
     // measured 1.5x slower on the selector-row stage)
-    __device__ __forceinline__ void st(BitRef r, B v) { if (m.lane == 0) m.bits[r.i] = v; }
+    __device__ __forceinline__ void st(BitRef r, B v) { if (m.lane == 0) m.bits[r.i] = v; POB_WAVE_FENCE(); }
     __device__ __forceinline__ void st(SmRef r, S v) { __builtin_amdgcn_raw_buffer_store_b32(v, m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void st(SiRef r, S v) { __builtin_amdgcn_raw_buffer_store_b32(v, m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void st(FrRef r, const F& v) {
@@ -400,6 +408,7 @@ struct GenP : DevPol {
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
         pob_v2i q; q.x = (int)(uint32_t)x; q.y = (int)(uint32_t)(x >> 32);
         __builtin_amdgcn_raw_buffer_store_b64(q, m.rs_bits, (int)run_off(n, i), 0, 0);
+        POB_WAVE_FENCE();
     }
 };
 
@@ -477,10 +486,11 @@ struct CheckP : DevPol {
 // .wtns emitter for ONE witness of the group (lane `sel`): canonical 32-byte LE value at wire index.
 struct EmitP : DevPol {
     static constexpr bool is_gen = false, is_check = false, is_emit = true, is_count = false;
-    uint8_t* out;      // canonical witness payload, 32 B per wire
-    uint32_t sel;
+    uint8_t* out;      // canonical witness payload of the wires [w0, w0 + wn) (the emission window), 32 B per wire
+    uint32_t sel, w0, wn;
     __device__ __forceinline__ void w32(uint32_t w, const F& canon) {
-        uint4* q = (uint4*)(out + (size_t)w * 32);
+        if (w - w0 >= wn) return;
+        uint4* q = (uint4*)(out + (size_t)(w - w0) * 32);
         q[0] = make_uint4(canon.l[0], canon.l[1], canon.l[2], canon.l[3]);
         q[1] = make_uint4(canon.l[4], canon.l[5], canon.l[6], canon.l[7]);
     }

@@ -1,13 +1,15 @@
 """Multi-GPU driver: witnesses are independent (no cross-witness state in the circuit), so a batch is
-cut into contiguous slices, one per rank / GPU; the only collective is ONE all-gather of the per-witness results
-(status u32 + 32-byte commitment = 36 B per witness) over RCCL/xGMI -- witness vectors never leave the GPU that
-produced them.  Backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU tests of this plumbing."""
+cut into contiguous slices, one per rank / GPU; the only collective is ONE all-gather of the per-witness result records
+({u32 status, u8 commitment[32]} = 36 B per witness, packed on the device by libpob_hip.so) over RCCL/xGMI -- witness vectors
+never leave the GPU that produced them.  Backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU tests of this plumbing."""
 from __future__ import annotations
 
 import os
 
 import torch
 import torch.distributed as dist
+
+RECORD_BYTES = 36
 
 
 def env_rank():
@@ -32,18 +34,44 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_results(status: torch.Tensor, outputs: torch.Tensor):
-    """status int32[n_local], outputs uint8[n_local, 32] (same n_local on every rank) -> concatenated over ranks"""
+def pack_records(status: torch.Tensor, outputs: torch.Tensor) -> torch.Tensor:
+    """status int32[n], outputs uint8[n, 32] -> uint8[n, 36] records (host-side twin of the device packing, for tests)"""
+    n = status.shape[0]
+    rec = torch.empty((n, RECORD_BYTES), dtype=torch.uint8, device=status.device)
+    rec[:, :4] = status.to(torch.int32).contiguous().view(torch.uint8).view(n, 4)
+    rec[:, 4:] = outputs
+    return rec
+
+
+def unpack_records(rec: torch.Tensor):
+    """uint8[n, 36] -> (status int32[n], outputs uint8[n, 32])"""
+    n = rec.shape[0]
+    return rec[:, :4].contiguous().view(torch.int32).view(n), rec[:, 4:].contiguous()
+
+
+def gather_records(rec: torch.Tensor, total: int | None = None) -> torch.Tensor:
+    """rec uint8[n_local, 36] of this rank -> uint8[total, 36] of the whole job, with ONE all_gather_into_tensor.
+    Slices may differ by one witness (shard_bounds): every rank pads to the largest slice and the result is trimmed, so an
+    uneven global batch neither hangs nor mis-aligns.  total=None: every rank holds the same number of witnesses."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return status, outputs
+        return rec
     world = dist.get_world_size()
-    if dist.get_backend() == "gloo" and status.is_cuda:      # plumbing tests of the N>1 path on one GPU: gather through host memory
-        status, outputs = status.cpu(), outputs.cpu()
-    st_all = torch.empty((world * status.shape[0],), dtype=status.dtype, device=status.device)
-    out_all = torch.empty((world * outputs.shape[0], 32), dtype=outputs.dtype, device=outputs.device)
-    dist.all_gather_into_tensor(st_all, status.contiguous())
-    dist.all_gather_into_tensor(out_all, outputs.contiguous())
-    return st_all, out_all
+    n_local = rec.shape[0]
+    if total is None:
+        counts = [n_local] * world
+    else:
+        counts = [hi - lo for lo, hi in (shard_bounds(total, r, world) for r in range(world))]
+        assert counts[dist.get_rank()] == n_local, "slice size does not match shard_bounds"
+    n_max = max(counts)
+    if dist.get_backend() == "gloo" and rec.is_cuda:          # plumbing tests of the N>1 path on one GPU: gather through host memory
+        rec = rec.cpu()
+    if n_local < n_max:
+        rec = torch.cat([rec, torch.zeros((n_max - n_local, RECORD_BYTES), dtype=torch.uint8, device=rec.device)])
+    out = torch.empty((world * n_max, RECORD_BYTES), dtype=torch.uint8, device=rec.device)
+    dist.all_gather_into_tensor(out, rec.contiguous())
+    if all(c == n_max for c in counts):
+        return out
+    return torch.cat([out[r * n_max:r * n_max + counts[r]] for r in range(world)])
 
 
 class _DevBuf:
@@ -53,8 +81,7 @@ class _DevBuf:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def device_results(calc, n: int):
-    d_status, d_out = calc.results_device_ptrs()
-    st = torch.as_tensor(_DevBuf(d_status, 4 * n), device="cuda").view(torch.int32)
-    out = torch.as_tensor(_DevBuf(d_out, 32 * n), device="cuda").view(n, 32)
-    return st, out
+def device_records(calc, n: int) -> torch.Tensor:
+    """zero-copy uint8[n, 36] view of the calculator's device-resident result records"""
+    ptr = calc.records_device_ptr()
+    return torch.as_tensor(_DevBuf(ptr, RECORD_BYTES * n), device=f"cuda:{calc.device}").view(n, RECORD_BYTES)

@@ -12,10 +12,8 @@ state root (proof_of_burn.circom:125-129).  Expected commitments are computed wi
 from __future__ import annotations
 
 import ctypes
-import functools
 import os
 import random
-import sys
 from dataclasses import dataclass, field
 
 from .witness import P, keccak256, load_library
@@ -27,17 +25,10 @@ EMPTY_CODE = bytes.fromhex("c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfa
 MAIN = (16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)   # circuits/main_proof_of_burn.circom:27
 
 
-@functools.lru_cache(maxsize=None)
-def _poseidon_mod():
-    if _ROOT not in sys.path:
-        sys.path.insert(0, _ROOT)
-    from tools import gen_poseidon
-    gen_poseidon.plain_constants = functools.lru_cache(maxsize=None)(gen_poseidon.plain_constants)
-    return gen_poseidon
-
-
 def poseidon(*inputs: int) -> int:
-    return _poseidon_mod().poseidon_plain(list(inputs))
+    """host-side Poseidon (circomlib parameters) for the input producer: burn address, nullifier, remaining coin"""
+    from . import poseidon_host
+    return poseidon_host.poseidon(list(inputs))
 
 
 def _min_bytes(v: int) -> bytes:
@@ -75,7 +66,7 @@ def hex_prefix_leaf(nibbles) -> bytes:
     return bytes(out)
 
 
-def pow_search(start_key: int, reveal: int, extra: int, zero_bytes: int, max_tries: int = 1 << 28, device: int | None = None) -> int:
+def pow_search(start_key: int, reveal: int, extra: int, zero_bytes: int, max_tries: int = 1 << 32, device: int | None = None) -> int:
     """first burn key >= start_key whose keccak(key | reveal | extra | "EIP-7503") starts with zero_bytes zero bytes
     (reference tests/main.py:47-56); device = GPU ordinal runs the search as a HIP kernel (same result)"""
     postfix = reveal.to_bytes(32, "big") + extra.to_bytes(32, "big") + b"EIP-7503"
@@ -104,12 +95,13 @@ class BurnKey:
     relax: int
 
 
-def make_burn_key(rng: random.Random, relax: int, pow_zero: int = 2, max_intended: int = 10 ** 19, max_actual: int = 10 ** 20) -> BurnKey:
+def make_burn_key(rng: random.Random, relax: int, pow_zero: int = 2, max_intended: int = 10 ** 19, max_actual: int = 10 ** 20,
+                  pow_device: int | None = None) -> BurnKey:
     extra = rng.randrange(P)
     intended = rng.randrange(1, max_intended + 1)
     reveal = rng.randrange(0, intended + 1)
     actual = intended + rng.randrange(0, min(max_actual - intended, 10 ** 17) + 1)
-    key = pow_search(rng.randrange(P - (1 << 64)), reveal, extra, pow_zero + relax)
+    key = pow_search(rng.randrange(P - (1 << 64)), reveal, extra, pow_zero + relax, device=pow_device)
     addr = poseidon(POSEIDON_PREFIX + 0, key, reveal, extra).to_bytes(32, "big")[:20]
     return BurnKey(key, reveal, extra, intended, actual, addr, keccak256(addr),
                    poseidon(POSEIDON_PREFIX + 1, key), poseidon(POSEIDON_PREFIX + 2, key, intended - reveal), relax)
@@ -160,18 +152,24 @@ class Batch:
     depth: int = 0
 
 
-def synthetic_batch(n: int, depth: int = 10, seed: int = 0xB0B, distinct_keys: int = 8, params=MAIN) -> Batch:
+def synthetic_batch(n: int, depth: int = 10, seed: int = 0xB0B, distinct_keys: int = 8, params=MAIN, first: int = 0,
+                    pow_device: int | None = None) -> Batch:
+    """witnesses [first, first + n) of the global synthetic batch of this seed: witness g depends only on (seed, g), so a rank's
+    slice is the same whoever generates it (the multi-GPU tests compare a 2-rank run with a single-rank run of the same seeds).
+    pow_device: run the proof-of-work searches as the HIP kernel on that GPU (3-zero-byte searches of the 16-layer shape)."""
     L, NB, HB, min_nib, amount_bytes, pow_zero, max_intended, max_actual = params
     LB, HBy = 136 * NB, 136 * HB
     assert 2 <= depth <= L
     leaf_nibbles = 64 - (depth - 1)
     relax = 0 if leaf_nibbles >= min_nib else (min_nib - leaf_nibbles + 1) // 2
-    keys = [make_burn_key(random.Random(seed * 1_000_003 + k), relax, pow_zero, min(max_intended, 256 ** amount_bytes - 1), max_actual)
-            for k in range(min(distinct_keys, n))]
+    nkeys = max(1, distinct_keys)
+    used = sorted({(first + w) % nkeys for w in range(n)})
+    keys = {k: make_burn_key(random.Random(seed * 1_000_003 + k), relax, pow_zero, min(max_intended, 256 ** amount_bytes - 1), max_actual, pow_device)
+            for k in used}
     out = Batch(distinct_keys=len(keys), depth=depth)
-    for w in range(n):
+    for w in range(first, first + n):
         rng = random.Random(seed + w)
-        bk = keys[w % len(keys)]
+        bk = keys[w % nkeys]
         layers, nn = account_proof(rng, bk, depth)
         hdr = block_header(rng, keccak256(layers[0]))
         assert len(hdr) < HBy and all(len(x) < LB for x in layers) and nn == leaf_nibbles
@@ -187,3 +185,77 @@ def synthetic_batch(n: int, depth: int = 10, seed: int = 0xB0B, distinct_keys: i
         out.inputs.append(inp)
         out.commitments.append(expected_commitment([int.from_bytes(keccak256(hdr), "big"), bk.nullifier, bk.remaining_coin, bk.reveal, bk.extra, proof_extra]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Real account proof -> input.json (reference tests/main.py:65-178, which obtains the proof from a JSON-RPC node)
+def rlp_decode(data: bytes):
+    """minimal RLP decoder: bytes -> nested lists of bytes (yellow paper app. B; the reference uses the `rlp` package)"""
+    def item(pos):
+        b0 = data[pos]
+        if b0 < 0x80:
+            return data[pos:pos + 1], pos + 1
+        if b0 < 0xB8:
+            n = b0 - 0x80
+            return data[pos + 1:pos + 1 + n], pos + 1 + n
+        if b0 < 0xC0:
+            ll = b0 - 0xB7
+            n = int.from_bytes(data[pos + 1:pos + 1 + ll], "big")
+            return data[pos + 1 + ll:pos + 1 + ll + n], pos + 1 + ll + n
+        if b0 < 0xF8:
+            n, start = b0 - 0xC0, pos + 1
+        else:
+            ll = b0 - 0xF7
+            n, start = int.from_bytes(data[pos + 1:pos + 1 + ll], "big"), pos + 1 + ll
+        out, p = [], start
+        while p < start + n:
+            x, p = item(p)
+            out.append(x)
+        if p != start + n:
+            raise ValueError("RLP: list payload overruns")
+        return out, start + n
+    v, end = item(0)
+    if end != len(data):
+        raise ValueError("RLP: trailing bytes")
+    return v
+
+
+def leaf_address_nibbles(leaf_node: bytes) -> int:
+    """number of address-hash nibbles stored in the leaf of an account proof = `numLeafAddressNibbles`
+    (reference tests/main.py:69-82: hex-prefix flag 2 -> even, 3 -> odd path)"""
+    key = rlp_decode(leaf_node)[0]
+    flag = key[0] >> 4
+    if flag == 2:
+        return 2 * (len(key) - 1)
+    if flag == 3:
+        return 2 * (len(key) - 1) + 1
+    raise ValueError("last proof node is not a leaf (hex-prefix flag %d)" % flag)
+
+
+def from_account_proof(account_proof, header_rlp: bytes, burn_key: int, actual_balance: int, intended_balance: int, reveal_amount: int,
+                       burn_extra_commitment: int, proof_extra_commitment: int, byte_security_relax: int = 0, params=MAIN) -> dict:
+    """eth_getProof's `accountProof` (list of RLP node byte strings, root first) + the RLP block header -> the circuit's input.json
+    dict, as the reference producer builds it (tests/main.py:65-82 leaf / nibble count, :84-122 header, :134-150 zero padding of
+    layers and header, unused layerLens = 256, :160-178 the dict)."""
+    L, NB, HB = params[0], params[1], params[2]
+    LB, HBy = 136 * NB, 136 * HB
+    layers = [bytes(x) for x in account_proof]
+    if not 1 <= len(layers) <= L:
+        raise ValueError(f"{len(layers)} proof nodes, circuit takes 1..{L}")
+    if any(len(x) >= LB for x in layers):
+        raise ValueError(f"a proof node has {max(len(x) for x in layers)} bytes, circuit takes < {LB}")
+    if len(header_rlp) >= HBy:
+        raise ValueError(f"block header has {len(header_rlp)} bytes, circuit takes < {HBy}")
+    hdr_fields = rlp_decode(bytes(header_rlp))
+    if len(hdr_fields) < 4 or len(hdr_fields[3]) != 32 or bytes(header_rlp[91:123]) != hdr_fields[3]:
+        raise ValueError("block header: the state root is not at bytes 91..122 (proof_of_burn.circom:125-129)")
+    if keccak256(layers[0]) != hdr_fields[3]:
+        raise ValueError("the first proof node does not hash to the header's state root")
+    return {
+        "burnKey": str(burn_key), "actualBalance": str(actual_balance), "intendedBalance": str(intended_balance), "revealAmount": str(reveal_amount),
+        "burnExtraCommitment": str(burn_extra_commitment), "numLeafAddressNibbles": str(leaf_address_nibbles(layers[-1])),
+        "layers": [list(x) + [0] * (LB - len(x)) for x in layers] + [[0] * LB] * (L - len(layers)),
+        "layerLens": [len(x) for x in layers] + [256] * (L - len(layers)),
+        "numLayers": len(layers), "blockHeader": list(header_rlp) + [0] * (HBy - len(header_rlp)), "blockHeaderLen": len(header_rlp),
+        "byteSecurityRelax": byte_security_relax, "_proofExtraCommitment": str(proof_extra_commitment),
+    }

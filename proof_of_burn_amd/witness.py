@@ -71,10 +71,16 @@ def load_library() -> ctypes.CDLL:
     lib.pob_sync.argtypes = [vp]
     lib.pob_results.argtypes = [vp, vp, vp, vp, vp]
     lib.pob_results_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.pob_results_records_device.argtypes = [vp, ctypes.POINTER(vp)]
     lib.pob_emit_witness.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64]
     lib.pob_write_wtns.argtypes = [vp, ctypes.c_uint32, ctypes.c_char_p]
+    lib.pob_emit_begin.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
+    lib.pob_emit_next.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.pob_emit_measure.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_time_kernel.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.pob_debug_xor_bits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
+    lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.pob_debug_ref.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
     lib.pob_keccak256.restype = None
     lib.pob_pow_search.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
@@ -86,8 +92,8 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_generate",
-                    "pob_constraint_check", "pob_sync", "pob_results", "pob_results_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_time_kernel", "pob_debug_xor_bits", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_constraint_check", "pob_sync", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -185,6 +191,7 @@ class WitnessCalculator:
         else:
             raise NotImplementedError(f"the HIP calculator implements the two `component main` circuits (ProofOfBurn, Spend); got {name}")
         self.lib = load_library()
+        self.device = device
         arr = (ctypes.c_uint64 * (4 * len(params)))()
         for i, v in enumerate(params):
             for k in range(4):
@@ -222,7 +229,9 @@ class WitnessCalculator:
 
     # ------------------------------------------------------------------ input packing (the emitted loadJson)
     def pack(self, inputs: Sequence[dict]):
-        """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n])"""
+        """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n]).
+        The byte arrays (layers, blockHeader: 99 % of an input) go through numpy in one conversion per key; only values that numpy
+        cannot hold as int64 (strings, huge ints -- the loader's mod-p path) fall back to per-element parsing."""
         n = len(inputs)
         nfr, nsm = self.info.n_fr_inputs, self.info.n_sm_inputs
         fr = np.zeros((n, nfr, 32), dtype=np.uint8)
@@ -233,28 +242,39 @@ class WitnessCalculator:
         shapes = {}
         if self.name == "ProofOfBurn":
             shapes = {"layers": self.L * self.NB * 136, "layerLens": self.L, "blockHeader": self.HB * 136}
+        want = set(fr_names) | set(sm_names)
         for w, d in enumerate(inputs):
             keys = set(d.keys())
-            want = set(fr_names) | set(sm_names)
             if keys != want:
                 raise KeyError(f"input {w}: missing {sorted(want - keys)} unexpected {sorted(keys - want)}")
             for k, name in enumerate(fr_names):
                 fr[w, k] = np.frombuffer(_scalar(d[name]).to_bytes(32, "little"), dtype=np.uint8)
             col = 0
             for name in sm_names:
+                cnt = shapes.get(name, 1)
+                a = None
                 if name in shapes:
+                    try:                       # fast path: a (nested) list of plain non-negative ints
+                        a = np.asarray(d[name], dtype=np.int64).reshape(-1)
+                        if a.size and int(a.min()) < 0:
+                            a = None
+                    except (ValueError, TypeError, OverflowError):
+                        a = None
+                if a is None:
                     vals = []
-                    _flat(d[name], vals)
-                    if len(vals) != shapes[name]:
-                        raise ValueError(f"input {w}: {name} has {len(vals)} elements, circuit expects {shapes[name]}")
-                else:
-                    vals = [_scalar(d[name])]
-                a = np.array([v if v < (1 << 31) else -1 for v in vals], dtype=np.int64)
-                if (a < 0).any():      # not representable as a small input: every such input is range-checked in-circuit
+                    if name in shapes:
+                        _flat(d[name], vals)
+                    else:
+                        vals = [_scalar(d[name])]
+                    a = np.array([v if v < (1 << 31) else -1 for v in vals], dtype=np.int64)
+                if a.size != cnt:
+                    raise ValueError(f"input {w}: {name} has {a.size} elements, circuit expects {cnt}")
+                big = (a < 0) | (a >= (1 << 31))
+                if big.any():      # not representable as a small input: every such input is range-checked in-circuit
                     forced[w] = FAIL_INPUT_RANGE
-                    a[a < 0] = 0x7FFFFFFF
-                sm[w, col:col + len(vals)] = a.astype(np.int32)
-                col += len(vals)
+                    a = np.where(big, 0x7FFFFFFF, a)
+                sm[w, col:col + cnt] = a.astype(np.int32)
+                col += cnt
             assert col == nsm
         return fr, sm, forced
 
@@ -320,10 +340,51 @@ class WitnessCalculator:
     def write_wtns(self, idx: int, path: str):
         self._ck(self.lib.pob_write_wtns(self.h, idx, os.fsencode(path)))
 
+    def witness_windows(self, idx: int = 0, window_wires: int = 0):
+        """stream the canonical payload of witness idx: yields (first_wire, uint8 view [n_wires * 32]) per window; a view is valid
+        until the next iteration (it aliases the handle's pinned buffer)"""
+        self._ck(self.lib.pob_emit_begin(self.h, idx, window_wires))
+        p, w0, wn = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        while True:
+            self._ck(self.lib.pob_emit_next(self.h, ctypes.byref(p), ctypes.byref(w0), ctypes.byref(wn)))
+            if wn.value == 0:
+                return
+            buf = (ctypes.c_uint8 * (32 * wn.value)).from_address(p.value)
+            yield w0.value, np.frombuffer(buf, dtype=np.uint8)
+
+    def emit_throughput(self, first_idx: int = 0, count: int = 1, window_wires: int = 0):
+        """(seconds, bytes) of `count` witnesses emitted back to back into pinned host memory"""
+        sec, nb = ctypes.c_double(), ctypes.c_uint64()
+        self._ck(self.lib.pob_emit_measure(self.h, first_idx, count, window_wires, ctypes.byref(sec), ctypes.byref(nb)))
+        return sec.value, nb.value
+
     def time_kernel(self, which: int, iters: int = 5, stream: int | None = None) -> float:
         ms = ctypes.c_float()
         self._ck(self.lib.pob_time_kernel(self.h, which, iters, ctypes.c_void_p(stream) if stream else None, ctypes.byref(ms)))
         return float(ms.value)
+
+    # ------------------------------------------------------------------ test hooks of the constraint evaluator
+    CLASS_BIT, CLASS_SM, CLASS_FR, CLASS_SB = 0, 1, 2, 3
+
+    def class_sizes(self) -> dict:
+        return {self.CLASS_BIT: int(self.info.n_bit), self.CLASS_SM: int(self.info.n_sm), self.CLASS_FR: int(self.info.n_fr), self.CLASS_SB: int(self.info.n_sb)}
+
+    def poke(self, cls: int, index: int, lane: int, xor_mask: int = 1, sub: int = 0, group: int = 0):
+        """XOR one stored value of one witness of the resident vector (storage class, rank in the class, lane)"""
+        self._ck(self.lib.pob_debug_poke(self.h, cls, group, index, sub, lane, xor_mask))
+
+    def debug_ref(self, name: str, k: int = 0):
+        cls, idx, wire = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = self.lib.pob_debug_ref(self.h, name.encode(), k, ctypes.byref(cls), ctypes.byref(idx), ctypes.byref(wire))
+        if rc != 0:
+            raise KeyError(f"no debug ref {name}[{k}]")
+        return cls.value, idx.value, wire.value
+
+    def records_device_ptr(self) -> int:
+        """device pointer of the packed per-witness result records {u32 status, u8 commitment[32]} (36 B each)"""
+        a = ctypes.c_void_p()
+        self._ck(self.lib.pob_results_records_device(self.h, ctypes.byref(a)))
+        return a.value
 
     def results_device_ptrs(self):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()

@@ -28,30 +28,86 @@ WORKER = textwrap.dedent("""
     from proof_of_burn_amd import distributed as D
     rank, local_rank, world = D.init("gloo")
     assert world == 2
+    # (a) hand-made records, EVEN slices, no `total`
     n = 5
     lo, hi = D.shard_bounds(2 * n, rank, world)
     status = torch.arange(lo, hi, dtype=torch.int32) * (rank + 1)
     outs = (torch.arange(n * 32, dtype=torch.int64).reshape(n, 32) + 100 * rank).to(torch.uint8)
-    st, out = D.gather_results(status, outs)
+    st, out = D.unpack_records(D.gather_records(D.pack_records(status, outs)))
     assert st.tolist() == [0, 1, 2, 3, 4, 10, 12, 14, 16, 18], st.tolist()
     assert out.shape == (10, 32) and out[0, 1].item() == 1 and out[5, 1].item() == 101
+    # (b) UNEVEN slices (7 = 4 + 3): padded to the largest slice, trimmed after the single all-gather
+    lo, hi = D.shard_bounds(7, rank, world)
+    status = torch.arange(lo, hi, dtype=torch.int32) + 1000
+    outs = torch.full((hi - lo, 32), rank + 7, dtype=torch.uint8)
+    st, out = D.unpack_records(D.gather_records(D.pack_records(status, outs), total=7))
+    assert st.tolist() == [1000 + i for i in range(7)] and out[:, 0].tolist() == [7, 7, 7, 7, 8, 8, 8]
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
 """) % ROOT
 
+# Two ranks, each running the REAL calculator (the product's kernels + host scheduler on the CPU shim of tests/hostsim) on its
+# slice of one global Spend(31) batch, records packed by the library's own k_collect, ONE all-gather; the gathered job must
+# equal a single-rank run of the whole batch.
+CALC_WORKER = textwrap.dedent("""
+    import ctypes, json, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from proof_of_burn_amd import distributed as D, witness as W
+    W.LIB_PATH, W._lib = %r, None
+    rank, local_rank, world = D.init("gloo")
+    s = next(x for x in json.load(open(os.path.join(%r, "tests", "golden", "suites.json"))) if x["name"] == "test_spend")
+    base = s["cases"][0]["input"]
+    inputs = []
+    for g in range(7):                                  # global batch of 7 (uneven: 4 + 3); witness 2 must fail (spend.circom:41)
+        d = dict(base); d["extraCommitment"] = 1000 + g; d["withdrawnBalance"] = str(5 + g)
+        if g == 2: d["withdrawnBalance"] = str(int(base["balance"]) + 1)
+        inputs.append(d)
+    def run(slice_inputs):
+        calc = W.WitnessCalculator("Spend(31)", max_batch=len(slice_inputs))
+        calc.calculate(slice_inputs)
+        n = len(slice_inputs)
+        buf = (ctypes.c_uint8 * (D.RECORD_BYTES * n)).from_address(calc.records_device_ptr())      # "device" memory of the shim
+        rec = torch.from_numpy(np.ctypeslib.as_array(buf).reshape(n, D.RECORD_BYTES).copy())
+        calc.close()
+        return rec
+    lo, hi = D.shard_bounds(len(inputs), rank, world)
+    got = D.gather_records(run(inputs[lo:hi]), total=len(inputs))
+    want = run(inputs)
+    assert got.shape == (7, D.RECORD_BYTES) and torch.equal(got, want)
+    st, out = D.unpack_records(got)
+    assert (st != 0).tolist() == [g == 2 for g in range(7)]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
 
-@pytest.mark.timeout(180)
-def test_gather_results_world2_gloo(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+
+def _run_two_ranks(script):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=150)[0] for p in procs]
+    outs = [p.communicate(timeout=170)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+@pytest.mark.timeout(180)
+def test_gather_records_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    _run_two_ranks(script)
+
+
+@pytest.mark.timeout(240)
+def test_two_ranks_run_the_calculator_and_gather(tmp_path):
+    from tests.hostsim import build as hb
+    lib = hb.build()
+    script = tmp_path / "calc_worker.py"
+    script.write_text(CALC_WORKER % (ROOT, lib, ROOT))
+    _run_two_ranks(script)

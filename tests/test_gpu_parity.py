@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from tests import evaluator_cases as EC
 from tests import oracle_ffi as O
 
 pytestmark = pytest.mark.gpu
@@ -37,6 +38,14 @@ def test_reference_suite_spend(pkg, capsys):
     """the reference's own test tuple for Spend(31) (tests/testcases/spend.py:58-72) through the run() shim"""
     from proof_of_burn_amd.harness import run
     s = _suite("test_spend")
+    got = run(s["main"], [(c["input"], c["expected"]) for c in s["cases"]])
+    assert got == [c["expected"] for c in s["cases"]]
+
+
+def test_reference_suite_proof_of_burn_through_run_shim(pkg):
+    """the reference's own test tuple for ProofOfBurn (tests/testcases/proof_of_burn.py:52-76) through the run() shim"""
+    from proof_of_burn_amd.harness import run
+    s = _suite("test_proof_of_burn")
     got = run(s["main"], [(c["input"], c["expected"]) for c in s["cases"]])
     assert got == [c["expected"] for c in s["cases"]]
 
@@ -138,6 +147,68 @@ def test_constraint_evaluator_corruption_sweep(pkg, which):
     assert all(r.bad_wire is None and r.check_status == 0 for r in calc.results(with_check=True))
     calc.close()
     assert not missed, f"{len(missed)} of {len(idxs)} corruptions mis-detected, first: {missed[:5]}"
+
+
+@pytest.mark.parametrize("which", ["spend", "pob"])
+def test_constraint_evaluator_detects_sm_sb_fr_pokes(pkg, which):
+    """the evaluator on every storage class, not only bits: >= 1000 SM, >= 500 SB, >= 300 FR (and 300 more BIT) uniformly drawn
+    stored values of a 64-witness group are corrupted, 63 lanes per pass (lane 0 = control); each pass must flag exactly the poked
+    lanes.  SM covers the IsZero.inv hints stored as operands and the Divide quotient/remainder, FR the Poseidon state, the
+    SubstringCheck M[] / IsEqual operands and inverses.  Then the named wires, one at a time, with the reported wire checked."""
+    if which == "spend":
+        s = _suite("test_spend"); main = "Spend(31)"
+        named = [("poseidon", k) for k in (1, 77, 200, 413, 640, 900)] + [("pad.div.out", 0), ("pad.div.rem", 0), ("pad.iseq.inv", 0), ("commitment", 0)]
+    else:
+        s = _suite("test_proof_of_burn"); main = POB_FIX
+        named = ([("poseidon", k) for k in (5, 300, 800)] + [("sc.M", k) for k in (0, 17, 300, 544)] + [("sc.exists", k) for k in (0, 5, 513)] +
+                 [("sc.isz.inv", k) for k in (0, 40, 513)] + [("pad.div.out", k) for k in (0, 1, 3)] + [("pad.div.rem", 2), ("pad.iseq.inv", 2), ("commitment", 0)])
+    calc = EC.open_identical_batch(pkg, main, s["cases"][0]["input"])
+    missed, done = EC.uniform_sweep(calc, {EC.SM: 1200, EC.SB: 600, EC.FR: 400, EC.BIT: 300})
+    assert done["SM"] >= 1000 and done["SB"] >= 500 and done["FR"] >= 300
+    assert not missed, f"{len(missed)} mis-detections of {done}: {missed[:8]}"
+    bad = EC.named_pokes(calc, named)
+    assert not bad, bad
+    calc.close()
+
+
+def test_failed_witness_is_not_emitted(pkg, tmp_path):
+    """like the reference binary (tests/test.py:65-68): an input that fails an assert produces no witness, also through the C ABI"""
+    s = _suite("test_spend")
+    calc = pkg.WitnessCalculator("Spend(31)", max_batch=4)
+    res = calc.calculate([c["input"] for c in s["cases"]])
+    bad = next(i for i, r in enumerate(res) if not r.ok)
+    with pytest.raises(RuntimeError, match="failed an assert"):
+        calc.witness_payload(bad)
+    with pytest.raises(RuntimeError, match="failed an assert"):
+        calc.write_wtns(bad, str(tmp_path / "x.wtns"))
+    assert not os.path.exists(tmp_path / "x.wtns")
+    calc.close()
+
+
+def test_calc_cli_is_the_reference_binary(pkg, tmp_path):
+    """`python -m proof_of_burn_amd.calc spend input.json witness.wtns` = `./main_spend input.json witness.wtns` (reference
+    Makefile:4-5): exit code, stderr only on failure (tests/test.py:65-68), no file on failure, file bytes = the oracle's"""
+    import subprocess
+    import sys
+    s = _suite("test_spend")
+    ok_case = next(c for c in s["cases"] if c["expected"] is not None)
+    bad_case = next(c for c in s["cases"] if c["expected"] is None)
+    for name, case, want_rc in (("ok", ok_case, 0), ("bad", bad_case, 1)):
+        inp, out = tmp_path / f"{name}.json", tmp_path / f"{name}.wtns"
+        inp.write_text(json.dumps(case["input"]))
+        r = subprocess.run([sys.executable, "-m", "proof_of_burn_amd.calc", "spend", str(inp), str(out)], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == want_rc, r.stderr
+        if want_rc == 0:
+            assert r.stderr.strip() == "" or "amdgpu.ids" in r.stderr      # (the image's libdrm prints a missing-file note)
+            ora = O.run("Spend(31)", case["input"])
+            assert np.array_equal(np.frombuffer(out.read_bytes(), dtype=np.uint8), ora.wtns_numpy())
+        else:
+            assert "Failed assert in template" in r.stderr and not out.exists()
+    # malformed input: missing key
+    d = dict(ok_case["input"]); d.pop("balance")
+    inp = tmp_path / "missing.json"; inp.write_text(json.dumps(d))
+    r = subprocess.run([sys.executable, "-m", "proof_of_burn_amd.calc", "spend", str(inp), str(tmp_path / "m.wtns")], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 1 and "input error" in r.stderr
 
 
 def test_main_instantiation_batch(pkg):
@@ -253,6 +324,59 @@ def test_max_depth_and_ragged_batches(pkg):
         exp = (deep.commitments + shallow.commitments) if len(batch) == 70 else shallow.commitments[:len(batch)]
         assert [r.outputs for r in res] == [[c] for c in exp]
     calc.close()
+
+
+def _run_bench(args, env_extra=None, nproc=1, timeout=900):
+    import socket
+    import subprocess
+    import sys
+    env = dict(os.environ, **(env_extra or {}))
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = next(ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{"))
+    return json.loads(line)
+
+
+def test_two_ranks_on_one_gpu_equal_a_single_rank_run(pkg, tmp_path):
+    """BASELINE config 4's shape on the hardware at hand: bench.py --gpus 2 as two ranks (own process, own handle, own slice of the
+    global batch) sharing GPU 0, result records through ONE all-gather (gloo here, RCCL on a node); the gathered 1024 records must
+    equal a single-rank run of the same 1024 seeds.  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
+    a, b = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
+    two = _run_bench(["--gpus", "2", "--batch", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-results", a],
+                     {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
+    one = _run_bench(["--gpus", "1", "--batch", "1024", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-results", b])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    ra, rb = np.load(a), np.load(b)
+    assert ra.shape == rb.shape == (1024, 36) and np.array_equal(ra, rb)
+    assert not ra[:, :4].any()                      # every status 0
+
+
+def test_max_depth_config5_payload_and_bench(pkg):
+    """BASELINE config 5's shape: 16-layer proofs (byteSecurityRelax = 1, 3-zero-byte proof of work found by the HIP search kernel)
+    on the production instantiation: evaluator clean, one full 6.9 GB witness payload bit-exact vs the oracle, and bench.py --depth 16."""
+    from proof_of_burn_amd import inputs as gen
+    main = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
+    deep = gen.synthetic_batch(3, depth=16, seed=4242, distinct_keys=2, pow_device=0)
+    calc = pkg.WitnessCalculator(main, max_batch=3)
+    res = calc.calculate(deep.inputs, check=True)
+    for r, exp in zip(res, deep.commitments):
+        assert r.ok and r.outputs == [exp] and r.check_status == 0 and r.bad_wire is None, r
+    ora = O.run(main, deep.inputs[2])
+    assert not ora.failed and ora.outputs() == [deep.commitments[2]]
+    gpu = calc.witness_payload(2)
+    ref = ora.witness_numpy()
+    assert np.array_equal(gpu, ref), f"first differing wire {_first_diff(gpu, ref)}"
+    calc.close()
+    line = _run_bench(["--gpus", "1", "--depth", "16", "--batch", "128", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--distinct-keys", "2"])
+    assert "16-layer" in line["config"]["workload"] and line["value"] > 0
 
 
 def test_pow_search_gpu_matches_host(pkg):

@@ -31,65 +31,13 @@ import os
 import random
 import sys
 
-P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-R_F = 8
-R_P_TABLE = {2: 56, 3: 57, 4: 56, 5: 60}  # indexed by t = nInputs + 1
-
-
-def inv(x: int) -> int:
-    return pow(x % P, -1, P)
-
-
-# ------------------------------------------------------------------ Grain LFSR
-
-def _grain_stream(t: int, rf: int, rp: int, n: int = 254):
-    bits = [int(b) for b in (
-        format(1, "02b") + format(0, "04b") + format(n, "012b") + format(t, "012b")
-        + format(rf, "010b") + format(rp, "010b"))] + [1] * 30
-    assert len(bits) == 80
-
-    def clock() -> int:
-        nb = bits[62] ^ bits[51] ^ bits[38] ^ bits[23] ^ bits[13] ^ bits[0]
-        bits.pop(0)
-        bits.append(nb)
-        return nb
-
-    for _ in range(160):
-        clock()
-
-    def next_bit() -> int:
-        b = clock()
-        while b == 0:
-            clock()
-            b = clock()
-        return clock()
-
-    while True:
-        x = 0
-        for _ in range(n):
-            x = (x << 1) | next_bit()
-        yield x
-
-
-def plain_constants(t: int):
-    rp = R_P_TABLE[t]
-    g = _grain_stream(t, R_F, rp)
-    c = []
-    while len(c) < (R_F + rp) * t:
-        x = next(g)
-        if x < P:
-            c.append(x)
-    rl = [next(g) % P for _ in range(2 * t)]
-    xs, ys = rl[:t], rl[t:]
-    m = [[inv(xs[i] + ys[j]) for j in range(t)] for i in range(t)]
-    return c, m
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the specification part (Grain LFSR constants, MDS, plain permutation) lives in the package: the input producer needs it at run time
+from proof_of_burn_amd.poseidon_host import P, R_F, R_P_TABLE, inv, _grain_stream, plain_constants, mat_vec, pow5  # noqa: E402,F401
+from proof_of_burn_amd.poseidon_host import poseidon as poseidon_plain  # noqa: E402
 
 
 # ------------------------------------------------------------------ tiny linear algebra mod p
-
-def mat_vec(a, v):
-    return [sum(a[i][j] * v[j] for j in range(len(v))) % P for i in range(len(a))]
-
 
 def mat_mul(a, b):
     n, k, m = len(a), len(b), len(b[0])
@@ -174,26 +122,6 @@ def optimized(t: int):
 
 # ------------------------------------------------------------------ reference evaluations
 
-def pow5(x):
-    x2 = x * x % P
-    return x2 * x2 % P * x % P
-
-
-def poseidon_plain(inputs):
-    t = len(inputs) + 1
-    rp = R_P_TABLE[t]
-    c, A = plain_constants(t)
-    s = [0] + [x % P for x in inputs]
-    for r in range(R_F + rp):
-        s = [(s[i] + c[r * t + i]) % P for i in range(t)]
-        if r < R_F // 2 or r >= R_F // 2 + rp:
-            s = [pow5(x) for x in s]
-        else:
-            s[0] = pow5(s[0])
-        s = mat_vec(A, s)
-    return s[0]
-
-
 def poseidon_opt_trace(inputs, params=None):
     """Evaluate circomlib's schedule; returns (hash, list of per-stage states) for wire checks."""
     t = len(inputs) + 1
@@ -238,8 +166,10 @@ def self_check(seed: int = 7503) -> None:
 
 
 def check_reference(path: str = "/root/reference") -> None:
-    sys.path.insert(0, path)
-    from tests import poseidon as ref  # type: ignore
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_poseidon", os.path.join(path, "tests", "poseidon.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
     for n_in in (1, 2, 3, 4):
         c, m = plain_constants(n_in + 1)
         assert c == [x.val for x in ref.POSEIDON_C[n_in - 1]], n_in
