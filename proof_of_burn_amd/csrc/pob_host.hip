@@ -115,8 +115,9 @@ struct pob_ctx {
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, emit_segs, chk_segs;        // per (stage, class) for generation; per class for emission; per FAMILY for evaluation
     hipStream_t stream2 = nullptr, stream3 = nullptr; bool own_stream3 = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
-    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; };
-    std::vector<KSeg> ksegs;
+    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; };
+    std::vector<KSeg> ksegs;                           // ev_done: recorded behind the segment's sponge kernels in pob_generate
+    hipStream_t stream_k = nullptr; hipEvent_t ev_joink = nullptr;      // the Keccak evaluation's own stream (see pob_constraint_check)
     // side tracks (Plan::track_fork/track_join): own light + BN254 streams, own fork/join events, start and end events
     // (ROCm multiplexes streams onto 4 hardware queues by default: the handle keeps to the caller's stream + 3 of its own --
     //  stream2, trackB (track 1), trackC (tracks 2 and 3, which run one after the other anyway); a track's BN254 and light
@@ -293,7 +294,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
             if (sg.count) h->segs.push_back(sg);
         }
-        pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0};
+        pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0, nullptr};
         bool first = true;
         for (uint32_t i = 0; i < pl.sponges.size(); i++) if (pl.sponges[i].stage == s) {
             if (first) { ks.sp_first = i; first = false; }
@@ -326,6 +327,9 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
+    HIPC(hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_lo));
+    HIPC(hipEventCreateWithFlags(&h->ev_joink, hipEventDisableTiming));
+    for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < pl.ntracks; t++) {
         pob_ctx::Track& T = h->tracks[t];
@@ -392,6 +396,9 @@ void pob_close(pob_handle h) {
         for (hipEvent_t e : {h->em.ev_made[k], h->em.ev_copied[k], h->em.ev_free[k]}) if (e) hipEventDestroy(e);
     }
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
+    if (h->stream_k) hipStreamDestroy(h->stream_k);
+    if (h->ev_joink) hipEventDestroy(h->ev_joink);
+    for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->own_stream3 && h->stream3) hipStreamDestroy(h->stream3);
@@ -453,6 +460,7 @@ int pob_generate(pob_handle h, void* stream_) {
                 launch_k_chain(K, false, ks.sp_count, G, sm);
                 K.first = ks.perm_first;
                 launch_k_rounds(K, false, ks.perm_count, G, sm);
+                HIPC(hipEventRecord(ks.ev_done, sm));       // every wire of these sponges exists: their evaluation may start (pob_constraint_check)
             }
             for (uint32_t u = pl.ntracks; u-- > t + 1;) if (pl.track_fork[u] == sid) {
                 HIPC(hipEventRecord(h->tracks[u].ev_start, sm)); HIPC(hipStreamWaitEvent(h->tracks[u].s_main, h->tracks[u].ev_start, 0));
@@ -475,41 +483,68 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipSetDevice(h->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
     const uint32_t G = (h->n + 63) / 64;
-    HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
-    HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
-    // The evaluation has no dependencies between launches: one kernel per family, spread over the caller's stream and the handle's
-    // two side streams so that the families' long units start together.  The HBM-streaming Keccak kernels follow on the caller's
-    // stream once every G family is done -- run beside them they saturate HBM and stretch every latency-bound unit ~3x
-    // (POB_CHECK_OVERLAP=1: do not wait for the side streams first).
-    static const int overlap = getenv("POB_CHECK_OVERLAP") ? atoi(getenv("POB_CHECK_OVERLAP")) : 0;
+    // The evaluation has no dependencies between launches: one kernel per family (+ the two Keccak kernels), spread over the
+    // caller's stream and the handle's two side streams.  The plan -- which stream runs what, in which order -- is a string:
+    // three ';'-separated sequences (caller's stream; side stream 2; side stream 3) of family numbers (circuits.hpp Fam) and 'K'
+    // (the HBM-streaming Keccak round + chain evaluation).  Default: the wide byte-range / selector-row families first on the
+    // caller's stream, then Keccak; the long serial families (RLP assembly, BN254) on the side streams, where they run BESIDE the
+    // Keccak streaming (their loads are latency-bound, the round evaluation is bandwidth-bound).  POB_CHECK_PLAN overrides it.
+    // POB_CHECK_EARLY_K=1: the Keccak evaluation does not wait for the END of the generation.  It reads only wires the
+    // sponge kernels wrote, so each sponge segment is evaluated on the handle's Keccak stream as soon as ITS generation kernels are
+    // done -- beside the generation's latency-bound tail (selector rows, SubstringCheck, commitment) and beside the G families,
+    // which do wait for the whole generation.  'K' in the plan is then ignored.
+    // Measured (profiles/round2_*): it gains nothing -- the generation's tail is latency-bound on the same memory system and stretches
+    // by what the evaluation saves -- so it is off by default.
+    static const int early_k = getenv("POB_CHECK_EARLY_K") ? atoi(getenv("POB_CHECK_EARLY_K")) : 0;
+    static const std::string plan = getenv("POB_CHECK_PLAN") ? getenv("POB_CHECK_PLAN") : (early_k ? "1,2,3;7,5;4,6,0" : "1,2,K;7,5,3,6,0;4");
+    hipStream_t ss[3] = {st, h->stream2, h->stream3};
+    bool keccak_done = false;
+    {   // reset of the evaluator's results: ahead of the FIRST kernel that may write them (the early Keccak evaluation)
+        hipStream_t sr = (early_k && !h->plan.sponges.empty()) ? h->stream_k : st;
+        HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, sr));
+        HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, sr));
+        if (sr != st) { HIPC(hipEventRecord(h->ev_joink, sr)); HIPC(hipStreamWaitEvent(st, h->ev_joink, 0)); }
+    }
+    if (early_k && !h->plan.sponges.empty()) {
+        KArgs K = kargs(h);
+        for (const pob_ctx::KSeg& ks : h->ksegs) {
+            HIPC(hipStreamWaitEvent(h->stream_k, ks.ev_done, 0));
+            K.first = ks.perm_first;
+            launch_k_rounds(K, true, ks.perm_count, G, h->stream_k);
+            launch_k_chain(K, true, ks.perm_count, G, h->stream_k);
+        }
+        HIPC(hipEventRecord(h->ev_joink, h->stream_k));
+        keccak_done = true;
+    }
     HIPC(hipEventRecord(h->ev_fork, st));
     HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     HIPC(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
-    // stream of each family: RL (longest serial units) and the BN254 families on the side streams, the wide light families on st
-    auto stream_of = [&](uint32_t fam) -> hipStream_t {
-        switch (fam) {
-        case F_RL: case F_POS: case F_MISC: return h->stream3;
-        case F_N2B: case F_SC: case F_LD: return h->stream2;
-        default: return st;
+    uint32_t done = 0; int si = 0;
+    auto run_item = [&](char c) -> int {
+        if (c == 'K') {
+            if (!h->plan.sponges.empty() && !keccak_done) {
+                KArgs K = kargs(h);
+                K.first = 0;
+                launch_k_rounds(K, true, h->nperms, G, ss[si]);
+                launch_k_chain(K, true, h->nperms, G, ss[si]);
+            }
+            keccak_done = true;
+        } else if (c >= '0' && c < '0' + (int)F_COUNT) {
+            const uint32_t fam = (uint32_t)(c - '0');
+            if (done & (1u << fam)) return POB_OK;
+            done |= 1u << fam;
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == fam) { A.first = sg.first; A.stage_lds = 0; launch_g_check(A, fam, sg.count, G, ss[si]); }
         }
+        return POB_OK;
     };
-    for (int pass = 0; pass < 2; pass++)                // the side streams' first launches are their long poles: RL, N2B
-        for (const pob_ctx::Seg& sg : h->chk_segs) {
-            const bool first = sg.lds == F_RL || sg.lds == F_N2B;
-            if (first != (pass == 0)) continue;
-            A.first = sg.first; A.stage_lds = 0;
-            launch_g_check(A, sg.lds, sg.count, G, stream_of(sg.lds));
-        }
+    for (char c : plan) { if (c == ';') { if (si < 2) si++; } else run_item(c); }
+    si = 0;                                              // whatever the plan left out runs on the caller's stream
+    for (uint32_t fam = 0; fam < F_COUNT; fam++) run_item((char)('0' + fam));
+    run_item('K');
     HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipEventRecord(h->ev_join3, h->stream3));
-    if (!overlap) { HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
-    if (!h->plan.sponges.empty()) {
-        KArgs K = kargs(h);
-        K.first = 0;
-        launch_k_rounds(K, true, h->nperms, G, st);
-        launch_k_chain(K, true, h->nperms, G, st);
-    }
-    if (overlap) { HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0)); }
+    HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
+    if (early_k && !h->plan.sponges.empty()) HIPC(hipStreamWaitEvent(st, h->ev_joink, 0));
     HIPC(hipGetLastError());
     return POB_OK;
 }

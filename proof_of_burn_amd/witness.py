@@ -340,6 +340,17 @@ class WitnessCalculator:
     def write_wtns(self, idx: int, path: str):
         self._ck(self.lib.pob_write_wtns(self.h, idx, os.fsencode(path)))
 
+    def write_wtns_reduced(self, idx: int, path: str, o1_map, window_wires: int = 0):
+        """O1-style reduced .wtns (circuit_model.o1.reduce_map): only the surviving wires, streamed window by window"""
+        keep = o1_map.keep
+        with open(path, "wb") as f:
+            f.write(wtns_header(len(keep)))
+            for w0, view in self.witness_windows(idx, window_wires):
+                n = view.size // 32
+                a, b = np.searchsorted(keep, w0), np.searchsorted(keep, w0 + n)
+                if b > a:
+                    f.write(view.reshape(n, 32)[keep[a:b] - w0].tobytes())
+
     def witness_windows(self, idx: int = 0, window_wires: int = 0):
         """stream the canonical payload of witness idx: yields (first_wire, uint8 view [n_wires * 32]) per window; a view is valid
         until the next iteration (it aliases the handle's pinned buffer)"""

@@ -29,3 +29,60 @@ def test_synthetic_small_instantiation_is_valid():
         assert O.run_main(main, inp) == [c]
     bad = dict(b.inputs[0]); bad["numLeafAddressNibbles"] = str(int(bad["numLeafAddressNibbles"]) - 1)
     assert O.run_main(main, bad) is None
+
+
+def test_from_account_proof_rebuilds_the_reference_fixture():
+    """the producer path of reference tests/main.py:65-178: feed the fixture's own UNPADDED proof nodes and header (what
+    eth_getProof / the block RPC return) and get the fixture's input.json back -- nibble count from the leaf's hex-prefix,
+    zero padding, unused layerLens = 256"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "test_pob_input.json")) as f:
+        fix = json.load(f)
+    params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
+    nodes = [bytes(fix["layers"][i][:fix["layerLens"][i]]) for i in range(fix["numLayers"])]
+    header = bytes(fix["blockHeader"][:fix["blockHeaderLen"]])
+    assert G.leaf_address_nibbles(nodes[-1]) == int(fix["numLeafAddressNibbles"])
+    got = G.from_account_proof(nodes, header, int(fix["burnKey"]), int(fix["actualBalance"]), int(fix["intendedBalance"]), int(fix["revealAmount"]),
+                               int(fix["burnExtraCommitment"]), int(fix["_proofExtraCommitment"]), fix["byteSecurityRelax"], params=params)
+    assert set(got) == set(fix)
+    for k in fix:
+        if isinstance(fix[k], list):
+            assert got[k] == fix[k], k
+        else:
+            assert int(got[k]) == int(fix[k]), k
+    main = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
+    assert O.run_main(main, got) == O.run_main(main, fix) and O.run_main(main, got) is not None
+    # and a synthetic proof goes through the same parser: producer and parser agree
+    b = G.synthetic_batch(1, depth=3, seed=11, distinct_keys=1, params=params)
+    inp = b.inputs[0]
+    nodes = [bytes(inp["layers"][i][:inp["layerLens"][i]]) for i in range(inp["numLayers"])]
+    again = G.from_account_proof(nodes, bytes(inp["blockHeader"][:inp["blockHeaderLen"]]), int(inp["burnKey"]), int(inp["actualBalance"]),
+                                 int(inp["intendedBalance"]), int(inp["revealAmount"]), int(inp["burnExtraCommitment"]), int(inp["_proofExtraCommitment"]),
+                                 inp["byteSecurityRelax"], params=params)
+    assert again["layers"] == inp["layers"] and again["layerLens"] == inp["layerLens"] and int(again["numLeafAddressNibbles"]) == int(inp["numLeafAddressNibbles"])
+    # malformed: state root not where the circuit reads it
+    import pytest
+    with pytest.raises(ValueError):
+        G.from_account_proof(nodes, bytes(inp["blockHeader"][1:inp["blockHeaderLen"]]), 1, 1, 1, 1, 1, 1, params=params)
+
+
+def test_pack_vectorised_equals_elementwise():
+    """WitnessCalculator.pack: the numpy fast path and the per-element (string / huge int) path agree"""
+    import numpy as np
+    from proof_of_burn_amd import witness as W
+    params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
+    b = G.synthetic_batch(2, depth=2, seed=3, distinct_keys=1, params=params)
+
+    class Fake:                      # pack() only needs the shapes
+        name, L, NB, HB = "ProofOfBurn", 4, 4, 5
+        class info:
+            n_fr_inputs, n_sm_inputs = 6, 1 + 4 * 544 + 4 + 1 + 680 + 2
+    a = W.WitnessCalculator.pack(Fake, b.inputs)
+    slow = [dict(d, layers=[[str(x) for x in row] for row in d["layers"]], blockHeader=[hex(x) for x in d["blockHeader"]]) for d in b.inputs]
+    c = W.WitnessCalculator.pack(Fake, slow)
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+    big = dict(b.inputs[0]); big["layerLens"] = list(big["layerLens"]); big["layerLens"][3] = 2 ** 40
+    assert W.WitnessCalculator.pack(Fake, [big])[2][0] == W.FAIL_INPUT_RANGE
