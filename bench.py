@@ -11,9 +11,9 @@ every rank gets its own 1024 (weak scaling), one slice per GPU, no data-path col
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
---halves H (default 2): the rank's batch is held by H calculators (B/H witnesses each, own streams) whose passes are enqueued
-interleaved, so that the latency-bound stages of one part run beside the HBM-streaming Keccak kernels of the other; every
-witness still goes through the same generate + evaluate kernels inside the timed region.
+--halves H (default 1): the rank's batch may be held by H calculators (B/H witnesses each, own streams) whose passes are enqueued
+interleaved, so that the latency-bound stages of one part run beside the HBM-streaming Keccak kernels of the other.  Measured
+(profiles/round2_*): H = 2 gains nothing -- both kinds of kernel wait on the same memory system -- so the default is one calculator.
 """
 import argparse
 import json
@@ -58,7 +58,7 @@ def cpu_baseline(batch, info, single_samples: int, budget_s: float = 25.0):
     except Exception:
         avail_gb = 32.0
     cores = os.cpu_count() or 1
-    nproc = max(1, min(cores, int(avail_gb * 0.6 / per_proc_gb), 64))
+    nproc = max(1, min(cores, int(avail_gb * 0.4 / per_proc_gb), 16))
     per = max(1, min(4, int(budget_s / max(t_single * 1.5, 0.1))))
     jobs = [(MAIN, [batch.inputs[(p * per + j) % len(batch.inputs)] for j in range(per)],
              [batch.commitments[(p * per + j) % len(batch.inputs)] for j in range(per)]) for p in range(nproc)]
@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU")
-    ap.add_argument("--halves", type=int, default=int(os.environ.get("POB_BENCH_HALVES", "2")), help="calculators per GPU whose passes are interleaved")
+    ap.add_argument("--halves", type=int, default=int(os.environ.get("POB_BENCH_HALVES", "1")), help="calculators per GPU whose passes are interleaved")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over the global batch")
     ap.add_argument("--cpu-samples", type=int, default=2, help="witnesses timed single-threaded on the CPU oracle (rank 0, N=1 only)")
@@ -190,9 +190,10 @@ def main():
     torch.cuda.synchronize()
     t_check_pass = ev0.elapsed_time(ev1) / 5
     resident = int(info.group_bytes) * groups_h * H
-    traffic = None                                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
+    traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_k_rounds.json")) as f:
+        pmc_file = next(p for p in ("round2_pmc_k_rounds.json", "round1_pmc_k_rounds.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups_h / pmc["groups"])
     except Exception:
@@ -200,7 +201,7 @@ def main():
     ms_step = dt / args.steps * 1e3
     roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/round1_pmc_k_rounds.json (rocprofv3 --pmc FETCH_SIZE pass of round 1, scaled to this launch's groups; not measured in this run)",
+                "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
                 "bytes_per_launch": launch_bytes, "avg_ms": round(t_chk, 4),
                 "gen_kernel": {"kernel": "k_rounds<GEN>", "achieved": round(info.n_perms * 24 * (102656 + 1600) * 8 * groups_h / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)},
@@ -209,6 +210,13 @@ def main():
                                "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "step": {"what": "generate (write the resident vector once) + evaluate (read it once)", "bytes": 2 * resident,
                          "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    # ---- .wtns emission (the step after the path): 2 witnesses back to back through the window pipeline into pinned host memory
+    emission = None
+    if rank == 0:
+        sec, nbytes = calcs[0].emit_throughput(0, count=2)
+        emission = {"what": "canonical 32 B/wire payload expanded on the GPU in 256 MiB windows, D2H double-buffered into pinned memory, 2 witnesses back to back",
+                    "GB_per_s": round(nbytes / sec / 1e9, 2), "ms_per_witness": round(sec / 2 * 1e3, 1), "bytes_per_witness": nbytes // 2}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -226,7 +234,7 @@ def main():
                        "canonical_bytes_per_witness": int(info.n_witness) * 32, "parallelism": f"one slice per GPU x{world}, {H} interleaved parts of {Bh} per GPU",
                        "input_synthesis_s": round(t_synth, 2), "json_to_packed_witnesses_per_s": round(B / max(t_pack, 1e-9), 1),
                        "h2d_s": round(t_h2d, 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "emission": emission,
         }
         print(json.dumps(line))
     for c in calcs:

@@ -873,7 +873,7 @@ struct Plan {
     // Side tracks: stage ids TRACK_STRIDE*t + s belong to track t.  Track 0 is the main sequence; track t > 0 starts once stage
     // track_fork[t] has completed and must have completed before stage track_join[t] starts.  A track may only be joined by a
     // lower-numbered track (the host enqueues a stage's forked tracks highest first, each one completely).
-    enum { TRACK_STRIDE = 32, MAX_TRACKS = 6 };
+    enum { TRACK_STRIDE = 32, MAX_TRACKS = 7 };
     uint32_t ntracks, track_fork[MAX_TRACKS], track_join[MAX_TRACKS];
     CountP p;
 
@@ -984,15 +984,20 @@ struct Plan {
         // (main stage 5).  track 2 (TR): the RlpMerklePatriciaTrieLeaf assembly, forked once BurnAddressHash is done (TB + 5) and
         // joined before the final comparisons (main stage 10).  track 3 (TC): RlpEmptyAccount's serial chain, joined before TR + 2.
         // track 4 (TN): the five Num2BigEndianBytes of PublicCommitment's inputs, forked once the Poseidons are done (TB + 1), joined
-        // before PublicCommitment (main stage 5); it runs on the main track's BN254 stream, which is idle until then.
+        // before PublicCommitment's track forks (main stage 4); it runs on the main track's BN254 stream, which is idle until then.
         const uint32_t TB = TRACK_STRIDE, TR = 2 * TRACK_STRIDE, TC = 3 * TRACK_STRIDE, TN = 4 * TRACK_STRIDE;
         ntracks = 6; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
-        track_fork[4] = TB + 1; track_join[4] = 5;
+        track_fork[4] = TB + 1; track_join[4] = 4;
         // track 5 (TP): everything of the layers / header that is NOT on the way to their Keccak sponges -- byte asserts, SelectorArray1D,
         // leaf detectors -- so that the main track is only inputs + KeccakBytes heads (0), byte ranges (1), sponges A (2), rows (3)
         // and the round expansion starts 0.5 ms earlier; joined before main stage 5.
         const uint32_t TP = 5 * TRACK_STRIDE;
         track_fork[5] = 0; track_join[5] = 5;
+        // track 6 (TQ): PublicCommitment -- KeccakBytes head, byte ranges, its 2-block sponge, selector rows, the commitment -- depends on the
+        // header hash (main stage 3) and the Num2BigEndianBytes of track 4 only, not on the SubstringChecks: forked after (empty) main stage 4,
+        // once track 4 is joined, it runs beside main stages 5..7 instead of extending them by four short dependent stages; joined before 10.
+        const uint32_t TQ = 6 * TRACK_STRIDE;
+        ntracks = 7; track_fork[6] = 4; track_join[6] = 10;
         PobMain& M = L.pm;
         const int Ln = prm.L, LB = 136 * prm.NB, HBy = 136 * prm.HB;
         p.cur = Cur{1, 0, 0, 0};                      // wire 0 = constant 1
@@ -1028,7 +1033,7 @@ struct Plan {
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot, M.blockHeaderLen.i - in0 + 1);       // :122
         for (int j = 0; j < 5; j++) unit(U_POB_N2B, TN + 1, j);                                    // :132-136
-        public_commitment(6, 5);                                                                // :137  (pre 5, ranges 6, sponge 7, rows/post 8, commitment 9)
+        public_commitment(6, TQ + 1);                                                           // :137  (track 6: pre 1, ranges 2, sponge 3, rows/post 4, commitment 5)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
             CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
             L.ll.out = p.sms(LB); L.ll.arr = p.sms(Ln * LB); L.ll.sel = p.sms(1); L.ll.T = p.sms(LB * Ln);

@@ -333,7 +333,8 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < pl.ntracks; t++) {
         pob_ctx::Track& T = h->tracks[t];
-        if (t <= 2) HIPC(hipStreamCreateWithPriority(&T.s_main, hipStreamNonBlocking, prio_hi)); else T.s_main = t == 3 ? h->tracks[2].s_main : h->stream2;      // tracks 4 and 5 follow each other on the BN254 stream
+        if (t <= 2) HIPC(hipStreamCreateWithPriority(&T.s_main, hipStreamNonBlocking, prio_hi));
+        else T.s_main = t == 3 ? h->tracks[2].s_main : t == 6 ? h->tracks[1].s_main : h->stream2;      // tracks 4 and 5 follow each other on the BN254 stream; 6 follows 1
         T.s_heavy = T.s_main;
         HIPC(hipEventCreateWithFlags(&T.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_join, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&T.ev_start, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_end, hipEventDisableTiming));

@@ -379,6 +379,32 @@ def test_max_depth_config5_payload_and_bench(pkg):
     assert "16-layer" in line["config"]["workload"] and line["value"] > 0
 
 
+def test_gpu_witness_satisfies_the_independent_r1cs(pkg):
+    """the referee (proof_of_burn_amd/circuit_model: the circuits restated as A*B = C rows over its own wire numbering) accepts the
+    GPU's witness of the fixture instantiation (64.4 M rows) and of Spend(31), and rejects a witness emitted from a poked resident
+    vector exactly at rows that touch the poked wire"""
+    from proof_of_burn_amd.circuit_model import check as CK, circuit
+    sp = _suite("test_spend")
+    calc = pkg.WitnessCalculator("Spend(31)", max_batch=1)
+    assert calc.calculate(sp["cases"][0]["input"])[0].ok
+    assert CK.check_witness(circuit("Spend(31)"), CK.Witness(calc.witness_payload(0))) == []
+    calc.close()
+    s = _suite("test_proof_of_burn")
+    c = circuit(POB_FIX)
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=1)
+    assert calc.calculate(s["cases"][0]["input"])[0].ok
+    assert CK.check_witness(c, CK.Witness(calc.witness_payload(0))) == []
+    for name, k in (("poseidon", 300), ("sc.M", 17), ("pad.div.out", 1)):
+        cls, idx, wire = calc.debug_ref(name, k)
+        calc.poke(cls, idx, 0, 4)
+        bad = CK.check_witness(c, CK.Witness(calc.witness_payload(0)))
+        calc.poke(cls, idx, 0, 4)
+        assert bad and all(wire in wires for _, wires in bad), (name, wire, bad[:3])
+    calc.close()
+    # (the production instantiation's 215.9 M rows x 6.9 GB payload go through the same code: `python -m proof_of_burn_amd.circuit_model
+    #  check "ProofOfBurn(16, 4, 16, ...)" witness.wtns`; not run here: it needs ~25 GB of host memory next to the other tests' buffers)
+
+
 def test_pow_search_gpu_matches_host(pkg):
     """row f1: the input producer's proof-of-work (tests/main.py:47-56) as a HIP kernel returns the same first key as the
     sequential host search, for 1..3 zero bytes, including a start key whose low 64 bits wrap."""
