@@ -19,6 +19,7 @@ struct GArgs {
     uint32_t* status; uint32_t* chk_status; uint32_t* bad_wire;
     uint8_t* emit_out; uint32_t emit_sel, emit_group;
     uint32_t emit_w0, emit_wn;                         // emission window: wires [emit_w0, emit_w0 + emit_wn) land at emit_out + 32 * (w - emit_w0)
+    unsigned long long* emit_probe;                    // probe pass: nothing is written, bit (w / emit_wn) of emit_probe[unit] is set instead
     uint32_t stage_lds;                                // 1: stage the Poseidon table in LDS (dynamic shared memory)
 };
 struct KArgs {

@@ -40,6 +40,12 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
+// emission window pre-fill (0xEE..: not a field element, so a wire nobody owns is caught by the byte compare); rocclr's fill kernel
+// took 4.5 ms per 256 MiB window, this one runs at the HBM write rate
+__global__ void __launch_bounds__(256) k_fill_ee(uint4* p, uint64_t n16) {
+    const uint4 v = make_uint4(0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
+}
 __global__ void k_xor_u8(uint8_t* p, uint8_t mask) { *p ^= mask; }
 
 // ---- proof-of-work search (input producer, reference tests/main.py:47-56): thread t hashes key = start + t
@@ -109,6 +115,10 @@ struct pob_ctx {
         uint64_t win_wires = 0, alloc_wires = 0, next_make = 0, next_take = 0, nwin = 0; uint32_t idx = 0; bool active = false;
         struct Run { uint32_t w, b, n; };
         std::vector<Run> runs;                          // the Keccak-owned BIT runs (wire index, BIT rank, count), sorted by wire index
+        // which G units write into which window (found by one probe pass per window size): a window launches only those
+        uint64_t probe_win = 0; uint32_t* d_order = nullptr; unsigned long long* d_probe = nullptr;
+        struct WSeg { uint32_t cls, first, count; };
+        std::vector<std::vector<WSeg>> wsegs;
     } em;
     // schedule
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
@@ -390,7 +400,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1]};
+                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_order, h->em.d_probe};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < 2; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -592,13 +602,15 @@ static int emit_make_window(pob_ctx* h, uint64_t k) {
     const uint64_t W = h->plan.total.w, w0 = k * E.win_wires, wn = std::min(E.win_wires, W - w0);
     hipStream_t st = h->stream;
     HIPC(hipStreamWaitEvent(st, E.ev_free[slot], 0));                       // the copy of the window that used this slot before is done
-    HIPC(hipMemsetAsync(E.d_win[slot], 0xEE, wn * 32, st));                 // any wire nobody owns stays 0xEE.. (not a field element)
+    hipLaunchKernelGGL(k_fill_ee, dim3(2048), dim3(256), 0, st, (uint4*)E.d_win[slot], wn * 2);    // any wire nobody owns stays 0xEE.. (not a field element)
     if (w0 == 0) { const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(E.d_win[slot], one, 32, hipMemcpyHostToDevice, st)); }   // wire 0 = 1
     GArgs A = gargs(h);
     A.emit_out = E.d_win[slot]; A.emit_sel = E.idx % 64; A.emit_group = E.idx / 64; A.emit_w0 = (uint32_t)w0; A.emit_wn = (uint32_t)wn;
-    for (const pob_ctx::Seg& sg : h->emit_segs) {
-        A.first = sg.first; A.stage_lds = 0;
-        launch_g_emit(A, sg.lds, sg.count, st);
+    if (E.probe_win == E.win_wires && k < E.wsegs.size()) {                 // only the units that write into this window
+        A.order = E.d_order;
+        for (const pob_ctx::Emit::WSeg& sg : E.wsegs[k]) { A.first = sg.first; A.stage_lds = 0; launch_g_emit(A, sg.cls, sg.count, st); }
+    } else {
+        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; A.stage_lds = 0; launch_g_emit(A, sg.lds, sg.count, st); }
     }
     const u64* Gp = (const u64*)h->d_bits + (uint64_t)(E.idx / 64) * h->plan.total.b;
     for (const pob_ctx::Emit::Run& r : E.runs) {                            // the Keccak kernels' wires: contiguous BIT runs cut to the window
@@ -649,6 +661,34 @@ int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
             HIPC(hipHostMalloc((void**)&E.h_pin[k], window_wires * 32, hipHostMallocDefault));
         }
         E.alloc_wires = window_wires;
+    }
+    const uint64_t nwin_ = (W + window_wires - 1) / window_wires;
+    if (E.probe_win != window_wires && nwin_ <= 64) {
+        // probe pass: every G unit runs once with the emitter's stores replaced by "mark window w / window_wires"; a window then
+        // launches only the units that can write into it (most windows hold nothing but Keccak round wires)
+        const size_t nu = h->plan.units.size();
+        if (!E.d_probe) HIPC(hipMalloc(&E.d_probe, nu * 8));
+        HIPC(hipMemset(E.d_probe, 0, nu * 8));
+        GArgs A = gargs(h);
+        A.emit_sel = 0; A.emit_group = idx / 64; A.emit_w0 = 0; A.emit_wn = (uint32_t)window_wires; A.emit_probe = E.d_probe; A.emit_out = nullptr;
+        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; A.stage_lds = 0; launch_g_emit(A, sg.lds, sg.count, h->stream); }
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> mask(nu);
+        HIPC(hipMemcpy(mask.data(), E.d_probe, nu * 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order;
+        E.wsegs.assign(nwin_, {});
+        for (uint64_t wi = 0; wi < nwin_; wi++)
+            for (const pob_ctx::Seg& sg : h->emit_segs) {
+                pob_ctx::Emit::WSeg ws{sg.lds, (uint32_t)order.size(), 0};
+                for (uint32_t j = 0; j < sg.count; j++) { const uint32_t u = h->order[sg.first + j]; if ((mask[u] >> wi) & 1) order.push_back(u); }
+                ws.count = (uint32_t)order.size() - ws.first;
+                if (ws.count) E.wsegs[wi].push_back(ws);
+            }
+        if (E.d_order) { HIPC(hipFree(E.d_order)); E.d_order = nullptr; }
+        HIPC(hipMalloc(&E.d_order, std::max<size_t>(order.size(), 1) * 4));
+        if (!order.empty()) HIPC(hipMemcpy(E.d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        E.probe_win = window_wires;
     }
     for (int k = 0; k < 2; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
     E.win_wires = window_wires; E.nwin = (W + window_wires - 1) / window_wires; E.idx = idx; E.next_make = 0; E.next_take = 0; E.active = true;

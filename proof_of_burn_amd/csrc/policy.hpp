@@ -487,8 +487,10 @@ struct CheckP : DevPol {
 struct EmitP : DevPol {
     static constexpr bool is_gen = false, is_check = false, is_emit = true, is_count = false;
     uint8_t* out;      // canonical witness payload of the wires [w0, w0 + wn) (the emission window), 32 B per wire
-    uint32_t sel, w0, wn;
+    uint32_t sel, w0, wn, unit;
+    unsigned long long* probe;      // probe pass (once per window size): which windows does this unit write to?  bit w / wn of probe[unit]
     __device__ __forceinline__ void w32(uint32_t w, const F& canon) {
+        if (probe) { atomicOr(probe + unit, 1ull << (w / wn)); return; }
         if (w - w0 >= wn) return;
         uint4* q = (uint4*)(out + (size_t)(w - w0) * 32);
         q[0] = make_uint4(canon.l[0], canon.l[1], canon.l[2], canon.l[3]);

@@ -74,6 +74,7 @@ template <class T> static inline void hs_buf_st(T v, hs_rsrc r, int voff, int so
 #define __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, aux) hs_buf_st<hs_v2i>(v, r, vo, so)
 
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
 // ---- runtime API (synchronous)
 typedef int hipError_t;
