@@ -58,7 +58,7 @@ def cpu_baseline(batch, info, single_samples: int, budget_s: float = 25.0):
     except Exception:
         avail_gb = 32.0
     cores = os.cpu_count() or 1
-    nproc = max(1, min(cores, int(avail_gb * 0.4 / per_proc_gb), 16))
+    nproc = max(1, min(cores, int(avail_gb * 0.4 / per_proc_gb), 32))
     per = max(1, min(4, int(budget_s / max(t_single * 1.5, 0.1))))
     jobs = [(MAIN, [batch.inputs[(p * per + j) % len(batch.inputs)] for j in range(per)],
              [batch.commitments[(p * per + j) % len(batch.inputs)] for j in range(per)]) for p in range(nproc)]
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over the global batch")
     ap.add_argument("--cpu-samples", type=int, default=2, help="witnesses timed single-threaded on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurement")
     ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records (uint8 [N*B, 36]) to this .npy")
     args = ap.parse_args()
 
@@ -213,7 +214,7 @@ def main():
 
     # ---- .wtns emission (the step after the path): 2 witnesses back to back through the window pipeline into pinned host memory
     emission = None
-    if rank == 0:
+    if rank == 0 and not args.no_emission:
         sec, nbytes = calcs[0].emit_throughput(0, count=2)
         emission = {"what": "canonical 32 B/wire payload expanded on the GPU in 256 MiB windows, D2H double-buffered into pinned memory, 2 witnesses back to back",
                     "GB_per_s": round(nbytes / sec / 1e9, 2), "ms_per_witness": round(sec / 2 * 1e3, 1), "bytes_per_witness": nbytes // 2}

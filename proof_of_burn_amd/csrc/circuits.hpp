@@ -1058,8 +1058,9 @@ struct Plan {
                 expect_cursor("SubstringCheck", p.cur, chk.cur);
                 const SmRef src = M.layers + (i - 1) * LB;
                 for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32)
-                    record(U_ABS_RANGE, 5, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
-                for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) record(U_SC_M, 5, start, i, lo, std::min<uint32_t>(lo + 32, LB));
+                    record(U_ABS_RANGE, TP + 1, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
+                // M[] depends on the layer's INPUT bytes only (not on any hash): with the byte asserts it runs on track 5, beside the expansion
+                for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) record(U_SC_M, TP + 1, start, i, lo, std::min<uint32_t>(lo + 32, LB));
                 const uint32_t kk = LB - 31 + 1;
                 for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
                 record(U_SC_SUMS, 7, sc.c_tail, i);

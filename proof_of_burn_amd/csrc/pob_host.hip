@@ -509,7 +509,8 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     // by what the evaluation saves -- so it is off by default.
     static const int early_k = getenv("POB_CHECK_EARLY_K") ? atoi(getenv("POB_CHECK_EARLY_K")) : 0;
     static const std::string plan = getenv("POB_CHECK_PLAN") ? getenv("POB_CHECK_PLAN") : (early_k ? "1,2,3;7,5;4,6,0" : "1,2,K;7,5,3,6,0;4");
-    hipStream_t ss[3] = {st, h->stream2, h->stream3};
+    // (a fourth sequence, if the plan has one, runs on track 2's stream, which is idle during the evaluation)
+    hipStream_t ss[4] = {st, h->stream2, h->stream3, h->plan.ntracks > 2 ? h->tracks[2].s_main : h->stream2};
     bool keccak_done = false;
     {   // reset of the evaluator's results: ahead of the FIRST kernel that may write them (the early Keccak evaluation)
         hipStream_t sr = (early_k && !h->plan.sponges.empty()) ? h->stream_k : st;
@@ -531,6 +532,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipEventRecord(h->ev_fork, st));
     HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     HIPC(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+    if (ss[3] != h->stream2) HIPC(hipStreamWaitEvent(ss[3], h->ev_fork, 0));
     uint32_t done = 0; int si = 0;
     auto run_item = [&](char c) -> int {
         if (c == 'K') {
@@ -549,12 +551,13 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         }
         return POB_OK;
     };
-    for (char c : plan) { if (c == ';') { if (si < 2) si++; } else run_item(c); }
+    for (char c : plan) { if (c == ';') { if (si < 3) si++; } else run_item(c); }
     si = 0;                                              // whatever the plan left out runs on the caller's stream
     for (uint32_t fam = 0; fam < F_COUNT; fam++) run_item((char)('0' + fam));
     run_item('K');
     HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipEventRecord(h->ev_join3, h->stream3));
     HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
+    if (ss[3] != h->stream2) { HIPC(hipEventRecord(h->ev_join4, ss[3])); HIPC(hipStreamWaitEvent(st, h->ev_join4, 0)); }
     if (early_k && !h->plan.sponges.empty()) HIPC(hipStreamWaitEvent(st, h->ev_joink, 0));
     HIPC(hipGetLastError());
     return POB_OK;
@@ -602,7 +605,9 @@ static int emit_make_window(pob_ctx* h, uint64_t k) {
     const uint64_t W = h->plan.total.w, w0 = k * E.win_wires, wn = std::min(E.win_wires, W - w0);
     hipStream_t st = h->stream;
     HIPC(hipStreamWaitEvent(st, E.ev_free[slot], 0));                       // the copy of the window that used this slot before is done
-    hipLaunchKernelGGL(k_fill_ee, dim3(2048), dim3(256), 0, st, (uint4*)E.d_win[slot], wn * 2);    // any wire nobody owns stays 0xEE.. (not a field element)
+    static const int own_fill = getenv("POB_EMIT_FILL") ? atoi(getenv("POB_EMIT_FILL")) : 1;
+    if (own_fill) hipLaunchKernelGGL(k_fill_ee, dim3(2048), dim3(256), 0, st, (uint4*)E.d_win[slot], wn * 2);    // any wire nobody owns stays 0xEE.. (not a field element)
+    else HIPC(hipMemsetAsync(E.d_win[slot], 0xEE, wn * 32, st));
     if (w0 == 0) { const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(E.d_win[slot], one, 32, hipMemcpyHostToDevice, st)); }   // wire 0 = 1
     GArgs A = gargs(h);
     A.emit_out = E.d_win[slot]; A.emit_sel = E.idx % 64; A.emit_group = E.idx / 64; A.emit_w0 = (uint32_t)w0; A.emit_wn = (uint32_t)wn;
@@ -663,7 +668,8 @@ int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
         E.alloc_wires = window_wires;
     }
     const uint64_t nwin_ = (W + window_wires - 1) / window_wires;
-    if (E.probe_win != window_wires && nwin_ <= 64) {
+    static const int use_probe = getenv("POB_EMIT_PROBE") ? atoi(getenv("POB_EMIT_PROBE")) : 1;
+    if (use_probe && E.probe_win != window_wires && nwin_ <= 64) {
         // probe pass: every G unit runs once with the emitter's stores replaced by "mark window w / window_wires"; a window then
         // launches only the units that can write into it (most windows hold nothing but Keccak round wires)
         const size_t nu = h->plan.units.size();
