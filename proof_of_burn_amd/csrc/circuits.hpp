@@ -27,7 +27,10 @@ enum UnitKind : uint32_t {
     U_RL_A, U_RL_SLROW, U_RL_ACC, U_RL_B, U_POW_PRE, U_POW_POST, U_POB_FINAL, U_ABS_RANGE, U_LD_HEAD, U_LD_SELR, U_LD_TAIL, U_POB_INPUT_FR, U_RL_ACC_B, U_RL_ACC_C,
     U_SP_INPUT, U_SP_HEAD,
     // evaluator-only units (UNIT_CHECK): sub-blocks of composite units run as wavefronts of their own, from STORED wires
+    U_SC_MI,             // SubstringCheck(a0).mainInput / mainLen copies (inputs only: runs on the pre-work track)
     CK_POS_SEG,          // a0 = T, a1 = segment (>= 1) of the Poseidon block at cur (gadgets.hpp gPoseidonSegStored)
+    CK_SR_COLS,          // columns [a2, a3) of temps[][] of the ShiftRight(a0, a1) block at cur (gadgets.hpp gShiftRightCols)
+    CK_SL_ROWS,          // rows [a1, a2) of the ShiftLeft(a0) block at cur, IsEqual children from cursor (a3, a4, a5) on (gShiftLeftRows)
     CK_N2BE,             // Num2BigEndianBytes(a0) at cur; a1,a2 = source FR wire; a3,a4,a5 = caller's copy of out[] (w, i, present)
     U_KIND_COUNT
 };
@@ -43,7 +46,7 @@ HD constexpr uint32_t fam_of(uint32_t k) {
     return (k == U_KB_RANGE || k == U_ABS_RANGE) ? F_RANGE
          : k == U_KB_SELROW ? F_SELROW
          : (k == U_LD_HEAD || k == U_LD_SELR || k == U_LD_TAIL || k == U_POB_LASTLAYER_RANGE || k == U_SC_SUMS) ? F_LD
-         : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B) ? F_RL
+         : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B || k == CK_SR_COLS || k == CK_SL_ROWS) ? F_RL
          : (k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE) ? F_SC
          : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG) ? F_POS
          : (k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_N2B || k == U_PC_POST || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == CK_N2BE) ? F_N2B
@@ -119,6 +122,7 @@ struct RaRefs {
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
 struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; uint32_t cost, flags; };
 
+#define SC_RANGE_POS 32          // positions of SubstringCheck's existence loop per unit (one batch inversion each; <= 64)
 #define MAX_KB 72
 #define MAX_SC 64
 // everything a unit body needs besides the policy; lives in device memory, read-only on the device
@@ -536,7 +540,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const int N = prm.amountBytes;
         p.cur = A.c_cb;
         const S length = p.put(A.len, gCountBytes(p, N, A.by));
-        SmRef r = gShiftLeft(p, N, A.by, N - length);
+        SmRef r = gShiftLeft(p, N, A.by, N - length, true);
         copy_n(p, A.be, r, (int)(N));
     } break;
     UCASE(U_RL_ACC_C) {           // RlpInteger outputs (:96-109), RlpEmptyAccount prefixes + Concat(4+N, 66) (empty_account.circom:40-133)
@@ -556,7 +560,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         p.put(A.pn + 1, nb + 66);
         p.cur = A.c_concat;
         S clen;
-        SmRef cc = gConcat(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen);
+        SmRef cc = gConcat(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen, true);
         { copy_n(p, A.ea_o, cc, (int)(maxAcc)); copy_n(p, R.acc, cc, (int)(maxAcc)); }
         p.put(R.accLen, p.put(A.ea_ol, clen));
     } break;
@@ -586,7 +590,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const S pl = p.put(R.pkLen, 3 + kl);
         p.cur = R.c_concat;
         S cl;
-        SmRef c = gConcat(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl);
+        SmRef c = gConcat(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl, true);
         { copy_n(p, R.o, c, (int)(maxOut)); copy_n(p, M.leaf, c, (int)(maxOut)); }
         p.put(M.leafLen, p.put(R.ol, cl));
     } break;
@@ -735,8 +739,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             const int mm = LB, sl = 31, kk = mm - sl + 1;
             sc.out = p.bits(1); sc.mi = p.sms(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
             sc.num = p.frs(1); sc.M = p.frs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
-            for (int k = 0; k < mm; k++) p.put(sc.mi + k, p.get(M.layers + ((i - 1) * LB + k)));
-            S mainLen = p.put(sc.ml, p.get(M.layerLens + (i - 1)));
+            const S mainLen = p.get(sc.ml);                  // mainInput[] / mainLen are written by U_SC_MI (inputs only: pre-work track)
             for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
             sc.c_abs_sub = p.cur;
             gAssertByteString(p, sl, sc.si);
@@ -753,6 +756,11 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             p.cur = cur_add(p.cur, Cur{3, 1, 2, 0}, 1);            // the final IsZero
             if (P::is_count) L.scs[i] = sc;
         }
+    } break;
+    UCASE(U_SC_MI) {              // SubstringCheck's own copies of its inputs: mainInput[mm] <== layers[i-1], mainLen <== layerLens[i-1] (:25-26)
+        const ScRefs& sc = L.scs[d.a[0]];
+        copy_n(p, sc.mi, M.layers + ((d.a[0] - 1) * LB), LB);
+        p.put(sc.ml, p.get(M.layerLens + (d.a[0] - 1)));
     } break;
     UCASE(U_SC_M) {               // M[k+1] <== mainInput[k]*256^k + M[k]  (substring_check.circom:45-49) for k in [a1, a2); reads the source
                                  // bytes; 256^k comes from a table in "double Montgomery" form so that byte * 256^k is ONE Montgomery
@@ -847,6 +855,12 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         else if (d.a[0] == 4) gPoseidonSegStored<P, 4>(p, pos_off(4), d.cur, d.a[1]);
         else gPoseidonSegStored<P, 5>(p, pos_off(5), d.cur, d.a[1]);
     } break;
+    UCASE(CK_SR_COLS) {
+        if constexpr (P::is_check || P::is_count) gShiftRightCols(p, (int)d.a[0], (int)d.a[1], d.cur, d.a[2], d.a[3]);
+    } break;
+    UCASE(CK_SL_ROWS) {
+        if constexpr (P::is_check || P::is_count) gShiftLeftRows(p, (int)d.a[0], d.cur, Cur{d.a[3], d.a[4], d.a[5], d.cur.f, d.cur.q}, d.a[1], d.a[2]);
+    } break;
     UCASE(CK_N2BE) {             // Num2BigEndianBytes(a0) at cur of the stored FR wire (a1, a2), caller's copy of out[] at (a3, a4) if a5
         if constexpr (P::is_check || P::is_count) {
             const FrRef src = {d.a[1], d.a[2]}; const SmRef also = {d.a[3], d.a[4]};
@@ -884,7 +898,7 @@ struct Plan {
     }
     void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0) {
         UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.cost = 0; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5;
-        d.flags = (kind == CK_POS_SEG || kind == CK_N2BE) ? UNIT_CHECK : (UNIT_GEN | UNIT_CHECK);
+        d.flags = (kind == CK_POS_SEG || kind == CK_N2BE || kind == CK_SR_COLS || kind == CK_SL_ROWS) ? UNIT_CHECK : (UNIT_GEN | UNIT_CHECK);
         units.push_back(d);
         if (stage > max_stage) max_stage = stage;
     }
@@ -893,15 +907,29 @@ struct Plan {
         const UnitDesc d = units.back();
         p.nnotes = 0;
         unit_run_all(p, d, L);             // CountP: advances p.cur over the unit's wires, fills the reference tables
-        // sub-blocks the evaluator runs as wavefronts of their own (they start from stored wires): Poseidon segments 1.., byte conversions
-        for (uint32_t k = 0; k < p.nnotes; k++) {
-            const PlanNote& nt = p.notes[k];
+        take_notes(p, stage);
+    }
+    // sub-blocks the evaluator runs as wavefronts of their own (they start from stored wires): Poseidon segments 1.., byte conversions,
+    // ShiftRight columns, ShiftLeft rows -- from the notes the counting policy took while it walked a composite unit
+    void take_notes(CountP& q, uint32_t stage) {
+        for (uint32_t k = 0; k < q.nnotes; k++) {
+            const PlanNote& nt = q.notes[k];
             if (nt.what == NOTE_POSEIDON) {
                 const uint32_t ns = pos_nseg(pos_off((int)nt.n).rp);
                 for (uint32_t seg = 1; seg < ns; seg++) record(CK_POS_SEG, stage, nt.cur, nt.n, seg);
             } else if (nt.what == NOTE_N2BE) record(CK_N2BE, stage, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4]);
+            else if (nt.what == NOTE_SHIFTRIGHT) { for (uint32_t j = 0; j < nt.n; j += 8) record(CK_SR_COLS, stage, nt.cur, nt.n, nt.a[0], j, std::min(j + 8, nt.n)); }
+            else if (nt.what == NOTE_SHIFTLEFT) { for (uint32_t i = 0; i < nt.n; i += 2) record(CK_SL_ROWS, stage, nt.cur, nt.n, i, std::min(i + 2, nt.n), nt.a[0], nt.a[1], nt.a[2]); }
         }
-        p.nnotes = 0;
+        q.nnotes = 0;
+    }
+    // a unit recorded at an explicit cursor (not walked by `unit`): walk it on a scratch counting policy for its notes
+    void record_composite(uint32_t kind, uint32_t stage, Cur cur) {
+        record(kind, stage, cur);
+        const UnitDesc d = units.back();
+        CountP q; q.nnotes = 0;
+        unit_run_all(q, d, L);
+        take_notes(q, stage);
     }
     // AssertByteString(N)(src) as range units; p.cur = start of the AssertByteString block
     void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32) {
@@ -980,8 +1008,8 @@ struct Plan {
         L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
         L.fp_n2be32 = n2be_footprint(32); L.fp_n2beN = n2be_footprint(prm.amountBytes);
         // track 1 (TB): everything that hangs off the main inputs only -- range checks, Poseidons, BurnAddressHash, ProofOfWorkChecker,
-        // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before PublicCommitment
-        // (main stage 5).  track 2 (TR): the RlpMerklePatriciaTrieLeaf assembly, forked once BurnAddressHash is done (TB + 5) and
+        // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before main stage 5
+        // (joining it only before the final stage 10 was measured: no gain, the tracks' streams just contend differently).  track 2 (TR): the RlpMerklePatriciaTrieLeaf assembly, forked once BurnAddressHash is done (TB + 5) and
         // joined before the final comparisons (main stage 10).  track 3 (TC): RlpEmptyAccount's serial chain, joined before TR + 2.
         // track 4 (TN): the five Num2BigEndianBytes of PublicCommitment's inputs, forked once the Poseidons are done (TB + 1), joined
         // before PublicCommitment's track forks (main stage 4); it runs on the main track's BN254 stream, which is idle until then.
@@ -1062,7 +1090,8 @@ struct Plan {
                 // M[] depends on the layer's INPUT bytes only (not on any hash): with the byte asserts it runs on track 5, beside the expansion
                 for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) record(U_SC_M, TP + 1, start, i, lo, std::min<uint32_t>(lo + 32, LB));
                 const uint32_t kk = LB - 31 + 1;
-                for (uint32_t lo = 0; lo < kk; lo += 32) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min(lo + 32, kk));
+                record(U_SC_MI, TP + 1, start, i);
+                for (uint32_t lo = 0; lo < kk; lo += SC_RANGE_POS) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min<uint32_t>(lo + SC_RANGE_POS, kk));
                 record(U_SC_SUMS, 7, sc.c_tail, i);
             }
         }
@@ -1091,10 +1120,10 @@ struct Plan {
                 unit(U_RL_ACC, TC + 1);                             // depends on the balance input only: its own track
                 expect_cursor("RlpEmptyAccount", p.cur, qa.cur);
                 p.cur = keep;
-                record(U_RL_ACC_B, TC + 2, L.ra.c_cb);
-                record(U_RL_ACC_C, TC + 3, L.ra.c_concat);          // long serial unit
+                record_composite(U_RL_ACC_B, TC + 2, L.ra.c_cb);
+                record_composite(U_RL_ACC_C, TC + 3, L.ra.c_concat);          // long serial unit
             }
-            record(U_RL_B, TR + 2, R.c_mux);
+            record_composite(U_RL_B, TR + 2, R.c_mux);
             p.cur = chk.cur;
         }
         {   // ProofOfWorkChecker :211

@@ -589,11 +589,18 @@ template <class P> GD SmRef gSelectorArray1D(P& p, int n, int q, SmRef src, S se
 
 // ============================================================================ circuits/utils/shift.circom
 // ShiftLeft(n) :17-37  [out[n] | in[n], count | isEq[n][n], temp[n][n]] || AssertLessEqThan(16)(count, n), IsEqual([i, j-count]) x n^2
-template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count) {
+// `split`: the caller is a composite unit of the device plan -- the evaluator runs the n rows (n^2 IsEqual gadgets: almost all of the
+// block) as CK_SL_ROWS units of their own and the composite only steps over them
+template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count, bool split = false) {
+    const Cur blk = p.cur;
     SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(n * n); SmRef temp = p.sms(n * n);
     count = p.put(cn, count);
     copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)n);
+    if constexpr (P::is_count) { if (split) p.note(NOTE_SHIFTLEFT, (uint32_t)n, blk, p.cur.w, p.cur.b, p.cur.s); }
+    if constexpr (P::is_check) {
+        if (split) { p.cur = cur_add(p.cur, Cur{6, 2, 4, 0, 0}, (uint32_t)(n * n)); return o; }
+    }
     for (int i = 0; i < n; i++) {
         S acc = 0;
         for (int j = 0; j < n; j++) {
@@ -604,22 +611,42 @@ template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count) {
     }
     return o;
 }
+// rows [i0, i1) of the ShiftLeft(n) block at `blk` (IsEqual children from `ciseq` on), from the stored count / in[]
+template <class P> GD void gShiftLeftRows(P& p, int n, Cur blk, Cur ciseq, uint32_t i0, uint32_t i1) {
+    const SmRef o = {blk.w, blk.s}, in = o + (uint32_t)n, cn = in + (uint32_t)n;
+    const BitRef isEq = {cn.w + 1, blk.b}; const SmRef temp = {isEq.w + (uint32_t)(n * n), cn.i + 1};
+    const S count = p.get(cn);
+    for (uint32_t i = i0; i < i1; i++) {
+        S acc = 0;
+        p.cur = cur_add(ciseq, Cur{6, 2, 4, 0, 0}, i * (uint32_t)n);
+        for (uint32_t j = 0; j < (uint32_t)n; j++) {
+            B e = p.put(isEq + (i * n + j), gIsEqualS(p, (S)i, (S)((S)j - count)));
+            acc += p.put(temp + (i * n + j), p.bit(e) ? p.get(in + j) : 0);
+        }
+        p.put(o + i, acc);
+    }
+}
 // ShiftRight(n, ms) :51-75  [out[n+ms] | in[n], count | isEq[ms+1], temps[ms+1][n]] || AssertLessEqThan(16)(count, ms), IsEqual([i, count]) x (ms+1)
-template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count) {
+// `split`: the caller is a composite unit of the device plan -- the evaluator runs the (ms+1) x n temps[][] (almost all of the block) as
+// CK_SR_COLS units of their own
+template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count, bool split = false) {
+    if constexpr (P::is_count) { if (split) p.note(NOTE_SHIFTRIGHT, (uint32_t)n, p.cur, (uint32_t)ms); }
     SmRef o = p.sms(n + ms), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(ms + 1); SmRef temps = p.sms((ms + 1) * n);
     count = p.put(cn, count);
     copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)ms);
     for (int i = 0; i <= ms; i++) p.put(isEq + i, gIsEqualS(p, (S)i, count));      // isEq[i] = [i == count]
     // temps[i][j] = isEq[i] * in[j]: each in[j] is read once (not once per i), the column is written without reading anything back
-    for (int j0 = 0; j0 < n; j0 += 8) {
-        S v[8];
+    if (!(P::is_check && split)) {
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            S v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = p.get(src + (uint32_t)(j0 + q < n ? j0 + q : n - 1));
-        for (int i = 0; i <= ms; i++) {
-            const bool hit = (uint32_t)i == (uint32_t)count;
+            for (int q = 0; q < 8; q++) v[q] = p.get(src + (uint32_t)(j0 + q < n ? j0 + q : n - 1));
+            for (int i = 0; i <= ms; i++) {
+                const bool hit = (uint32_t)i == (uint32_t)count;
 #pragma unroll
-            for (int q = 0; q < 8; q++) if (j0 + q < n) p.put(temps + (uint32_t)(i * n + j0 + q), hit ? v[q] : 0);
+                for (int q = 0; q < 8; q++) if (j0 + q < n) p.put(temps + (uint32_t)(i * n + j0 + q), hit ? v[q] : 0);
+            }
         }
     }
     // out[t] = sum_{i+j=t} temps[i][j] = in[t - count] when 0 <= t - count < n (exactly one isEq is set), read per witness
@@ -638,6 +665,23 @@ template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count)
     }
     return o;
 }
+// columns [j0, j1) of temps[][] of the ShiftRight(n, ms) block at `blk`: temps[i][j] == isEq[i] * in[j] on the STORED isEq[] / in[]
+template <class P> GD void gShiftRightCols(P& p, int n, int ms, Cur blk, uint32_t j0, uint32_t j1) {
+    const SmRef o = {blk.w, blk.s}, in = o + (uint32_t)(n + ms), cn = in + (uint32_t)n;
+    const BitRef isEq = {cn.w + 1, blk.b}; const SmRef temps = {isEq.w + (uint32_t)(ms + 1), cn.i + 1};
+    uint64_t hits = 0;                                   // bit i: isEq[i] of this lane's witness (ms + 1 <= 64)
+    for (int i = 0; i <= ms; i++) hits |= (uint64_t)p.bit(p.get(isEq + (uint32_t)i)) << i;
+    for (uint32_t c0 = j0; c0 < j1; c0 += 8) {
+        S v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) v[q] = p.get(in + (c0 + q < j1 ? c0 + q : j1 - 1));
+        for (int i = 0; i <= ms; i++) {
+            const bool hit = (hits >> i) & 1;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) if (c0 + q < j1) p.put(temps + ((uint32_t)i * (uint32_t)n + c0 + q), hit ? v[q] : 0);
+        }
+    }
+}
 // Mask(n) :18-30  [out[n] | in[n], count | filter[n]] || Filter(n)
 template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef flt = p.bits(n);
@@ -652,7 +696,7 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
 }
 // Concat(A,B) :47-83  [out[A+B], outLen | a[A], aLen, b[B], bLen | maskedA[A], maskedB[B], shiftedB[A+B]]
 //   || AssertLessEqThan(16) x2, Mask(A), Mask(B), ShiftRight(B, A)
-template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef b, S bLen, S& outLen) {
+template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef b, S bLen, S& outLen, bool split = false) {
     SmRef o = p.sms(La + Lb), ol = p.sms(1), ia = p.sms(La), ial = p.sms(1), ib = p.sms(Lb), ibl = p.sms(1);
     SmRef mA = p.sms(La), mB = p.sms(Lb), sB = p.sms(La + Lb);
     copy_n(p, ia, a, (int)(La));
@@ -665,7 +709,7 @@ template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef
     copy_n(p, mA, x, (int)(La));
     x = gMask(p, Lb, ib, bLen);
     copy_n(p, mB, x, (int)(Lb));
-    x = gShiftRight(p, Lb, La, mB, aLen);
+    x = gShiftRight(p, Lb, La, mB, aLen, split);
     for (int i = 0; i < La + Lb; i++) {
         S s = p.put(sB + i, p.get(x + i));
         p.put(o + i, i < La ? p.get(mA + i) + s : s);

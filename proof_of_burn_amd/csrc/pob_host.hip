@@ -125,9 +125,10 @@ struct pob_ctx {
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, emit_segs, chk_segs;        // per (stage, class) for generation; per class for emission; per FAMILY for evaluation
     hipStream_t stream2 = nullptr, stream3 = nullptr; bool own_stream3 = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
-    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; };
+    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; uint32_t is_long; };
     std::vector<KSeg> ksegs;                           // ev_done: recorded behind the segment's sponge kernels in pob_generate
     hipStream_t stream_k = nullptr; hipEvent_t ev_joink = nullptr;      // the Keccak evaluation's own stream (see pob_constraint_check)
+    hipStream_t stream_long = nullptr; hipEvent_t ev_long_fork = nullptr, ev_long_join = nullptr;   // a stage's LONG sponges (>= POB_LONG_SPONGE blocks)
     // side tracks (Plan::track_fork/track_join): own light + BN254 streams, own fork/join events, start and end events
     // (ROCm multiplexes streams onto 4 hardware queues by default: the handle keeps to the caller's stream + 3 of its own --
     //  stream2, trackB (track 1), trackC (tracks 2 and 3, which run one after the other anyway); a track's BN254 and light
@@ -285,7 +286,13 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         pl.L.prefix[0] = base; pl.L.prefix[1] = fr_add(base, fr_one_mont()); pl.L.prefix[2] = fr_add(pl.L.prefix[1], fr_one_mont());
     }
     // ---- schedule: sponges sorted by stage, perms flattened; units grouped by (stage, needs LDS table)
-    std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [](const SpongeDesc& a, const SpongeDesc& b) { return a.stage < b.stage; });
+    // A stage's LONG sponges (the header's 16 blocks: 0.7 ms of serial chain) go to a stream of their own, so that the round expansion
+    // of the short ones (the layers' 4-block sponges: 0.18 ms of chain) does not wait for the long chain.  POB_LONG_SPONGE=8 turns it on.
+    // Measured: the long chain beside the expansion takes 4.3-4.8 ms instead of 0.7 and the step does not get shorter: off by default.
+    const uint32_t long_n = getenv("POB_LONG_SPONGE") ? (uint32_t)atoi(getenv("POB_LONG_SPONGE")) : 0;
+    auto is_long = [&](const SpongeDesc& sp) { return long_n && sp.n >= long_n ? 1u : 0u; };
+    std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [&](const SpongeDesc& a, const SpongeDesc& b) {
+        return a.stage != b.stage ? a.stage < b.stage : is_long(a) < is_long(b); });
     std::vector<uint32_t> perm_sponge, perm_block;
     for (uint32_t s = 0; s <= pl.max_stage; s++) {
         // a stage's heavy units go into ONE launch (with the LDS table if any of them needs it) unless there are many of them
@@ -304,15 +311,20 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
             if (sg.count) h->segs.push_back(sg);
         }
-        pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0, nullptr};
-        bool first = true;
-        for (uint32_t i = 0; i < pl.sponges.size(); i++) if (pl.sponges[i].stage == s) {
-            if (first) { ks.sp_first = i; first = false; }
-            ks.sp_count++;
-            for (uint32_t b = 0; b < pl.sponges[i].n; b++) { perm_sponge.push_back(i); perm_block.push_back(b); }
+        for (uint32_t lg = 0; lg < 2; lg++) {
+            pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0, nullptr, lg};
+            bool first = true;
+            for (uint32_t i = 0; i < pl.sponges.size(); i++) if (pl.sponges[i].stage == s && is_long(pl.sponges[i]) == lg) {
+                if (first) { ks.sp_first = i; first = false; }
+                ks.sp_count++;
+                for (uint32_t b = 0; b < pl.sponges[i].n; b++) { perm_sponge.push_back(i); perm_block.push_back(b); }
+            }
+            ks.perm_count = (uint32_t)perm_sponge.size() - ks.perm_first;
+            if (ks.sp_count) h->ksegs.push_back(ks);
         }
-        ks.perm_count = (uint32_t)perm_sponge.size() - ks.perm_first;
-        if (ks.sp_count) h->ksegs.push_back(ks);
+    }
+    {   // a long segment only pays off beside a short one of the same stage
+        for (pob_ctx::KSeg& a : h->ksegs) if (a.is_long) { bool has_short = false; for (const pob_ctx::KSeg& b : h->ksegs) has_short |= b.stage == a.stage && !b.is_long; if (!has_short) a.is_long = 0; }
     }
     h->nperms = (uint32_t)perm_sponge.size();
     for (uint32_t cls = 0; cls < 4; cls++) {             // emission: every generation unit once, grouped by class
@@ -338,6 +350,8 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
     HIPC(hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_lo));
+    HIPC(hipStreamCreateWithPriority(&h->stream_long, hipStreamNonBlocking, prio_hi));
+    HIPC(hipEventCreateWithFlags(&h->ev_long_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_long_join, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_joink, hipEventDisableTiming));
     for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -408,6 +422,9 @@ void pob_close(pob_handle h) {
     }
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
     if (h->stream_k) hipStreamDestroy(h->stream_k);
+    if (h->stream_long) hipStreamDestroy(h->stream_long);
+    if (h->ev_long_fork) hipEventDestroy(h->ev_long_fork);
+    if (h->ev_long_join) hipEventDestroy(h->ev_long_join);
     if (h->ev_joink) hipEventDestroy(h->ev_joink);
     for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -466,13 +483,21 @@ int pob_generate(pob_handle h, void* stream_) {
                 } else launch_g_gen(A, 0, sg.count, G, sm);
             }
             if (forked) { HIPC(hipEventRecord(ej, sh)); HIPC(hipStreamWaitEvent(sm, ej, 0)); }
-            for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid) {
-                K.first = ks.sp_first;
-                launch_k_chain(K, false, ks.sp_count, G, sm);
-                K.first = ks.perm_first;
-                launch_k_rounds(K, false, ks.perm_count, G, sm);
-                HIPC(hipEventRecord(ks.ev_done, sm));       // every wire of these sponges exists: their evaluation may start (pob_constraint_check)
-            }
+            bool long_forked = false;
+            for (int pass = 0; pass < 2; pass++)             // the long sponges first (their own stream), then the short ones on this track's stream
+                for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid && (ks.is_long != 0) == (pass == 0)) {
+                    hipStream_t sk = sm;
+                    if (ks.is_long) {
+                        if (!long_forked) { HIPC(hipEventRecord(h->ev_long_fork, sm)); HIPC(hipStreamWaitEvent(h->stream_long, h->ev_long_fork, 0)); long_forked = true; }
+                        sk = h->stream_long;
+                    }
+                    K.first = ks.sp_first;
+                    launch_k_chain(K, false, ks.sp_count, G, sk);
+                    K.first = ks.perm_first;
+                    launch_k_rounds(K, false, ks.perm_count, G, sk);
+                    HIPC(hipEventRecord(ks.ev_done, sk));       // every wire of these sponges exists: their evaluation may start (pob_constraint_check)
+                }
+            if (long_forked) { HIPC(hipEventRecord(h->ev_long_join, h->stream_long)); HIPC(hipStreamWaitEvent(sm, h->ev_long_join, 0)); }
             for (uint32_t u = pl.ntracks; u-- > t + 1;) if (pl.track_fork[u] == sid) {
                 HIPC(hipEventRecord(h->tracks[u].ev_start, sm)); HIPC(hipStreamWaitEvent(h->tracks[u].s_main, h->tracks[u].ev_start, 0));
                 int rc = run_track(u); if (rc) return rc;
@@ -498,9 +523,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     // The evaluation has no dependencies between launches: one kernel per family (+ the two Keccak kernels), spread over the
     // caller's stream and the handle's two side streams.  The plan -- which stream runs what, in which order -- is a string:
     // three ';'-separated sequences (caller's stream; side stream 2; side stream 3) of family numbers (circuits.hpp Fam) and 'K'
-    // (the HBM-streaming Keccak round + chain evaluation).  Default: the wide byte-range / selector-row families first on the
-    // caller's stream, then Keccak; the long serial families (RLP assembly, BN254) on the side streams, where they run BESIDE the
-    // Keccak streaming (their loads are latency-bound, the round evaluation is bandwidth-bound).  POB_CHECK_PLAN overrides it.
+    // (the HBM-streaming Keccak round + chain evaluation).  Default: Keccak alone on the caller's stream from the start, the eight G
+    // families on the two side streams BESIDE it (N2B, SC, LD, RANGE | RL, POS, MISC, SELROW: about 3.5-4.5 ms each under the
+    // bandwidth-bound round evaluation, which takes 5.0 ms beside them and 4.35 alone).  POB_CHECK_PLAN overrides it.
     // POB_CHECK_EARLY_K=1: the Keccak evaluation does not wait for the END of the generation.  It reads only wires the
     // sponge kernels wrote, so each sponge segment is evaluated on the handle's Keccak stream as soon as ITS generation kernels are
     // done -- beside the generation's latency-bound tail (selector rows, SubstringCheck, commitment) and beside the G families,
@@ -508,7 +533,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     // Measured (profiles/round2_*): it gains nothing -- the generation's tail is latency-bound on the same memory system and stretches
     // by what the evaluation saves -- so it is off by default.
     static const int early_k = getenv("POB_CHECK_EARLY_K") ? atoi(getenv("POB_CHECK_EARLY_K")) : 0;
-    static const std::string plan = getenv("POB_CHECK_PLAN") ? getenv("POB_CHECK_PLAN") : (early_k ? "1,2,3;7,5;4,6,0" : "1,2,K;7,5,3,6,0;4");
+    static const std::string plan = getenv("POB_CHECK_PLAN") ? getenv("POB_CHECK_PLAN") : (early_k ? "1,2,3;7,5;4,6,0" : "K;7,5,3,1;4,6,0,2");
     // (a fourth sequence, if the plan has one, runs on track 2's stream, which is idle during the evaluation)
     hipStream_t ss[4] = {st, h->stream2, h->stream3, h->plan.ntracks > 2 ? h->tracks[2].s_main : h->stream2};
     bool keccak_done = false;

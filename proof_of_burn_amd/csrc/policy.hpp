@@ -62,7 +62,7 @@ struct PolBase {
 // ------------------------------------------------------------------ host-side layout planner policy
 // sub-blocks of a composite unit that the constraint evaluator runs as wavefronts of their own (circuits.hpp CK_* units);
 // the counting policy notes them while the planner walks the composite
-enum : uint32_t { NOTE_POSEIDON = 1, NOTE_N2BE = 2 };
+enum : uint32_t { NOTE_POSEIDON = 1, NOTE_N2BE = 2, NOTE_SHIFTRIGHT = 3, NOTE_SHIFTLEFT = 4 };
 struct PlanNote { uint32_t what, n; Cur cur; uint32_t a[5]; };
 struct CountP : PolBase {
     static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
