@@ -38,11 +38,14 @@ struct GenIO {
         u64* q = base + off + 3 * lane; q[0] = o; q[1] = a; q[2] = b;
     }
 };
-struct CheckIO {
+// NT: non-temporal loads -- the round evaluation streams 27 GB through the L2s once and never re-reads a line; without the hint it
+// evicts the working sets of the latency-bound G families that run beside it
+template <bool NT> struct CheckIOT {
     const u64* base; uint32_t lane; u64 bad;
-    __device__ __forceinline__ void arr(uint32_t off, u64 v) { bad |= base[off + lane] ^ v; }
+    __device__ __forceinline__ u64 ldw(const u64* p) const { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+    __device__ __forceinline__ void arr(uint32_t off, u64 v) { bad |= ldw(base + off + lane) ^ v; }
     __device__ __forceinline__ void gate(uint32_t off, u64 o, u64 a, u64 b) {
-        const u64* q = base + off + 3 * lane; bad |= (q[0] ^ o) | (q[1] ^ a) | (q[2] ^ b);
+        const u64* q = base + off + 3 * lane; bad |= (ldw(q) ^ o) | (ldw(q + 1) ^ a) | (ldw(q + 2) ^ b);
         POB_OPAQUE(bad);                     // opaque point: stops LLVM from reassociating one 4800-term OR tree (compile time)
     }
 };
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
 
 // One KeccakfRound block per wavefront: grid.x = (permutation, round), grid.y = group.  Reads midRound[r] (written by
 // k_chain), writes (GenIO) or verifies (CheckIO) the 102 656 wires of the round.  This is the HBM-streaming kernel.
-template <bool CHECK> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
+template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
     const uint32_t lane = threadIdx.x;
     const uint32_t pi = A.first + blockIdx.x / 24, r = blockIdx.x % 24;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
@@ -289,7 +292,7 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
 #pragma unroll
     for (int i = 0; i < 25; i++) in[i] = G[Kf + KF_MID + 1600 * r + 64 * i + lane];
     if (CHECK) {
-        CheckIO io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane; io.bad = 0;
+        CheckIOT<NT> io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane; io.bad = 0;
         round_walk(io, in, (int)r, out);
         u64 bad = io.bad;
 #pragma unroll

@@ -74,3 +74,23 @@ def test_no_gpu_means_loud_failure():
 def test_wtns_header_equals_oracle_writer():
     r = O.run("Poseidon(2)", {"inputs": [1, 2]})
     assert bytes(r.wtns_numpy()[:76]) == pkg.wtns_header(r.nwitness)
+
+
+def test_plan_rejects_unsupported_and_oversized_instantiations():
+    """template parameters are validated limb-exactly and an instantiation whose wire / class counts would overflow the layout's
+    32-bit offsets is refused up front instead of wrapping silently (C ABI: POB_E_ARG; here: ValueError from plan_info)"""
+    from proof_of_burn_amd import plan_info
+    ok = plan_info("ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)")
+    assert int(ok.n_witness) == 215_907_954 and int(ok.n_bit) < (1 << 29)
+    for bad in ("ProofOfBurn(32, 8, 16, 50, 31, 2, 10 ** 19, 10 ** 20)",           # 276 Keccak-f permutations: ~690 M BIT wires
+                "ProofOfBurn(64, 16, 32, 50, 31, 2, 10 ** 19, 10 ** 20)",
+                f"ProofOfBurn({2 ** 64 + 16}, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)",     # upper limbs must be zero
+                "ProofOfBurn(16, 4, 16, 500, 31, 2, 10 ** 19, 10 ** 20)",                  # minLeafAddressNibbles > 64
+                "ProofOfBurn(16, 4, 16, 50, 32, 2, 10 ** 19, 10 ** 20)",                   # amountBytes > 31
+                "ProofOfBurn(16, 4, 16, 50, 31, 99, 10 ** 19, 10 ** 20)",                  # powMinimumZeroBytes > 32
+                "ProofOfBurn(1, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)",
+                "Spend(32)", "Spend(0)"):
+        with pytest.raises(ValueError):
+            plan_info(bad)
+    # the balance bounds are field elements: values >= p are reduced, not truncated
+    assert int(plan_info(f"ProofOfBurn(4, 4, 5, 20, 31, 2, {W.P + 10 ** 18}, 10 ** 19)").n_witness) == 64_355_038
