@@ -93,3 +93,37 @@ def test_evaluator_detects_pokes_fixture(pkg):
     bad = EC.named_pokes(calc, [("poseidon", 300), ("sc.M", 17), ("sc.exists", 5), ("sc.isz.inv", 40), ("pad.div.out", 1), ("pad.iseq.inv", 2)])
     assert not bad, bad
     calc.close()
+
+
+@pytest.mark.parametrize("env", [{"POB_CHECK_EARLY_K": "1"}, {"POB_CHECK_PLAN": "2,K;1,7,5;3,6,0;4"}, {"POB_LONG_SPONGE": "4", "POB_KCHK_NT": "0"},
+                                 {"POB_EMIT_PROBE": "0", "POB_EMIT_FILL": "0"}])
+def test_scheduling_switches_keep_the_results(pkg, tmp_path, env):
+    """the optional schedules (early Keccak evaluation, other stream plans, long sponges on their own stream, emitter without the
+    probe pass) are the same work in a different order: fixture instantiation, outputs + clean evaluator + a detected poke + the
+    first 200 000 wires of the payload, in a fresh process with the switch set (the library reads them once)"""
+    from tests.hostsim import build as hb
+    script = tmp_path / "w.py"
+    script.write_text(f"""
+import json, os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from proof_of_burn_amd import witness as W
+from tests import oracle_ffi as O
+W.LIB_PATH, W._lib = {hb.build()!r}, None
+s = next(x for x in json.load(open(os.path.join({ROOT!r}, "tests", "golden", "suites.json"))) if x["name"] == "test_proof_of_burn")
+calc = W.WitnessCalculator(s["main"], max_batch=8)
+res = calc.calculate([c["input"] for c in s["cases"]], check=True)
+assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
+assert all(r.check_status == 0 and r.bad_wire is None for r in res if r.ok)
+cls, idx, wire = calc.debug_ref("sc.M", 9)
+calc.poke(cls, idx, 3, 2); calc.constraint_check(); r2 = calc.results(with_check=True); calc.poke(cls, idx, 3, 2)
+assert r2[3].bad_wire is not None and r2[0].bad_wire is None
+ref = O.run(s["main"], s["cases"][0]["input"]).witness_numpy()
+for w0, v in calc.witness_windows(0, 200_000):
+    assert np.array_equal(v, ref[32 * w0:32 * w0 + v.size]); break
+print("ok")
+""")
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
