@@ -23,7 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # the handles' side streams need their own hardware queues (ROCm default: 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")     # every stream of the job needs its own hardware queue (ROCm default: 4): 2 callers + gather + 7 of the library
 
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -76,10 +76,12 @@ def cpu_baseline(batch, info, single_samples: int, budget_s: float = 25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU")
     ap.add_argument("--halves", type=int, default=int(os.environ.get("POB_BENCH_HALVES", "1")), help="calculators per GPU whose passes are interleaved")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("POB_BENCH_PIPELINE", "1")),
+                    help="1: two calculators work on consecutive batches (pob_set_partner): batch k+1's latency-bound generation stages run beside batch k's evaluation")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over the global batch")
     ap.add_argument("--cpu-samples", type=int, default=2, help="witnesses timed single-threaded on the CPU oracle (rank 0, N=1 only)")
@@ -100,6 +102,9 @@ def main():
     dev_index = int(os.environ.get("POB_FORCE_DEVICE", local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
     torch.cuda.set_device(dev_index)
     B, H = args.batch, max(1, args.halves)
+    PIPE = bool(args.pipeline)
+    if PIPE:
+        H = 1
     while H > 1 and (B % H or (B // H) % 64):
         H -= 1                                                          # parts are whole 64-witness groups
     Bh = B // H
@@ -109,16 +114,19 @@ def main():
     batch = gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=rank * B,
                                 pow_device=dev_index if args.depth > 12 else None)
     t_synth = time.time() - t0
-    calcs = [WitnessCalculator(MAIN, max_batch=Bh, device=dev_index) for _ in range(H)]
+    NC = 2 if PIPE else H                                 # pipeline: two calculators, each holds a whole batch (consecutive batches of the job)
+    calcs = [WitnessCalculator(MAIN, max_batch=Bh, device=dev_index) for _ in range(NC)]
     t0 = time.time()
     packed = [calcs[h].pack(batch.inputs[h * Bh:(h + 1) * Bh]) for h in range(H)]
     t_pack = time.time() - t0
     t0 = time.time()
-    for h in range(H):
-        calcs[h].upload_packed(*packed[h])                # H2D happens here, outside the timed region
+    for c in range(NC):
+        calcs[c].upload_packed(*packed[c if not PIPE else 0])             # H2D happens here, outside the timed region
     t_h2d = time.time() - t0
-    streams = [torch.cuda.Stream(device=dev_index) for _ in range(H)]      # (not the legacy default stream: it synchronises with every blocking stream)
-    recs = [D.device_records(calcs[h], Bh) for h in range(H)]
+    streams = [torch.cuda.Stream(device=dev_index) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
+    recs = [D.device_records(calcs[c], Bh) for c in range(NC)]
+    if PIPE:
+        calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
 
     gs = torch.cuda.Stream(device=dev_index)              # result records: packed at the end of generation, gathered beside the evaluation
 
@@ -135,30 +143,60 @@ def main():
             calcs[h].constraint_check(streams[h].cuda_stream)
         return out
 
+    used = set() if PIPE else set(range(NC))              # calculators that have generated a batch (a one-step pipelined run uses one)
+
+    def run_pipelined(nsteps):
+        """nsteps batches through the two-calculator pipeline, fill and drain included: batch k is generated by calculator k % 2 while
+        batch k-1 is evaluated by the other one; every batch is generated AND evaluated inside the call"""
+        out, prev = None, None
+        for k in range(nsteps):
+            cur = k % 2
+            used.add(cur)
+            if prev is not None:
+                calcs[prev].constraint_check(streams[prev].cuda_stream)
+            streams[cur].wait_stream(gs)                  # the gather of this calculator's previous batch has read its records
+            calcs[cur].generate(streams[cur].cuda_stream)
+            gs.wait_stream(streams[cur])
+            with torch.cuda.stream(gs):
+                out = D.gather_records(recs[cur])
+            prev = cur
+        if prev is not None:
+            calcs[prev].constraint_check(streams[prev].cuda_stream)
+        return out
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec_all = step()
-    fence()
-    dt = time.perf_counter() - t0
+    if PIPE:
+        if args.warmup:
+            run_pipelined(args.warmup)
+        fence()
+        t0 = time.perf_counter()
+        rec_all = run_pipelined(args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+    else:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rec_all = step()
+        fence()
+        dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # ---- the work was real: every witness valid, commitments equal the host-side formula, evaluator clean
-    for h in range(H):
+    for h in sorted(used):
         res = calcs[h].results(with_check=True)
         assert all(r.ok for r in res), [r.message() for r in res if not r.ok][:3]
-        assert [r.outputs[0] for r in res] == batch.commitments[h * Bh:(h + 1) * Bh], "commitment mismatch"
+        assert [r.outputs[0] for r in res] == (batch.commitments if PIPE else batch.commitments[h * Bh:(h + 1) * Bh]), "commitment mismatch"
         assert all(r.check_status == 0 and r.bad_wire is None for r in res), "constraint evaluator flagged a witness"
     st_all, out_all = D.unpack_records(rec_all.cpu())
     assert int(st_all.shape[0]) == world * B and int((st_all != 0).sum().item()) == 0
@@ -232,7 +270,7 @@ def main():
             "config": {"workload": f"batch={B}/GPU proof_of_burn witnesses, {MAIN}, synthetic {args.depth}-layer MPT proofs "
                                    f"({args.distinct_keys} distinct PoW burn keys tiled), generate + per-gate constraint evaluation + result gather",
                        "wires_per_witness": int(info.n_witness), "resident_bytes_per_witness": int(info.group_bytes // 64),
-                       "canonical_bytes_per_witness": int(info.n_witness) * 32, "parallelism": f"one slice per GPU x{world}, {H} interleaved parts of {Bh} per GPU",
+                       "canonical_bytes_per_witness": int(info.n_witness) * 32, "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {Bh} (fill and drain inside the timed region)" if PIPE else f"{H} interleaved parts of {Bh} per GPU"),
                        "input_synthesis_s": round(t_synth, 2), "json_to_packed_witnesses_per_s": round(B / max(t_pack, 1e-9), 1),
                        "h2d_s": round(t_h2d, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "emission": emission,

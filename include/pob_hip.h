@@ -63,6 +63,13 @@ int pob_generate(pob_handle h, void* stream);
  * e.g. assert.circom:46,62,78, divide.circom:32): re-reads every wire, asynchronous.                             */
 int pob_constraint_check(pob_handle h, void* stream);
 int pob_sync(pob_handle h);
+/* Two-batch pipeline (no counterpart in the reference, whose calculator runs one witness per process, Makefile:4-5): links two
+ * handles of one device that work on consecutive batches.  While linked, a handle's pob_generate starts once the partner's
+ * generation is complete -- so its latency-bound stages run beside the partner's (read-streaming) evaluation -- and its Keccak
+ * round expansion, the HBM-write-saturating kernel, follows the end of that evaluation; pob_constraint_check then runs on streams
+ * the generation does not use.  Call order per batch: pob_constraint_check(previous), pob_generate(next).  Link both ways;
+ * partner = NULL unlinks.                                                                                          */
+int pob_set_partner(pob_handle h, pob_handle partner);
 
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.
  * status[i] = 0 ok, else (template id << 12 | source line) of the first failing assert; outputs[i][32] = public

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <functional>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pob_hip.h"
@@ -124,11 +125,11 @@ struct pob_ctx {
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, emit_segs, chk_segs;        // per (stage, class) for generation; per class for emission; per FAMILY for evaluation
-    hipStream_t stream2 = nullptr, stream3 = nullptr; bool own_stream3 = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; uint32_t is_long; };
     std::vector<KSeg> ksegs;                           // ev_done: recorded behind the segment's sponge kernels in pob_generate
     hipStream_t stream_k = nullptr; hipEvent_t ev_joink = nullptr;      // the Keccak evaluation's own stream (see pob_constraint_check)
-    hipStream_t stream_long = nullptr; hipEvent_t ev_long_fork = nullptr, ev_long_join = nullptr;   // a stage's LONG sponges (>= POB_LONG_SPONGE blocks)
+    hipStream_t stream_long = nullptr; hipEvent_t ev_long_fork = nullptr, ev_long_join = nullptr, ev_rounds_fork = nullptr;   // a stage's LONG sponges (>= POB_LONG_SPONGE blocks)
     // side tracks (Plan::track_fork/track_join): own light + BN254 streams, own fork/join events, start and end events
     // (ROCm multiplexes streams onto 4 hardware queues by default: the handle keeps to the caller's stream + 3 of its own --
     //  stream2, trackB (track 1), trackC (tracks 2 and 3, which run one after the other anyway); a track's BN254 and light
@@ -137,7 +138,18 @@ struct pob_ctx {
     Track tracks[Plan::MAX_TRACKS];
     uint32_t nperms = 0;
     bool generated = false;
+    // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
+    // waits for the end of that evaluation; the evaluation then uses the pool's two evaluation streams
+    pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
+    hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false;
 };
+
+// The side streams are shared by every handle of a device (a handle's launches on them are ordered by events anyway): ROCm multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues and two handles with six streams each fall off that cliff (two calculators in
+// flight ran at 1/30 of the speed).  chk1/chk2 are created on first use (pipeline mode only).
+struct StreamPool { int device = 0, refs = 0; hipStream_t stream2 = nullptr, stream_k = nullptr, stream_long = nullptr, track1 = nullptr, track2 = nullptr, chk1 = nullptr, chk2 = nullptr; };
+static std::mutex g_pool_mu;
+static std::vector<StreamPool*> g_pools;
 
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
@@ -347,23 +359,35 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     // 30k workgroups of a Keccak expansion running on the caller's stream
     int prio_lo = 0, prio_hi = 0;
     HIPC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
+    {   // the device's shared side streams (see StreamPool)
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        StreamPool* P = nullptr;
+        for (StreamPool* q : g_pools) if (q->device == device) P = q;
+        if (!P) {
+            P = new StreamPool(); P->device = device; g_pools.push_back(P);
+            HIPC(hipStreamCreateWithPriority(&P->stream2, hipStreamNonBlocking, prio_hi));
+            HIPC(hipStreamCreateWithPriority(&P->stream_k, hipStreamNonBlocking, prio_lo));
+            if (getenv("POB_LONG_SPONGE") && atoi(getenv("POB_LONG_SPONGE")) > 0) HIPC(hipStreamCreateWithPriority(&P->stream_long, hipStreamNonBlocking, prio_hi));
+            HIPC(hipStreamCreateWithPriority(&P->track1, hipStreamNonBlocking, prio_hi));
+            HIPC(hipStreamCreateWithPriority(&P->track2, hipStreamNonBlocking, prio_hi));
+        }
+        P->refs++; h->pool = P;
+    }
+    h->stream2 = h->pool->stream2; h->stream_k = h->pool->stream_k; h->stream_long = h->pool->stream_long;
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
-    HIPC(hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_lo));
-    HIPC(hipStreamCreateWithPriority(&h->stream_long, hipStreamNonBlocking, prio_hi));
     HIPC(hipEventCreateWithFlags(&h->ev_long_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_long_join, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&h->ev_joink, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_joink, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_gen_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_check_done, hipEventDisableTiming));
     for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    for (uint32_t t = 1; t < pl.ntracks; t++) {
+    for (uint32_t t = 1; t < Plan::MAX_TRACKS; t++) {        // (streams for every track slot: the evaluation uses tracks 1 and 2's whatever the circuit)
         pob_ctx::Track& T = h->tracks[t];
-        if (t <= 2) HIPC(hipStreamCreateWithPriority(&T.s_main, hipStreamNonBlocking, prio_hi));
-        else T.s_main = t == 3 ? h->tracks[2].s_main : t == 6 ? h->tracks[1].s_main : h->stream2;      // tracks 4 and 5 follow each other on the BN254 stream; 6 follows 1
+        T.s_main = t == 1 ? h->pool->track1 : t == 2 ? h->pool->track2 : t == 3 ? h->pool->track2 : t == 6 ? h->pool->track1 : h->stream2;   // tracks 4 and 5 follow each other on the BN254 stream; 3 follows 2; 6 follows 1
         T.s_heavy = T.s_main;
         HIPC(hipEventCreateWithFlags(&T.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_join, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&T.ev_start, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_end, hipEventDisableTiming));
     }
-    if (pl.ntracks > 1) h->stream3 = h->tracks[1].s_main; else { HIPC(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi)); h->own_stream3 = true; }
+    h->stream3 = h->pool->track1;
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
@@ -420,18 +444,27 @@ void pob_close(pob_handle h) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
         for (hipEvent_t e : {h->em.ev_made[k], h->em.ev_copied[k], h->em.ev_free[k]}) if (e) hipEventDestroy(e);
     }
+    hipDeviceSynchronize();                             // (the pool's streams may still carry this handle's work)
+    if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
-    if (h->stream_k) hipStreamDestroy(h->stream_k);
-    if (h->stream_long) hipStreamDestroy(h->stream_long);
+    if (h->pool) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        StreamPool* P = h->pool;
+        if (--P->refs == 0) {
+            for (hipStream_t q : {P->stream2, P->stream_k, P->stream_long, P->track1, P->track2, P->chk1, P->chk2}) if (q) hipStreamDestroy(q);
+            g_pools.erase(std::find(g_pools.begin(), g_pools.end(), P));
+            delete P;
+        }
+    }
+    if (h->ev_gen_done) hipEventDestroy(h->ev_gen_done);
+    if (h->ev_check_done) hipEventDestroy(h->ev_check_done);
     if (h->ev_long_fork) hipEventDestroy(h->ev_long_fork);
     if (h->ev_long_join) hipEventDestroy(h->ev_long_join);
     if (h->ev_joink) hipEventDestroy(h->ev_joink);
+    if (h->ev_rounds_fork) hipEventDestroy(h->ev_rounds_fork);
     for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
-    if (h->stream2) hipStreamDestroy(h->stream2);
-    if (h->own_stream3 && h->stream3) hipStreamDestroy(h->stream3);
     for (pob_ctx::Track& T : h->tracks) {
-        if (T.s_main && &T <= &h->tracks[2]) hipStreamDestroy(T.s_main);
         for (hipEvent_t e : {T.ev_fork, T.ev_join, T.ev_start, T.ev_end}) if (e) hipEventDestroy(e);
     }
     if (h->ev_join4) hipEventDestroy(h->ev_join4);
@@ -461,6 +494,9 @@ int pob_generate(pob_handle h, void* stream_) {
     HIPC(hipSetDevice(h->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
     const uint32_t G = (h->n + 63) / 64;
+    // pipeline: this generation's latency-bound work starts with the partner's evaluation (= once the partner's generation is complete)
+    // (starting them even earlier, beside the partner's expansion, was measured: no gain)
+    if (h->partner && h->partner->gen_done_rec) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
     HIPC(hipMemsetAsync(h->d_status_raw, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
@@ -468,15 +504,24 @@ int pob_generate(pob_handle h, void* stream_) {
     // one track: its stages in order; within a stage the BN254 units run on the track's second stream beside the light ones (the
     // Poseidon ones stage their table in LDS), then the stage's Keccak sponges.  Tracks forked after a stage are enqueued completely
     // (highest first) before the next stage, so every event is recorded before anything waits on it.
+    static const int rounds_async_env = getenv("POB_ROUNDS_ASYNC") ? atoi(getenv("POB_ROUNDS_ASYNC")) : 0;
+    const int rounds_async = h->partner ? std::max(rounds_async_env, 1) : rounds_async_env;
+    std::vector<hipEvent_t> pending;
     std::function<int(uint32_t)> run_track = [&](uint32_t t) -> int {
         hipStream_t sm = t ? h->tracks[t].s_main : st, sh = t ? h->tracks[t].s_heavy : h->stream2;
         hipEvent_t ef = t ? h->tracks[t].ev_fork : h->ev_fork, ej = t ? h->tracks[t].ev_join : h->ev_join;
         for (uint32_t sid = t * Plan::TRACK_STRIDE; sid < (t + 1) * Plan::TRACK_STRIDE && sid <= pl.max_stage; sid++) {
             for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) HIPC(hipStreamWaitEvent(sm, h->tracks[u].ev_end, 0));
             bool forked = false;
+            // a stage with ONE kind of launch needs no second stream: the fork / join pair costs ~0.15 ms of hand-over latency, and the
+            // generation's tail is a chain of such stages (SubstringCheck heads | existence loop | sums | final)
+            uint32_t n_light = 0, n_heavy = 0;
+            for (const pob_ctx::Seg& sg : h->segs) if (sg.stage == sid) { if (sg.lds) n_heavy++; else n_light++; }
+            const bool one_stream = n_light == 0 && n_heavy == 1;
             for (const pob_ctx::Seg& sg : h->segs) if (sg.stage == sid) {
                 A.first = sg.first; A.stage_lds = sg.lds == 2;
-                if (sg.lds) {
+                if (sg.lds && one_stream) launch_g_gen(A, sg.lds, sg.count, G, sm);
+                else if (sg.lds) {
                     if (!forked) { HIPC(hipEventRecord(ef, sm)); HIPC(hipStreamWaitEvent(sh, ef, 0)); }
                     launch_g_gen(A, sg.lds, sg.count, G, sh);
                     forked = true;
@@ -494,6 +539,14 @@ int pob_generate(pob_handle h, void* stream_) {
                     K.first = ks.sp_first;
                     launch_k_chain(K, false, ks.sp_count, G, sk);
                     K.first = ks.perm_first;
+                    if (rounds_async && t == 0 && !ks.is_long) {
+                        // nothing in the generation reads a KeccakfRound block's wires (k_chain wrote every state a later stage uses): the
+                        // main track's HBM-streaming expansion leaves the track here and is only joined before the results are collected
+                        HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->stream_k, h->ev_rounds_fork, 0));
+                        // pipeline: the write-saturating expansion does not run beside the partner's evaluation (it follows it)
+                        if (h->partner && h->partner->check_done_rec) HIPC(hipStreamWaitEvent(h->stream_k, h->partner->ev_check_done, 0));
+                        sk = h->stream_k; pending.push_back(ks.ev_done);
+                    }
                     launch_k_rounds(K, false, ks.perm_count, G, sk);
                     HIPC(hipEventRecord(ks.ev_done, sk));       // every wire of these sponges exists: their evaluation may start (pob_constraint_check)
                 }
@@ -507,9 +560,11 @@ int pob_generate(pob_handle h, void* stream_) {
         return POB_OK;
     };
     { int rc = run_track(0); if (rc) return rc; }
+    for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
     const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
     hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs, h->d_records, G * 64);
     HIPC(hipGetLastError());
+    HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
     h->generated = true;
     return POB_OK;
 }
@@ -535,7 +590,18 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     static const int early_k = getenv("POB_CHECK_EARLY_K") ? atoi(getenv("POB_CHECK_EARLY_K")) : 0;
     static const std::string plan = getenv("POB_CHECK_PLAN") ? getenv("POB_CHECK_PLAN") : (early_k ? "1,2,3;7,5;4,6,0" : "K;7,5,3,1;4,6,0,2");
     // (a fourth sequence, if the plan has one, runs on track 2's stream, which is idle during the evaluation)
-    hipStream_t ss[4] = {st, h->stream2, h->stream3, h->plan.ntracks > 2 ? h->tracks[2].s_main : h->stream2};
+    // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
+    // pool's two evaluation streams
+    hipStream_t side2 = h->stream2, side3 = h->stream3;
+    if (h->partner) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int prio_lo = 0, prio_hi = 0;
+        HIPC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        if (!h->pool->chk1) HIPC(hipStreamCreateWithPriority(&h->pool->chk1, hipStreamNonBlocking, prio_hi));
+        if (!h->pool->chk2) HIPC(hipStreamCreateWithPriority(&h->pool->chk2, hipStreamNonBlocking, prio_hi));
+        side2 = h->pool->chk1; side3 = h->pool->chk2;
+    }
+    hipStream_t ss[4] = {st, side2, side3, h->partner ? side2 : h->tracks[2].s_main};
     bool keccak_done = false;
     {   // reset of the evaluator's results: ahead of the FIRST kernel that may write them (the early Keccak evaluation)
         hipStream_t sr = (early_k && !h->plan.sponges.empty()) ? h->stream_k : st;
@@ -555,9 +621,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         keccak_done = true;
     }
     HIPC(hipEventRecord(h->ev_fork, st));
-    HIPC(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    HIPC(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
-    if (ss[3] != h->stream2) HIPC(hipStreamWaitEvent(ss[3], h->ev_fork, 0));
+    HIPC(hipStreamWaitEvent(side2, h->ev_fork, 0));
+    HIPC(hipStreamWaitEvent(side3, h->ev_fork, 0));
+    if (ss[3] != side2) HIPC(hipStreamWaitEvent(ss[3], h->ev_fork, 0));
     uint32_t done = 0; int si = 0;
     auto run_item = [&](char c) -> int {
         if (c == 'K') {
@@ -580,11 +646,18 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     si = 0;                                              // whatever the plan left out runs on the caller's stream
     for (uint32_t fam = 0; fam < F_COUNT; fam++) run_item((char)('0' + fam));
     run_item('K');
-    HIPC(hipEventRecord(h->ev_join, h->stream2)); HIPC(hipEventRecord(h->ev_join3, h->stream3));
+    HIPC(hipEventRecord(h->ev_join, side2)); HIPC(hipEventRecord(h->ev_join3, side3));
     HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
-    if (ss[3] != h->stream2) { HIPC(hipEventRecord(h->ev_join4, ss[3])); HIPC(hipStreamWaitEvent(st, h->ev_join4, 0)); }
+    if (ss[3] != side2) { HIPC(hipEventRecord(h->ev_join4, ss[3])); HIPC(hipStreamWaitEvent(st, h->ev_join4, 0)); }
     if (early_k && !h->plan.sponges.empty()) HIPC(hipStreamWaitEvent(st, h->ev_joink, 0));
+    HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true;
     HIPC(hipGetLastError());
+    return POB_OK;
+}
+
+int pob_set_partner(pob_handle h, pob_handle partner) {
+    if (!h || h == partner || (partner && partner->device != h->device)) return POB_E_ARG;
+    h->partner = partner; h->gen_done_rec = h->check_done_rec = false;
     return POB_OK;
 }
 

@@ -69,6 +69,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_generate.argtypes = [vp, vp]
     lib.pob_constraint_check.argtypes = [vp, vp]
     lib.pob_sync.argtypes = [vp]
+    lib.pob_set_partner.argtypes = [vp, vp]
     lib.pob_results.argtypes = [vp, vp, vp, vp, vp]
     lib.pob_results_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     lib.pob_results_records_device.argtypes = [vp, ctypes.POINTER(vp)]
@@ -92,7 +93,7 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_generate",
-                    "pob_constraint_check", "pob_sync", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
+                    "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
                     "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
@@ -301,6 +302,10 @@ class WitnessCalculator:
 
     def sync(self):
         self._ck(self.lib.pob_sync(self.h))
+
+    def set_partner(self, other: "WitnessCalculator | None"):
+        """two-batch pipeline (include/pob_hip.h pob_set_partner): link this calculator with the one working on the neighbouring batch"""
+        self._ck(self.lib.pob_set_partner(self.h, other.h if other is not None else None))
 
     def results(self, with_check: bool = False) -> list[Result]:
         n = self.n

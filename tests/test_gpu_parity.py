@@ -345,14 +345,22 @@ def _run_bench(args, env_extra=None, nproc=1, timeout=900):
     return json.loads(line)
 
 
+def test_two_calculators_pipelined_over_consecutive_batches(pkg):
+    """pob_set_partner on the GPU: the same three-batch scenario as on the CPU shim (tests/test_hostsim_cpu.py) -- there the streams are
+    synchronous, here the event gating between the two handles is real"""
+    from tests.test_hostsim_cpu import test_two_calculators_pipelined_over_consecutive_batches as scenario
+    scenario(pkg)
+
+
 def test_two_ranks_on_one_gpu_equal_a_single_rank_run(pkg, tmp_path):
     """BASELINE config 4's shape on the hardware at hand: bench.py --gpus 2 as two ranks (own process, own handle, own slice of the
     global batch) sharing GPU 0, result records through ONE all-gather (gloo here, RCCL on a node); the gathered 1024 records must
-    equal a single-rank run of the same 1024 seeds.  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
+    equal a single-rank run of the same 1024 seeds (the two ranks in bench.py's default two-calculator pipeline, the single rank
+    without it).  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
     a, b = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
     two = _run_bench(["--gpus", "2", "--batch", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-results", a],
                      {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
-    one = _run_bench(["--gpus", "1", "--batch", "1024", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-results", b])
+    one = _run_bench(["--gpus", "1", "--batch", "1024", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pipeline", "0", "--dump-results", b])
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
     ra, rb = np.load(a), np.load(b)
     assert ra.shape == rb.shape == (1024, 36) and np.array_equal(ra, rb)
