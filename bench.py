@@ -143,6 +143,7 @@ def main():
             calcs[h].constraint_check(streams[h].cuda_stream)
         return out
 
+    gathered = [None, None]
     used = set() if PIPE else set(range(NC))              # calculators that have generated a batch (a one-step pipelined run uses one)
 
     def run_pipelined(nsteps):
@@ -154,11 +155,13 @@ def main():
             used.add(cur)
             if prev is not None:
                 calcs[prev].constraint_check(streams[prev].cuda_stream)
-            streams[cur].wait_stream(gs)                  # the gather of this calculator's previous batch has read its records
+            if gathered[cur] is not None:
+                streams[cur].wait_event(gathered[cur])    # the gather of THIS calculator's previous batch has read its records
             calcs[cur].generate(streams[cur].cuda_stream)
             gs.wait_stream(streams[cur])
             with torch.cuda.stream(gs):
                 out = D.gather_records(recs[cur])
+                gathered[cur] = torch.cuda.Event(); gathered[cur].record(gs)
             prev = cur
         if prev is not None:
             calcs[prev].constraint_check(streams[prev].cuda_stream)

@@ -424,7 +424,22 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const uint32_t kk = LB - 31 + 1;
         p.put(sc.alw, ~(B)0);
         S sum = p.put(sc.sums, 0);
-        for (uint32_t k = 0; k < kk; k++) sum = p.put(sc.sums + k + 1, sum + (S)p.bit(p.get(sc.alw + k + 1) & p.get(sc.ex + k)));
+        // allowed[] / exists[] as lane-distributed runs (64 wires per load, every load issued ahead): one load per wire made this unit 1 030
+        // dependent round trips -- 0.12 ms alone, 1.9 ms beside the other batch's round evaluation
+        const uint32_t ln = p.lane_id();
+        for (uint32_t c0 = 0; c0 * 64 < kk; c0 += 8) {                  // 8 runs = 512 positions per batch of loads
+            B rr[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint32_t k0 = 64 * (c0 + c), n = k0 < kk ? (kk - k0 < 64 ? kk - k0 : 64) : 0;
+                rr[c] = n ? (p.run_get(n, sc.alw.i + k0 + 1 + ln) & p.run_get(n, sc.ex.i + k0 + ln)) : 0;
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint32_t k0 = 64 * (c0 + c), n = k0 < kk ? (kk - k0 < 64 ? kk - k0 : 64) : 0;
+                for (uint32_t j = 0; j < n; j++) sum = p.put(sc.sums + (k0 + j + 1), sum + (S)p.bit(p.run_bcast(rr[c], j)));
+            }
+        }
         p.cur = sc.c_tail;
         B none = p.put(sc.dne, gIsZeroS(p, sum));
         B out = p.put(M.substringCheckers + (i - 1), p.put(sc.out, ~none));
@@ -573,9 +588,16 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         p.put(R.t_on + 1, r * p.get(R.t_shf));
         const B rbit = p.ballot(r & 1);
         p.cur = R.c_mux;
-        for (int i = 0; i < n2; i++) {
-            if (i < n2 - 1) p.put(R.t_on + i + 2, gMux1S(p, p.get(R.t_shf + i), p.get(R.t_shf + i + 1), rbit));
-            else p.put(R.t_on + i + 2, (1 - r) * p.get(R.t_shf + i));
+        for (int i0 = 0; i0 < n2; i0 += 8) {              // (9 operands requested together per 8 multiplexers)
+            S v[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) v[q] = p.get(R.t_shf + (i0 + q < n2 ? i0 + q : n2 - 1));
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = i0 + q;
+                if (i < n2 - 1) p.put(R.t_on + i + 2, gMux1S(p, v[q], v[q + 1], rbit));
+                else p.put(R.t_on + i + 2, (1 - r) * v[q]);
+            }
         }
         SmRef by = gNibbles2Bytes(p, ab + 1, R.t_on);
         { copy_n(p, R.t_o, by, (int)(ab + 1)); copy_n(p, R.key, by, (int)(ab + 1)); }
@@ -583,10 +605,10 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         gAssertGreaterEqThanS(p, 16, kl, (S)2);
         const S al = p.get(R.accLen);
         p.put(R.val, 0xb8); p.put(R.val + 1, al);
-        for (int i = 0; i < maxAcc; i++) p.put(R.val + 2 + i, p.get(R.acc + i));
+        copy_n(p, R.val + 2, R.acc, maxAcc);
         const S vl = p.put(R.valLen, 2 + al);
         p.put(R.pk, 0xf8); p.put(R.pk + 1, (kl + 1) + vl); p.put(R.pk + 2, 0x80 + kl);
-        for (int i = 0; i < maxKey; i++) p.put(R.pk + 3 + i, p.get(R.key + i));
+        copy_n(p, R.pk + 3, R.key, maxKey);
         const S pl = p.put(R.pkLen, 3 + kl);
         p.cur = R.c_concat;
         S cl;
@@ -606,12 +628,19 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         for (int i = 0; i < prm.L; i++) cnt += (S)p.bit(p.get(M.isLeaf + i));
         p.require(p.ballot(cnt == 1), FAILCODE(T_POB, 186));
         p.require(p.get(M.isLastLayerLeaf), FAILCODE(T_POB, 188));
-        bool ok = true;
-        for (int i = 0; i < 32; i++) ok = ok && (p.get(M.layerKeccaks + i) == p.get(M.stateRoot + i));
-        p.require(p.ballot(ok), FAILCODE(T_POB, 192));
-        ok = true;
-        for (int i = 0; i < 139; i++) ok = ok && (p.get(M.leaf + i) == p.get(M.lastLayer + i));
-        p.require(p.ballot(ok), FAILCODE(T_POB, 204));
+        auto same = [&](SmRef a, SmRef b, int n) {       // a[i] == b[i] for every i < n, 16 loads requested together
+            bool ok = true;
+            for (int i0 = 0; i0 < n; i0 += 8) {
+                S x[8], y[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { const int i = i0 + q < n ? i0 + q : n - 1; x[q] = p.get(a + i); y[q] = p.get(b + i); }
+#pragma unroll
+                for (int q = 0; q < 8; q++) ok = ok && x[q] == y[q];
+            }
+            return ok;
+        };
+        p.require(p.ballot(same(M.layerKeccaks, M.stateRoot, 32)), FAILCODE(T_POB, 192));
+        p.require(p.ballot(same(M.leaf, M.lastLayer, 139)), FAILCODE(T_POB, 204));
         p.require(p.ballot(p.get(M.leafLen) == p.get(M.lastLayerLen)), FAILCODE(T_POB, 206));
     } break;
     UCASE(U_POB_INPUT_FR) {  // FR main inputs (canonical LE -> Montgomery)
@@ -889,6 +918,7 @@ struct Plan {
     // lower-numbered track (the host enqueues a stage's forked tracks highest first, each one completely).
     enum { TRACK_STRIDE = 32, MAX_TRACKS = 7 };
     uint32_t ntracks, track_fork[MAX_TRACKS], track_join[MAX_TRACKS];
+    uint32_t wide_tracks = 0;                // tracks made of chip-filling launches (bit t); the others are narrow serial chains
     CountP p;
 
     static bool same(Cur a, Cur b) { return a.w == b.w && a.b == b.b && a.s == b.s && a.f == b.f && a.q == b.q; }
@@ -1020,7 +1050,7 @@ struct Plan {
         // leaf detectors -- so that the main track is only inputs + KeccakBytes heads (0), byte ranges (1), sponges A (2), rows (3)
         // and the round expansion starts 0.5 ms earlier; joined before main stage 5.
         const uint32_t TP = 5 * TRACK_STRIDE;
-        track_fork[5] = 0; track_join[5] = 5;
+        track_fork[5] = 0; track_join[5] = 5; wide_tracks = 1u << 5;
         // track 6 (TQ): PublicCommitment -- KeccakBytes head, byte ranges, its 2-block sponge, selector rows, the commitment -- depends on the
         // header hash (main stage 3) and the Num2BigEndianBytes of track 4 only, not on the SubstringChecks: forked after (empty) main stage 4,
         // once track 4 is joined, it runs beside main stages 5..7 instead of extending them by four short dependent stages; joined before 10.

@@ -495,8 +495,16 @@ int pob_generate(pob_handle h, void* stream_) {
     hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
     const uint32_t G = (h->n + 63) / 64;
     // pipeline: this generation's latency-bound work starts with the partner's evaluation (= once the partner's generation is complete)
-    // (starting them even earlier, beside the partner's expansion, was measured: no gain)
-    if (h->partner && h->partner->gen_done_rec) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
+    // (starting ALL of them even earlier, beside the partner's expansion, was measured: no gain -- the chip-filling launches take from the
+    //  expansion what they gain).  The first stage and the NARROW tracks forked after it (the burn-address / RLP / account chains: a few
+    //  dozen wavefronts, next to no bandwidth) do start at once, i.e. beside the partner's expansion (+1.2 % on average of nine A/B pairs;
+    //  POB_PIPE_CHAINS=0 gates them too); the main track from its second stage on and the wide pre-work track wait for the partner's
+    //  generation to be complete.  Track 4 is then enqueued AHEAD of the wide track 5, whose stream it normally shares: it moves to track 2's.
+    static const int pipe_chains = getenv("POB_PIPE_CHAINS") ? atoi(getenv("POB_PIPE_CHAINS")) : 1;
+    const bool gate = h->partner && h->partner->gen_done_rec;
+    const bool gate_late = gate && pipe_chains && h->plan.ntracks > 1;
+    auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner && pipe_chains) ? h->pool->track2 : h->tracks[t].s_main; };
+    if (gate && !gate_late) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
     HIPC(hipMemsetAsync(h->d_status_raw, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
@@ -508,7 +516,7 @@ int pob_generate(pob_handle h, void* stream_) {
     const int rounds_async = h->partner ? std::max(rounds_async_env, 1) : rounds_async_env;
     std::vector<hipEvent_t> pending;
     std::function<int(uint32_t)> run_track = [&](uint32_t t) -> int {
-        hipStream_t sm = t ? h->tracks[t].s_main : st, sh = t ? h->tracks[t].s_heavy : h->stream2;
+        hipStream_t sm = t ? track_stream(t) : st, sh = t ? track_stream(t) : h->stream2;
         hipEvent_t ef = t ? h->tracks[t].ev_fork : h->ev_fork, ej = t ? h->tracks[t].ev_join : h->ev_join;
         for (uint32_t sid = t * Plan::TRACK_STRIDE; sid < (t + 1) * Plan::TRACK_STRIDE && sid <= pl.max_stage; sid++) {
             for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) HIPC(hipStreamWaitEvent(sm, h->tracks[u].ev_end, 0));
@@ -551,10 +559,13 @@ int pob_generate(pob_handle h, void* stream_) {
                     HIPC(hipEventRecord(ks.ev_done, sk));       // every wire of these sponges exists: their evaluation may start (pob_constraint_check)
                 }
             if (long_forked) { HIPC(hipEventRecord(h->ev_long_join, h->stream_long)); HIPC(hipStreamWaitEvent(sm, h->ev_long_join, 0)); }
-            for (uint32_t u = pl.ntracks; u-- > t + 1;) if (pl.track_fork[u] == sid) {
-                HIPC(hipEventRecord(h->tracks[u].ev_start, sm)); HIPC(hipStreamWaitEvent(h->tracks[u].s_main, h->tracks[u].ev_start, 0));
-                int rc = run_track(u); if (rc) return rc;
-                HIPC(hipEventRecord(h->tracks[u].ev_end, h->tracks[u].s_main));
+            for (int wide = 0; wide < 2; wide++) {          // narrow tracks first; (pipeline) the partner gate; then the wide ones
+                if (wide && gate_late && t == 0 && sid == 0) HIPC(hipStreamWaitEvent(sm, h->partner->ev_gen_done, 0));
+                for (uint32_t u = pl.ntracks; u-- > t + 1;) if (pl.track_fork[u] == sid && (int)((pl.wide_tracks >> u) & 1) == wide) {
+                    HIPC(hipEventRecord(h->tracks[u].ev_start, sm)); HIPC(hipStreamWaitEvent(track_stream(u), h->tracks[u].ev_start, 0));
+                    int rc = run_track(u); if (rc) return rc;
+                    HIPC(hipEventRecord(h->tracks[u].ev_end, track_stream(u)));
+                }
             }
         }
         return POB_OK;
