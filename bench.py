@@ -23,7 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")     # every stream of the job needs its own hardware queue (ROCm default: 4): 2 callers + gather + 7 of the library
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job needs its own hardware queue (ROCm default: 4): 2 callers + gather + 7 of the library (+ RCCL's at N > 1)
 
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
