@@ -418,32 +418,43 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         BitRef f = gFilter(p, prm.L, nl);
         copy_n(p, M.layerExists, f, (int)(prm.L));
     } break;
-    UCASE(U_SC_SUMS) {            // sums[] (:94), doesNotExist, out (:98-99), substringCheckers[i-1] and the constraint of proof_of_burn.circom:179
-        const uint32_t i = d.a[0];
+    UCASE(U_SC_SUMS) {            // sums[a1+1 .. a2] (:94); the unit of the last range also doesNotExist, out (:98-99), substringCheckers[i-1]
+                                 // and the constraint of proof_of_burn.circom:179
+        const uint32_t i = d.a[0], lo = d.a[1], hi = d.a[2];
         const ScRefs& sc = L.scs[i];
-        const uint32_t kk = LB - 31 + 1;
-        p.put(sc.alw, ~(B)0);
-        S sum = p.put(sc.sums, 0);
-        // allowed[] / exists[] as lane-distributed runs (64 wires per load, every load issued ahead): one load per wire made this unit 1 030
-        // dependent round trips -- 0.12 ms alone, 1.9 ms beside the other batch's round evaluation
-        const uint32_t ln = p.lane_id();
-        for (uint32_t c0 = 0; c0 * 64 < kk; c0 += 8) {                  // 8 runs = 512 positions per batch of loads
-            B rr[8];
+        const uint32_t kk = LB - 31 + 1, ln = p.lane_id();
+        // allowed[] / exists[] come as lane-distributed runs (64 wires per load).  One unit per 64 positions: generation rebuilds the sum entering
+        // its range from the runs below it (register work only, no wire is read back), the evaluator starts from the STORED sums[a1] (the
+        // relation is local).  As one unit per layer this was 515 dependent stores behind 1 030 loads: 0.12 ms alone, 1-2 ms beside the other
+        // batch's round evaluation, at the very end of the generation.
+        S sum = 0;
+        if (lo == 0) { p.put(sc.alw, ~(B)0); sum = p.put(sc.sums, 0); }
+        else if constexpr (P::is_gen) {
+            for (uint32_t c0 = 0; c0 * 64 < lo; c0 += 8) {
+                B rr[8];
 #pragma unroll
-            for (uint32_t c = 0; c < 8; c++) {
-                const uint32_t k0 = 64 * (c0 + c), n = k0 < kk ? (kk - k0 < 64 ? kk - k0 : 64) : 0;
-                rr[c] = n ? (p.run_get(n, sc.alw.i + k0 + 1 + ln) & p.run_get(n, sc.ex.i + k0 + ln)) : 0;
-            }
+                for (uint32_t c = 0; c < 8; c++) {
+                    const uint32_t k0 = 64 * (c0 + c), n = k0 < lo ? (lo - k0 < 64 ? lo - k0 : 64) : 0;
+                    rr[c] = n ? (p.run_get(n, sc.alw.i + k0 + 1 + ln) & p.run_get(n, sc.ex.i + k0 + ln)) : 0;
+                }
 #pragma unroll
-            for (uint32_t c = 0; c < 8; c++) {
-                const uint32_t k0 = 64 * (c0 + c), n = k0 < kk ? (kk - k0 < 64 ? kk - k0 : 64) : 0;
-                for (uint32_t j = 0; j < n; j++) sum = p.put(sc.sums + (k0 + j + 1), sum + (S)p.bit(p.run_bcast(rr[c], j)));
+                for (uint32_t c = 0; c < 8; c++) {
+                    const uint32_t k0 = 64 * (c0 + c), n = k0 < lo ? (lo - k0 < 64 ? lo - k0 : 64) : 0;
+                    for (uint32_t j = 0; j < n; j++) sum += (S)p.bit(p.run_bcast(rr[c], j));
+                }
             }
+        } else sum = p.get(sc.sums + lo);
+        for (uint32_t k0 = lo; k0 < hi; k0 += 64) {
+            const uint32_t n = hi - k0 < 64 ? hi - k0 : 64;
+            const B rr = p.run_get(n, sc.alw.i + k0 + 1 + ln) & p.run_get(n, sc.ex.i + k0 + ln);
+            for (uint32_t j = 0; j < n; j++) sum = p.put(sc.sums + (k0 + j + 1), sum + (S)p.bit(p.run_bcast(rr, j)));
         }
-        p.cur = sc.c_tail;
-        B none = p.put(sc.dne, gIsZeroS(p, sum));
-        B out = p.put(M.substringCheckers + (i - 1), p.put(sc.out, ~none));
-        p.require(out | ~p.get(M.layerExists + i), FAILCODE(T_POB, 179));
+        if (hi == kk) {
+            p.cur = sc.c_tail;
+            B none = p.put(sc.dne, gIsZeroS(p, sum));
+            B out = p.put(M.substringCheckers + (i - 1), p.put(sc.out, ~none));
+            p.require(out | ~p.get(M.layerExists + i), FAILCODE(T_POB, 179));
+        }
     } break;
     UCASE(U_LD_HEAD) {            // LeafDetector(N) :247-278 up to keyLen; selector heads (select input, sum[0], range check)
         LdRefs R = L.lds[d.a[0]];
@@ -903,6 +914,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
 template <class P> GD void unit_run_all(P& p, const UnitDesc& d, CircuitLayout& L) { unit_run<P, FAM_ALL>(p, d, L); }
 
 // ---------------------------------------------------------------------------- host planner
+#include <stdlib.h>
 #include <algorithm>
 #include <stdexcept>
 #include <string>
@@ -1122,7 +1134,9 @@ struct Plan {
                 const uint32_t kk = LB - 31 + 1;
                 record(U_SC_MI, TP + 1, start, i);
                 for (uint32_t lo = 0; lo < kk; lo += SC_RANGE_POS) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min<uint32_t>(lo + SC_RANGE_POS, kk));
-                record(U_SC_SUMS, 7, sc.c_tail, i);
+                // (POB_SC_SUMS_SPLIT=0: one unit per layer, for A/B runs)
+                const uint32_t sums_step = (getenv("POB_SC_SUMS_SPLIT") && atoi(getenv("POB_SC_SUMS_SPLIT")) == 0) ? kk : 64;
+                for (uint32_t lo = 0; lo < kk; lo += sums_step) record(U_SC_SUMS, 7, sc.c_tail, i, lo, std::min<uint32_t>(lo + sums_step, kk));
             }
         }
         leaf_detector(Ln, TP + 2, M.lastLayer, M.lastLayerLen, M.isLastLayerLeaf);                    // :187 (lastLayer is written in stage 1)
