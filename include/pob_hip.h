@@ -67,8 +67,8 @@ int pob_sync(pob_handle h);
  * handles of one device that work on consecutive batches.  While linked, a handle's pob_generate starts once the partner's
  * generation is complete -- so its latency-bound stages run beside the partner's (read-streaming) evaluation -- and its Keccak
  * round expansion, the HBM-write-saturating kernel, follows the end of that evaluation; pob_constraint_check then runs on streams
- * the generation does not use.  Call order per batch: pob_constraint_check(previous), pob_generate(next).  Link both ways;
- * partner = NULL unlinks.                                                                                          */
+ * the generation does not use.  Call order per batch: pob_constraint_check(previous), pob_generate(next).  The link is
+ * symmetric (one call links both handles and drops their previous links); partner = NULL unlinks; pob_close unlinks. */
 int pob_set_partner(pob_handle h, pob_handle partner);
 
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.

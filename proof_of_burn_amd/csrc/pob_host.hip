@@ -130,9 +130,9 @@ struct pob_ctx {
     std::vector<KSeg> ksegs;                           // ev_done: recorded behind the segment's sponge kernels in pob_generate
     hipStream_t stream_k = nullptr; hipEvent_t ev_joink = nullptr;      // the Keccak evaluation's own stream (see pob_constraint_check)
     hipStream_t stream_long = nullptr; hipEvent_t ev_long_fork = nullptr, ev_long_join = nullptr, ev_rounds_fork = nullptr;   // a stage's LONG sponges (>= POB_LONG_SPONGE blocks)
-    // side tracks (Plan::track_fork/track_join): own light + BN254 streams, own fork/join events, start and end events
-    // (ROCm multiplexes streams onto 4 hardware queues by default: the handle keeps to the caller's stream + 3 of its own --
-    //  stream2, trackB (track 1), trackC (tracks 2 and 3, which run one after the other anyway); a track's BN254 and light
+    // side tracks (Plan::track_fork/track_join): streams of the device's pool (StreamPool below), own fork/join events, start and end events
+    // (ROCm multiplexes streams onto few hardware queues: a lone handle keeps to the caller's stream + 4 of the pool's --
+    //  stream2, track 1's (also track 6), track 2's (also track 3, which runs before it anyway), the round expansion's; a track's BN254 and light
     //  launches of one stage share its stream)
     struct Track { hipStream_t s_main = nullptr, s_heavy = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_end = nullptr; };
     Track tracks[Plan::MAX_TRACKS];
@@ -668,7 +668,10 @@ int pob_constraint_check(pob_handle h, void* stream_) {
 
 int pob_set_partner(pob_handle h, pob_handle partner) {
     if (!h || h == partner || (partner && partner->device != h->device)) return POB_E_ARG;
+    // the link is symmetric (neither side may be left pointing at a handle that has another partner or is closed): undo both old links first
+    for (pob_handle q : {h, partner}) if (q && q->partner) { q->partner->partner = nullptr; q->partner = nullptr; }
     h->partner = partner; h->gen_done_rec = h->check_done_rec = false;
+    if (partner) { partner->partner = h; partner->gen_done_rec = partner->check_done_rec = false; }
     return POB_OK;
 }
 
