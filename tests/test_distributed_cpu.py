@@ -84,6 +84,57 @@ CALC_WORKER = textwrap.dedent("""
 """)
 
 
+# The job as bench.py runs it at N > 1: every rank pipelines TWO linked calculators (pob_set_partner) over consecutive global batches --
+# evaluate batch k-1, generate batch k, gather batch k's records -- on its slices; every gathered batch must equal a lone calculator's
+# run of the whole batch, and every evaluation must come back clean for the witnesses that are valid.
+PIPE_WORKER = textwrap.dedent("""
+    import ctypes, json, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from proof_of_burn_amd import distributed as D, witness as W
+    W.LIB_PATH, W._lib = %r, None
+    rank, local_rank, world = D.init("gloo")
+    s = next(x for x in json.load(open(os.path.join(%r, "tests", "golden", "suites.json"))) if x["name"] == "test_spend")
+    base = s["cases"][0]["input"]
+    def batch(k):                                       # global batch k: 6 witnesses, witness k of it fails (spend.circom:41)
+        out = []
+        for g in range(6):
+            d = dict(base); d["extraCommitment"] = 100 * k + g; d["withdrawnBalance"] = str(3 + g + k)
+            if g == k: d["withdrawnBalance"] = str(int(base["balance"]) + 1)
+            out.append(d)
+        return out
+    def records(calc, n):
+        buf = (ctypes.c_uint8 * (D.RECORD_BYTES * n)).from_address(calc.records_device_ptr())
+        return torch.from_numpy(np.ctypeslib.as_array(buf).reshape(n, D.RECORD_BYTES).copy())
+    lo, hi = D.shard_bounds(6, rank, world)
+    a, b = W.WitnessCalculator("Spend(31)", max_batch=hi - lo), W.WitnessCalculator("Spend(31)", max_batch=hi - lo)
+    a.set_partner(b)
+    calcs, prev, gathered, checked = [a, b], None, [], []
+    for k in range(3):
+        cur = calcs[k %% 2]
+        if prev is not None:
+            prev[0].constraint_check(); checked.append((prev[1], prev[0].results(with_check=True)))
+        cur.upload_packed(*cur.pack(batch(k)[lo:hi])); cur.generate()
+        cur.sync()
+        gathered.append(D.gather_records(records(cur, hi - lo), total=6))
+        prev = (cur, k)
+    prev[0].constraint_check(); checked.append((prev[1], prev[0].results(with_check=True)))
+    lone = W.WitnessCalculator("Spend(31)", max_batch=6)
+    for k in range(3):
+        lone.calculate(batch(k))
+        assert torch.equal(gathered[k], records(lone, 6)), k
+        st, _ = D.unpack_records(gathered[k])
+        assert (st != 0).tolist() == [g == k for g in range(6)]
+    for k, res in checked:
+        for g, r in zip(range(lo, hi), res):
+            assert r.ok == (g != k) and (not r.ok or (r.check_status == 0 and r.bad_wire is None)), (k, g, r)
+    for c in (a, b, lone): c.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
 def _run_two_ranks(script):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -110,4 +161,13 @@ def test_two_ranks_run_the_calculator_and_gather(tmp_path):
     lib = hb.build()
     script = tmp_path / "calc_worker.py"
     script.write_text(CALC_WORKER % (ROOT, lib, ROOT))
+    _run_two_ranks(script)
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_pipeline_two_calculators_each(tmp_path):
+    from tests.hostsim import build as hb
+    lib = hb.build()
+    script = tmp_path / "pipe_worker.py"
+    script.write_text(PIPE_WORKER % (ROOT, lib, ROOT))
     _run_two_ranks(script)
