@@ -208,6 +208,36 @@ def main():
     if rank == 0 and args.dump_results:
         np.save(args.dump_results, rec_all.cpu().numpy())
 
+    # ---- the same job without the pipeline (one calculator, generate -> gather -> evaluate per batch), 10 steps: reported beside `value`
+    # so that both are measured in the same run on the same box
+    single = None
+    if PIPE and 0 in used:
+        calcs[0].set_partner(None)
+
+        def step1():
+            streams[0].wait_stream(gs)
+            calcs[0].generate(streams[0].cuda_stream)
+            gs.wait_stream(streams[0])
+            with torch.cuda.stream(gs):
+                D.gather_records(recs[0])
+            calcs[0].constraint_check(streams[0].cuda_stream)
+
+        for _ in range(2):
+            step1()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            step1()
+        fence()
+        dt1 = time.perf_counter() - t1
+        if world > 1:
+            t1max = torch.tensor([dt1], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(t1max, op=dist.ReduceOp.MAX)
+            dt1 = float(t1max.item())
+        single = {"what": "one calculator per GPU, no pipeline (bench.py --pipeline 0), 10 steps after the timed region", "value": round(world * B * 10 / dt1, 1),
+                  "ms_per_step": round(dt1 / 10 * 1e3, 3)}
+        calcs[0].set_partner(calcs[1])
+
     info = calcs[0].info
     groups_h = (Bh + 63) // 64
     stream0 = streams[0].cuda_stream
@@ -276,7 +306,7 @@ def main():
                        "canonical_bytes_per_witness": int(info.n_witness) * 32, "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {Bh} (fill and drain inside the timed region)" if PIPE else f"{H} interleaved parts of {Bh} per GPU"),
                        "input_synthesis_s": round(t_synth, 2), "json_to_packed_witnesses_per_s": round(B / max(t_pack, 1e-9), 1),
                        "h2d_s": round(t_h2d, 3)},
-            "roofline": roofline, "cpu_baseline": cpu, "emission": emission,
+            "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single,
         }
         print(json.dumps(line))
     for c in calcs:
