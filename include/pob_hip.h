@@ -55,6 +55,14 @@ const char* pob_strerror(pob_handle h);
  *                  every one of them is range-constrained to <= 16 bits in-circuit)
  * Host pointers; the copy to HBM is synchronous.                                                                */
 int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n);
+/* The same for a service loop: the copies are enqueued on `stream` (NULL = the handle's upload stream) behind this handle's previous
+ * generation (which reads the input buffers) and the following pob_generate waits for them, so batch k+2 is uploaded while batches
+ * k and k+1 are in flight.  The host buffers must be pinned (pob_host_alloc) for the copy to be asynchronous and must stay
+ * untouched until that pob_generate has been enqueued and its stream has passed the copy (e.g. until the batch's results are in). */
+int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n, void* stream);
+/* Pinned host memory for the above (hipHostMalloc), so that a ctypes / cgo caller need not link the HIP runtime itself. */
+int pob_host_alloc(void** p, uint64_t bytes);
+void pob_host_free(void* p);
 
 /* Replaces the run of the calculator (all `<==` / `<--` / `===`; reference Makefile:4-5): enqueues every stage on
  * `stream` (a hipStream_t, NULL = the handle's own stream) for the n uploaded inputs.  Asynchronous.              */
@@ -78,16 +86,29 @@ int pob_set_partner(pob_handle h, pob_handle partner);
 int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* check_status, uint32_t* bad_wire);
 /* Device-resident results for the RCCL gather: status u32[max_batch_padded], outputs u8[max_batch_padded][32]. */
 int pob_results_device(pob_handle h, void** d_status, void** d_outputs);
-/* The same results as ONE packed record per witness, {u32 status, u8 commitment[32]} = 36 bytes, device-resident
- * (u8[max_batch_padded][36]): what a rank contributes to the single all-gather of the multi-GPU path.          */
-#define POB_RECORD_BYTES 36
+/* The same results as ONE packed record per witness (reference: one pass/fail + outputs per run, tests/test.py:40-47,65-68),
+ *   {u32 status, u32 check_status, u32 bad_wire, u8 commitment[32]} = 44 bytes,
+ * device-resident (u8[max_batch_padded][44]): what a rank contributes to the single all-gather of the multi-GPU path.
+ * Written at the end of pob_generate with check_status = bad_wire = POB_NOT_EVALUATED and re-written at the end of
+ * pob_constraint_check with the evaluator's verdict (0xFFFFFFFF there = clean), i.e. AFTER the evaluation of the batch.         */
+#define POB_RECORD_BYTES 44
+#define POB_NOT_EVALUATED 0xFFFFFFFEu
 int pob_results_records_device(pob_handle h, void** d_records);
+/* Per-batch, host-visible verdicts without stalling the device: pob_results_fetch enqueues the D2H copy of the batch's records into
+ * pinned memory owned by the handle, behind the handle's last pob_constraint_check (or pob_generate, if no evaluation was enqueued
+ * since); pob_results_wait blocks on THAT copy only (an event of this handle -- a partner handle's work is not waited for) and hands
+ * out the records (n x POB_RECORD_BYTES).  Two buffers alternate: the pointer stays valid until the fetch after the next one.
+ * The handle's next pob_generate is ordered behind the copy, so the records cannot be overwritten under it.                     */
+int pob_results_fetch(pob_handle h);
+int pob_results_wait(pob_handle h, const uint8_t** records, uint32_t* n);
 
 /* Replaces writeBinWitness (patch point `fclose(write_ptr)` at reference tests/test.py:36): expands witness `idx`
  * of the batch to canonical 32-byte LE values.  pob_emit_witness: payload only (32*W bytes) into host memory;
  * pob_write_wtns: full iden3 .wtns file.                                                                         */
 int pob_emit_witness(pob_handle h, uint32_t idx, uint8_t* dst, uint64_t cap);
 int pob_write_wtns(pob_handle h, uint32_t idx, const char* path);
+/* .wtns of the reduced witness (pob_emit_begin_reduced): nWitness = n_keep. */
+int pob_write_wtns_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uint64_t n_keep, const char* path);
 /* The streaming form underneath both: the canonical payload is expanded from the compact resident vector in WINDOWS of
  * `window_wires` wires (0 = 8 Mi wires = 256 MiB), double-buffered on the device and in pinned host memory, so that expanding window
  * k+1, copying it D2H and the caller's consumption of window k overlap, and a whole 32*W-byte device buffer never exists.
@@ -95,9 +116,18 @@ int pob_write_wtns(pob_handle h, uint32_t idx, const char* path);
  * wire and wire count; n_wires = 0 ends the witness.  The buffers are kept for the next witness.  A witness whose status is non-zero
  * is refused (POB_E_STATE): like the reference binary, a failed input produces no witness (reference tests/test.py:65-68).         */
 int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires);
+/* Reduced witness (reference: the circuits are compiled with --O0 today, Makefile:2-3; the deployed keys use the compiler's default
+ * simplification, .github/workflows/circuitscan.yml:29,36): only the wires keep[0..n_keep) (strictly increasing O0 wire indices,
+ * keep[0] == 0; which representative circom keeps is data of the caller, see circuit_model/o1.py) are expanded and copied, in windows of
+ * `window_wires` KEPT wires; a Keccak round block whose wires are all dropped costs nothing.  pob_emit_next then hands out windows
+ * of the reduced payload (first_wire / n_wires count kept wires).  The map is uploaded once per (handle, keep pointer contents).   */
+int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uint64_t n_keep, uint64_t window_wires);
 int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires);
 /* Measurement: `count` witnesses from `first_idx` on, back to back through the window pipeline into pinned host memory.          */
 int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes);
+/* The same with an optional reduced map (keep != NULL: pob_emit_begin_reduced).  The first witness a handle emits at a window size
+ * also allocates the window buffers (2 x device, 2 x pinned host) and runs the probe pass: call twice to separate that from the steady state. */
+int pob_emit_measure_ex(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, const uint32_t* keep, uint64_t n_keep, double* seconds, uint64_t* bytes);
 
 /* Measurement: average duration (ms, HIP events on `stream`) of `iters` back-to-back launches of one kernel over
  * the current batch.  which: 0 = Keccak round expansion (generate), 1 = Keccak round constraint evaluation,

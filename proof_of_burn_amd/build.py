@@ -9,10 +9,11 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-UNITS = ["g_gen_pos.hip", "g_emit_light.hip", "g_emit_heavy.hip", "g_check_pos.hip", "g_check_n2b.hip", "g_gen_n2b.hip", "g_gen_light.hip", "g_check_rl.hip", "g_check_ld.hip", "g_check_misc.hip", "g_check_sc.hip", "g_gen_sc.hip", "g_check_range.hip", "g_check_selrow.hip", "k_keccak.hip", "pob_host.hip"]
-HEADERS = ["fr_dev.hpp", "policy.hpp", "gadgets.hpp", "circuits.hpp", "kernels_common.hpp", "g_units.hpp", "keccak_kernels.hpp",
+UNITS = ["g_gen_poswide.hip", "g_emit_light.hip", "g_emit_heavy.hip", "g_check_pos.hip", "g_check_n2b.hip", "g_gen_n2b.hip", "g_gen_light.hip", "g_check_rl.hip", "g_check_ld.hip", "g_check_misc.hip", "g_check_sc.hip", "g_gen_sc.hip", "g_check_range.hip", "g_check_selrow.hip", "k_keccak.hip", "pob_host.hip"]
+HEADERS = ["fr_dev.hpp", "policy.hpp", "gadgets.hpp", "circuits.hpp", "kernels_common.hpp", "g_units.hpp", "keccak_kernels.hpp", "poseidon_wide.hpp",
            "poseidon_consts.h", os.path.join("..", "..", "include", "pob_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# (host pass at -O1: the only host code of any size is the layout planner, which runs once per pob_open)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-Xarch_host", "-O1", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 LIB = os.path.join(CSRC, "libpob_hip.so")
 
 
@@ -23,12 +24,23 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(src: str, obj: str):
+    """the headers a translation unit really includes (hipcc -MD dependency file of its last build); every header if there is none"""
+    dfile = obj[:-2] + ".d"
+    if os.path.exists(dfile) and os.path.exists(obj):
+        with open(dfile) as f:
+            toks = f.read().replace("\\\n", " ").split()
+        found = [t for t in toks[1:] if os.path.exists(t) and (t.startswith(CSRC) or "/include/pob_hip.h" in t)]
+        if found:
+            return found
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+
+
 def _compile(src: str, verbose: bool) -> str:
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
-    if _newer(obj, deps):
+    if _newer(obj, _deps(src, obj)):
         t0 = time.time()
-        cmd = ["hipcc", *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = ["hipcc", *FLAGS, "-MD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

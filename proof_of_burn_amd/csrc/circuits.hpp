@@ -31,10 +31,14 @@ enum UnitKind : uint32_t {
     CK_POS_SEG,          // a0 = T, a1 = segment (>= 1) of the Poseidon block at cur (gadgets.hpp gPoseidonSegStored)
     CK_SR_COLS,          // columns [a2, a3) of temps[][] of the ShiftRight(a0, a1) block at cur (gadgets.hpp gShiftRightCols)
     CK_SL_ROWS,          // rows [a1, a2) of the ShiftLeft(a0) block at cur, IsEqual children from cursor (a3, a4, a5) on (gShiftLeftRows)
-    CK_N2BE,             // Num2BigEndianBytes(a0) at cur; a1,a2 = source FR wire; a3,a4,a5 = caller's copy of out[] (w, i, present)
+    CK_N2BE,             // Num2BigEndianBytes(a0) at cur; a1,a2 = source FR wire; a3,a4,a5 = caller's copy of out[] (w, i, present);
+                         // also a GENERATION unit (same stage as its composite): a6,a7 = a wire of an earlier stage with the source's value
+    // generation-only unit (UNIT_GEN): the Poseidon(a0 - 1) block at cur with the state spread over lanes (poseidon_wide.hpp);
+    // a1 = prefix index, a2..a4 = FR ranks of inputs 1.., a5 = FR rank subtracted from the last input, a6 = FR rank of the caller's copy
+    U_POS_WIDE,
     U_KIND_COUNT
 };
-enum : uint32_t { UNIT_GEN = 1, UNIT_CHECK = 2 };      // UnitDesc.flags: generation + emission / constraint evaluation
+enum : uint32_t { UNIT_GEN = 1, UNIT_CHECK = 2, UNIT_EMIT = 4 };      // UnitDesc.flags: generation / constraint evaluation / .wtns emission
 // Kernel FAMILIES: every family is compiled as a kernel of its own (own register allocation -- one kernel over every unit kind
 // spilled ~1.9 k VGPRs in the evaluator); generation merges families into the classes of its stage scheduler.
 enum Fam : uint32_t { F_MISC = 0, F_RANGE, F_SELROW, F_LD, F_RL, F_SC, F_POS, F_N2B, F_COUNT };
@@ -48,7 +52,7 @@ HD constexpr uint32_t fam_of(uint32_t k) {
          : (k == U_LD_HEAD || k == U_LD_SELR || k == U_LD_TAIL || k == U_POB_LASTLAYER_RANGE || k == U_SC_SUMS) ? F_LD
          : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B || k == CK_SR_COLS || k == CK_SL_ROWS) ? F_RL
          : (k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE) ? F_SC
-         : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG) ? F_POS
+         : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG || k == U_POS_WIDE) ? F_POS
          : (k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_N2B || k == U_PC_POST || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == CK_N2BE) ? F_N2B
          : F_MISC;
 }
@@ -120,7 +124,7 @@ struct RaRefs {
     Cur c_cb, c_sl, c_lt, c_concat, c_end;
 };
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
-struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[6]; uint32_t cost, flags; };
+struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[8]; uint32_t cost, flags; };
 
 #define SC_RANGE_POS 32          // positions of SubstringCheck's existence loop per unit (one batch inversion each; <= 64)
 #define MAX_KB 72
@@ -338,7 +342,6 @@ HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; 
 // compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
 // this lane-per-witness code); F_SC / F_POS / F_N2B do BN254 arithmetic.
 HD bool unit_is_heavy(uint32_t k) { return fam_of(k) >= F_SC; }
-HD bool unit_uses_lds(uint32_t k) { return k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD; }   // generation: Poseidon table staged in LDS
 
 template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
 
@@ -671,19 +674,23 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         gAssertLessEqThanF(p, AB8, reveal, intended);
     } break;
     UCASE(U_POB_POSEIDONS) {      // :113 (a[0] = 0) remainingCoin = Poseidon3, :116 (a[0] = 1) nullifier = Poseidon2 -- two parallel units
+        // (evaluation / emission only: generation runs the two blocks as U_POS_WIDE units, which also write remainingCoin / nullifier)
         F bk = p.get(M.burnKey);
         if (d.a[0] == 0) {
             F in3[3] = {L.prefix[2], bk, fr_sub(p.get(M.intendedBalance), p.get(M.revealAmount))};
-            p.put(M.remainingCoin, gPoseidonU<P, 4>(p, pos_off(4), in3));
+            const PosSrc ps = {2, {M.burnKey.i, M.intendedBalance.i, POS_NONE}, M.revealAmount.i, M.remainingCoin.i};
+            p.put(M.remainingCoin, gPoseidonU<P, 4>(p, pos_off(4), in3, ps));
         } else {
             F in2[2] = {L.prefix[1], bk};
-            p.put(M.nullifier, gPoseidonU<P, 3>(p, pos_off(3), in2));
+            const PosSrc ps = {1, {M.burnKey.i, POS_NONE, POS_NONE}, POS_NONE, M.nullifier.i};
+            p.put(M.nullifier, gPoseidonU<P, 3>(p, pos_off(3), in2, ps));
         }
     } break;
     UCASE(U_BAH_PRE) {            // BurnAddressHash burn_address.circom:67-79 up to the sponge
         F bk = p.put(L.bah.in, p.get(M.burnKey)), ra = p.put(L.bah.in + 1, p.get(M.revealAmount)), bec = p.put(L.bah.in + 2, p.get(M.burnExtraCommitment));
         F hc;
-        gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec, L.fp_n2be32, &hc);
+        const PosSrc ps = {0, {M.burnKey.i, M.revealAmount.i, M.burnExtraCommitment.i}, POS_NONE, POS_NONE};
+        gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec, L.fp_n2be32, ps, &hc);
         // addressBytes, Fit(20, 136) [out[136] | in[20]] and the Keccak block: the 20 bytes again, written per witness (nothing read back)
         SmRef fo = p.sms(136), fi = p.sms(20);
         for (int i = 0; i < 136; i++) {
@@ -718,9 +725,13 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         A.isb = p.bits(1); A.isz = p.bits(1); A.frb = p.sms(1);
         F x = p.put(A.ri_i, bal);
         const SmRef r = {p.cur.w, p.cur.s};                 // Num2BigEndianBytes.out[N] = the block's first wires
-        gNum2BigEndianBytesFU(p, N, A.ri_i, x, L.fp_n2beN);
+        F xc;
+        gNum2BigEndianBytesFU(p, N, A.ri_i, x, L.fp_n2beN, M.actualBalance, nullptr, &xc);
         S lead = 0; bool still = true;
-        for (int j = 0; j < N; j++) { S b = p.put(A.by + j, p.get(r + j)); still = still && b == 0; lead += still; }
+        for (int j = 0; j < N; j++) {           // bytes[] <== Num2BigEndianBytes.out (generation: from the canonical value, the block is written beside this unit)
+            S b = p.put(A.by + j, P::is_gen ? canon_byte(xc, N - 1 - j) : p.get(r + j));
+            still = still && b == 0; lead += still;
+        }
         A.c_cb = p.cur;
         { CountP q; q.cur = p.cur; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
         p.cur = A.c_lt;
@@ -736,16 +747,20 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
     UCASE(U_POW_PRE) {            // ProofOfWorkChecker proof_of_work.circom:54-71 up to the sponge
         F bk = p.put(L.pw.in, p.get(M.burnKey)), ra = p.put(L.pw.in + 1, p.get(M.revealAmount)), bec = p.put(L.pw.in + 2, p.get(M.burnExtraCommitment));
         p.put(L.pw.mzb, (S)((uint32_t)prm.powZero + (uint32_t)p.get(M.byteSecurityRelax)));
-        gNum2BigEndianBytesFU(p, 32, L.pw.in, bk, L.fp_n2be32, &L.pw.keyBytes);
-        gNum2BigEndianBytesFU(p, 32, L.pw.in + 1, ra, L.fp_n2be32, &L.pw.raBytes);
-        gNum2BigEndianBytesFU(p, 32, L.pw.in + 2, bec, L.fp_n2be32, &L.pw.becBytes);
+        F cb, cr, ce;
+        gNum2BigEndianBytesFU(p, 32, L.pw.in, bk, L.fp_n2be32, M.burnKey, &L.pw.keyBytes, &cb);
+        gNum2BigEndianBytesFU(p, 32, L.pw.in + 1, ra, L.fp_n2be32, M.revealAmount, &L.pw.raBytes, &cr);
+        gNum2BigEndianBytesFU(p, 32, L.pw.in + 2, bec, L.fp_n2be32, M.burnExtraCommitment, &L.pw.becBytes, &ce);
         SmRef e = p.sms(8);                              // EIP7503 :11-21  [out[8]]
         const uint64_t tag = 0x333035372D504945ULL;      // "EIP-7503", first character in the low byte
         for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)((tag >> (8 * i)) & 0xff)));
         SmRef co = p.sms(104), ci = p.sms(104);          // ConcatFixed4(32,32,32,8) :28-48  [out | a,b,c,d]
         for (int i = 0; i < 104; i++) {
             SmRef s = i < 32 ? L.pw.keyBytes + i : i < 64 ? L.pw.raBytes + (i - 32) : i < 96 ? L.pw.becBytes + (i - 64) : L.pw.eip + (i - 96);
-            p.put(L.pw.hin + i, p.put(co + i, p.put(ci + i, p.get(s))));
+            S v;       // generation: the three byte strings are written beside this unit (CK_N2BE), so the bytes come from the canonical values
+            if constexpr (P::is_gen) v = i < 32 ? canon_byte(cb, 31 - i) : i < 64 ? canon_byte(cr, 63 - i) : i < 96 ? canon_byte(ce, 95 - i) : (S)((tag >> (8 * (i - 96))) & 0xff);
+            else v = p.get(s);
+            p.put(L.pw.hin + i, p.put(co + i, p.put(ci + i, v)));
         }
         SmRef f = gFitS(p, 104, 136, L.pw.hin);
         copy_n(p, L.pw.block, f, (int)(136));
@@ -761,13 +776,17 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         F bk = p.get(L.sm.burnKey), bal = p.get(L.sm.balance), wd = p.get(L.sm.withdrawnBalance), ec = p.get(L.sm.extraCommitment);
         gAssertGreaterEqThanF(p, L.spend.maxAmountBytes * 8, bal, wd);
         F in3[3] = {L.prefix[2], bk, bal};
-        F coin = p.put(L.sm.coin, gPoseidonU<P, 4>(p, pos_off(4), in3));
+        const FrRef pos1 = {p.cur.w, p.cur.f};                 // Poseidon.out of the first block
+        const PosSrc ps1 = {2, {L.sm.burnKey.i, L.sm.balance.i, POS_NONE}, POS_NONE, POS_NONE};
+        F coin = p.put(L.sm.coin, gPoseidonU<P, 4>(p, pos_off(4), in3, ps1));
         in3[2] = fr_sub(bal, wd);
-        F rc = p.put(L.sm.remainingCoin, gPoseidonU<P, 4>(p, pos_off(4), in3));
-        gNum2BigEndianBytesFU(p, 32, L.sm.coin, coin, L.fp_n2be32, &L.sm.coinBytes);
-        gNum2BigEndianBytesFU(p, 32, L.sm.withdrawnBalance, wd, L.fp_n2be32, &L.sm.withdrawnBalanceBytes);
-        gNum2BigEndianBytesFU(p, 32, L.sm.remainingCoin, rc, L.fp_n2be32, &L.sm.remainingCoinBytes);
-        gNum2BigEndianBytesFU(p, 32, L.sm.extraCommitment, ec, L.fp_n2be32, &L.sm.extraCommitmentBytes);
+        const FrRef pos2 = {p.cur.w, p.cur.f};
+        const PosSrc ps2 = {2, {L.sm.burnKey.i, L.sm.balance.i, POS_NONE}, L.sm.withdrawnBalance.i, POS_NONE};
+        F rc = p.put(L.sm.remainingCoin, gPoseidonU<P, 4>(p, pos_off(4), in3, ps2));
+        gNum2BigEndianBytesFU(p, 32, L.sm.coin, coin, L.fp_n2be32, pos1, &L.sm.coinBytes);
+        gNum2BigEndianBytesFU(p, 32, L.sm.withdrawnBalance, wd, L.fp_n2be32, L.sm.withdrawnBalance, &L.sm.withdrawnBalanceBytes);
+        gNum2BigEndianBytesFU(p, 32, L.sm.remainingCoin, rc, L.fp_n2be32, pos2, &L.sm.remainingCoinBytes);
+        gNum2BigEndianBytesFU(p, 32, L.sm.extraCommitment, ec, L.fp_n2be32, L.sm.extraCommitment, &L.sm.extraCommitmentBytes);
     } break;
     UCASE(U_POB_LAYER_POST) {     // :166-170 Fit(32,31) + the head of SubstringCheck (:24-41): own inputs, AssertByteString(sl),
                                  // AssertLessEqThan x2, LittleEndianBytes2Num(sl); AssertByteString(mm) runs as U_ABS_RANGE units
@@ -902,8 +921,8 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         if constexpr (P::is_check || P::is_count) gShiftLeftRows(p, (int)d.a[0], d.cur, Cur{d.a[3], d.a[4], d.a[5], d.cur.f, d.cur.q}, d.a[1], d.a[2]);
     } break;
     UCASE(CK_N2BE) {             // Num2BigEndianBytes(a0) at cur of the stored FR wire (a1, a2), caller's copy of out[] at (a3, a4) if a5
-        if constexpr (P::is_check || P::is_count) {
-            const FrRef src = {d.a[1], d.a[2]}; const SmRef also = {d.a[3], d.a[4]};
+        if constexpr (P::is_check || P::is_count || P::is_gen) {
+            const FrRef src = P::is_gen ? FrRef{d.a[6], d.a[7]} : FrRef{d.a[1], d.a[2]}; const SmRef also = {d.a[3], d.a[4]};
             gNum2BigEndianBytesFv(p, (int)d.a[0], p.get(src), also, d.a[5] != 0);
         }
     } break;
@@ -938,9 +957,13 @@ struct Plan {
     void expect_cursor(const char* what, Cur got, Cur want) {
         if (!same(got, want)) throw std::runtime_error(std::string("layout planner: split units disagree with the monolithic template: ") + what);
     }
-    void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0) {
-        UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.cost = 0; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5;
-        d.flags = (kind == CK_POS_SEG || kind == CK_N2BE || kind == CK_SR_COLS || kind == CK_SL_ROWS) ? UNIT_CHECK : (UNIT_GEN | UNIT_CHECK);
+    void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0, uint32_t a6 = 0, uint32_t a7 = 0) {
+        UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.cost = 0; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5; d.a[6] = a6; d.a[7] = a7;
+        d.flags = (kind == CK_POS_SEG || kind == CK_SR_COLS || kind == CK_SL_ROWS) ? UNIT_CHECK      // sub-blocks the evaluator runs on their own
+                : kind == CK_N2BE ? (UNIT_GEN | UNIT_CHECK)                                            // ... and the generator too
+                : kind == U_POS_WIDE ? UNIT_GEN
+                : kind == U_POB_POSEIDONS ? (UNIT_CHECK | UNIT_EMIT)                                   // generation: nothing but the two U_POS_WIDE blocks
+                : (UNIT_GEN | UNIT_CHECK | UNIT_EMIT);
         units.push_back(d);
         if (stage > max_stage) max_stage = stage;
     }
@@ -954,12 +977,16 @@ struct Plan {
     // sub-blocks the evaluator runs as wavefronts of their own (they start from stored wires): Poseidon segments 1.., byte conversions,
     // ShiftRight columns, ShiftLeft rows -- from the notes the counting policy took while it walked a composite unit
     void take_notes(CountP& q, uint32_t stage) {
+        if (q.notes_overflow) throw std::runtime_error("layout planner: a composite unit has more split sub-blocks than PLAN_MAX_NOTES");
         for (uint32_t k = 0; k < q.nnotes; k++) {
             const PlanNote& nt = q.notes[k];
             if (nt.what == NOTE_POSEIDON) {
                 const uint32_t ns = pos_nseg(pos_off((int)nt.n).rp);
                 for (uint32_t seg = 1; seg < ns; seg++) record(CK_POS_SEG, stage, nt.cur, nt.n, seg);
-            } else if (nt.what == NOTE_N2BE) record(CK_N2BE, stage, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4]);
+                // generation: the block one stage ahead of the composite that continues from its output
+                if (stage % TRACK_STRIDE == 0) throw std::runtime_error("layout planner: a Poseidon composite needs a stage before it");
+                record(U_POS_WIDE, stage - 1, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4], nt.a[5]);
+            } else if (nt.what == NOTE_N2BE) record(CK_N2BE, stage, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4], nt.a[5], nt.a[6]);
             else if (nt.what == NOTE_SHIFTRIGHT) { for (uint32_t j = 0; j < nt.n; j += 8) record(CK_SR_COLS, stage, nt.cur, nt.n, nt.a[0], j, std::min(j + 8, nt.n)); }
             else if (nt.what == NOTE_SHIFTLEFT) { for (uint32_t i = 0; i < nt.n; i += 2) record(CK_SL_ROWS, stage, nt.cur, nt.n, i, std::min(i + 2, nt.n), nt.a[0], nt.a[1], nt.a[2]); }
         }
@@ -1043,7 +1070,10 @@ struct Plan {
 
     // cost estimate (wires written, FR wires x8) of every unit, by replaying it on the counting policy
     void estimate_costs() {
-        for (UnitDesc& d : units) { CountP q; const UnitDesc dd = d; unit_run_all(q, dd, L); d.cost = q.nput * (unit_is_heavy(d.kind) ? 4 : 1); }
+        for (UnitDesc& d : units) {
+            if (d.kind == U_POS_WIDE) { d.cost = 8 * pos_wires((int)d.a[0], pos_off((int)d.a[0]).rp); continue; }
+            CountP q; const UnitDesc dd = d; unit_run_all(q, dd, L); d.cost = q.nput * (unit_is_heavy(d.kind) ? 4 : 1);
+        }
     }
     void plan_pob(const PobParams& prm) {
         memset(&L, 0, sizeof L);
@@ -1056,7 +1086,7 @@ struct Plan {
         // track 4 (TN): the five Num2BigEndianBytes of PublicCommitment's inputs, forked once the Poseidons are done (TB + 1), joined
         // before PublicCommitment's track forks (main stage 4); it runs on the main track's BN254 stream, which is idle until then.
         const uint32_t TB = TRACK_STRIDE, TR = 2 * TRACK_STRIDE, TC = 3 * TRACK_STRIDE, TN = 4 * TRACK_STRIDE;
-        ntracks = 6; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 5; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
+        ntracks = 6; track_fork[1] = 0; track_join[1] = 5; track_fork[2] = TB + 6; track_join[2] = 10; track_fork[3] = 0; track_join[3] = TR + 2;
         track_fork[4] = TB + 1; track_join[4] = 4;
         // track 5 (TP): everything of the layers / header that is NOT on the way to their Keccak sponges -- byte asserts, SelectorArray1D,
         // leaf detectors -- so that the main track is only inputs + KeccakBytes heads (0), byte ranges (1), sponges A (2), rows (3)
@@ -1090,15 +1120,17 @@ struct Plan {
         unit(U_POB_RANGE, TB + 1);
         for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, TP + 1, i); abs_units(TP + 1, LB, M.layers + i * LB); }
         unit(U_POB_HDR_ASSERT, TP + 1); abs_units(TP + 1, HBy, M.blockHeader);
-        unit(U_POB_POSEIDONS, TB + 1, 0);
-        unit(U_POB_POSEIDONS, TB + 1, 1);
+        // The three Poseidon blocks (:113, :116, burn_address.circom:55) run in TB + 1 as U_POS_WIDE units (state spread over lanes);
+        // the composites that continue from their outputs follow in TB + 2, with the Num2BigEndianBytes blocks beside them (CK_N2BE).
+        unit(U_POB_POSEIDONS, TB + 2, 0);
+        unit(U_POB_POSEIDONS, TB + 2, 1);
         {   // BurnAddressHash :119
             L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
             L.bah.kb = L.nkb++;
-            unit(U_BAH_PRE, TB + 1);
-            kb_ranges(L.bah.kb, TB + 2, L.bah.block);
-            keccak_tail(L.bah.kb, TB + 2, L.bah.hash, true);      // sponge TB+3, rows/post TB+4
-            unit(U_BAH_POST, TB + 5);
+            unit(U_BAH_PRE, TB + 2);
+            kb_ranges(L.bah.kb, TB + 3, L.bah.block);
+            keccak_tail(L.bah.kb, TB + 3, L.bah.hash, true);      // sponge TB+4, rows/post TB+5
+            unit(U_BAH_POST, TB + 6);
         }
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot, M.blockHeaderLen.i - in0 + 1);       // :122
@@ -1174,10 +1206,10 @@ struct Plan {
             L.pw.in = p.frs(3); L.pw.mzb = p.sms(1); L.pw.keyBytes = p.sms(32); L.pw.raBytes = p.sms(32); L.pw.becBytes = p.sms(32); L.pw.eip = p.sms(8);
             L.pw.hin = p.sms(104); L.pw.block = p.sms(136); L.pw.keccak = p.sms(32); L.pw.sbz = p.bits(32);
             L.pw.kb = L.nkb++;
-            unit(U_POW_PRE, TB + 1);
-            kb_ranges(L.pw.kb, TB + 2, L.pw.block);
-            keccak_tail(L.pw.kb, TB + 2, L.pw.keccak, true);
-            unit(U_POW_POST, TB + 5);
+            unit(U_POW_PRE, TB + 2);                              // (inputs only; in step with BurnAddressHash so that the two sponges share their launches)
+            kb_ranges(L.pw.kb, TB + 3, L.pw.block);
+            keccak_tail(L.pw.kb, TB + 3, L.pw.keccak, true);
+            unit(U_POW_POST, TB + 6);
         }
         unit(U_POB_FINAL, 10);
         total = p.cur;
@@ -1195,8 +1227,8 @@ struct Plan {
         M.extraCommitmentBytes = p.sms(32);
         nfr_in = 4; nsm_in = 0;
         unit(U_SP_INPUT, 0);
-        unit(U_SP_HEAD, 1);
-        public_commitment(4, 2);
+        unit(U_SP_HEAD, 2);                                       // (the two Poseidon blocks: U_POS_WIDE units in stage 1)
+        public_commitment(4, 3);
         total = p.cur;
         estimate_costs();
     }

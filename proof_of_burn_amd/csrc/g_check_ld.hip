@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_check_ld, CheckP, FAM_BIT(F_LD), 8, false)
+POB_DEFINE_G_LAUNCH(launch_g_check_ld, CheckP, FAM_BIT(F_LD), 8)

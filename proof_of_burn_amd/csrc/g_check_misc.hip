@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_check_misc, CheckP, FAM_BIT(F_MISC), 7, false)
+POB_DEFINE_G_LAUNCH(launch_g_check_misc, CheckP, FAM_BIT(F_MISC), 7)

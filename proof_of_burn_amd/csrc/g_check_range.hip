@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_check_range, CheckP, FAM_BIT(F_RANGE), 6, false)
+POB_DEFINE_G_LAUNCH(launch_g_check_range, CheckP, FAM_BIT(F_RANGE), 6)

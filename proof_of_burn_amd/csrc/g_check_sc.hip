@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_check_sc, CheckP, FAM_BIT(F_SC), 4, false)
+POB_DEFINE_G_LAUNCH(launch_g_check_sc, CheckP, FAM_BIT(F_SC), 4)

@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_gen_light, GenP, FAM_LIGHT, 8, false)
+POB_DEFINE_G_LAUNCH(launch_g_gen_light, GenP, FAM_LIGHT, 8)

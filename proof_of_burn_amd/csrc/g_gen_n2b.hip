@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_gen_n2b, GenP, FAM_BIT(F_N2B), 4, false)
+POB_DEFINE_G_LAUNCH(launch_g_gen_n2b, GenP, FAM_HEAVY, 4)

@@ -2,11 +2,8 @@
 #pragma once
 #include "kernels_common.hpp"
 
-extern __shared__ uint32_t g_lds[];
-
-// MASK = families (circuits.hpp Fam) this kernel serves; WAVES = waves per SIMD it is compiled for (VGPR budget 512 / WAVES);
-// LDS = may stage the Poseidon table in LDS (generation's Poseidon kernel)
-template <class P, uint32_t MASK, int WAVES, bool LDS> __global__ void __launch_bounds__(64, WAVES) g_units(GArgs A) {
+// MASK = families (circuits.hpp Fam) this kernel serves; WAVES = waves per SIMD it is compiled for (VGPR budget 512 / WAVES)
+template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(64, WAVES) g_units(GArgs A) {
     // the few long BN254 chains share their SIMDs with thousands of short light / Keccak waves: let the arbiter favour them
     if constexpr ((MASK & ~FAM_LIGHT) != 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
@@ -29,16 +26,9 @@ template <class P, uint32_t MASK, int WAVES, bool LDS> __global__ void __launch_
         p.m.rs_sb = __builtin_amdgcn_make_buffer_rsrc(sbp, 0, (int)(A.sb_stride > 0xFFFFFFFFull ? 0xFFFFFFFFull : A.sb_stride), 0x00020000);
     }
     p.m.pos_tab = A.pos_tab;
-    if constexpr (LDS) {
-        if (A.stage_lds) {   // Poseidon round constants + MDS/sparse matrices -> LDS, broadcast reads from there
-            for (uint32_t i = lane; i < POS_TABLE_LEN * 8; i += 64) g_lds[i] = A.pos_tab[i];
-            __syncthreads();
-            p.m.pos_tab = g_lds;
-        }
-    }
     if constexpr (P::is_gen) p.status = 0;
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false; }
-    if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.unit = A.order[A.first + blockIdx.x]; }
+    if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.unit = A.order[A.first + blockIdx.x]; }
     for (int pass = 0;; pass++) {
         const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
         if constexpr ((MASK & ~FAM_LIGHT) == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
@@ -56,7 +46,7 @@ template <class P, uint32_t MASK, int WAVES, bool LDS> __global__ void __launch_
     }
 }
 // one launcher per kernel (each in its own translation unit, compiled in parallel)
-#define POB_DEFINE_G_LAUNCH(name, POL, MASK, WAVES, LDS)                                                                       \
+#define POB_DEFINE_G_LAUNCH(name, POL, MASK, WAVES)                                                                            \
     void name(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st) {                                             \
-        hipLaunchKernelGGL((g_units<POL, (MASK), WAVES, LDS>), dim3(nunits, ngroups), dim3(64), (LDS && A.stage_lds) ? sizeof(POS_TABLE_MONT) : 0, st, A); \
+        hipLaunchKernelGGL((g_units<POL, (MASK), WAVES>), dim3(nunits, ngroups), dim3(64), 0, st, A);                          \
     }

@@ -13,8 +13,10 @@
 #include <type_traits>
 #include "policy.hpp"
 
-#ifdef __HIPCC__
+#if defined(__HIPCC__) && (defined(__HIP_DEVICE_COMPILE__) || defined(POB_HOSTSIM))
 #define GD __host__ __device__ __forceinline__   // the policy object must stay in registers: one non-inlined callee taking P& forces it (and every p.cur/p.m access) through memory
+#elif defined(__HIPCC__)
+#define GD __host__ __device__ inline            // host pass (layout planner): no forced inlining -- it only made the planner's translation unit slow to compile
 #else
 #define GD
 #endif
@@ -393,15 +395,23 @@ template <class P, int T> GD void gPoseidonSegStored(P& p, const PosOff& k, Cur 
     gPoseidonSeg<P, T>(p, k, base, seg, st);
 }
 
-// Poseidon as a composite unit sees it: generation / counting / emission run the whole block; the evaluator checks the head
-// (the inputs) here, leaves segments 1.. to CK_POS_SEG units and continues from the block's STORED output wire.
-template <class P, int T> GD F gPoseidonU(P& p, const PosOff& k, const F* inputs) {
-    if constexpr (P::is_count) p.note(NOTE_POSEIDON, (uint32_t)T, p.cur);
-    if constexpr (P::is_check) {
+// Poseidon as a composite unit sees it.  The block never runs inside the composite on the device:
+//   * generation runs it as a U_POS_WIDE unit of its own, one stage EARLIER, with the state spread over lanes (poseidon_wide.hpp):
+//     the composite continues from the block's stored output wire.  `src` says which wires feed the block (FR ranks of wires written
+//     in earlier stages) and where the caller's copy of the hash goes;
+//   * the evaluator checks the head (the inputs) here, leaves segments 1.. to CK_POS_SEG units and continues from the stored output;
+//   * counting and emission walk the whole block.
+#define POS_NONE 0xFFFFFFFFu
+struct PosSrc { uint32_t pre, in[3], sub, also; };   // input 0 = POSEIDON_PREFIX + pre; in[] = inputs 1.. ; the LAST input is in - sub; also = copy of out
+template <class P, int T> GD F gPoseidonU(P& p, const PosOff& k, const F* inputs, const PosSrc& src) {
+    if constexpr (P::is_count) p.note(NOTE_POSEIDON, (uint32_t)T, p.cur, src.pre, src.in[0], src.in[1], src.in[2], src.sub, src.also);
+    if constexpr (P::is_check || P::is_gen) {
         const Cur base = p.cur;
-        p.frs(1);
-        typename PosSt<P>::type st[T];
-        gPoseidonSeg0<P, T>(p, k, inputs, st);
+        if constexpr (P::is_check) {
+            p.frs(1);
+            typename PosSt<P>::type st[T];
+            gPoseidonSeg0<P, T>(p, k, inputs, st);
+        }
         const uint32_t n = pos_wires(T, k.rp);
         p.cur = Cur{base.w + n, base.b, base.s, base.f + n, base.q};
         return p.get(FrRef{base.w, base.f});
@@ -809,11 +819,13 @@ template <class P> GD SmRef gNum2BigEndianBytesF(P& p, int N, const F& in, const
 }
 // footprint of Num2BigEndianBytes(N) (every wire count is a function of N only)
 HD Cur n2be_footprint(int N) { CountP q; q.cur = Cur{0, 0, 0, 0, 0}; gNum2BigEndianBytesF(q, N, fr_zero()); return q.cur; }
-// Num2BigEndianBytes as a composite unit sees it: `src` = the caller's stored wire that feeds it.  The evaluator runs the block
-// as a CK_N2BE unit of its own (from the stored `src`) and the composite only steps over it; *cout = canonical value of x.
-template <class P> GD void gNum2BigEndianBytesFU(P& p, int N, FrRef src, const F& x, Cur fp, const SmRef* also = nullptr, F* cout = nullptr) {
-    if constexpr (P::is_count) p.note(NOTE_N2BE, (uint32_t)N, p.cur, src.w, src.i, also ? also->w : 0u, also ? also->i : 0u, also ? 1u : 0u);
-    if constexpr (P::is_check) {
+// Num2BigEndianBytes as a composite unit sees it: `src` = the caller's stored wire that feeds it.  Generation and the evaluator run
+// the block as a CK_N2BE unit of its own and the composite only steps over it; *cout = canonical value of x (the composite takes
+// the bytes it needs from there: nothing of the block is read back).  The evaluator's unit starts from the stored `src`; the
+// generator's runs in the SAME stage as the composite, so it reads `gen_src`: a wire of an EARLIER stage that carries the same value.
+template <class P> GD void gNum2BigEndianBytesFU(P& p, int N, FrRef src, const F& x, Cur fp, FrRef gen_src, const SmRef* also = nullptr, F* cout = nullptr) {
+    if constexpr (P::is_count) p.note(NOTE_N2BE, (uint32_t)N, p.cur, src.w, src.i, also ? also->w : 0u, also ? also->i : 0u, also ? 1u : 0u, gen_src.w, gen_src.i);
+    if constexpr (P::is_check || P::is_gen) {
         p.cur = cur_add(p.cur, fp, 1);
         if (cout) *cout = fr_from_mont(x);
     } else gNum2BigEndianBytesF(p, N, x, also, cout);
@@ -1066,12 +1078,13 @@ template <class P> GD B gLeafDetector(P& p, int N, SmRef src, S layerLen) {
 
 // ============================================================================ circuits/utils/burn_address.circom:47-58
 // BurnAddress  [addressBytes[20] | burnKey, revealAmount, burnExtraCommitment | hash, hashBytes[32]] || Poseidon(4), Num2BigEndianBytes(32), Fit(32,20)
-template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec, Cur fp_n2be32, F* hash_canon = nullptr) {
+template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec, Cur fp_n2be32, const PosSrc& psrc, F* hash_canon = nullptr) {
     SmRef o = p.sms(20); FrRef in = p.frs(3), h = p.frs(1); SmRef hb = p.sms(32);
     F pin[4]; pin[0] = prefix0; pin[1] = p.put(in, bk); pin[2] = p.put(in + 1, ra); pin[3] = p.put(in + 2, bec);
-    F hash = p.put(h, gPoseidonU<P, 5>(p, k5, pin));
+    const FrRef pos_out = {p.cur.w, p.cur.f};            // Poseidon.out: the block's first wire
+    F hash = p.put(h, gPoseidonU<P, 5>(p, k5, pin, psrc));
     F c;
-    gNum2BigEndianBytesFU(p, 32, h, hash, fp_n2be32, &hb, &c);   // hashBytes[i] = big-endian byte i = little-endian byte 31 - i, written per witness
+    gNum2BigEndianBytesFU(p, 32, h, hash, fp_n2be32, pos_out, &hb, &c);   // hashBytes[i] = big-endian byte i = little-endian byte 31 - i, written per witness
     SmRef fo = p.sms(20), fi = p.sms(32);                // Fit(32, 20)  [out[20] | in[32]]
     for (int i = 0; i < 32; i++) { const S by = canon_byte(c, 31 - i); p.put(fi + i, by); if (i < 20) { p.put(fo + i, by); p.put(o + i, by); } }
     if (hash_canon) *hash_canon = c;

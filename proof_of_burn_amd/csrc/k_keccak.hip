@@ -6,13 +6,27 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
     else hipLaunchKernelGGL(k_chain<false>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
 }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
-    // non-temporal loads: 4.35 -> 4.09 ms per launch at batch 1024 (0.785 -> 0.836 of the HBM peak); POB_KCHK_NT=0 for the plain loads
-    static const int nt = getenv("POB_KCHK_NT") ? atoi(getenv("POB_KCHK_NT")) : 1;
-    if (check && nt) hipLaunchKernelGGL((k_rounds<true, true>), dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
-    else if (check) hipLaunchKernelGGL(k_rounds<true>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
-    else hipLaunchKernelGGL(k_rounds<false>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
+    // (non-temporal loads in the evaluation: 4.35 -> 4.09 ms per launch at batch 1024, 0.785 -> 0.836 of the HBM peak)
+    // experiment switches (A/B on one box): POB_KR_PERSIST_CHECK / POB_KR_PERSIST_GEN = waves per SIMD of the persistent form, 0 = one wavefront per item
+    static const int pc = getenv("POB_KR_PERSIST_CHECK") ? atoi(getenv("POB_KR_PERSIST_CHECK")) : 0;
+    static const int pg = getenv("POB_KR_PERSIST_GEN") ? atoi(getenv("POB_KR_PERSIST_GEN")) : 0;
+    const uint32_t gx = nperms * 24, total = gx * ngroups;
+    const int wps = check ? pc : pg;
+    if (wps > 0 && K.work_counter && total > 1024u * (uint32_t)wps) {
+        hipMemsetAsync(K.work_counter, 0, 4, st);
+        if (check) hipLaunchKernelGGL((k_rounds_persist<true, true>), dim3(1024u * (uint32_t)wps), dim3(64), 0, st, K, gx, total, K.work_counter);
+        else hipLaunchKernelGGL((k_rounds_persist<false>), dim3(1024u * (uint32_t)wps), dim3(64), 0, st, K, gx, total, K.work_counter);
+        return;
+    }
+    if (check) hipLaunchKernelGGL((k_rounds<true, true>), dim3(gx, ngroups), dim3(64), 0, st, K);
+    else hipLaunchKernelGGL(k_rounds<false>, dim3(gx, ngroups), dim3(64), 0, st, K);
 }
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
     uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_emit_bits, dim3(blocks), dim3(256), 0, st, G, out, wire_base, bit_base, count, sel);
+}
+void launch_k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t bit_base, uint32_t count, uint32_t sel, const unsigned long long* rbits, const uint32_t* rpre,
+                            uint32_t k0, uint32_t kn, hipStream_t st) {
+    uint32_t blocks = (count + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_emit_bits_red, dim3(blocks), dim3(256), 0, st, G, out, wire0, bit_base, count, sel, rbits, rpre, k0, kn);
 }

@@ -280,14 +280,13 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
     if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
 }
 
-// One KeccakfRound block per wavefront: grid.x = (permutation, round), grid.y = group.  Reads midRound[r] (written by
-// k_chain), writes (GenIO) or verifies (CheckIO) the 102 656 wires of the round.  This is the HBM-streaming kernel.
-template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t pi = A.first + blockIdx.x / 24, r = blockIdx.x % 24;
+// One KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain), writes (GenIO) or verifies
+// (CheckIO) the 102 656 wires of the round.  This is the HBM-streaming kernel.
+template <bool CHECK, bool NT> __device__ __forceinline__ void rounds_item(const KArgs& A, uint32_t x, uint32_t y, uint32_t lane) {
+    const uint32_t pi = A.first + x / 24, r = x % 24;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t Kf = sp.abs_b + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF;
-    u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    u64* G = A.bits + (uint64_t)y * A.group_stride;
     u64 in[25], out[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) in[i] = G[Kf + KF_MID + 1600 * r + 64 * i + lane];
@@ -299,10 +298,28 @@ template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_r
         for (int i = 0; i < 25; i++) bad |= out[i] ^ G[Kf + KF_MID + 1600 * (r + 1) + 64 * i + lane];   // midRound[r+1] <== round.out
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
-        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
+        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
     } else {
         GenIO io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane;
         round_walk(io, in, (int)r, out);
+    }
+}
+// grid = (24 * permutations, groups): one wavefront per item
+template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
+    rounds_item<CHECK, NT>(A, blockIdx.x, blockIdx.y, threadIdx.x);
+}
+// Persistent form: a FIXED number of wavefronts (waves per SIMD x 1 024 SIMDs) pull items from a counter.  A streaming kernel
+// launched as 32 000 short-lived wavefronts loses its register slots to whatever else is queued each time one of them retires --
+// the latency-bound G kernels that run beside it take the slot and hold it for a long time -- and its bandwidth goes with its
+// occupancy.  Resident wavefronts keep their slots for the whole pass; the kernels beside it get the registers it leaves free.
+template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds_persist(KArgs A, uint32_t gx, uint32_t total, uint32_t* counter) {
+    const uint32_t lane = threadIdx.x;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1u);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(item, 0, 64));       // lane 0's item, wave-uniform
+        if (item >= total) break;
+        rounds_item<CHECK, NT>(A, item % gx, item / gx, lane);
     }
 }
 
@@ -311,6 +328,20 @@ __global__ void __launch_bounds__(256) k_emit_bits(const u64* G, uint8_t* out, u
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         const uint32_t v = (uint32_t)((G[bit_base + t] >> sel) & 1);
         uint4* q = (uint4*)(out + (uint64_t)(wire_base + t) * 32);
+        q[0] = make_uint4(v, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
+    }
+}
+// the same for the reduced witness (policy.hpp EmitP::w32): thread per wire of the run, dropped wires cost one bitmap test
+__global__ void __launch_bounds__(256) k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t bit_base, uint32_t count, uint32_t sel,
+                                                       const unsigned long long* rbits, const uint32_t* rpre, uint32_t k0, uint32_t kn) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const uint32_t w = wire0 + t;
+        const unsigned long long word = rbits[w >> 6];
+        if (!((word >> (w & 63)) & 1)) continue;
+        const uint32_t p = rpre[w >> 6] + (uint32_t)__popcll(word & ((1ull << (w & 63)) - 1)) - k0;
+        if (p >= kn) continue;
+        const uint32_t v = (uint32_t)((G[bit_base + t] >> sel) & 1);
+        uint4* q = (uint4*)(out + (uint64_t)p * 32);
         q[0] = make_uint4(v, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
     }
 }

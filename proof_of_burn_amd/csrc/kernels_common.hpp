@@ -20,7 +20,7 @@ struct GArgs {
     uint8_t* emit_out; uint32_t emit_sel, emit_group;
     uint32_t emit_w0, emit_wn;                         // emission window: wires [emit_w0, emit_w0 + emit_wn) land at emit_out + 32 * (w - emit_w0)
     unsigned long long* emit_probe;                    // probe pass: nothing is written, bit (w / emit_wn) of emit_probe[unit] is set instead
-    uint32_t stage_lds;                                // 1: stage the Poseidon table in LDS (dynamic shared memory)
+    const unsigned long long* emit_rbits; const uint32_t* emit_rpre;   // reduced witness: kept-wire bitmap + per-word rank (policy.hpp EmitP); null = O0 payload
 };
 struct KArgs {
     u64* bits;                 // BIT slabs, all groups
@@ -30,14 +30,15 @@ struct KArgs {
     const uint32_t* perm_block;
     uint32_t* bad_wire;        // per witness: lowest inconsistent wire (CheckIO)
     uint32_t first, count;
+    uint32_t* work_counter;    // item counter of the persistent round kernels (one word per stream that may run them at a time)
 };
 
-// grid = (nunits, ngroups) wavefronts.  Generation: one kernel per scheduling class (light | SubstringCheck BN254 | Poseidon with the
-// table in LDS, serving every BN254 family | the non-Poseidon BN254 units at <= 128 VGPRs); constraint evaluation: one kernel per
-// family (circuits.hpp Fam); emission: light | BN254 | SubstringCheck.
+// grid = (nunits, ngroups) wavefronts.  Generation: one kernel per scheduling class (light | SubstringCheck BN254 | the other BN254
+// units at <= 128 VGPRs) + the Poseidon blocks (poseidon_wide.hpp, 8 wavefronts per unit and group); constraint evaluation: one kernel
+// per family (circuits.hpp Fam); emission: light | BN254 | SubstringCheck.
 void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_g_gen_pos(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_pos_wide(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_n2b(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_misc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_range(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
@@ -53,3 +54,5 @@ void launch_g_emit_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStre
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);
+// reduced form: wires [wire0, wire0 + count) with BIT ranks from bit_base; kept wires land at out + 32 * (rank - k0) when rank - k0 < kn
+void launch_k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t bit_base, uint32_t count, uint32_t sel, const unsigned long long* rbits, const uint32_t* rpre, uint32_t k0, uint32_t kn, hipStream_t st);

@@ -23,8 +23,10 @@ __global__ void k_init_invlut(uint32_t* lut) {   // canonical inverses of -4096.
     for (int j = 0; j < 8; j++) lut[t * 8 + j] = c.l[j];
 }
 // status/outputs of the batch: commitment FR (Montgomery) -> canonical LE; 0xFFFFFFFF -> 0 (ok)
-// and the same as ONE record per witness {u32 status, u8 commitment[32]} (36 B): the payload of the multi-GPU result gather
-__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, const uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t* records, uint32_t n) {
+// and the same as ONE record per witness {u32 status, u32 check_status, u32 bad_wire, u8 commitment[32]} (44 B): what the host reads
+// per batch and the payload of the multi-GPU result gather.  chk / bad = the evaluator's words (null: not evaluated yet)
+__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, const uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t* records,
+                          const uint32_t* chk, const uint32_t* bad, uint32_t n) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
     const uint32_t g = w / 64, lane = w % 64;
@@ -35,9 +37,11 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
     uint32_t s = status_raw[w];
     s = s == 0xFFFFFFFFu ? 0 : s;
     status[w] = s;
-    uint32_t* rec = records + (uint64_t)w * 9;
+    uint32_t* rec = records + (uint64_t)w * (POB_RECORD_BYTES / 4);
     rec[0] = s;
-    for (int k = 0; k < 8; k++) rec[1 + k] = c.l[k];
+    rec[1] = chk ? chk[w] : POB_NOT_EVALUATED;
+    rec[2] = bad ? bad[w] : POB_NOT_EVALUATED;
+    for (int k = 0; k < 8; k++) rec[3 + k] = c.l[k];
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
@@ -108,6 +112,7 @@ struct pob_ctx {
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
     uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
+    uint32_t* d_work = nullptr;                        // item counters of the persistent Keccak round kernels: [0] generation, [1] evaluation
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
     struct Emit {
@@ -117,19 +122,22 @@ struct pob_ctx {
         struct Run { uint32_t w, b, n; };
         std::vector<Run> runs;                          // the Keccak-owned BIT runs (wire index, BIT rank, count), sorted by wire index
         // which G units write into which window (found by one probe pass per window size): a window launches only those
-        uint64_t probe_win = 0; uint32_t* d_order = nullptr; unsigned long long* d_probe = nullptr;
+        uint64_t probe_win = 0, probe_map = 0; uint32_t* d_order = nullptr; unsigned long long* d_probe = nullptr;
         struct WSeg { uint32_t cls, first, count; };
         std::vector<std::vector<WSeg>> wsegs;
+        // reduced witness (pob_emit_begin_reduced): the kept O0 wire indices (host copy for the run intersections), their bitmap and the
+        // per-word rank on the device; map_id = 0: O0 payload.  total = wires of the payload being emitted (W or the kept count)
+        bool red = false; uint64_t map_id = 0, total = 0; std::vector<uint32_t> keep; unsigned long long* d_rbits = nullptr; uint32_t* d_rpre = nullptr;
     } em;
     // schedule
     std::vector<uint32_t> order;                       // unit indices grouped by (stage, lds flag)
     struct Seg { uint32_t stage, lds, first, count; };
     std::vector<Seg> segs, emit_segs, chk_segs;        // per (stage, class) for generation; per class for emission; per FAMILY for evaluation
-    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
-    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; uint32_t is_long; };
+    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; };
     std::vector<KSeg> ksegs;                           // ev_done: recorded behind the segment's sponge kernels in pob_generate
-    hipStream_t stream_k = nullptr; hipEvent_t ev_joink = nullptr;      // the Keccak evaluation's own stream (see pob_constraint_check)
-    hipStream_t stream_long = nullptr; hipEvent_t ev_long_fork = nullptr, ev_long_join = nullptr, ev_rounds_fork = nullptr;   // a stage's LONG sponges (>= POB_LONG_SPONGE blocks)
+    hipStream_t stream_k = nullptr;                                     // the main track's round expansion in pipeline mode (pob_generate)
+    hipEvent_t ev_rounds_fork = nullptr;
     // side tracks (Plan::track_fork/track_join): streams of the device's pool (StreamPool below), own fork/join events, start and end events
     // (ROCm multiplexes streams onto few hardware queues: a lone handle keeps to the caller's stream + 4 of the pool's --
     //  stream2, track 1's (also track 6), track 2's (also track 3, which runs before it anyway), the round expansion's; a track's BN254 and light
@@ -141,23 +149,34 @@ struct pob_ctx {
     // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
     // waits for the end of that evaluation; the evaluation then uses the pool's two evaluation streams
     pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
-    hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false;
+    hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false, evaluated = false;
+    // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
+    hipStream_t s_upload = nullptr, s_fetch = nullptr; hipEvent_t ev_upload = nullptr, ev_fetched[2] = {nullptr, nullptr};
+    uint8_t* h_records[2] = {nullptr, nullptr}; int fetch_slot = 0; bool upload_pending = false, fetch_pending = false; uint32_t fetch_n = 0;
 };
 
 // The side streams are shared by every handle of a device (a handle's launches on them are ordered by events anyway): ROCm multiplexes
 // streams onto GPU_MAX_HW_QUEUES hardware queues and two handles with six streams each fall off that cliff (two calculators in
 // flight ran at 1/30 of the speed).  chk1/chk2 are created on first use (pipeline mode only).
-struct StreamPool { int device = 0, refs = 0; hipStream_t stream2 = nullptr, stream_k = nullptr, stream_long = nullptr, track1 = nullptr, track2 = nullptr, chk1 = nullptr, chk2 = nullptr; };
+struct StreamPool { int device = 0, refs = 0; hipStream_t stream2 = nullptr, stream_k = nullptr, track1 = nullptr, track2 = nullptr, chk1 = nullptr, chk2 = nullptr; };
 static std::mutex g_pool_mu;
 static std::vector<StreamPool*> g_pools;
 
+// hardware queues the HIP runtime was (most likely) initialised with: the variable is read once, at runtime initialisation
+#define POB_PIPELINE_HW_QUEUES 12
+static int hw_queues_env() { const char* e = getenv("GPU_MAX_HW_QUEUES"); return e ? atoi(e) : 4; }
+// loaded before the HIP runtime initialises (the usual case for a ctypes / cgo caller): ask for enough queues unless the caller decided otherwise
+__attribute__((constructor)) static void pob_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
-// generation scheduling class: 0 = light, 1 = BN254 (no Poseidon), 2 = BN254 + Poseidon table in LDS, 3 = SubstringCheck BN254
-static uint32_t unit_class(uint32_t kind) { return fam_of(kind) == F_SC ? 3 : unit_uses_lds(kind) ? 2 : unit_is_heavy(kind) ? 1 : 0; }
+// generation scheduling class: 0 = light, 1 = BN254 (byte conversions, range checks, the composites around the Poseidon blocks),
+// 3 = SubstringCheck BN254, 4 = Poseidon blocks with the state spread over lanes (poseidon_wide.hpp)
+#define N_GEN_CLASSES 5
+static uint32_t unit_class(uint32_t kind) { return kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : unit_is_heavy(kind) ? 1 : 0; }
 static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (cls == 3) launch_g_gen_sc(A, nunits, ngroups, st);
-    else if (cls == 2 || (cls == 1 && A.stage_lds)) launch_g_gen_pos(A, nunits, ngroups, st);
+    if (cls == 4) launch_pos_wide(A, nunits, ngroups, st);
+    else if (cls == 3) launch_g_gen_sc(A, nunits, ngroups, st);
     else if (cls == 1) launch_g_gen_n2b(A, nunits, ngroups, st);
     else launch_g_gen_light(A, nunits, ngroups, st);
 }
@@ -193,8 +212,9 @@ static GArgs gargs(pob_ctx* h) {
     A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
     return A;
 }
-static KArgs kargs(pob_ctx* h) {
+static KArgs kargs(pob_ctx* h, bool check = false) {
     KArgs K; memset(&K, 0, sizeof K);
+    K.work_counter = h->d_work ? h->d_work + (check ? 1 : 0) : nullptr;
     K.bits = (u64*)h->d_bits; K.group_stride = h->plan.total.b; K.sponges = h->d_sponges;
     K.perm_sponge = h->d_perm_sponge; K.perm_block = h->d_perm_block; K.bad_wire = h->d_bad;
     return K;
@@ -298,35 +318,26 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         pl.L.prefix[0] = base; pl.L.prefix[1] = fr_add(base, fr_one_mont()); pl.L.prefix[2] = fr_add(pl.L.prefix[1], fr_one_mont());
     }
     // ---- schedule: sponges sorted by stage, perms flattened; units grouped by (stage, needs LDS table)
-    // A stage's LONG sponges (the header's 16 blocks: 0.7 ms of serial chain) go to a stream of their own, so that the round expansion
-    // of the short ones (the layers' 4-block sponges: 0.18 ms of chain) does not wait for the long chain.  POB_LONG_SPONGE=8 turns it on.
-    // Measured: the long chain beside the expansion takes 4.3-4.8 ms instead of 0.7 and the step does not get shorter: off by default.
-    const uint32_t long_n = getenv("POB_LONG_SPONGE") ? (uint32_t)atoi(getenv("POB_LONG_SPONGE")) : 0;
-    auto is_long = [&](const SpongeDesc& sp) { return long_n && sp.n >= long_n ? 1u : 0u; };
-    std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [&](const SpongeDesc& a, const SpongeDesc& b) {
-        return a.stage != b.stage ? a.stage < b.stage : is_long(a) < is_long(b); });
+    // (a stage's LONG sponges -- the header's 16 blocks -- on a stream of their own, so that the layers' expansion does not wait for the
+    //  long chain, was measured in round 2: the long chain beside the expansion takes 4.3-4.8 ms instead of 0.7 and the step does not
+    //  get shorter; removed)
+    std::stable_sort(pl.sponges.begin(), pl.sponges.end(), [&](const SpongeDesc& a, const SpongeDesc& b) { return a.stage < b.stage; });
     std::vector<uint32_t> perm_sponge, perm_block;
     for (uint32_t s = 0; s <= pl.max_stage; s++) {
-        // a stage's heavy units go into ONE launch (with the LDS table if any of them needs it) unless there are many of them
-        uint32_t n_heavy = 0, n_lds = 0;
-        for (const UnitDesc& u : pl.units) if (u.stage == s && (u.flags & UNIT_GEN)) { n_heavy += unit_class(u.kind) != 0; n_lds += unit_class(u.kind) == 2; }
-        const bool merge = n_lds && n_heavy <= 64;
-        for (uint32_t lds = 4; lds-- > 0;) {              // BN254 units first: they run on the second stream beside the light ones
+        for (uint32_t lds = N_GEN_CLASSES; lds-- > 0;) {  // Poseidon / BN254 units first: they run on the second stream beside the light ones
             pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
             for (uint32_t u = 0; u < pl.units.size(); u++) {
                 if (!(pl.units[u].flags & UNIT_GEN)) continue;
-                uint32_t cls = unit_class(pl.units[u].kind);
-                if (merge && cls == 1) cls = 2;
-                if (pl.units[u].stage == s && cls == lds) h->order.push_back(u);
+                if (pl.units[u].stage == s && unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
             }
             sg.count = (uint32_t)h->order.size() - sg.first;
             std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
             if (sg.count) h->segs.push_back(sg);
         }
-        for (uint32_t lg = 0; lg < 2; lg++) {
-            pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0, nullptr, lg};
+        {
+            pob_ctx::KSeg ks{s, 0, 0, (uint32_t)perm_sponge.size(), 0, nullptr};
             bool first = true;
-            for (uint32_t i = 0; i < pl.sponges.size(); i++) if (pl.sponges[i].stage == s && is_long(pl.sponges[i]) == lg) {
+            for (uint32_t i = 0; i < pl.sponges.size(); i++) if (pl.sponges[i].stage == s) {
                 if (first) { ks.sp_first = i; first = false; }
                 ks.sp_count++;
                 for (uint32_t b = 0; b < pl.sponges[i].n; b++) { perm_sponge.push_back(i); perm_block.push_back(b); }
@@ -335,13 +346,10 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             if (ks.sp_count) h->ksegs.push_back(ks);
         }
     }
-    {   // a long segment only pays off beside a short one of the same stage
-        for (pob_ctx::KSeg& a : h->ksegs) if (a.is_long) { bool has_short = false; for (const pob_ctx::KSeg& b : h->ksegs) has_short |= b.stage == a.stage && !b.is_long; if (!has_short) a.is_long = 0; }
-    }
     h->nperms = (uint32_t)perm_sponge.size();
     for (uint32_t cls = 0; cls < 4; cls++) {             // emission: every generation unit once, grouped by class
         pob_ctx::Seg sg{0, cls, (uint32_t)h->order.size(), 0};
-        for (uint32_t u = 0; u < pl.units.size(); u++) if ((pl.units[u].flags & UNIT_GEN) && unit_class(pl.units[u].kind) == cls) h->order.push_back(u);
+        for (uint32_t u = 0; u < pl.units.size(); u++) if ((pl.units[u].flags & UNIT_EMIT) && unit_class(pl.units[u].kind) == cls) h->order.push_back(u);
         sg.count = (uint32_t)h->order.size() - sg.first;
         if (sg.count) h->emit_segs.push_back(sg);
     }
@@ -363,20 +371,24 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         std::lock_guard<std::mutex> lk(g_pool_mu);
         StreamPool* P = nullptr;
         for (StreamPool* q : g_pools) if (q->device == device) P = q;
-        if (!P) {
-            P = new StreamPool(); P->device = device; g_pools.push_back(P);
-            HIPC(hipStreamCreateWithPriority(&P->stream2, hipStreamNonBlocking, prio_hi));
-            HIPC(hipStreamCreateWithPriority(&P->stream_k, hipStreamNonBlocking, prio_lo));
-            if (getenv("POB_LONG_SPONGE") && atoi(getenv("POB_LONG_SPONGE")) > 0) HIPC(hipStreamCreateWithPriority(&P->stream_long, hipStreamNonBlocking, prio_hi));
-            HIPC(hipStreamCreateWithPriority(&P->track1, hipStreamNonBlocking, prio_hi));
-            HIPC(hipStreamCreateWithPriority(&P->track2, hipStreamNonBlocking, prio_hi));
+        if (!P) {       // (registered only when every stream exists: a half-built pool must not be found by the next pob_open)
+            P = new StreamPool(); P->device = device;
+            hipStream_t* want[6] = {&P->stream2, &P->stream_k, &P->track1, &P->track2, &P->chk1, &P->chk2};
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < 6 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi);
+            if (e != hipSuccess) {
+                for (hipStream_t* q : want) if (*q) hipStreamDestroy(*q);
+                delete P;
+                h->err = std::string("hipStreamCreateWithPriority: ") + hipGetErrorString(e);
+                return POB_E_HIP;
+            }
+            g_pools.push_back(P);
         }
         P->refs++; h->pool = P;
     }
-    h->stream2 = h->pool->stream2; h->stream_k = h->pool->stream_k; h->stream_long = h->pool->stream_long;
-    HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&h->ev_long_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_long_join, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&h->ev_joink, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
+    h->stream2 = h->pool->stream2; h->stream_k = h->pool->stream_k;
+    HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_gen_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_check_done, hipEventDisableTiming));
     for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -415,7 +427,8 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_status_raw, npad * 4)); HIPC(hipMalloc(&h->d_status, npad * 4));
     HIPC(hipMalloc(&h->d_chk, npad * 4)); HIPC(hipMalloc(&h->d_bad, npad * 4));
     HIPC(hipMalloc(&h->d_outputs, npad * 32));
-    HIPC(hipMalloc(&h->d_records, npad * 36));
+    HIPC(hipMalloc(&h->d_records, npad * POB_RECORD_BYTES));
+    HIPC(hipMalloc(&h->d_work, 8)); HIPC(hipMemset(h->d_work, 0, 8));
     HIPC(hipMemcpy(h->d_units, pl.units.data(), pl.units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_order, h->order.data(), h->order.size() * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_L, &pl.L, sizeof(CircuitLayout), hipMemcpyHostToDevice));
@@ -438,36 +451,36 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_order, h->em.d_probe};
+                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->d_work, h->em.d_win[0], h->em.d_win[1], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < 2; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
         for (hipEvent_t e : {h->em.ev_made[k], h->em.ev_copied[k], h->em.ev_free[k]}) if (e) hipEventDestroy(e);
     }
     hipDeviceSynchronize();                             // (the pool's streams may still carry this handle's work)
+    for (int k = 0; k < 2; k++) { if (h->h_records[k]) hipHostFree(h->h_records[k]); if (h->ev_fetched[k]) hipEventDestroy(h->ev_fetched[k]); }
+    if (h->ev_upload) hipEventDestroy(h->ev_upload);
+    if (h->s_upload) hipStreamDestroy(h->s_upload);
+    if (h->s_fetch) hipStreamDestroy(h->s_fetch);
     if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
     if (h->pool) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         StreamPool* P = h->pool;
         if (--P->refs == 0) {
-            for (hipStream_t q : {P->stream2, P->stream_k, P->stream_long, P->track1, P->track2, P->chk1, P->chk2}) if (q) hipStreamDestroy(q);
+            for (hipStream_t q : {P->stream2, P->stream_k, P->track1, P->track2, P->chk1, P->chk2}) if (q) hipStreamDestroy(q);
             g_pools.erase(std::find(g_pools.begin(), g_pools.end(), P));
             delete P;
         }
     }
     if (h->ev_gen_done) hipEventDestroy(h->ev_gen_done);
     if (h->ev_check_done) hipEventDestroy(h->ev_check_done);
-    if (h->ev_long_fork) hipEventDestroy(h->ev_long_fork);
-    if (h->ev_long_join) hipEventDestroy(h->ev_long_join);
-    if (h->ev_joink) hipEventDestroy(h->ev_joink);
     if (h->ev_rounds_fork) hipEventDestroy(h->ev_rounds_fork);
     for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
     for (pob_ctx::Track& T : h->tracks) {
         for (hipEvent_t e : {T.ev_fork, T.ev_join, T.ev_start, T.ev_end}) if (e) hipEventDestroy(e);
     }
-    if (h->ev_join4) hipEventDestroy(h->ev_join4);
     if (h->ev_join3) hipEventDestroy(h->ev_join3);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -483,9 +496,39 @@ int pob_get_info(pob_handle h, pob_info_t* info) {
 int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n) {
     if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
+    if (h->gen_done_rec) HIPC(hipEventSynchronize(h->ev_gen_done));        // the previous generation reads the input buffers
     HIPC(hipMemcpy(h->d_in_fr, fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice));
     if (h->plan.nsm_in) HIPC(hipMemcpy(h->d_in_sm, sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice));
-    h->n = n; h->generated = false;
+    h->n = n; h->generated = false; h->upload_pending = false;
+    return POB_OK;
+}
+
+int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n, void* stream_) {
+    if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    if (!h->s_upload) { HIPC(hipStreamCreateWithFlags(&h->s_upload, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
+    hipStream_t su = stream_ ? (hipStream_t)stream_ : h->s_upload;
+    if (h->gen_done_rec) HIPC(hipStreamWaitEvent(su, h->ev_gen_done, 0));  // the previous generation reads the input buffers
+    HIPC(hipMemcpyAsync(h->d_in_fr, fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
+    if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm, sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, su));
+    HIPC(hipEventRecord(h->ev_upload, su));
+    h->n = n; h->generated = false; h->upload_pending = true;
+    return POB_OK;
+}
+
+int pob_host_alloc(void** p, uint64_t bytes) {
+    if (!p || bytes == 0) return POB_E_ARG;
+    return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess ? POB_OK : POB_E_NOMEM;
+}
+void pob_host_free(void* p) { if (p) hipHostFree(p); }
+
+// status / outputs of the batch and its result records; `evaluated`: the evaluator's verdict is part of the record
+static int enqueue_collect(pob_ctx* h, hipStream_t st, bool evaluated) {
+    const uint32_t G = (h->n + 63) / 64;
+    const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
+    hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs,
+                       h->d_records, evaluated ? h->d_chk : nullptr, evaluated ? h->d_bad : nullptr, G * 64);
+    HIPC(hipGetLastError());
     return POB_OK;
 }
 
@@ -494,26 +537,26 @@ int pob_generate(pob_handle h, void* stream_) {
     HIPC(hipSetDevice(h->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
     const uint32_t G = (h->n + 63) / 64;
+    if (h->upload_pending) { HIPC(hipStreamWaitEvent(st, h->ev_upload, 0)); h->upload_pending = false; }
+    if (h->fetch_pending) HIPC(hipStreamWaitEvent(st, h->ev_fetched[h->fetch_slot], 0));    // the previous batch's records are being copied out
     // pipeline: this generation's latency-bound work starts with the partner's evaluation (= once the partner's generation is complete)
     // (starting ALL of them even earlier, beside the partner's expansion, was measured: no gain -- the chip-filling launches take from the
     //  expansion what they gain).  The first stage and the NARROW tracks forked after it (the burn-address / RLP / account chains: a few
-    //  dozen wavefronts, next to no bandwidth) do start at once, i.e. beside the partner's expansion (+1.2 % on average of nine A/B pairs;
-    //  POB_PIPE_CHAINS=0 gates them too); the main track from its second stage on and the wide pre-work track wait for the partner's
-    //  generation to be complete.  Track 4 is then enqueued AHEAD of the wide track 5, whose stream it normally shares: it moves to track 2's.
-    static const int pipe_chains = getenv("POB_PIPE_CHAINS") ? atoi(getenv("POB_PIPE_CHAINS")) : 1;
+    //  dozen wavefronts, next to no bandwidth) do start at once, i.e. beside the partner's expansion (+1.2 % on average of nine A/B pairs);
+    //  the main track from its second stage on and the wide pre-work track wait for the partner's generation to be complete.  Track 4 is
+    //  then enqueued AHEAD of the wide track 5, whose stream it normally shares: it moves to track 2's.
     const bool gate = h->partner && h->partner->gen_done_rec;
-    const bool gate_late = gate && pipe_chains && h->plan.ntracks > 1;
-    auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner && pipe_chains) ? h->pool->track2 : h->tracks[t].s_main; };
+    const bool gate_late = gate && h->plan.ntracks > 1;
+    auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner) ? h->pool->track2 : h->tracks[t].s_main; };
     if (gate && !gate_late) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
     HIPC(hipMemsetAsync(h->d_status_raw, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
     const Plan& pl = h->plan;
-    // one track: its stages in order; within a stage the BN254 units run on the track's second stream beside the light ones (the
-    // Poseidon ones stage their table in LDS), then the stage's Keccak sponges.  Tracks forked after a stage are enqueued completely
-    // (highest first) before the next stage, so every event is recorded before anything waits on it.
-    static const int rounds_async_env = getenv("POB_ROUNDS_ASYNC") ? atoi(getenv("POB_ROUNDS_ASYNC")) : 0;
-    const int rounds_async = h->partner ? std::max(rounds_async_env, 1) : rounds_async_env;
+    // one track: its stages in order; within a stage the BN254 / Poseidon units run on the track's second stream beside the light ones,
+    // then the stage's Keccak sponges.  Tracks forked after a stage are enqueued completely (highest first) before the next stage, so every
+    // event is recorded before anything waits on it.
+    const bool rounds_async = h->partner != nullptr;          // the main track's round expansion leaves the track (pipeline mode)
     std::vector<hipEvent_t> pending;
     std::function<int(uint32_t)> run_track = [&](uint32_t t) -> int {
         hipStream_t sm = t ? track_stream(t) : st, sh = t ? track_stream(t) : h->stream2;
@@ -527,7 +570,7 @@ int pob_generate(pob_handle h, void* stream_) {
             for (const pob_ctx::Seg& sg : h->segs) if (sg.stage == sid) { if (sg.lds) n_heavy++; else n_light++; }
             const bool one_stream = n_light == 0 && n_heavy == 1;
             for (const pob_ctx::Seg& sg : h->segs) if (sg.stage == sid) {
-                A.first = sg.first; A.stage_lds = sg.lds == 2;
+                A.first = sg.first;
                 if (sg.lds && one_stream) launch_g_gen(A, sg.lds, sg.count, G, sm);
                 else if (sg.lds) {
                     if (!forked) { HIPC(hipEventRecord(ef, sm)); HIPC(hipStreamWaitEvent(sh, ef, 0)); }
@@ -536,29 +579,22 @@ int pob_generate(pob_handle h, void* stream_) {
                 } else launch_g_gen(A, 0, sg.count, G, sm);
             }
             if (forked) { HIPC(hipEventRecord(ej, sh)); HIPC(hipStreamWaitEvent(sm, ej, 0)); }
-            bool long_forked = false;
-            for (int pass = 0; pass < 2; pass++)             // the long sponges first (their own stream), then the short ones on this track's stream
-                for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid && (ks.is_long != 0) == (pass == 0)) {
-                    hipStream_t sk = sm;
-                    if (ks.is_long) {
-                        if (!long_forked) { HIPC(hipEventRecord(h->ev_long_fork, sm)); HIPC(hipStreamWaitEvent(h->stream_long, h->ev_long_fork, 0)); long_forked = true; }
-                        sk = h->stream_long;
-                    }
-                    K.first = ks.sp_first;
-                    launch_k_chain(K, false, ks.sp_count, G, sk);
-                    K.first = ks.perm_first;
-                    if (rounds_async && t == 0 && !ks.is_long) {
-                        // nothing in the generation reads a KeccakfRound block's wires (k_chain wrote every state a later stage uses): the
-                        // main track's HBM-streaming expansion leaves the track here and is only joined before the results are collected
-                        HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->stream_k, h->ev_rounds_fork, 0));
-                        // pipeline: the write-saturating expansion does not run beside the partner's evaluation (it follows it)
-                        if (h->partner && h->partner->check_done_rec) HIPC(hipStreamWaitEvent(h->stream_k, h->partner->ev_check_done, 0));
-                        sk = h->stream_k; pending.push_back(ks.ev_done);
-                    }
-                    launch_k_rounds(K, false, ks.perm_count, G, sk);
-                    HIPC(hipEventRecord(ks.ev_done, sk));       // every wire of these sponges exists: their evaluation may start (pob_constraint_check)
+            for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid) {
+                hipStream_t sk = sm;
+                K.first = ks.sp_first;
+                launch_k_chain(K, false, ks.sp_count, G, sk);
+                K.first = ks.perm_first;
+                if (rounds_async && t == 0) {
+                    // nothing in the generation reads a KeccakfRound block's wires (k_chain wrote every state a later stage uses): the
+                    // main track's HBM-streaming expansion leaves the track here and is only joined before the results are collected
+                    HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->stream_k, h->ev_rounds_fork, 0));
+                    // pipeline: the write-saturating expansion does not run beside the partner's evaluation (it follows it)
+                    if (h->partner && h->partner->check_done_rec) HIPC(hipStreamWaitEvent(h->stream_k, h->partner->ev_check_done, 0));
+                    sk = h->stream_k; pending.push_back(ks.ev_done);
                 }
-            if (long_forked) { HIPC(hipEventRecord(h->ev_long_join, h->stream_long)); HIPC(hipStreamWaitEvent(sm, h->ev_long_join, 0)); }
+                launch_k_rounds(K, false, ks.perm_count, G, sk);
+                HIPC(hipEventRecord(ks.ev_done, sk));
+            }
             for (int wide = 0; wide < 2; wide++) {          // narrow tracks first; (pipeline) the partner gate; then the wide ones
                 if (wide && gate_late && t == 0 && sid == 0) HIPC(hipStreamWaitEvent(sm, h->partner->ev_gen_done, 0));
                 for (uint32_t u = pl.ntracks; u-- > t + 1;) if (pl.track_fork[u] == sid && (int)((pl.wide_tracks >> u) & 1) == wide) {
@@ -572,11 +608,9 @@ int pob_generate(pob_handle h, void* stream_) {
     };
     { int rc = run_track(0); if (rc) return rc; }
     for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
-    const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
-    hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs, h->d_records, G * 64);
-    HIPC(hipGetLastError());
+    { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
     HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
-    h->generated = true;
+    h->generated = true; h->evaluated = false;
     return POB_OK;
 }
 
@@ -587,87 +621,46 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     const uint32_t G = (h->n + 63) / 64;
     GArgs A = gargs(h);
     // The evaluation has no dependencies between launches: one kernel per family (+ the two Keccak kernels), spread over the
-    // caller's stream and the handle's two side streams.  The plan -- which stream runs what, in which order -- is a string:
-    // three ';'-separated sequences (caller's stream; side stream 2; side stream 3) of family numbers (circuits.hpp Fam) and 'K'
-    // (the HBM-streaming Keccak round + chain evaluation).  Default: Keccak alone on the caller's stream from the start, the eight G
-    // families on the two side streams BESIDE it (N2B, SC, LD, RANGE | RL, POS, MISC, SELROW: about 3.5-4.5 ms each under the
-    // bandwidth-bound round evaluation, which takes 5.0 ms beside them and 4.35 alone).  POB_CHECK_PLAN overrides it.
-    // POB_CHECK_EARLY_K=1: the Keccak evaluation does not wait for the END of the generation.  It reads only wires the
-    // sponge kernels wrote, so each sponge segment is evaluated on the handle's Keccak stream as soon as ITS generation kernels are
-    // done -- beside the generation's latency-bound tail (selector rows, SubstringCheck, commitment) and beside the G families,
-    // which do wait for the whole generation.  'K' in the plan is then ignored.
-    // Measured (profiles/round2_*): it gains nothing -- the generation's tail is latency-bound on the same memory system and stretches
-    // by what the evaluation saves -- so it is off by default.
-    static const int early_k = getenv("POB_CHECK_EARLY_K") ? atoi(getenv("POB_CHECK_EARLY_K")) : 0;
-    static const std::string plan = getenv("POB_CHECK_PLAN") ? getenv("POB_CHECK_PLAN") : (early_k ? "1,2,3;7,5;4,6,0" : "K;7,5,3,1;4,6,0,2");
-    // (a fourth sequence, if the plan has one, runs on track 2's stream, which is idle during the evaluation)
+    // caller's stream and two side streams: the HBM-streaming Keccak round + chain evaluation alone on the caller's stream from the start,
+    // the eight G families on the side streams BESIDE it (N2B, SC, LD, RANGE | RL, POS, MISC, SELROW).  What was measured on the way to this
+    // plan (30 configurations, profiles/round2_scheduling_experiments.txt): the Keccak evaluation after the families costs 8.1 ms per
+    // pass, beside them 5.8; starting it before the END of the generation (per sponge segment, beside the generation's tail) gains
+    // nothing -- the tail is latency-bound on the same memory system and stretches by what the evaluation saves.
+    static const uint32_t side_plan[2][4] = {{F_N2B, F_SC, F_LD, F_RANGE}, {F_RL, F_POS, F_MISC, F_SELROW}};
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
-    hipStream_t side2 = h->stream2, side3 = h->stream3;
-    if (h->partner) {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        int prio_lo = 0, prio_hi = 0;
-        HIPC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        if (!h->pool->chk1) HIPC(hipStreamCreateWithPriority(&h->pool->chk1, hipStreamNonBlocking, prio_hi));
-        if (!h->pool->chk2) HIPC(hipStreamCreateWithPriority(&h->pool->chk2, hipStreamNonBlocking, prio_hi));
-        side2 = h->pool->chk1; side3 = h->pool->chk2;
-    }
-    hipStream_t ss[4] = {st, side2, side3, h->partner ? side2 : h->tracks[2].s_main};
-    bool keccak_done = false;
-    {   // reset of the evaluator's results: ahead of the FIRST kernel that may write them (the early Keccak evaluation)
-        hipStream_t sr = (early_k && !h->plan.sponges.empty()) ? h->stream_k : st;
-        HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, sr));
-        HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, sr));
-        if (sr != st) { HIPC(hipEventRecord(h->ev_joink, sr)); HIPC(hipStreamWaitEvent(st, h->ev_joink, 0)); }
-    }
-    if (early_k && !h->plan.sponges.empty()) {
-        KArgs K = kargs(h);
-        for (const pob_ctx::KSeg& ks : h->ksegs) {
-            HIPC(hipStreamWaitEvent(h->stream_k, ks.ev_done, 0));
-            K.first = ks.perm_first;
-            launch_k_rounds(K, true, ks.perm_count, G, h->stream_k);
-            launch_k_chain(K, true, ks.perm_count, G, h->stream_k);
-        }
-        HIPC(hipEventRecord(h->ev_joink, h->stream_k));
-        keccak_done = true;
-    }
+    hipStream_t side[2] = {h->partner ? h->pool->chk1 : h->stream2, h->partner ? h->pool->chk2 : h->stream3};
+    HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
+    HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipEventRecord(h->ev_fork, st));
-    HIPC(hipStreamWaitEvent(side2, h->ev_fork, 0));
-    HIPC(hipStreamWaitEvent(side3, h->ev_fork, 0));
-    if (ss[3] != side2) HIPC(hipStreamWaitEvent(ss[3], h->ev_fork, 0));
-    uint32_t done = 0; int si = 0;
-    auto run_item = [&](char c) -> int {
-        if (c == 'K') {
-            if (!h->plan.sponges.empty() && !keccak_done) {
-                KArgs K = kargs(h);
-                K.first = 0;
-                launch_k_rounds(K, true, h->nperms, G, ss[si]);
-                launch_k_chain(K, true, h->nperms, G, ss[si]);
-            }
-            keccak_done = true;
-        } else if (c >= '0' && c < '0' + (int)F_COUNT) {
-            const uint32_t fam = (uint32_t)(c - '0');
-            if (done & (1u << fam)) return POB_OK;
-            done |= 1u << fam;
-            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == fam) { A.first = sg.first; A.stage_lds = 0; launch_g_check(A, fam, sg.count, G, ss[si]); }
-        }
-        return POB_OK;
-    };
-    for (char c : plan) { if (c == ';') { if (si < 3) si++; } else run_item(c); }
-    si = 0;                                              // whatever the plan left out runs on the caller's stream
-    for (uint32_t fam = 0; fam < F_COUNT; fam++) run_item((char)('0' + fam));
-    run_item('K');
-    HIPC(hipEventRecord(h->ev_join, side2)); HIPC(hipEventRecord(h->ev_join3, side3));
+    for (int k = 0; k < 2; k++) {
+        HIPC(hipStreamWaitEvent(side[k], h->ev_fork, 0));
+        for (uint32_t fam : side_plan[k])
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == fam) { A.first = sg.first; launch_g_check(A, fam, sg.count, G, side[k]); }
+    }
+    if (!h->plan.sponges.empty()) {
+        KArgs K = kargs(h, true);
+        K.first = 0;
+        launch_k_rounds(K, true, h->nperms, G, st);
+        launch_k_chain(K, true, h->nperms, G, st);
+    }
+    HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
     HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
-    if (ss[3] != side2) { HIPC(hipEventRecord(h->ev_join4, ss[3])); HIPC(hipStreamWaitEvent(st, h->ev_join4, 0)); }
-    if (early_k && !h->plan.sponges.empty()) HIPC(hipStreamWaitEvent(st, h->ev_joink, 0));
-    HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true;
+    { int rc = enqueue_collect(h, st, true); if (rc) return rc; }          // the batch's records, now with the evaluator's verdict
+    HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true;
     HIPC(hipGetLastError());
     return POB_OK;
 }
 
 int pob_set_partner(pob_handle h, pob_handle partner) {
     if (!h || h == partner || (partner && partner->device != h->device)) return POB_E_ARG;
+    if (partner && hw_queues_env() < POB_PIPELINE_HW_QUEUES) {
+        // ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two linked handles keep ~10 streams busy and a job with
+        // more live streams than queues runs 30-150x slower (unrelated kernels serialise behind each other): refuse instead of crawling
+        h->err = "the two-calculator pipeline needs GPU_MAX_HW_QUEUES >= " + std::to_string(POB_PIPELINE_HW_QUEUES) + " in the environment BEFORE the HIP runtime "
+                 "initialises (it is " + std::to_string(hw_queues_env()) + "); libpob_hip.so sets it when it is loaded first and the variable is unset";
+        return POB_E_STATE;
+    }
     // the link is symmetric (neither side may be left pointing at a handle that has another partner or is closed): undo both old links first
     for (pob_handle q : {h, partner}) if (q && q->partner) { q->partner->partner = nullptr; q->partner = nullptr; }
     h->partner = partner; h->gen_done_rec = h->check_done_rec = false;
@@ -678,19 +671,56 @@ int pob_set_partner(pob_handle h, pob_handle partner) {
 int pob_sync(pob_handle h) {
     if (!h) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
+    // this handle's work only: its last generation / evaluation (the side streams are joined into those events) and its copies
+    if (h->gen_done_rec) HIPC(hipEventSynchronize(h->ev_gen_done));
+    if (h->check_done_rec && h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
+    if (h->fetch_pending) HIPC(hipEventSynchronize(h->ev_fetched[h->fetch_slot]));
     HIPC(hipStreamSynchronize(h->stream));
-    HIPC(hipDeviceSynchronize());
+    return POB_OK;
+}
+
+// D2H of the batch's records into one of two pinned buffers, behind the handle's last evaluation (or generation); only this handle's
+// events are involved: a partner handle that is generating or evaluating meanwhile is neither waited for nor delayed
+int pob_results_fetch(pob_handle h) {
+    if (!h || !h->generated) return POB_E_STATE;
+    HIPC(hipSetDevice(h->device));
+    if (!h->s_fetch) {
+        HIPC(hipStreamCreateWithFlags(&h->s_fetch, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIPC(hipEventCreateWithFlags(&h->ev_fetched[k], hipEventDisableTiming));
+            HIPC(hipHostMalloc((void**)&h->h_records[k], (uint64_t)h->groups * 64 * POB_RECORD_BYTES, hipHostMallocDefault));
+        }
+    }
+    const int slot = h->fetch_slot ^ 1;
+    HIPC(hipStreamWaitEvent(h->s_fetch, h->evaluated ? h->ev_check_done : h->ev_gen_done, 0));
+    HIPC(hipMemcpyAsync(h->h_records[slot], h->d_records, (uint64_t)h->n * POB_RECORD_BYTES, hipMemcpyDeviceToHost, h->s_fetch));
+    HIPC(hipEventRecord(h->ev_fetched[slot], h->s_fetch));
+    h->fetch_slot = slot; h->fetch_pending = true; h->fetch_n = h->n;
+    return POB_OK;
+}
+
+int pob_results_wait(pob_handle h, const uint8_t** records, uint32_t* n) {
+    if (!h || !records) return POB_E_ARG;
+    if (!h->fetch_pending) { h->err = "pob_results_wait without pob_results_fetch"; return POB_E_STATE; }
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipEventSynchronize(h->ev_fetched[h->fetch_slot]));
+    *records = h->h_records[h->fetch_slot];
+    if (n) *n = h->fetch_n;
     return POB_OK;
 }
 
 int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* check_status, uint32_t* bad_wire) {
     if (!h || !h->generated) return POB_E_STATE;
-    HIPC(hipSetDevice(h->device));
-    HIPC(hipDeviceSynchronize());
-    if (status) HIPC(hipMemcpy(status, h->d_status, (uint64_t)h->n * 4, hipMemcpyDeviceToHost));
-    if (outputs) HIPC(hipMemcpy(outputs, h->d_outputs, (uint64_t)h->n * 32, hipMemcpyDeviceToHost));
-    if (check_status) HIPC(hipMemcpy(check_status, h->d_chk, (uint64_t)h->n * 4, hipMemcpyDeviceToHost));
-    if (bad_wire) HIPC(hipMemcpy(bad_wire, h->d_bad, (uint64_t)h->n * 4, hipMemcpyDeviceToHost));
+    int rc = pob_results_fetch(h); if (rc) return rc;
+    const uint8_t* rec = nullptr; uint32_t n = 0;
+    rc = pob_results_wait(h, &rec, &n); if (rc) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* r = (const uint32_t*)(rec + (uint64_t)i * POB_RECORD_BYTES);
+        if (status) status[i] = r[0];
+        if (check_status) check_status[i] = r[1] == POB_NOT_EVALUATED ? 0xFFFFFFFFu : r[1];
+        if (bad_wire) bad_wire[i] = r[2] == POB_NOT_EVALUATED ? 0xFFFFFFFFu : r[2];
+        if (outputs) memcpy(outputs + (uint64_t)i * 32, r + 3, 32);
+    }
     return POB_OK;
 }
 
@@ -714,26 +744,35 @@ int pob_results_records_device(pob_handle h, void** d_records) {
 static int emit_make_window(pob_ctx* h, uint64_t k) {
     pob_ctx::Emit& E = h->em;
     const int slot = (int)(k & 1);
-    const uint64_t W = h->plan.total.w, w0 = k * E.win_wires, wn = std::min(E.win_wires, W - w0);
+    const uint64_t w0 = k * E.win_wires, wn = std::min(E.win_wires, E.total - w0);      // positions of the payload (kept wires in reduced mode)
     hipStream_t st = h->stream;
     HIPC(hipStreamWaitEvent(st, E.ev_free[slot], 0));                       // the copy of the window that used this slot before is done
-    static const int own_fill = getenv("POB_EMIT_FILL") ? atoi(getenv("POB_EMIT_FILL")) : 1;
-    if (own_fill) hipLaunchKernelGGL(k_fill_ee, dim3(2048), dim3(256), 0, st, (uint4*)E.d_win[slot], wn * 2);    // any wire nobody owns stays 0xEE.. (not a field element)
-    else HIPC(hipMemsetAsync(E.d_win[slot], 0xEE, wn * 32, st));
-    if (w0 == 0) { const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(E.d_win[slot], one, 32, hipMemcpyHostToDevice, st)); }   // wire 0 = 1
+    // any wire nobody owns stays 0xEE.. (not a field element: the byte compare with the oracle catches it); rocclr's fill kernel took
+    // 4.5 ms per 256 MiB window, this one runs at the HBM write rate
+    hipLaunchKernelGGL(k_fill_ee, dim3(2048), dim3(256), 0, st, (uint4*)E.d_win[slot], wn * 2);
+    if (w0 == 0) { const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(E.d_win[slot], one, 32, hipMemcpyHostToDevice, st)); }   // wire 0 = 1 (always kept)
     GArgs A = gargs(h);
     A.emit_out = E.d_win[slot]; A.emit_sel = E.idx % 64; A.emit_group = E.idx / 64; A.emit_w0 = (uint32_t)w0; A.emit_wn = (uint32_t)wn;
-    if (E.probe_win == E.win_wires && k < E.wsegs.size()) {                 // only the units that write into this window
+    if (E.red) { A.emit_rbits = E.d_rbits; A.emit_rpre = E.d_rpre; }
+    if (E.probe_win == E.win_wires && E.probe_map == E.map_id && k < E.wsegs.size()) {      // only the units that write into this window
         A.order = E.d_order;
-        for (const pob_ctx::Emit::WSeg& sg : E.wsegs[k]) { A.first = sg.first; A.stage_lds = 0; launch_g_emit(A, sg.cls, sg.count, st); }
+        for (const pob_ctx::Emit::WSeg& sg : E.wsegs[k]) { A.first = sg.first; launch_g_emit(A, sg.cls, sg.count, st); }
     } else {
-        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; A.stage_lds = 0; launch_g_emit(A, sg.lds, sg.count, st); }
+        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, st); }
     }
     const u64* Gp = (const u64*)h->d_bits + (uint64_t)(E.idx / 64) * h->plan.total.b;
-    for (const pob_ctx::Emit::Run& r : E.runs) {                            // the Keccak kernels' wires: contiguous BIT runs cut to the window
-        const uint64_t lo = std::max<uint64_t>(r.w, w0), hi = std::min<uint64_t>((uint64_t)r.w + r.n, w0 + wn);
+    // the Keccak kernels' wires: contiguous BIT runs cut to the window (reduced: cut to the window's wire range, runs without a kept wire skipped)
+    const uint64_t wire_lo = E.red ? E.keep[w0] : w0, wire_hi = E.red ? (uint64_t)E.keep[w0 + wn - 1] + 1 : w0 + wn;
+    for (const pob_ctx::Emit::Run& r : E.runs) {
+        const uint64_t lo = std::max<uint64_t>(r.w, wire_lo), hi = std::min<uint64_t>((uint64_t)r.w + r.n, wire_hi);
         if (lo >= hi) continue;
-        launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), E.idx % 64, st);
+        if (!E.red) launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), E.idx % 64, st);
+        else {
+            const auto a = std::lower_bound(E.keep.begin() + w0, E.keep.begin() + w0 + wn, (uint32_t)lo), b = std::lower_bound(a, E.keep.begin() + w0 + wn, (uint32_t)hi);
+            if (a == b) continue;                                           // (a round block whose wires are all dropped costs nothing)
+            const uint64_t lo2 = *a, hi2 = (uint64_t)*(b - 1) + 1;
+            launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), E.idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
+        }
     }
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(E.ev_made[slot], st));
@@ -744,20 +783,30 @@ static int emit_make_window(pob_ctx* h, uint64_t k) {
     return POB_OK;
 }
 
-int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
-    if (!h) return POB_E_ARG;
-    if (!h->generated || idx >= h->n) { h->err = "nothing generated / witness index out of range"; return POB_E_STATE; }
-    HIPC(hipSetDevice(h->device));
-    HIPC(hipDeviceSynchronize());
+static uint64_t fnv64(const void* p, size_t n) {
+    const uint8_t* q = (const uint8_t*)p; uint64_t hsh = 1469598103934665603ull;
+    // (8 bytes at a time: the map of a production witness has ~20 M entries)
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t v; memcpy(&v, q + i, 8); hsh = (hsh ^ v) * 1099511628211ull; }
+    for (; i < n; i++) hsh = (hsh ^ q[i]) * 1099511628211ull;
+    return hsh ? hsh : 1;
+}
+
+// common part of pob_emit_begin / pob_emit_begin_reduced: E.red / E.map_id / E.total are set
+static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
+    pob_ctx::Emit& E = h->em;
+    // this handle's work only (a partner handle may be busy): the generation of the batch, and the copies of a previous witness
+    HIPC(hipEventSynchronize(h->ev_gen_done));
+    if (h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
+    if (E.s_copy) HIPC(hipStreamSynchronize(E.s_copy));
     {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
         uint32_t st_w = 0;
-        HIPC(hipMemcpy(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpyAsync(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
         if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; return POB_E_STATE; }
     }
-    pob_ctx::Emit& E = h->em;
-    const uint64_t W = h->plan.total.w;
     if (window_wires == 0) window_wires = 8ull << 20;                       // 8 Mi wires = 256 MiB windows
-    window_wires = std::min<uint64_t>(window_wires, W);
+    window_wires = std::min<uint64_t>(window_wires, E.total);
     if (!E.s_copy) {
         HIPC(hipStreamCreateWithPriority(&E.s_copy, hipStreamNonBlocking, 0));
         for (int k = 0; k < 2; k++) {
@@ -779,21 +828,21 @@ int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
         }
         E.alloc_wires = window_wires;
     }
-    const uint64_t nwin_ = (W + window_wires - 1) / window_wires;
-    static const int use_probe = getenv("POB_EMIT_PROBE") ? atoi(getenv("POB_EMIT_PROBE")) : 1;
-    if (use_probe && E.probe_win != window_wires && nwin_ <= 64) {
-        // probe pass: every G unit runs once with the emitter's stores replaced by "mark window w / window_wires"; a window then
+    const uint64_t nwin_ = (E.total + window_wires - 1) / window_wires;
+    if ((E.probe_win != window_wires || E.probe_map != E.map_id) && nwin_ <= 64) {
+        // probe pass: every G unit runs once with the emitter's stores replaced by "mark window position / window_wires"; a window then
         // launches only the units that can write into it (most windows hold nothing but Keccak round wires)
         const size_t nu = h->plan.units.size();
         if (!E.d_probe) HIPC(hipMalloc(&E.d_probe, nu * 8));
-        HIPC(hipMemset(E.d_probe, 0, nu * 8));
+        HIPC(hipMemsetAsync(E.d_probe, 0, nu * 8, h->stream));
         GArgs A = gargs(h);
         A.emit_sel = 0; A.emit_group = idx / 64; A.emit_w0 = 0; A.emit_wn = (uint32_t)window_wires; A.emit_probe = E.d_probe; A.emit_out = nullptr;
-        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; A.stage_lds = 0; launch_g_emit(A, sg.lds, sg.count, h->stream); }
+        if (E.red) { A.emit_rbits = E.d_rbits; A.emit_rpre = E.d_rpre; }
+        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, h->stream); }
         HIPC(hipGetLastError());
-        HIPC(hipStreamSynchronize(h->stream));
         std::vector<unsigned long long> mask(nu);
-        HIPC(hipMemcpy(mask.data(), E.d_probe, nu * 8, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpyAsync(mask.data(), E.d_probe, nu * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
         std::vector<uint32_t> order;
         E.wsegs.assign(nwin_, {});
         for (uint64_t wi = 0; wi < nwin_; wi++)
@@ -806,25 +855,64 @@ int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
         if (E.d_order) { HIPC(hipFree(E.d_order)); E.d_order = nullptr; }
         HIPC(hipMalloc(&E.d_order, std::max<size_t>(order.size(), 1) * 4));
         if (!order.empty()) HIPC(hipMemcpy(E.d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
-        E.probe_win = window_wires;
+        E.probe_win = window_wires; E.probe_map = E.map_id;
     }
     for (int k = 0; k < 2; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
-    E.win_wires = window_wires; E.nwin = (W + window_wires - 1) / window_wires; E.idx = idx; E.next_make = 0; E.next_take = 0; E.active = true;
+    E.win_wires = window_wires; E.nwin = nwin_; E.idx = idx; E.next_make = 0; E.next_take = 0; E.active = true;
     for (; E.next_make < std::min<uint64_t>(1, E.nwin); E.next_make++) { int rc = emit_make_window(h, E.next_make); if (rc) return rc; }
     return POB_OK;
+}
+
+int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires) {
+    if (!h) return POB_E_ARG;
+    if (!h->generated || idx >= h->n) { h->err = "nothing generated / witness index out of range"; return POB_E_STATE; }
+    HIPC(hipSetDevice(h->device));
+    h->em.red = false; h->em.map_id = 0; h->em.total = h->plan.total.w;
+    return emit_start(h, idx, window_wires);
+}
+
+int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uint64_t n_keep, uint64_t window_wires) {
+    if (!h || !keep || n_keep == 0) return POB_E_ARG;
+    if (!h->generated || idx >= h->n) { h->err = "nothing generated / witness index out of range"; return POB_E_STATE; }
+    HIPC(hipSetDevice(h->device));
+    pob_ctx::Emit& E = h->em;
+    const uint64_t W = h->plan.total.w;
+    const uint64_t id = fnv64(keep, n_keep * 4) ^ (n_keep << 1);
+    if (id != E.map_id || E.keep.size() != n_keep) {
+        // a new map: validate (wire 0 first, strictly increasing, inside the circuit), build the bitmap and the per-word ranks, upload
+        if (keep[0] != 0 || keep[n_keep - 1] >= W) { h->err = "reduced map: keep[0] must be wire 0 and every index must be < nWitness"; return POB_E_ARG; }
+        const uint64_t nwords = (W + 63) / 64;
+        std::vector<unsigned long long> bits(nwords, 0); std::vector<uint32_t> pre(nwords, 0);
+        for (uint64_t i = 0; i < n_keep; i++) {
+            if (i && keep[i] <= keep[i - 1]) { h->err = "reduced map: wire indices must be strictly increasing"; return POB_E_ARG; }
+            bits[keep[i] >> 6] |= 1ull << (keep[i] & 63);
+        }
+        uint32_t acc = 0;
+        for (uint64_t i = 0; i < nwords; i++) { pre[i] = acc; acc += (uint32_t)__builtin_popcountll(bits[i]); }
+        if (E.s_copy) HIPC(hipStreamSynchronize(E.s_copy));
+        HIPC(hipStreamSynchronize(h->stream));
+        if (E.d_rbits) { HIPC(hipFree(E.d_rbits)); E.d_rbits = nullptr; }
+        if (E.d_rpre) { HIPC(hipFree(E.d_rpre)); E.d_rpre = nullptr; }
+        HIPC(hipMalloc(&E.d_rbits, nwords * 8)); HIPC(hipMalloc(&E.d_rpre, nwords * 4));
+        HIPC(hipMemcpy(E.d_rbits, bits.data(), nwords * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(E.d_rpre, pre.data(), nwords * 4, hipMemcpyHostToDevice));
+        E.keep.assign(keep, keep + n_keep);
+    }
+    E.red = true; E.map_id = id; E.total = n_keep;
+    return emit_start(h, idx, window_wires);
 }
 
 int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires) {
     if (!h || !data || !first_wire || !n_wires) return POB_E_ARG;
     pob_ctx::Emit& E = h->em;
     if (!E.active) { h->err = "pob_emit_next without pob_emit_begin"; return POB_E_STATE; }
-    if (E.next_take == E.nwin) { E.active = false; *data = nullptr; *first_wire = h->plan.total.w; *n_wires = 0; return POB_OK; }
+    if (E.next_take == E.nwin) { E.active = false; *data = nullptr; *first_wire = E.total; *n_wires = 0; return POB_OK; }
     HIPC(hipSetDevice(h->device));
     // the window handed out by the previous call is released now: its slot takes the window after the one returned here
     if (E.next_make < E.nwin && E.next_make <= E.next_take + 1) { int rc = emit_make_window(h, E.next_make); if (rc) return rc; E.next_make++; }
     const uint64_t k = E.next_take++;
     HIPC(hipEventSynchronize(E.ev_copied[k & 1]));
-    *data = E.h_pin[k & 1]; *first_wire = k * E.win_wires; *n_wires = std::min(E.win_wires, h->plan.total.w - k * E.win_wires);
+    *data = E.h_pin[k & 1]; *first_wire = k * E.win_wires; *n_wires = std::min(E.win_wires, E.total - k * E.win_wires);
     return POB_OK;
 }
 
@@ -844,14 +932,11 @@ int pob_emit_witness(pob_handle h, uint32_t idx, uint8_t* dst, uint64_t cap) {
     return POB_OK;
 }
 
-int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
-    if (!h || !path) return POB_E_ARG;
-    int rc = pob_emit_begin(h, idx, 0);
-    if (rc) return rc;
-    const uint64_t W = h->plan.total.w, bytes = W * 32;
+// iden3 .wtns container around the window stream ("wtns" v2, 2 sections: (1) n8 = 32, prime, nWitness  (2) values); the emission is begun
+static int write_wtns_stream(pob_ctx* h, const char* path) {
+    const uint64_t W = h->em.total, bytes = W * 32;
     FILE* f = fopen(path, "wb");
     if (!f) { h->err = std::string("cannot open ") + path; h->em.active = false; return POB_E_IO; }
-    // iden3 .wtns container: "wtns" v2, 2 sections: (1) n8=32, prime, nWitness  (2) values
     uint8_t hdr[76];
     const uint64_t P64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
     uint32_t u32; uint64_t u64v;
@@ -862,7 +947,7 @@ int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
     bool ok = fwrite(hdr, 1, 76, f) == 76;
     for (;;) {
         const uint8_t* p; uint64_t w0, wn;
-        rc = pob_emit_next(h, &p, &w0, &wn);
+        int rc = pob_emit_next(h, &p, &w0, &wn);
         if (rc) { fclose(f); remove(path); return rc; }
         if (!wn) break;
         if (ok) ok = fwrite(p, 1, wn * 32, f) == wn * 32;
@@ -871,16 +956,27 @@ int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
     if (!ok) { remove(path); h->err = "write failed"; return POB_E_IO; }
     return POB_OK;
 }
+int pob_write_wtns(pob_handle h, uint32_t idx, const char* path) {
+    if (!h || !path) return POB_E_ARG;
+    int rc = pob_emit_begin(h, idx, 0);
+    return rc ? rc : write_wtns_stream(h, path);
+}
+int pob_write_wtns_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uint64_t n_keep, const char* path) {
+    if (!h || !path) return POB_E_ARG;
+    int rc = pob_emit_begin_reduced(h, idx, keep, n_keep, 0);
+    return rc ? rc : write_wtns_stream(h, path);
+}
 
-// emission throughput: K witnesses back to back through the window pipeline, the windows only touched (first + last cache line)
-int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes) {
+// emission throughput: K witnesses back to back through the window pipeline, the windows only touched (first + last cache line).
+// keep != NULL: the reduced form.  The buffers (two device windows, two pinned host windows, the probe tables) are set up by the
+// first witness a handle emits at a window size: time a first call to see that cost, a second one for the steady state.
+int pob_emit_measure_ex(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, const uint32_t* keep, uint64_t n_keep, double* seconds, uint64_t* bytes) {
     if (!h || !seconds || !bytes || count == 0) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
-    HIPC(hipDeviceSynchronize());
     uint64_t total = 0; volatile uint8_t sink = 0;
     timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint32_t i = 0; i < count; i++) {
-        int rc = pob_emit_begin(h, first_idx + i, window_wires);
+        int rc = keep ? pob_emit_begin_reduced(h, first_idx + i, keep, n_keep, window_wires) : pob_emit_begin(h, first_idx + i, window_wires);
         if (rc) return rc;
         for (;;) {
             const uint8_t* p; uint64_t w0, wn;
@@ -894,6 +990,9 @@ int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t 
     *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec); *bytes = total;
     return POB_OK;
 }
+int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes) {
+    return pob_emit_measure_ex(h, first_idx, count, window_wires, nullptr, 0, seconds, bytes);
+}
 
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* avg_ms) {
     if (!h || !h->generated || iters < 1 || !avg_ms) return POB_E_STATE;
@@ -902,7 +1001,7 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
     const uint32_t G = (h->n + 63) / 64;
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
-    KArgs K = kargs(h); K.first = 0;
+    KArgs K = kargs(h, which == 1); K.first = 0;
     GArgs A = gargs(h);
     uint32_t* d_sel = nullptr; uint32_t nsel = 0, sel_cls = 0, sel_fam = 0;
     if (which >= 100 && which < 300) {   // 100 + kind: evaluation, 200 + kind: generation of all units of one kind, alone on the device
@@ -912,19 +1011,19 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
         if (sel.empty()) { *avg_ms = 0; hipEventDestroy(e0); hipEventDestroy(e1); return POB_OK; }
         nsel = (uint32_t)sel.size(); sel_cls = unit_class(kind); sel_fam = fam_of(kind);
         HIPC(hipMalloc(&d_sel, nsel * 4)); HIPC(hipMemcpy(d_sel, sel.data(), nsel * 4, hipMemcpyHostToDevice));
-        A.order = d_sel; A.first = 0; A.stage_lds = which >= 200 && sel_cls == 2;
+        A.order = d_sel; A.first = 0;
     }
     HIPC(hipEventRecord(e0, st));
     for (int it = 0; it < iters; it++) {
         if (which >= 300) {          // 300 + family: that family's evaluation kernel alone
-            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == (uint32_t)which - 300) { A.first = sg.first; A.stage_lds = 0; launch_g_check(A, sg.lds, sg.count, G, st); }
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == (uint32_t)which - 300) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         } else if (which >= 200) launch_g_gen(A, sel_cls, nsel, G, st);
         else if (which >= 100) launch_g_check(A, sel_fam, nsel, G, st);
         else if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
         else if (which == 1) launch_k_rounds(K, true, h->nperms, G, st);
         else if (which == 2) {
             for (const pob_ctx::Seg& sg : h->chk_segs) {
-                A.first = sg.first; A.stage_lds = 0;
+                A.first = sg.first;
                 launch_g_check(A, sg.lds, sg.count, G, st);
             }
         } else launch_k_chain(K, false, (uint32_t)h->plan.sponges.size(), G, st);

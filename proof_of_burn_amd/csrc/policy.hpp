@@ -63,13 +63,17 @@ struct PolBase {
 // sub-blocks of a composite unit that the constraint evaluator runs as wavefronts of their own (circuits.hpp CK_* units);
 // the counting policy notes them while the planner walks the composite
 enum : uint32_t { NOTE_POSEIDON = 1, NOTE_N2BE = 2, NOTE_SHIFTRIGHT = 3, NOTE_SHIFTLEFT = 4 };
-struct PlanNote { uint32_t what, n; Cur cur; uint32_t a[5]; };
+struct PlanNote { uint32_t what, n; Cur cur; uint32_t a[7]; };
+#define PLAN_MAX_NOTES 8
 struct CountP : PolBase {
     static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
     uint32_t nput = 0;    // wires written: the planner's cost estimate of a unit (long units are dispatched first)
-    PlanNote notes[8]; uint32_t nnotes = 0;
-    HD void note(uint32_t what, uint32_t n, Cur c, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0) {
-        if (nnotes < 8) { PlanNote& x = notes[nnotes++]; x.what = what; x.n = n; x.cur = c; x.a[0] = a0; x.a[1] = a1; x.a[2] = a2; x.a[3] = a3; x.a[4] = a4; }
+    PlanNote notes[PLAN_MAX_NOTES]; uint32_t nnotes = 0;
+    bool notes_overflow = false;          // a composite with more split sub-blocks than the table holds: the planner refuses the plan (Plan::take_notes)
+    HD void note(uint32_t what, uint32_t n, Cur c, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0, uint32_t a6 = 0) {
+        if (nnotes >= PLAN_MAX_NOTES) { notes_overflow = true; return; }
+        PlanNote& x = notes[nnotes++]; x.what = what; x.n = n; x.cur = c;
+        x.a[0] = a0; x.a[1] = a1; x.a[2] = a2; x.a[3] = a3; x.a[4] = a4; x.a[5] = a5; x.a[6] = a6;
     }
     HD B put(BitRef, B v) { nput++; return v; }
     HD S put(SmRef, S v) { nput++; return v; }
@@ -489,7 +493,15 @@ struct EmitP : DevPol {
     uint8_t* out;      // canonical witness payload of the wires [w0, w0 + wn) (the emission window), 32 B per wire
     uint32_t sel, w0, wn, unit;
     unsigned long long* probe;      // probe pass (once per window size): which windows does this unit write to?  bit w / wn of probe[unit]
+    // reduced witness (pob_emit_begin_reduced): bit w of rbits = wire w survives, rpre[w / 64] = kept wires below 64 * (w / 64); a
+    // surviving wire lands at its RANK among the kept wires and windows count kept wires.  Null: the O0 payload, position = wire index.
+    const unsigned long long* rbits; const uint32_t* rpre;
     __device__ __forceinline__ void w32(uint32_t w, const F& canon) {
+        if (rbits) {
+            const unsigned long long word = rbits[w >> 6];
+            if (!((word >> (w & 63)) & 1)) return;
+            w = rpre[w >> 6] + (uint32_t)__popcll(word & ((1ull << (w & 63)) - 1));
+        }
         if (probe) { atomicOr(probe + unit, 1ull << (w / wn)); return; }
         if (w - w0 >= wn) return;
         uint4* q = (uint4*)(out + (size_t)(w - w0) * 32);

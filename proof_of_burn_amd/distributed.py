@@ -1,6 +1,7 @@
 """Multi-GPU driver: witnesses are independent (no cross-witness state in the circuit), so a batch is
 cut into contiguous slices, one per rank / GPU; the only collective is ONE all-gather of the per-witness result records
-({u32 status, u8 commitment[32]} = 36 B per witness, packed on the device by libpob_hip.so) over RCCL/xGMI -- witness vectors
+({u32 status, u32 check_status, u32 bad_wire, u8 commitment[32]} = 44 B per witness, packed on the device by libpob_hip.so AFTER the
+batch's constraint evaluation) over RCCL/xGMI -- witness vectors
 never leave the GPU that produced them.  Backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU tests of this plumbing."""
 from __future__ import annotations
 
@@ -9,7 +10,9 @@ import os
 import torch
 import torch.distributed as dist
 
-RECORD_BYTES = 36
+RECORD_BYTES = 44            # include/pob_hip.h POB_RECORD_BYTES
+NOT_EVALUATED = 0xFFFFFFFE   # POB_NOT_EVALUATED: check_status / bad_wire of a batch whose evaluation has not run
+CLEAN = 0xFFFFFFFF           # check_status / bad_wire of an evaluated witness without findings
 
 
 def env_rank():
@@ -34,23 +37,36 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_records(status: torch.Tensor, outputs: torch.Tensor) -> torch.Tensor:
-    """status int32[n], outputs uint8[n, 32] -> uint8[n, 36] records (host-side twin of the device packing, for tests)"""
+def pack_records(status: torch.Tensor, outputs: torch.Tensor, check_status: torch.Tensor | None = None, bad_wire: torch.Tensor | None = None) -> torch.Tensor:
+    """status int32[n], outputs uint8[n, 32] (+ the evaluator's words) -> uint8[n, 44] records (host-side twin of the device packing, for tests)"""
     n = status.shape[0]
     rec = torch.empty((n, RECORD_BYTES), dtype=torch.uint8, device=status.device)
-    rec[:, :4] = status.to(torch.int32).contiguous().view(torch.uint8).view(n, 4)
-    rec[:, 4:] = outputs
+    words = torch.full((n, 3), NOT_EVALUATED - (1 << 32), dtype=torch.int32, device=status.device)
+    words[:, 0] = status.to(torch.int32)
+    if check_status is not None:
+        words[:, 1] = check_status.to(torch.int32)
+    if bad_wire is not None:
+        words[:, 2] = bad_wire.to(torch.int32)
+    rec[:, :12] = words.contiguous().view(torch.uint8).view(n, 12)
+    rec[:, 12:] = outputs
     return rec
 
 
 def unpack_records(rec: torch.Tensor):
-    """uint8[n, 36] -> (status int32[n], outputs uint8[n, 32])"""
+    """uint8[n, 44] -> (status int32[n], outputs uint8[n, 32])"""
     n = rec.shape[0]
-    return rec[:, :4].contiguous().view(torch.int32).view(n), rec[:, 4:].contiguous()
+    return rec[:, :4].contiguous().view(torch.int32).view(n), rec[:, 12:].contiguous()
+
+
+def unpack_verdicts(rec: torch.Tensor):
+    """uint8[n, 44] -> (check_status int64[n], bad_wire int64[n]) as unsigned values (CLEAN = no finding, NOT_EVALUATED = not run)"""
+    n = rec.shape[0]
+    w = rec[:, 4:12].contiguous().view(torch.int32).view(n, 2).to(torch.int64) & 0xFFFFFFFF
+    return w[:, 0], w[:, 1]
 
 
 def gather_records(rec: torch.Tensor, total: int | None = None) -> torch.Tensor:
-    """rec uint8[n_local, 36] of this rank -> uint8[total, 36] of the whole job, with ONE all_gather_into_tensor.
+    """rec uint8[n_local, 44] of this rank -> uint8[total, 44] of the whole job, with ONE all_gather_into_tensor.
     Slices may differ by one witness (shard_bounds): every rank pads to the largest slice and the result is trimmed, so an
     uneven global batch neither hangs nor mis-aligns.  total=None: every rank holds the same number of witnesses."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -82,6 +98,6 @@ class _DevBuf:
 
 
 def device_records(calc, n: int) -> torch.Tensor:
-    """zero-copy uint8[n, 36] view of the calculator's device-resident result records"""
+    """zero-copy uint8[n, 44] view of the calculator's device-resident result records"""
     ptr = calc.records_device_ptr()
     return torch.as_tensor(_DevBuf(ptr, RECORD_BYTES * n), device=f"cuda:{calc.device}").view(n, RECORD_BYTES)

@@ -45,6 +45,10 @@ class PobInfo(ctypes.Structure):
                 ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64), ("n_sb", ctypes.c_uint64)]
 
 
+# one result record (include/pob_hip.h POB_RECORD_BYTES = 44)
+RECORD_DTYPE = np.dtype([("status", "<u4"), ("check_status", "<u4"), ("bad_wire", "<u4"), ("commitment", "u1", (32,))])
+NOT_EVALUATED, CLEAN = 0xFFFFFFFE, 0xFFFFFFFF
+
 _lib = None
 
 
@@ -66,6 +70,15 @@ def load_library() -> ctypes.CDLL:
     lib.pob_strerror.argtypes = [vp]
     lib.pob_strerror.restype = ctypes.c_char_p
     lib.pob_upload_inputs.argtypes = [vp, vp, vp, ctypes.c_uint32]
+    lib.pob_upload_inputs_async.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
+    lib.pob_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
+    lib.pob_host_free.argtypes = [vp]
+    lib.pob_host_free.restype = None
+    lib.pob_results_fetch.argtypes = [vp]
+    lib.pob_results_wait.argtypes = [vp, ctypes.POINTER(vp), u32p]
+    lib.pob_emit_begin_reduced.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint64]
+    lib.pob_write_wtns_reduced.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_char_p]
+    lib.pob_emit_measure_ex.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_generate.argtypes = [vp, vp]
     lib.pob_constraint_check.argtypes = [vp, vp]
     lib.pob_sync.argtypes = [vp]
@@ -92,7 +105,8 @@ def load_library() -> ctypes.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_generate",
+EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free",
+                    "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
                     "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
@@ -294,6 +308,17 @@ class WitnessCalculator:
         self.n = n
         self._forced = forced if forced is not None else np.zeros(n, dtype=np.uint32)
 
+    def upload_packed_async(self, fr: np.ndarray, sm: np.ndarray, forced: np.ndarray | None = None, stream: int | None = None):
+        """service-loop upload (pob_upload_inputs_async): fr / sm must live in pinned memory (PinnedInputs) and stay untouched until the
+        batch's results are in; the copy is ordered behind this calculator's previous generation, the next generate() behind the copy"""
+        n = fr.shape[0]
+        if n > self.max_batch:
+            raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
+        assert fr.dtype == np.uint8 and sm.dtype == np.int32 and fr.flags.c_contiguous and sm.flags.c_contiguous
+        self._ck(self.lib.pob_upload_inputs_async(self.h, fr.ctypes.data, sm.ctypes.data, n, ctypes.c_void_p(stream) if stream else None))
+        self.n = n
+        self._forced = forced if forced is not None else np.zeros(n, dtype=np.uint32)
+
     def generate(self, stream: int | None = None):
         self._ck(self.lib.pob_generate(self.h, ctypes.c_void_p(stream) if stream else None))
 
@@ -306,6 +331,18 @@ class WitnessCalculator:
     def set_partner(self, other: "WitnessCalculator | None"):
         """two-batch pipeline (include/pob_hip.h pob_set_partner): link this calculator with the one working on the neighbouring batch"""
         self._ck(self.lib.pob_set_partner(self.h, other.h if other is not None else None))
+
+    def fetch_records(self):
+        """enqueue the D2H copy of this batch's result records behind its evaluation (pob_results_fetch); does not block"""
+        self._ck(self.lib.pob_results_fetch(self.h))
+
+    def wait_records(self) -> np.ndarray:
+        """block on THAT copy only and return the records as a structured array (fields status, check_status, bad_wire, commitment[32]);
+        the view aliases the handle's pinned buffer: valid until the fetch after the next one"""
+        p, n = ctypes.c_void_p(), ctypes.c_uint32()
+        self._ck(self.lib.pob_results_wait(self.h, ctypes.byref(p), ctypes.byref(n)))
+        buf = (ctypes.c_uint8 * (RECORD_DTYPE.itemsize * n.value)).from_address(p.value)
+        return np.frombuffer(buf, dtype=RECORD_DTYPE)
 
     def results(self, with_check: bool = False) -> list[Result]:
         n = self.n
@@ -345,21 +382,25 @@ class WitnessCalculator:
     def write_wtns(self, idx: int, path: str):
         self._ck(self.lib.pob_write_wtns(self.h, idx, os.fsencode(path)))
 
-    def write_wtns_reduced(self, idx: int, path: str, o1_map, window_wires: int = 0):
-        """O1-style reduced .wtns (circuit_model.o1.reduce_map): only the surviving wires, streamed window by window"""
-        keep = o1_map.keep
-        with open(path, "wb") as f:
-            f.write(wtns_header(len(keep)))
-            for w0, view in self.witness_windows(idx, window_wires):
-                n = view.size // 32
-                a, b = np.searchsorted(keep, w0), np.searchsorted(keep, w0 + n)
-                if b > a:
-                    f.write(view.reshape(n, 32)[keep[a:b] - w0].tobytes())
+    @staticmethod
+    def _keep_array(keep) -> np.ndarray:
+        keep = getattr(keep, "keep", keep)                 # circuit_model.o1.ReducedMap or a plain array of surviving O0 wire indices
+        return np.ascontiguousarray(keep, dtype=np.uint32)
 
-    def witness_windows(self, idx: int = 0, window_wires: int = 0):
+    def write_wtns_reduced(self, idx: int, path: str, keep):
+        """O1-style reduced .wtns (circuit_model.o1.reduce_map): only the surviving wires are expanded on the GPU and cross PCIe
+        (pob_write_wtns_reduced); `keep` = sorted O0 wire indices (wire 0 first) or an object with a .keep array"""
+        k = self._keep_array(keep)
+        self._ck(self.lib.pob_write_wtns_reduced(self.h, idx, k.ctypes.data, k.size, os.fsencode(path)))
+
+    def witness_windows(self, idx: int = 0, window_wires: int = 0, keep=None):
         """stream the canonical payload of witness idx: yields (first_wire, uint8 view [n_wires * 32]) per window; a view is valid
-        until the next iteration (it aliases the handle's pinned buffer)"""
-        self._ck(self.lib.pob_emit_begin(self.h, idx, window_wires))
+        until the next iteration (it aliases the handle's pinned buffer).  keep: the reduced payload (positions count kept wires)"""
+        if keep is None:
+            self._ck(self.lib.pob_emit_begin(self.h, idx, window_wires))
+        else:
+            k = self._keep_array(keep)
+            self._ck(self.lib.pob_emit_begin_reduced(self.h, idx, k.ctypes.data, k.size, window_wires))
         p, w0, wn = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
         while True:
             self._ck(self.lib.pob_emit_next(self.h, ctypes.byref(p), ctypes.byref(w0), ctypes.byref(wn)))
@@ -368,10 +409,21 @@ class WitnessCalculator:
             buf = (ctypes.c_uint8 * (32 * wn.value)).from_address(p.value)
             yield w0.value, np.frombuffer(buf, dtype=np.uint8)
 
-    def emit_throughput(self, first_idx: int = 0, count: int = 1, window_wires: int = 0):
-        """(seconds, bytes) of `count` witnesses emitted back to back into pinned host memory"""
+    def witness_payload_reduced(self, idx: int, keep, window_wires: int = 0) -> np.ndarray:
+        """the reduced payload (32 B per kept wire) as one array"""
+        k = self._keep_array(keep)
+        out = np.empty(32 * k.size, dtype=np.uint8)
+        for w0, view in self.witness_windows(idx, window_wires, keep=k):
+            out[32 * w0:32 * w0 + view.size] = view
+        return out
+
+    def emit_throughput(self, first_idx: int = 0, count: int = 1, window_wires: int = 0, keep=None):
+        """(seconds, bytes) of `count` witnesses emitted back to back into pinned host memory (keep: the reduced form).  The first
+        emission of a calculator also allocates its window buffers: call twice for the steady state."""
         sec, nb = ctypes.c_double(), ctypes.c_uint64()
-        self._ck(self.lib.pob_emit_measure(self.h, first_idx, count, window_wires, ctypes.byref(sec), ctypes.byref(nb)))
+        k = None if keep is None else self._keep_array(keep)
+        self._ck(self.lib.pob_emit_measure_ex(self.h, first_idx, count, window_wires, k.ctypes.data if k is not None else None, k.size if k is not None else 0,
+                                              ctypes.byref(sec), ctypes.byref(nb)))
         return sec.value, nb.value
 
     def time_kernel(self, which: int, iters: int = 5, stream: int | None = None) -> float:
@@ -397,7 +449,7 @@ class WitnessCalculator:
         return cls.value, idx.value, wire.value
 
     def records_device_ptr(self) -> int:
-        """device pointer of the packed per-witness result records {u32 status, u8 commitment[32]} (36 B each)"""
+        """device pointer of the packed per-witness result records {u32 status, u32 check_status, u32 bad_wire, u8 commitment[32]} (44 B each)"""
         a = ctypes.c_void_p()
         self._ck(self.lib.pob_results_records_device(self.h, ctypes.byref(a)))
         return a.value
@@ -406,6 +458,36 @@ class WitnessCalculator:
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         self._ck(self.lib.pob_results_device(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+
+class PinnedInputs:
+    """packed inputs of one batch in pinned host memory (pob_host_alloc), the source of upload_packed_async"""
+
+    def __init__(self, calc: "WitnessCalculator", n: int):
+        self.lib = calc.lib
+        nfr, nsm = int(calc.info.n_fr_inputs), max(int(calc.info.n_sm_inputs), 1)
+        self._p = []
+        arrs = []
+        for shape, dt in (((n, nfr, 32), np.uint8), ((n, nsm), np.int32)):
+            nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+            p = ctypes.c_void_p()
+            if self.lib.pob_host_alloc(ctypes.byref(p), nbytes) != 0:
+                raise MemoryError("pob_host_alloc")
+            self._p.append(p)
+            arrs.append(np.frombuffer((ctypes.c_uint8 * nbytes).from_address(p.value), dtype=dt).reshape(shape))
+        self.fr, self.sm = arrs
+        self.forced = np.zeros(n, dtype=np.uint32)
+
+    def fill(self, fr, sm, forced=None):
+        self.fr[...] = fr
+        self.sm[...] = sm
+        self.forced[...] = 0 if forced is None else forced
+        return self
+
+    def free(self):
+        for p in self._p:
+            self.lib.pob_host_free(p)
+        self._p = []
 
 
 def wtns_header(nwitness: int) -> bytes:

@@ -73,8 +73,10 @@ template <class T> static inline void hs_buf_st(T v, hs_rsrc r, int voff, int so
 #define __builtin_amdgcn_raw_buffer_store_b8(v, r, vo, so, aux) hs_buf_st<char>(v, r, vo, so)
 #define __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, aux) hs_buf_st<hs_v2i>(v, r, vo, so)
 
+#define __popcll(x) __builtin_popcountll(x)
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 
 // ---- runtime API (synchronous)
 typedef int hipError_t;
@@ -89,6 +91,7 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }

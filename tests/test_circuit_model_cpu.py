@@ -78,7 +78,9 @@ def test_product_witness_on_the_cpu_shim_satisfies_every_constraint(tmp_path):
         from proof_of_burn_amd.circuit_model.o1 import reduce_map
         m = reduce_map(circuit("Spend(31)"))
         red = str(tmp_path / "spend_o1.wtns")
-        calc.write_wtns_reduced(0, red, m, window_wires=300_000)
+        calc.write_wtns_reduced(0, red, m)                         # expanded and cut on the device (pob_write_wtns_reduced)
+        red_windows = calc.witness_payload_reduced(0, m, window_wires=30_000)       # the same through 9 windows of kept wires
+        full_again = calc.witness_payload(0)                       # and the O0 payload after a reduced emission (the probe tables are per map)
         calc.close()
     finally:
         W.LIB_PATH, W._lib = old
@@ -89,6 +91,7 @@ def test_product_witness_on_the_cpu_shim_satisfies_every_constraint(tmp_path):
     data = np.fromfile(red, dtype=np.uint8)
     assert struct.unpack("<I", data[60:64].tobytes())[0] == len(m.keep) and len(m.keep) < full.shape[0] // 8
     assert np.array_equal(data[76:].reshape(-1, 32), full[m.keep])
+    assert np.array_equal(red_windows.reshape(-1, 32), full[m.keep]) and np.array_equal(full_again.reshape(-1, 32), full)
     dropped = np.nonzero(m.alias >= 0)[0]
     assert np.array_equal(full[dropped], full[m.alias[dropped]])
     for w, v in list(zip(m.const_wires, m.const_values))[:2000]:

@@ -10,6 +10,7 @@ def main(path, which=3, thr=0.15):
     def short(n):
         if n in names: return names[n]
         if 'g_units' in n: return ('gCHK' if 'CheckP' in n else 'gGEN') + '[' + n.split('Lj')[1].split('E')[0] + ']'
+        if 'k_poseidon_wide' in n: return 'posWide'
         return n[:20]
     sel = rows[idx[which - 1]:idx[which] + 1]
     t0 = sel[0][1]
