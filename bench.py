@@ -1,19 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- proof_of_burn witnesses/s on N MI355X GPUs (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch: witness generation (every wire of the O0 witness, resident in
-HBM in the compact typed layout) + the per-gate constraint evaluation over that resident vector + the RCCL gather
-of the per-witness result records.  Workload at N=1: BASELINE.json configs[2] -- batch = 1024 proof_of_burn witnesses of
-the production instantiation ProofOfBurn(16,4,16,50,31,2,1e19,1e20) on synthetic 10-layer MPT proofs; for N > 1
-every rank gets its own 1024 (weak scaling), one slice per GPU, no data-path collective except ONE all-gather of the
-36-byte result records.  Inputs are resident in HBM before the timed region.
+A "step" = one batch through the hot path as a SERVICE LOOP would run it: the batch's packed inputs go H2D from pinned memory
+(pob_upload_inputs_async), every wire of the O0 witness is generated (resident in HBM in the compact typed layout), the per-gate
+constraint evaluation reads that resident vector back, the per-witness result records {status, evaluator verdict, commitment} are packed
+AFTER the evaluation, copied to pinned host memory and VALIDATED on the host (every record of every batch: status 0, evaluator clean,
+commitment equal to the host-side formula) -- all of it inside the timed region.  Consecutive batches carry DIFFERENT inputs
+(--distinct-batches of them, cycled).  Workload at N=1: BASELINE.json configs[2] -- batch = 1024 proof_of_burn witnesses of the
+production instantiation ProofOfBurn(16,4,16,50,31,2,1e19,1e20) on synthetic 10-layer MPT proofs; for N > 1 every rank gets its own 1024
+(weak scaling; --total-batch B splits ONE global batch over the ranks instead: BASELINE config 4 as written), one slice per GPU, no
+data-path collective except ONE all-gather of the 44-byte result records per batch.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-
---halves H (default 1): the rank's batch may be held by H calculators (B/H witnesses each, own streams) whose passes are enqueued
-interleaved, so that the latency-bound stages of one part run beside the HBM-streaming Keccak kernels of the other.  Measured
-(profiles/round2_*): H = 2 gains nothing -- both kinds of kernel wait on the same memory system -- so the default is one calculator.
 """
 import argparse
 import json
@@ -23,7 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job needs its own hardware queue (ROCm default: 4): 2 callers + gather + 7 of the library (+ RCCL's at N > 1)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job needs its own hardware queue (ROCm default: 4); libpob_hip.so refuses the pipeline below 12
 
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -76,24 +75,27 @@ def cpu_baseline(batch, info, single_samples: int, budget_s: float = 25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU")
-    ap.add_argument("--halves", type=int, default=int(os.environ.get("POB_BENCH_HALVES", "1")), help="calculators per GPU whose passes are interleaved")
+    ap.add_argument("--steps", type=int, default=150, help="timed batches (150 x 13 ms = a 2 s timed region)")
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU per step (weak scaling)")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: ONE global batch of this many witnesses per step, split over the ranks (BASELINE config 4: 8192)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("POB_BENCH_PIPELINE", "1")),
                     help="1: two calculators work on consecutive batches (pob_set_partner): batch k+1's latency-bound generation stages run beside batch k's evaluation")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
-    ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over the global batch")
+    ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
+    ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
     ap.add_argument("--cpu-samples", type=int, default=2, help="witnesses timed single-threaded on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurement")
-    ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records (uint8 [N*B, 36]) to this .npy")
+    ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurements")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-calculator steps after the timed region")
+    ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records of the LAST batch (uint8 [N*B, 44]) to this .npy")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from proof_of_burn_amd import WitnessCalculator, inputs as gen
+    from proof_of_burn_amd import WitnessCalculator, PinnedInputs, inputs as gen
+    from proof_of_burn_amd import witness as W
     from proof_of_burn_amd import distributed as D
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
@@ -101,71 +103,100 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev_index = int(os.environ.get("POB_FORCE_DEVICE", local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
     torch.cuda.set_device(dev_index)
-    B, H = args.batch, max(1, args.halves)
+    strong = args.total_batch > 0
+    if strong:
+        lo, hi = D.shard_bounds(args.total_batch, rank, world)
+        B, first0, GB = hi - lo, lo, args.total_batch                   # this rank's slice of every global batch
+    else:
+        B, first0, GB = args.batch, rank * args.batch, world * args.batch
     PIPE = bool(args.pipeline)
-    if PIPE:
-        H = 1
-    while H > 1 and (B % H or (B // H) % 64):
-        H -= 1                                                          # parts are whole 64-witness groups
-    Bh = B // H
+    NB = max(1, args.distinct_batches)
 
-    # ---- synthetic inputs (seeded; rank r holds witnesses [r*B, (r+1)*B) of the global batch: witness g depends only on (seed, g))
+    # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
     t0 = time.time()
-    batch = gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=rank * B,
-                                pow_device=dev_index if args.depth > 12 else None)
-    t_synth = time.time() - t0
-    NC = 2 if PIPE else H                                 # pipeline: two calculators, each holds a whole batch (consecutive batches of the job)
-    calcs = [WitnessCalculator(MAIN, max_batch=Bh, device=dev_index) for _ in range(NC)]
+    batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + first0,
+                                   pow_device=dev_index if args.depth > 12 else None) for b in range(NB)]
+    t_synth = (time.time() - t0) / NB
+    NC = 2 if PIPE else 1
+    calcs = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(NC)]
+    info = calcs[0].info
+    # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch); the Python packer beside it
+    texts = [[json.dumps(inp).encode() for inp in bt.inputs] for bt in batches]
+    pinned = [PinnedInputs(calcs[0], B) for _ in range(NB)]
     t0 = time.time()
-    packed = [calcs[h].pack(batch.inputs[h * Bh:(h + 1) * Bh]) for h in range(H)]
-    t_pack = time.time() - t0
+    for b in range(NB):
+        calcs[0].pack_json(texts[b], out=pinned[b])
+    t_pack_native = (time.time() - t0) / NB
     t0 = time.time()
-    for c in range(NC):
-        calcs[c].upload_packed(*packed[c if not PIPE else 0])             # H2D happens here, outside the timed region
-    t_h2d = time.time() - t0
+    ref = calcs[0].pack(batches[0].inputs[:min(B, 128)])
+    t_pack_py = (time.time() - t0) / min(B, 128) * B
+    assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].sm, pinned[0].forced))), "native loader differs from the Python loader"
+    expect = [np.array([list(c.to_bytes(32, "little")) for c in bt.commitments], dtype=np.uint8) for bt in batches]
     streams = [torch.cuda.Stream(device=dev_index) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
-    recs = [D.device_records(calcs[c], Bh) for c in range(NC)]
+    recs = [D.device_records(calcs[c], B) for c in range(NC)]
     if PIPE:
         calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
+    gs = torch.cuda.Stream(device=dev_index)              # the record gather of the multi-GPU job: after the batch's evaluation, beside the next batch's work
+    gathered_ev = [None] * NC
+    gather_bad = torch.zeros(1, dtype=torch.int64, device=f"cuda:{dev_index}")      # witnesses of OTHER ranks with a non-clean record, accumulated on the device
+    state = {"last_gather": None, "validated": 0, "kchk_ms": [], "h2d_bytes": 0}
 
-    gs = torch.cuda.Stream(device=dev_index)              # result records: packed at the end of generation, gathered beside the evaluation
+    def validate(c, b):
+        """every record of the batch calculator c has just finished: host-visible, checked before the clock stops"""
+        rec = calcs[c].wait_records()
+        assert rec.shape[0] == B
+        assert not rec["status"].any(), ("a witness failed", np.nonzero(rec["status"])[0][:4], rec["status"][np.nonzero(rec["status"])[0][:4]])
+        assert (rec["check_status"] == W.CLEAN).all() and (rec["bad_wire"] == W.CLEAN).all(), "the constraint evaluator flagged a witness (or did not run)"
+        assert np.array_equal(rec["commitment"], expect[b]), "commitment mismatch"
+        state["validated"] += B
+        if probing:
+            state["kchk_ms"].append(calcs[c].probe_check_kernel(True, read=True))
 
-    def step():
-        for h in range(H):
-            streams[h].wait_stream(gs)                    # the previous step's gather has read the records this generation overwrites
-            calcs[h].generate(streams[h].cuda_stream)
-        for h in range(H):
-            gs.wait_stream(streams[h])
-        with torch.cuda.stream(gs):
-            rec = recs[0] if H == 1 else torch.cat(recs)
-            out = D.gather_records(rec)
-        for h in range(H):
-            calcs[h].constraint_check(streams[h].cuda_stream)
-        return out
-
-    gathered = [None, None]
-    used = set() if PIPE else set(range(NC))              # calculators that have generated a batch (a one-step pipelined run uses one)
-
-    def run_pipelined(nsteps):
-        """nsteps batches through the two-calculator pipeline, fill and drain included: batch k is generated by calculator k % 2 while
-        batch k-1 is evaluated by the other one; every batch is generated AND evaluated inside the call"""
-        out, prev = None, None
-        for k in range(nsteps):
-            cur = k % 2
-            used.add(cur)
-            if prev is not None:
-                calcs[prev].constraint_check(streams[prev].cuda_stream)
-            if gathered[cur] is not None:
-                streams[cur].wait_event(gathered[cur])    # the gather of THIS calculator's previous batch has read its records
-            calcs[cur].generate(streams[cur].cuda_stream)
-            gs.wait_stream(streams[cur])
+    def finish(c):
+        """evaluation of calculator c's batch, its records (now with the verdict) to the host and to the other ranks"""
+        calcs[c].constraint_check(streams[c].cuda_stream)
+        calcs[c].fetch_records()
+        if world > 1:
+            gs.wait_stream(streams[c])
             with torch.cuda.stream(gs):
-                out = D.gather_records(recs[cur])
-                gathered[cur] = torch.cuda.Event(); gathered[cur].record(gs)
-            prev = cur
+                out = D.gather_records(recs[c], total=GB if strong else None)
+                st, _ = D.unpack_records(out)
+                cs, bw = D.unpack_verdicts(out)
+                gather_bad.add_(((st != 0) | (cs != D.CLEAN) | (bw != D.CLEAN)).sum())
+                gathered_ev[c] = torch.cuda.Event(); gathered_ev[c].record(gs)
+                state["last_gather"] = out
+
+    def start(c, b):
+        pin = pinned[b]
+        calcs[c].upload_packed_async(pin.fr, pin.sm, pin.forced)          # H2D from pinned memory on the calculator's upload stream
+        state["h2d_bytes"] += pin.fr.nbytes + pin.sm.nbytes
+        if gathered_ev[c] is not None:
+            streams[c].wait_event(gathered_ev[c])                         # the gather of THIS calculator's previous batch has read its records
+        calcs[c].generate(streams[c].cuda_stream)
+
+    def run(nsteps, k0=0):
+        """nsteps batches through the service loop, fill and drain included: every batch is uploaded, generated, evaluated, fetched and validated
+        inside the call.  Pipeline: batch k is generated by calculator k % 2 while batch k-1 is evaluated by the other one; the host validates
+        batch k-2 after it has enqueued batch k, so the device never waits for the host."""
+        pend = []                                         # (calculator, distinct batch) enqueued but not yet validated, oldest first
+        prev = None
+        for k in range(k0, k0 + nsteps):
+            c, b = (k % 2 if PIPE else 0), k % NB
+            if PIPE:
+                if prev is not None:
+                    finish(prev[0]); pend.append(prev)
+                start(c, b)
+                prev = (c, b)
+                while len(pend) > 1:
+                    validate(*pend.pop(0))
+            else:
+                start(c, b)
+                finish(c); pend.append((c, b))
+                validate(*pend.pop(0))
         if prev is not None:
-            calcs[prev].constraint_check(streams[prev].cuda_stream)
-        return out
+            finish(prev[0]); pend.append(prev)
+        while pend:
+            validate(*pend.pop(0))
 
     def fence():
         torch.cuda.synchronize()
@@ -173,144 +204,158 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if PIPE:
-        if args.warmup:
-            run_pipelined(args.warmup)
-        fence()
-        t0 = time.perf_counter()
-        rec_all = run_pipelined(args.steps)
-        fence()
-        dt = time.perf_counter() - t0
-    else:
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            rec_all = step()
-        fence()
-        dt = time.perf_counter() - t0
+    probing = False
+    if args.warmup:
+        run(args.warmup)
+    fence()
+    probing = True
+    for c in calcs:
+        c.probe_check_kernel(True)                        # HIP events around the dominant kernel of every evaluation from here on
+    state.update(validated=0, h2d_bytes=0)
+    t0 = time.perf_counter()
+    run(args.steps, k0=args.warmup)
+    fence()
+    dt = time.perf_counter() - t0
+    probing = False
+    for c in calcs:
+        c.probe_check_kernel(False)
+    assert state["validated"] == args.steps * B, "not every batch was validated inside the timed region"
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        assert int(gather_bad.item()) == 0, "a gathered record of some rank is not clean"
+        rec_all = state["last_gather"].cpu()
+        assert int(rec_all.shape[0]) == GB
+        mine = rec_all[first0:first0 + B].numpy() if strong else rec_all[rank * B:(rank + 1) * B].numpy()
+        assert np.array_equal(mine[:, 12:], expect[(args.warmup + args.steps - 1) % NB]), "gathered records differ from this rank's commitments"
+        if rank == 0 and args.dump_results:
+            np.save(args.dump_results, rec_all.numpy())
+    elif rank == 0 and args.dump_results:
+        np.save(args.dump_results, recs[(args.warmup + args.steps - 1) % NC].cpu().numpy())
+    kchk_in_step = float(np.mean(state["kchk_ms"])) if state["kchk_ms"] else None
+    h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
 
-    # ---- the work was real: every witness valid, commitments equal the host-side formula, evaluator clean
-    for h in sorted(used):
-        res = calcs[h].results(with_check=True)
-        assert all(r.ok for r in res), [r.message() for r in res if not r.ok][:3]
-        assert [r.outputs[0] for r in res] == (batch.commitments if PIPE else batch.commitments[h * Bh:(h + 1) * Bh]), "commitment mismatch"
-        assert all(r.check_status == 0 and r.bad_wire is None for r in res), "constraint evaluator flagged a witness"
-    st_all, out_all = D.unpack_records(rec_all.cpu())
-    assert int(st_all.shape[0]) == world * B and int((st_all != 0).sum().item()) == 0
-    mine = out_all[rank * B:(rank + 1) * B].numpy()
-    assert [int.from_bytes(bytes(mine[i].tobytes()), "little") for i in range(B)] == batch.commitments, "gathered records differ from this rank's commitments"
-    if rank == 0 and args.dump_results:
-        np.save(args.dump_results, rec_all.cpu().numpy())
-
-    # ---- the same job without the pipeline (one calculator, generate -> gather -> evaluate per batch), 10 steps: reported beside `value`
-    # so that both are measured in the same run on the same box
+    # ---- the same service loop without the pipeline (one calculator), 10 batches: reported beside `value`, same run, same box
     single = None
-    if PIPE and 0 in used:
+    if PIPE and not args.no_single:
         calcs[0].set_partner(None)
-
-        def step1():
-            streams[0].wait_stream(gs)
-            calcs[0].generate(streams[0].cuda_stream)
-            gs.wait_stream(streams[0])
-            with torch.cuda.stream(gs):
-                D.gather_records(recs[0])
-            calcs[0].constraint_check(streams[0].cuda_stream)
-
-        for _ in range(2):
-            step1()
+        PIPE_save, PIPE = PIPE, False
+        run(2)
         fence()
         t1 = time.perf_counter()
-        for _ in range(10):
-            step1()
+        run(10)
         fence()
         dt1 = time.perf_counter() - t1
+        PIPE = PIPE_save
         if world > 1:
             t1max = torch.tensor([dt1], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
             dist.all_reduce(t1max, op=dist.ReduceOp.MAX)
             dt1 = float(t1max.item())
-        single = {"what": "one calculator per GPU, no pipeline (bench.py --pipeline 0), 10 steps after the timed region", "value": round(world * B * 10 / dt1, 1),
-                  "ms_per_step": round(dt1 / 10 * 1e3, 3)}
+        single = {"what": "one calculator per GPU, no pipeline (bench.py --pipeline 0), 10 batches of the same service loop after the timed region",
+                  "value": round(GB * 10 / dt1, 1), "ms_per_step": round(dt1 / 10 * 1e3, 3)}
         calcs[0].set_partner(calcs[1])
 
-    info = calcs[0].info
-    groups_h = (Bh + 63) // 64
+    groups = (B + 63) // 64
     stream0 = streams[0].cuda_stream
     # ---- roofline of the dominant kernel: Keccak round constraint evaluation, HBM-read bound.
     # algorithmic bytes per launch = every wire of every KeccakfRound block as resident (8 B per BIT wire per 64 witnesses)
-    #                                + the round input/output states it is checked against.  A launch covers one calculator's part.
+    #                                + the round input/output states it is checked against.
     t_chk = calcs[0].time_kernel(1, iters=5, stream=stream0)
     t_gen = calcs[0].time_kernel(0, iters=5, stream=stream0)
     round_bytes = (102656 + 2 * 1600) * 8
-    launch_bytes = info.n_perms * 24 * round_bytes * groups_h
-    achieved = launch_bytes / (t_chk * 1e-3) / 1e9
+    launch_bytes = info.n_perms * 24 * round_bytes * groups
+    alone = launch_bytes / (t_chk * 1e-3) / 1e9
+    in_step = launch_bytes / (kchk_in_step * 1e-3) / 1e9 if kchk_in_step else None
     # whole evaluation pass and whole step against the resident vector (write once, read once)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     ev0.record(streams[0])
     for _ in range(5):
-        for h in range(H):
-            calcs[h].constraint_check(streams[h].cuda_stream)
-    for h in range(1, H):
-        streams[0].wait_stream(streams[h])
+        calcs[0].constraint_check(streams[0].cuda_stream)
     ev1.record(streams[0])
     torch.cuda.synchronize()
     t_check_pass = ev0.elapsed_time(ev1) / 5
-    resident = int(info.group_bytes) * groups_h * H
+    resident = int(info.group_bytes) * groups
     traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
-        pmc_file = next(p for p in ("round2_pmc_k_rounds.json", "round1_pmc_k_rounds.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        pmc_file = next(p for p in ("round3_pmc_k_rounds.json", "round2_pmc_k_rounds.json", "round1_pmc_k_rounds.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
-        traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups_h / pmc["groups"])
+        traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups / pmc["groups"])
     except Exception:
         pass
     ms_step = dt / args.steps * 1e3
-    roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+    # `achieved` / `frac`: the kernel as it runs IN the timed loop (HIP events on its own stream around every launch, averaged over the timed
+    # steps), i.e. beside the other batch's generation; `frac_alone`: the same kernel alone on an idle device (5 back-to-back launches)
+    roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
+                "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
+                "measured": "in the timed loop: HIP events on the kernel's stream around each of its launches, mean over the timed steps (pob_probe_check_kernel)" if in_step else "alone",
+                "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
+                "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
+                "traffic": traffic,
                 "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
-                "bytes_per_launch": launch_bytes, "avg_ms": round(t_chk, 4),
-                "gen_kernel": {"kernel": "k_rounds<GEN>", "achieved": round(info.n_perms * 24 * (102656 + 1600) * 8 * groups_h / (t_gen * 1e-3) / 1e9, 1),
+                "bytes_per_launch": launch_bytes,
+                "gen_kernel": {"kernel": "k_rounds<GEN>, alone", "achieved": round(info.n_perms * 24 * (102656 + 1600) * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)},
-                "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains)", "bytes": resident,
+                "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,
                                "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),
                                "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "step": {"what": "generate (write the resident vector once) + evaluate (read it once)", "bytes": 2 * resident,
+                "step": {"what": "generate (write the resident vector once) + evaluate (read it once) per timed step", "bytes": 2 * resident,
                          "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
-    # ---- .wtns emission (the step after the path): 2 witnesses back to back through the window pipeline into pinned host memory
+    # ---- .wtns emission (the step after the path): the O0 payload and the reduced (O1-style) one, through the window pipeline into pinned memory
     emission = None
     if rank == 0 and not args.no_emission:
-        sec, nbytes = calcs[0].emit_throughput(0, count=2)
-        emission = {"what": "canonical 32 B/wire payload expanded on the GPU in 256 MiB windows, D2H double-buffered into pinned memory, 2 witnesses back to back",
-                    "GB_per_s": round(nbytes / sec / 1e9, 2), "ms_per_witness": round(sec / 2 * 1e3, 1), "bytes_per_witness": nbytes // 2}
+        cold_s, cold_b = calcs[0].emit_throughput(0, count=1)              # first emission of this calculator: allocates the windows (2 x 256 MiB device + pinned), probe pass
+        sec, nbytes = calcs[0].emit_throughput(1, count=2)
+        emission = {"what": "canonical 32 B/wire payload expanded on the GPU in 256 MiB windows, D2H double-buffered into pinned memory; steady state = 2 witnesses back to back "
+                            "after a first one that set the buffers up (first_witness_ms includes hipHostMalloc of 512 MiB and the probe pass)",
+                    "GB_per_s": round(nbytes / sec / 1e9, 2), "ms_per_witness": round(sec / 2 * 1e3, 1), "bytes_per_witness": nbytes // 2,
+                    "first_witness_ms": round(cold_s * 1e3, 1)}
+        try:
+            from proof_of_burn_amd.circuit_model import keepmap
+            keep, _ = keepmap.load(MAIN)
+            calcs[0].emit_throughput(0, count=1, keep=keep, window_wires=1 << 24)
+            rsec, rbytes = calcs[0].emit_throughput(1, count=4, keep=keep, window_wires=1 << 24)
+            emission["reduced"] = {"what": "O1-style reduced witness (circuit_model/o1.py map, stored under circuit_model/data/): only the kept wires are expanded and copied "
+                                           "(pob_emit_begin_reduced), 4 witnesses back to back after a first one",
+                                   "kept_wires": int(keep.size), "of": int(info.n_witness), "ms_per_witness": round(rsec / 4 * 1e3, 2),
+                                   "GB_per_s": round(rbytes / rsec / 1e9, 2), "bytes_per_witness": rbytes // 4}
+        except FileNotFoundError:
+            pass
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batch, info, args.cpu_samples)
+        cpu = cpu_baseline(batches[0], info, args.cpu_samples)
 
     if rank == 0:
-        value = world * B * args.steps / dt
+        value = GB * args.steps / dt
         line = {
             "metric": "proof_of_burn witnesses/sec", "value": round(value, 1), "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u64 bit-sliced lanes + BN254 Fr (8x32-bit Montgomery)", "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU proof_of_burn witnesses, {MAIN}, synthetic {args.depth}-layer MPT proofs "
-                                   f"({args.distinct_keys} distinct PoW burn keys tiled), generate + per-gate constraint evaluation + result gather",
+            "config": {"workload": (f"global batch={GB} split over {world} GPUs" if strong else f"batch={B}/GPU") + f" proof_of_burn witnesses per step, {MAIN}, synthetic "
+                                   f"{args.depth}-layer MPT proofs ({args.distinct_keys} distinct PoW burn keys tiled, {NB} distinct input batches cycled); per step, inside the timed "
+                                   f"region: H2D of the packed inputs from pinned memory, generate, per-gate constraint evaluation, records {{status, verdict, commitment}} D2H, "
+                                   f"every record validated on the host" + (", one all-gather of the records" if world > 1 else ""),
                        "wires_per_witness": int(info.n_witness), "resident_bytes_per_witness": int(info.group_bytes // 64),
-                       "canonical_bytes_per_witness": int(info.n_witness) * 32, "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {Bh} (fill and drain inside the timed region)" if PIPE else f"{H} interleaved parts of {Bh} per GPU"),
-                       "input_synthesis_s": round(t_synth, 2), "json_to_packed_witnesses_per_s": round(B / max(t_pack, 1e-9), 1),
-                       "h2d_s": round(t_h2d, 3)},
+                       "canonical_bytes_per_witness": int(info.n_witness) * 32,
+                       "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {B} (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
+                       "validated_witnesses": state["validated"], "h2d_bytes_per_step": int(h2d_per_step),
+                       "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "input_synthesis_s_per_batch": round(t_synth, 2),
+                       "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),
+                       "json_to_packed": {"what": "input.json texts -> packed rows in pinned memory, pob_pack_json_batch on all host cores (bit-equal to the Python loader on a sample of this batch)",
+                                          "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
             "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single,
         }
         print(json.dumps(line))
     for c in calcs:
         c.close()
+    for pin in pinned:
+        pin.free()
     if world > 1:
         dist.destroy_process_group()
 

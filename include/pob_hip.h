@@ -60,6 +60,17 @@ int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_
  * k and k+1 are in flight.  The host buffers must be pinned (pob_host_alloc) for the copy to be asynchronous and must stay
  * untouched until that pob_generate has been enqueued and its stream has passed the copy (e.g. until the batch's results are in). */
 int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n, void* stream);
+/* The emitted loader itself, natively (reference: loadJson of the emitted calculator; tests/test.py:57-59 and tests/main.py:160-178 write
+ * the input.json it reads): one input.json TEXT -> the packed row of pob_upload_inputs (fr_row[n_fr_inputs][32], sm_row[n_sm_inputs],
+ * *forced = 0 or the failure code of an input that cannot fit its row: such a witness is reported as failed whatever the device computes).
+ * Accepts what the host mirror (witness.py WitnessCalculator.pack) accepts: exact key set, scalars possibly wrapped in one-element arrays,
+ * nested arrays flattened, JSON integers of any size / booleans / decimal or 0x strings, reduced mod p; anything else is POB_E_ARG with
+ * the reason in err[errcap].  params as for pob_open.  No GPU is touched.
+ * pob_pack_json_batch: n texts on `threads` host threads (0 = all) into witness-major arrays, e.g. pinned memory from pob_host_alloc. */
+int pob_pack_json(int circuit, const uint64_t* params, int nparams, const char* json, uint64_t len, uint8_t* fr_row, int32_t* sm_row,
+                  uint32_t* forced, char* err, uint32_t errcap);
+int pob_pack_json_batch(int circuit, const uint64_t* params, int nparams, const char* const* json, const uint64_t* len, uint32_t n, int threads,
+                        uint8_t* fr, int32_t* sm, uint32_t* forced, char* err, uint32_t errcap);
 /* Pinned host memory for the above (hipHostMalloc), so that a ctypes / cgo caller need not link the HIP runtime itself. */
 int pob_host_alloc(void** p, uint64_t bytes);
 void pob_host_free(void* p);
@@ -135,6 +146,10 @@ int pob_emit_measure_ex(pob_handle h, uint32_t first_idx, uint32_t count, uint64
  * generation of all units of kind k (circuits.hpp UnitKind) alone on the device; 300 + f = the evaluation kernel of family f
  * (circuits.hpp Fam) alone (tools/unit_times.py).                                                                */
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream, float* avg_ms);
+/* Measurement INSIDE a running job: enable = 1 makes every following pob_constraint_check record HIP events (on the stream the kernel is
+ * launched on) around its Keccak round evaluation kernel -- the dominant kernel as it runs in the step, beside the other batch's
+ * generation; *ms (may be NULL) = duration of the last such kernel, whose batch must be complete.  enable = 0 stops recording.    */
+int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 
 /* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);

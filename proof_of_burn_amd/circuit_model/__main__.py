@@ -5,6 +5,8 @@
     r1cs   MAIN out.r1cs             iden3 binary .r1cs (every <== and ===)
     check  MAIN witness.wtns         evaluate every constraint on a witness (`snarkjs wtns check` equivalent); exit 1 on violations
     o1     MAIN in.wtns out.wtns     O1-style reduced witness (signal-to-signal / constant copies dropped)
+    keepmap MAIN                     derive that map and store it compressed under circuit_model/data/ (keepmap.py: the device-side
+                                     reduced emission of the bench and the GPU tests read it from there)
 """
 import sys
 
@@ -20,6 +22,10 @@ def main(argv=None) -> int:
     if len(argv) < 2:
         print(__doc__, file=sys.stderr)
         return 2
+    if argv[0] == "keepmap":
+        from . import keepmap
+        print(keepmap.generate(argv[1]))
+        return 0
     cmd, c = argv[0], circuit(argv[1])
     if cmd == "info":
         print(f"wires {c.n_wires} constraints {c.n_constraints} outputs {c.n_outputs} inputs {c.n_inputs}")

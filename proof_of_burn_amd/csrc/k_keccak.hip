@@ -12,10 +12,11 @@ void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngrou
     static const int pg = getenv("POB_KR_PERSIST_GEN") ? atoi(getenv("POB_KR_PERSIST_GEN")) : 0;
     const uint32_t gx = nperms * 24, total = gx * ngroups;
     const int wps = check ? pc : pg;
-    if (wps > 0 && K.work_counter && total > 1024u * (uint32_t)wps) {
+    if (wps > 0 && K.work_counter) {
+        const uint32_t nw = total < 1024u * (uint32_t)wps ? total : 1024u * (uint32_t)wps;
         hipMemsetAsync(K.work_counter, 0, 4, st);
-        if (check) hipLaunchKernelGGL((k_rounds_persist<true, true>), dim3(1024u * (uint32_t)wps), dim3(64), 0, st, K, gx, total, K.work_counter);
-        else hipLaunchKernelGGL((k_rounds_persist<false>), dim3(1024u * (uint32_t)wps), dim3(64), 0, st, K, gx, total, K.work_counter);
+        if (check) hipLaunchKernelGGL((k_rounds_persist<true, true>), dim3(nw), dim3(64), 0, st, K, gx, total, K.work_counter);
+        else hipLaunchKernelGGL((k_rounds_persist<false>), dim3(nw), dim3(64), 0, st, K, gx, total, K.work_counter);
         return;
     }
     if (check) hipLaunchKernelGGL((k_rounds<true, true>), dim3(gx, ngroups), dim3(64), 0, st, K);

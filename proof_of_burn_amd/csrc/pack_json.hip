@@ -1,0 +1,301 @@
+// Native input loader: input.json text -> the packed row of pob_upload_inputs.
+//
+// Replaces the calculator's emitted loadJson (reference: tests/test.py:57-59 writes input.json, tests/main.py:160-178 is the producer of
+// the two circuits' files).  Same acceptance as the Python host's WitnessCalculator.pack (witness.py), which the tests hold it to
+// bit for bit:
+//   * the object's keys must be exactly the circuit's `signal input` names (proof_of_burn.circom:43-72, spend.circom:33-36);
+//   * a scalar may come wrapped in one-element arrays (tests/testcases/divide.py:4), array inputs may be nested (layers[L][136 NB]) and are
+//     flattened row-major; the element count must match the circuit's;
+//   * a value is a JSON integer of any size and sign, true / false, or a string holding a decimal or 0x-hex integer; it is reduced mod p
+//     (tests/testcases/convert.py:36 passes p - 1 as a string); fractions / exponents / null are refused;
+//   * the byte-sized inputs are range-constrained in-circuit (AssertByteString, AssertBits(16) ...): a value that does not fit the int32
+//     row (>= 2^31 after reduction, e.g. a negative number) marks the witness as failed up front (FAIL_INPUT_RANGE) and is stored as
+//     0x7FFFFFFF (tests/testcases/rlp/integer.py:51-53, assertion.py:87 feed out-of-range values that must fail, not wrap).
+// Host code only (no kernel in this translation unit); pob_pack_json_batch spreads the texts over host threads and writes straight
+// into the caller's (pinned) arrays.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pob_hip.h"
+
+namespace {
+typedef unsigned __int128 u128;
+const uint64_t P64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+const uint32_t FAIL_INPUT_RANGE = (11u << 12) | 1u;          // witness.py FAIL_INPUT_RANGE
+
+struct U256 { uint64_t l[4]; };
+bool geq_p(const uint64_t* v5) {                              // v (5 limbs) >= p ?
+    if (v5[4]) return true;
+    for (int i = 3; i >= 0; i--) if (v5[i] != P64[i]) return v5[i] > P64[i];
+    return true;
+}
+void sub_p(uint64_t* v5) {
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) { const u128 d = (u128)v5[i] - P64[i] - br; v5[i] = (uint64_t)d; br = (d >> 127) & 1; }
+    v5[4] -= (uint64_t)br;
+}
+// v <- (v * mul + add) mod p, v < p, mul <= 2^32
+void muladd_mod(U256& v, uint64_t mul, uint64_t add) {
+    uint64_t t[5]; u128 c = add;
+    for (int i = 0; i < 4; i++) { c += (u128)v.l[i] * mul; t[i] = (uint64_t)c; c >>= 64; }
+    t[4] = (uint64_t)c;
+    // t < p * 2^32 + 2^64: subtract p << k for the bits of the quotient (at most 34 conditional subtractions, only for multi-limb values)
+    if (!t[4] && !t[3] && !t[2] && !t[1]) { v.l[0] = t[0]; v.l[1] = v.l[2] = v.l[3] = 0; return; }
+    for (int k = 35; k >= 0; k--) {
+        uint64_t ps[5] = {0, 0, 0, 0, 0};                      // p << k
+        for (int i = 0; i < 4; i++) { ps[i] |= P64[i] << k; if (k) ps[i + 1] |= P64[i] >> (64 - k); }
+        bool ge = true;
+        for (int i = 4; i >= 0; i--) if (t[i] != ps[i]) { ge = t[i] > ps[i]; break; }
+        if (ge) { u128 br = 0; for (int i = 0; i < 5; i++) { const u128 d = (u128)t[i] - ps[i] - br; t[i] = (uint64_t)d; br = (d >> 127) & 1; } }
+    }
+    while (geq_p(t)) sub_p(t);
+    for (int i = 0; i < 4; i++) v.l[i] = t[i];
+}
+void neg_mod(U256& v) {                                       // v <- (-v) mod p
+    if (!(v.l[0] | v.l[1] | v.l[2] | v.l[3])) return;
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) { const u128 d = (u128)P64[i] - v.l[i] - br; v.l[i] = (uint64_t)d; br = (d >> 127) & 1; }
+}
+
+struct Parser {
+    const char* s; const char* e; std::string err;
+    void ws() { while (s < e && (*s == ' ' || *s == '\n' || *s == '\t' || *s == '\r')) s++; }
+    bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+    // an integer literal (digits [s, t), optional sign consumed by the caller), base 10 or 16, reduced mod p
+    bool digits(const char* a, const char* b, int base, bool neg, U256& out) {
+        if (a == b) return fail("empty number");
+        out = U256{{0, 0, 0, 0}};
+        if (base == 10 && b - a <= 18) {                       // the common case: bytes and lengths
+            uint64_t v = 0;
+            for (const char* q = a; q < b; q++) { if (*q < '0' || *q > '9') return fail("bad digit in number"); v = v * 10 + (uint64_t)(*q - '0'); }
+            out.l[0] = v;
+        } else {
+            for (const char* q = a; q < b; q++) {
+                int d;
+                if (*q >= '0' && *q <= '9') d = *q - '0';
+                else if (base == 16 && *q >= 'a' && *q <= 'f') d = *q - 'a' + 10;
+                else if (base == 16 && *q >= 'A' && *q <= 'F') d = *q - 'A' + 10;
+                else return fail("bad digit in number");
+                muladd_mod(out, (uint64_t)base, (uint64_t)d);
+            }
+        }
+        if (neg) neg_mod(out);
+        return true;
+    }
+    // one scalar JSON value (number / string / true / false) -> field element
+    bool scalar(U256& out) {
+        ws();
+        if (s >= e) return fail("unexpected end of input");
+        if (*s == '"') {
+            const char* a = ++s;
+            while (s < e && *s != '"') { if (*s == '\\') return fail("escape in a numeric string"); s++; }
+            if (s >= e) return fail("unterminated string");
+            const char* b = s++;
+            // witness.to_field: base 16 iff the string itself starts with 0x (Python's int(v, 16)), otherwise base 10 with optional sign;
+            // int() strips surrounding whitespace (underscore digit separators are refused here)
+            const bool hex = b - a >= 2 && a[0] == '0' && (a[1] == 'x' || a[1] == 'X');
+            while (a < b && (*a == ' ' || *a == '\t' || *a == '\n')) a++;
+            while (b > a && (b[-1] == ' ' || b[-1] == '\t' || b[-1] == '\n')) b--;
+            if (hex) return digits(a + 2, b, 16, false, out);
+            bool neg = false;
+            if (a < b && (*a == '-' || *a == '+')) { neg = *a == '-'; a++; }
+            return digits(a, b, 10, neg, out);
+        }
+        if (*s == 't' && e - s >= 4 && !memcmp(s, "true", 4)) { s += 4; out = U256{{1, 0, 0, 0}}; return true; }
+        if (*s == 'f' && e - s >= 5 && !memcmp(s, "false", 5)) { s += 5; out = U256{{0, 0, 0, 0}}; return true; }
+        bool neg = false;
+        if (*s == '-') { neg = true; s++; }
+        const char* a = s;
+        while (s < e && *s >= '0' && *s <= '9') s++;
+        if (s < e && (*s == '.' || *s == 'e' || *s == 'E')) return fail("a JSON number with a fraction or exponent is not an integer input");
+        if (a == s) return fail("unsupported input value");
+        return digits(a, s, 10, neg, out);
+    }
+    // a scalar, possibly wrapped in one-element arrays
+    bool wrapped_scalar(U256& out) {
+        ws();
+        int depth = 0;
+        while (s < e && *s == '[') { s++; depth++; ws(); }
+        if (!scalar(out)) return false;
+        for (; depth; depth--) { ws(); if (s >= e || *s != ']') return fail("a scalar input must be a value or a one-element array"); s++; }
+        return true;
+    }
+    // a (nested) array flattened row-major into int32 slots; returns the element count through n
+    bool flat(int32_t* dst, uint32_t cap, uint32_t& n, bool& big) {
+        ws();
+        if (s < e && *s == '[') {
+            s++; ws();
+            if (s < e && *s == ']') { s++; return true; }
+            for (;;) {
+                if (!flat(dst, cap, n, big)) return false;
+                ws();
+                if (s < e && *s == ',') { s++; continue; }
+                if (s < e && *s == ']') { s++; return true; }
+                return fail("expected , or ] in array");
+            }
+        }
+        if (s < e && *s >= '0' && *s <= '9') {                  // the bulk of an input: short non-negative decimal numbers (bytes, lengths)
+            const char* a = s; uint64_t v = 0;
+            while (s < e && *s >= '0' && *s <= '9' && s - a < 10) { v = v * 10 + (uint64_t)(*s - '0'); s++; }
+            if (s < e && (*s == ',' || *s == ']' || *s == ' ' || *s == '\n')) {
+                if (n < cap) { if (v >= (1ull << 31)) { big = true; dst[n] = 0x7FFFFFFF; } else dst[n] = (int32_t)v; }
+                n++;
+                return true;
+            }
+            s = a;                                                 // longer, or a fraction / exponent follows: the general path decides
+        }
+        U256 v;
+        if (!scalar(v)) return false;
+        if (n < cap) {
+            if (v.l[1] | v.l[2] | v.l[3] || v.l[0] >= (1ull << 31)) { big = true; dst[n] = 0x7FFFFFFF; } else dst[n] = (int32_t)v.l[0];
+        }
+        n++;
+        return true;
+    }
+    bool skip_value() {                                          // (an unexpected key: skipped, then reported)
+        ws();
+        if (s >= e) return fail("unexpected end of input");
+        if (*s == '[' || *s == '{') {
+            const char open = *s, close = open == '[' ? ']' : '}'; int d = 0;
+            for (; s < e; s++) { if (*s == '"') { s++; while (s < e && *s != '"') s += (*s == '\\') ? 2 : 1; } else if (*s == open) d++; else if (*s == close && --d == 0) { s++; return true; } }
+            return fail("unterminated value");
+        }
+        if (*s == '"') { s++; while (s < e && *s != '"') s += (*s == '\\') ? 2 : 1; if (s < e) s++; return true; }
+        while (s < e && *s != ',' && *s != '}' && *s != ']') s++;
+        return true;
+    }
+};
+
+struct Shape { int circuit; uint32_t nfr, nsm; uint32_t L, LB, HBy; };
+const char* const POB_FR[6] = {"burnKey", "actualBalance", "intendedBalance", "revealAmount", "burnExtraCommitment", "_proofExtraCommitment"};
+const char* const SPEND_FR[4] = {"burnKey", "balance", "withdrawnBalance", "extraCommitment"};
+const char* const POB_SM[7] = {"numLeafAddressNibbles", "layers", "layerLens", "numLayers", "blockHeader", "blockHeaderLen", "byteSecurityRelax"};
+
+bool make_shape(int circuit, const uint64_t* params, int nparams, Shape& sh, std::string& err) {
+    sh.circuit = circuit;
+    if (circuit == POB_CIRCUIT_PROOF_OF_BURN) {
+        if (nparams != 8) { err = "ProofOfBurn takes 8 template parameters"; return false; }
+        for (int k = 0; k < 3; k++) if (params[4 * k + 1] | params[4 * k + 2] | params[4 * k + 3] || params[4 * k] == 0 || params[4 * k] > 64) { err = "unsupported ProofOfBurn parameters"; return false; }
+        sh.L = (uint32_t)params[0]; sh.LB = 136u * (uint32_t)params[4]; sh.HBy = 136u * (uint32_t)params[8];
+        sh.nfr = 6; sh.nsm = 1 + sh.L * sh.LB + sh.L + 1 + sh.HBy + 2;
+        return true;
+    }
+    if (circuit == POB_CIRCUIT_SPEND) { sh.L = sh.LB = sh.HBy = 0; sh.nfr = 4; sh.nsm = 0; return true; }
+    err = "unknown circuit";
+    return false;
+}
+
+bool pack_one(const Shape& sh, const char* json, uint64_t len, uint8_t* fr_row, int32_t* sm_row, uint32_t* forced, std::string& err) {
+    Parser p{json, json + len, {}};
+    const int nfr = (int)sh.nfr, nsmn = sh.circuit == POB_CIRCUIT_PROOF_OF_BURN ? 7 : 0;
+    const char* const* frn = sh.circuit == POB_CIRCUIT_PROOF_OF_BURN ? POB_FR : SPEND_FR;
+    // slot of every small input in the int32 row (declaration order) and its element count
+    uint32_t off[7] = {0, 0, 0, 0, 0, 0, 0}, cnt[7] = {1, 1, 1, 1, 1, 1, 1};
+    if (nsmn) { cnt[1] = sh.L * sh.LB; cnt[2] = sh.L; cnt[4] = sh.HBy; uint32_t o = 0; for (int k = 0; k < 7; k++) { off[k] = o; o += cnt[k]; } }
+    uint32_t seen_fr = 0, seen_sm = 0; bool big = false;
+    std::string unexpected;
+    p.ws();
+    if (p.s >= p.e || *p.s != '{') { err = "input.json must be an object"; return false; }
+    p.s++; p.ws();
+    if (p.s < p.e && *p.s == '}') p.s++;
+    else for (;;) {
+        p.ws();
+        if (p.s >= p.e || *p.s != '"') { err = "expected a key"; return false; }
+        const char* a = ++p.s;
+        while (p.s < p.e && *p.s != '"') p.s++;
+        if (p.s >= p.e) { err = "unterminated key"; return false; }
+        const size_t kl = (size_t)(p.s - a); p.s++;
+        p.ws();
+        if (p.s >= p.e || *p.s != ':') { err = "expected :"; return false; }
+        p.s++;
+        int hit = -1;
+        for (int k = 0; k < nfr && hit < 0; k++) if (strlen(frn[k]) == kl && !memcmp(frn[k], a, kl)) hit = k;
+        if (hit >= 0) {
+            U256 v;
+            if (!p.wrapped_scalar(v)) { err = std::string(frn[hit]) + ": " + p.err; return false; }
+            memcpy(fr_row + 32 * hit, v.l, 32);
+            seen_fr |= 1u << hit;
+        } else {
+            for (int k = 0; k < nsmn && hit < 0; k++) if (strlen(POB_SM[k]) == kl && !memcmp(POB_SM[k], a, kl)) hit = k;
+            if (hit >= 0) {
+                if (cnt[hit] == 1 && hit != 2) {               // scalar small input (layerLens is an array even when maxNumLayers = 1)
+                    U256 v;
+                    if (!p.wrapped_scalar(v)) { err = std::string(POB_SM[hit]) + ": " + p.err; return false; }
+                    if (v.l[1] | v.l[2] | v.l[3] || v.l[0] >= (1ull << 31)) { big = true; sm_row[off[hit]] = 0x7FFFFFFF; } else sm_row[off[hit]] = (int32_t)v.l[0];
+                } else {
+                    uint32_t n = 0;
+                    if (!p.flat(sm_row + off[hit], cnt[hit], n, big)) { err = std::string(POB_SM[hit]) + ": " + p.err; return false; }
+                    if (n != cnt[hit]) { err = std::string(POB_SM[hit]) + " has " + std::to_string(n) + " elements, circuit expects " + std::to_string(cnt[hit]); return false; }
+                }
+                seen_sm |= 1u << hit;
+            } else {
+                if (!unexpected.empty()) unexpected += ", ";
+                unexpected.append(a, kl);
+                if (!p.skip_value()) { err = p.err; return false; }
+            }
+        }
+        p.ws();
+        if (p.s < p.e && *p.s == ',') { p.s++; continue; }
+        if (p.s < p.e && *p.s == '}') { p.s++; break; }
+        err = "expected , or } in object"; return false;
+    }
+    p.ws();
+    if (p.s != p.e) { err = "trailing characters after the object"; return false; }
+    std::string missing;
+    for (int k = 0; k < nfr; k++) if (!((seen_fr >> k) & 1)) { if (!missing.empty()) missing += ", "; missing += frn[k]; }
+    for (int k = 0; k < nsmn; k++) if (!((seen_sm >> k) & 1)) { if (!missing.empty()) missing += ", "; missing += POB_SM[k]; }
+    if (!missing.empty() || !unexpected.empty()) { err = "missing [" + missing + "] unexpected [" + unexpected + "]"; return false; }
+    *forced = big ? FAIL_INPUT_RANGE : 0;
+    return true;
+}
+void put_err(char* dst, uint32_t cap, const std::string& m) { if (dst && cap) { snprintf(dst, cap, "%s", m.c_str()); } }
+}  // namespace
+
+extern "C" {
+
+int pob_pack_json(int circuit, const uint64_t* params, int nparams, const char* json, uint64_t len, uint8_t* fr_row, int32_t* sm_row, uint32_t* forced, char* err, uint32_t errcap) {
+    if (!params || !json || !fr_row || !forced) return POB_E_ARG;
+    Shape sh; std::string e;
+    if (!make_shape(circuit, params, nparams, sh, e)) { put_err(err, errcap, e); return POB_E_ARG; }
+    if (sh.nsm && !sm_row) return POB_E_ARG;
+    if (!pack_one(sh, json, len, fr_row, sm_row, forced, e)) { put_err(err, errcap, e); return POB_E_ARG; }
+    return POB_OK;
+}
+
+int pob_pack_json_batch(int circuit, const uint64_t* params, int nparams, const char* const* json, const uint64_t* len, uint32_t n, int threads,
+                        uint8_t* fr, int32_t* sm, uint32_t* forced, char* err, uint32_t errcap) {
+    if (!params || !json || !len || !fr || !forced || n == 0) return POB_E_ARG;
+    Shape sh; std::string e;
+    if (!make_shape(circuit, params, nparams, sh, e)) { put_err(err, errcap, e); return POB_E_ARG; }
+    if (sh.nsm && !sm) return POB_E_ARG;
+    uint32_t nt = threads > 0 ? (uint32_t)threads : std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (threads <= 0 && nt > (n + 7) / 8) nt = (n + 7) / 8;   // default: at least 8 texts per thread (a thread costs about as much as parsing one text)
+    if (nt > n) nt = n;
+    std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu);
+    std::vector<std::string> errs(nt);
+    const uint32_t smw = sh.nsm ? sh.nsm : 1;                   // (witness.py keeps one dummy column for circuits without small inputs)
+    auto work = [&](uint32_t t) {
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n) return;
+            std::string em;
+            if (!pack_one(sh, json[i], len[i], fr + (uint64_t)i * sh.nfr * 32, sm ? sm + (uint64_t)i * smw : nullptr, forced + i, em)) {
+                uint32_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+                if (errs[t].empty()) errs[t] = "input " + std::to_string(i) + ": " + em;
+            }
+        }
+    };
+    if (nt == 1) work(0);
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; t++) th.emplace_back(work, t); for (std::thread& x : th) x.join(); }
+    if (bad.load() != 0xFFFFFFFFu) { for (const std::string& m : errs) if (!m.empty()) { put_err(err, errcap, m); break; } return POB_E_ARG; }
+    return POB_OK;
+}
+
+}  // extern "C"

@@ -112,7 +112,7 @@ struct pob_ctx {
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
     uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
-    uint32_t* d_work = nullptr;                        // item counters of the persistent Keccak round kernels: [0] generation, [1] evaluation
+    uint32_t* d_work = nullptr;                        // item counters of the persistent Keccak round kernels: [0] measurements, [1] evaluation, [2 + i] generation's sponge segment i (segments of different tracks run side by side)
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
     struct Emit {
@@ -152,6 +152,7 @@ struct pob_ctx {
     hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false, evaluated = false;
     // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
     hipStream_t s_upload = nullptr, s_fetch = nullptr; hipEvent_t ev_upload = nullptr, ev_fetched[2] = {nullptr, nullptr};
+    hipEvent_t ev_kchk[2] = {nullptr, nullptr};         // timing events around the Keccak round evaluation of the last pob_constraint_check (pob_probe_check_kernel)
     uint8_t* h_records[2] = {nullptr, nullptr}; int fetch_slot = 0; bool upload_pending = false, fetch_pending = false; uint32_t fetch_n = 0;
 };
 
@@ -428,7 +429,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_chk, npad * 4)); HIPC(hipMalloc(&h->d_bad, npad * 4));
     HIPC(hipMalloc(&h->d_outputs, npad * 32));
     HIPC(hipMalloc(&h->d_records, npad * POB_RECORD_BYTES));
-    HIPC(hipMalloc(&h->d_work, 8)); HIPC(hipMemset(h->d_work, 0, 8));
+    HIPC(hipMalloc(&h->d_work, (2 + h->ksegs.size()) * 4)); HIPC(hipMemset(h->d_work, 0, (2 + h->ksegs.size()) * 4));
     HIPC(hipMemcpy(h->d_units, pl.units.data(), pl.units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_order, h->order.data(), h->order.size() * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_L, &pl.L, sizeof(CircuitLayout), hipMemcpyHostToDevice));
@@ -460,6 +461,7 @@ void pob_close(pob_handle h) {
     hipDeviceSynchronize();                             // (the pool's streams may still carry this handle's work)
     for (int k = 0; k < 2; k++) { if (h->h_records[k]) hipHostFree(h->h_records[k]); if (h->ev_fetched[k]) hipEventDestroy(h->ev_fetched[k]); }
     if (h->ev_upload) hipEventDestroy(h->ev_upload);
+    for (hipEvent_t e : h->ev_kchk) if (e) hipEventDestroy(e);
     if (h->s_upload) hipStreamDestroy(h->s_upload);
     if (h->s_fetch) hipStreamDestroy(h->s_fetch);
     if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
@@ -581,6 +583,7 @@ int pob_generate(pob_handle h, void* stream_) {
             if (forked) { HIPC(hipEventRecord(ej, sh)); HIPC(hipStreamWaitEvent(sm, ej, 0)); }
             for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid) {
                 hipStream_t sk = sm;
+                K.work_counter = h->d_work + 2 + (&ks - h->ksegs.data());
                 K.first = ks.sp_first;
                 launch_k_chain(K, false, ks.sp_count, G, sk);
                 K.first = ks.perm_first;
@@ -641,7 +644,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     if (!h->plan.sponges.empty()) {
         KArgs K = kargs(h, true);
         K.first = 0;
+        if (h->ev_kchk[0]) HIPC(hipEventRecord(h->ev_kchk[0], st));          // measurement (pob_probe_check_kernel): the dominant kernel inside the step
         launch_k_rounds(K, true, h->nperms, G, st);
+        if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
         launch_k_chain(K, true, h->nperms, G, st);
     }
     HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
@@ -992,6 +997,22 @@ int pob_emit_measure_ex(pob_handle h, uint32_t first_idx, uint32_t count, uint64
 }
 int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes) {
     return pob_emit_measure_ex(h, first_idx, count, window_wires, nullptr, 0, seconds, bytes);
+}
+
+// Measurement inside a running job: enable = 1 makes every following pob_constraint_check record HIP events (on the stream the kernel is
+// launched on) around its Keccak round evaluation kernel; ms (may be NULL) = the duration of the LAST such kernel, which must have
+// completed (e.g. its batch's results are in).  enable = 0 stops recording.
+int pob_probe_check_kernel(pob_handle h, int enable, float* ms) {
+    if (!h) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    if (ms) {
+        if (!h->ev_kchk[0] || !h->evaluated) { h->err = "no timed evaluation yet"; return POB_E_STATE; }
+        HIPC(hipEventSynchronize(h->ev_kchk[1]));
+        HIPC(hipEventElapsedTime(ms, h->ev_kchk[0], h->ev_kchk[1]));
+    }
+    if (enable && !h->ev_kchk[0]) { HIPC(hipEventCreate(&h->ev_kchk[0])); HIPC(hipEventCreate(&h->ev_kchk[1])); }
+    if (!enable) for (hipEvent_t& e : h->ev_kchk) if (e) { hipEventDestroy(e); e = nullptr; }
+    return POB_OK;
 }
 
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* avg_ms) {

@@ -72,6 +72,9 @@ def load_library() -> ctypes.CDLL:
     lib.pob_upload_inputs.argtypes = [vp, vp, vp, ctypes.c_uint32]
     lib.pob_upload_inputs_async.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
     lib.pob_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
+    lib.pob_pack_json.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, vp, vp, vp, ctypes.c_char_p, ctypes.c_uint32]
+    lib.pob_pack_json_batch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.c_uint32, ctypes.c_int, vp, vp, vp, ctypes.c_char_p, ctypes.c_uint32]
     lib.pob_host_free.argtypes = [vp]
     lib.pob_host_free.restype = None
     lib.pob_results_fetch.argtypes = [vp]
@@ -92,6 +95,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_emit_next.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_emit_measure.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_time_kernel.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.pob_probe_check_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     lib.pob_debug_xor_bits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
     lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.pob_debug_ref.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
@@ -105,15 +109,18 @@ def load_library() -> ctypes.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free",
+EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
     """wire / storage-class counts of an instantiation from the host-side layout planner (no GPU needed)"""
-    name, params = parse_main(main)
+    return plan_info_of(*parse_main(main))
+
+
+def plan_info_of(name: str, params) -> PobInfo:
     circuit = {"ProofOfBurn": 0, "Spend": 1}[name]
     arr = (ctypes.c_uint64 * (4 * len(params)))()
     for i, v in enumerate(params):
@@ -170,6 +177,97 @@ def _flat(v, out):
             _flat(x, out)
     else:
         out.append(to_field(v))
+
+
+def _main_of(main):
+    return parse_main(main) if isinstance(main, str) else (main[0], list(main[1]))
+
+
+def pack_inputs(main, inputs: Sequence[dict], info: PobInfo | None = None):
+    """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n]): the emitted loader (loadJson) in Python.
+    The byte arrays (layers, blockHeader: 99 % of an input) go through numpy in one conversion per key; only values that numpy
+    cannot hold as int64 (strings, huge ints -- the loader's mod-p path) fall back to per-element parsing.  Needs no GPU."""
+    name, params = _main_of(main)
+    info = info or plan_info_of(name, params)
+    n = len(inputs)
+    nfr, nsm = info.n_fr_inputs, info.n_sm_inputs
+    fr = np.zeros((n, nfr, 32), dtype=np.uint8)
+    sm = np.zeros((n, max(nsm, 1)), dtype=np.int32)
+    forced = np.zeros(n, dtype=np.uint32)
+    fr_names = POB_FR_INPUTS if name == "ProofOfBurn" else SPEND_FR_INPUTS
+    sm_names = POB_SM_INPUTS if name == "ProofOfBurn" else []
+    shapes = {}
+    if name == "ProofOfBurn":
+        shapes = {"layers": params[0] * params[1] * 136, "layerLens": params[0], "blockHeader": params[2] * 136}
+    want = set(fr_names) | set(sm_names)
+    for w, d in enumerate(inputs):
+        keys = set(d.keys())
+        if keys != want:
+            raise KeyError(f"input {w}: missing {sorted(want - keys)} unexpected {sorted(keys - want)}")
+        for k, key in enumerate(fr_names):
+            fr[w, k] = np.frombuffer(_scalar(d[key]).to_bytes(32, "little"), dtype=np.uint8)
+        col = 0
+        for name in sm_names:
+            cnt = shapes.get(name, 1)
+            a = None
+            if name in shapes:
+                try:                       # fast path: a (nested) list of plain non-negative ints
+                    a = np.asarray(d[name])
+                    # only integer / bool data takes the shortcut: floats (1.7 would be truncated to 1) and strings (numpy's own
+                    # parsing rules) go through to_field element by element, which refuses / parses them like the loader does
+                    a = a.astype(np.int64).reshape(-1) if a.dtype.kind in "iub" else None
+                    if a is not None and a.size and int(a.min()) < 0:
+                        a = None
+                except (ValueError, TypeError, OverflowError):
+                    a = None
+            if a is None:
+                vals = []
+                if name in shapes:
+                    _flat(d[name], vals)
+                else:
+                    vals = [_scalar(d[name])]
+                a = np.array([v if v < (1 << 31) else -1 for v in vals], dtype=np.int64)
+            if a.size != cnt:
+                raise ValueError(f"input {w}: {name} has {a.size} elements, circuit expects {cnt}")
+            big = (a < 0) | (a >= (1 << 31))
+            if big.any():      # not representable as a small input: every such input is range-checked in-circuit
+                forced[w] = FAIL_INPUT_RANGE
+                a = np.where(big, 0x7FFFFFFF, a)
+            sm[w, col:col + cnt] = a.astype(np.int32)
+            col += cnt
+        assert col == nsm
+    return fr, sm, forced
+
+
+def pack_json(main, texts: Sequence[bytes | str], threads: int = 0, out: "PinnedInputs | None" = None, info: PobInfo | None = None):
+    """input.json TEXTS -> (fr, sm, forced) through the native loader (pob_pack_json_batch: hand-written parser, `threads` host
+    threads, 0 = all cores) -- same acceptance and the same bits as pack_inputs on the parsed dicts; out = pinned arrays to fill in place.
+    Needs no GPU."""
+    name, params = _main_of(main)
+    info = info or plan_info_of(name, params)
+    n = len(texts)
+    nfr, nsm = info.n_fr_inputs, info.n_sm_inputs
+    if out is not None:
+        fr, sm, forced = out.fr, out.sm, out.forced
+        assert fr.shape[0] == n
+    else:
+        fr = np.zeros((n, nfr, 32), dtype=np.uint8)
+        sm = np.zeros((n, max(nsm, 1)), dtype=np.int32)
+        forced = np.zeros(n, dtype=np.uint32)
+    raw = [t.encode() if isinstance(t, str) else bytes(t) for t in texts]
+    ptrs = (ctypes.c_char_p * n)(*raw)
+    lens = (ctypes.c_uint64 * n)(*[len(t) for t in raw])
+    circuit = 0 if name == "ProofOfBurn" else 1
+    arr = (ctypes.c_uint64 * (4 * len(params)))()
+    for i, v in enumerate(params):
+        for k in range(4):
+            arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    err = ctypes.create_string_buffer(512)
+    rc = load_library().pob_pack_json_batch(circuit, arr, len(params), ptrs, lens, n, threads, fr.ctypes.data, sm.ctypes.data, forced.ctypes.data, err, 512)
+    if rc != 0:
+        msg = err.value.decode(errors="replace")
+        raise (KeyError if "missing [" in msg else ValueError)(msg)
+    return fr, sm, forced
 
 
 @dataclass
@@ -244,54 +342,12 @@ class WitnessCalculator:
 
     # ------------------------------------------------------------------ input packing (the emitted loadJson)
     def pack(self, inputs: Sequence[dict]):
-        """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n]).
-        The byte arrays (layers, blockHeader: 99 % of an input) go through numpy in one conversion per key; only values that numpy
-        cannot hold as int64 (strings, huge ints -- the loader's mod-p path) fall back to per-element parsing."""
-        n = len(inputs)
-        nfr, nsm = self.info.n_fr_inputs, self.info.n_sm_inputs
-        fr = np.zeros((n, nfr, 32), dtype=np.uint8)
-        sm = np.zeros((n, max(nsm, 1)), dtype=np.int32)
-        forced = np.zeros(n, dtype=np.uint32)
-        fr_names = POB_FR_INPUTS if self.name == "ProofOfBurn" else SPEND_FR_INPUTS
-        sm_names = POB_SM_INPUTS if self.name == "ProofOfBurn" else []
-        shapes = {}
-        if self.name == "ProofOfBurn":
-            shapes = {"layers": self.L * self.NB * 136, "layerLens": self.L, "blockHeader": self.HB * 136}
-        want = set(fr_names) | set(sm_names)
-        for w, d in enumerate(inputs):
-            keys = set(d.keys())
-            if keys != want:
-                raise KeyError(f"input {w}: missing {sorted(want - keys)} unexpected {sorted(keys - want)}")
-            for k, name in enumerate(fr_names):
-                fr[w, k] = np.frombuffer(_scalar(d[name]).to_bytes(32, "little"), dtype=np.uint8)
-            col = 0
-            for name in sm_names:
-                cnt = shapes.get(name, 1)
-                a = None
-                if name in shapes:
-                    try:                       # fast path: a (nested) list of plain non-negative ints
-                        a = np.asarray(d[name], dtype=np.int64).reshape(-1)
-                        if a.size and int(a.min()) < 0:
-                            a = None
-                    except (ValueError, TypeError, OverflowError):
-                        a = None
-                if a is None:
-                    vals = []
-                    if name in shapes:
-                        _flat(d[name], vals)
-                    else:
-                        vals = [_scalar(d[name])]
-                    a = np.array([v if v < (1 << 31) else -1 for v in vals], dtype=np.int64)
-                if a.size != cnt:
-                    raise ValueError(f"input {w}: {name} has {a.size} elements, circuit expects {cnt}")
-                big = (a < 0) | (a >= (1 << 31))
-                if big.any():      # not representable as a small input: every such input is range-checked in-circuit
-                    forced[w] = FAIL_INPUT_RANGE
-                    a = np.where(big, 0x7FFFFFFF, a)
-                sm[w, col:col + cnt] = a.astype(np.int32)
-                col += cnt
-            assert col == nsm
-        return fr, sm, forced
+        """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n]) (module-level pack_inputs)"""
+        return pack_inputs((self.name, self.params), inputs, self.info)
+
+    def pack_json(self, texts: Sequence[bytes | str], threads: int = 0, out: "PinnedInputs | None" = None):
+        """input.json TEXTS -> (fr, sm, forced) through the native loader (module-level pack_json)"""
+        return pack_json((self.name, self.params), texts, threads, out, self.info)
 
     # ------------------------------------------------------------------ the calculator
     def upload(self, inputs: Sequence[dict]):
@@ -430,6 +486,13 @@ class WitnessCalculator:
         ms = ctypes.c_float()
         self._ck(self.lib.pob_time_kernel(self.h, which, iters, ctypes.c_void_p(stream) if stream else None, ctypes.byref(ms)))
         return float(ms.value)
+
+    def probe_check_kernel(self, enable: bool = True, read: bool = False) -> float | None:
+        """HIP events around the Keccak round evaluation kernel of every following constraint_check (pob_probe_check_kernel); read=True
+        returns the duration (ms) of the last one, whose batch must be complete"""
+        ms = ctypes.c_float()
+        self._ck(self.lib.pob_probe_check_kernel(self.h, 1 if enable else 0, ctypes.byref(ms) if read else None))
+        return float(ms.value) if read else None
 
     # ------------------------------------------------------------------ test hooks of the constraint evaluator
     CLASS_BIT, CLASS_SM, CLASS_FR, CLASS_SB = 0, 1, 2, 3

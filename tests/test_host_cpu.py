@@ -94,3 +94,88 @@ def test_plan_rejects_unsupported_and_oversized_instantiations():
             plan_info(bad)
     # the balance bounds are field elements: values >= p are reduced, not truncated
     assert int(plan_info(f"ProofOfBurn(4, 4, 5, 20, 31, 2, {W.P + 10 ** 18}, 10 ** 19)").n_witness) == 64_355_038
+
+
+def _loader_cases():
+    """inputs of the fixture instantiation that exercise the loader's acceptance (reference tests/testcases/divide.py:4 one-element arrays,
+    convert.py:36 p - 1 as a string, rlp/integer.py:51-53 and assertion.py:87 out-of-range values, tests/main.py:160-178 the producer's mix of
+    strings and numbers)"""
+    import copy
+    with open(os.path.join(ROOT, "tests", "golden", "test_pob_input.json")) as f:
+        base = json.load(f)
+    out = [("as produced by tests/main.py", base)]
+
+    def mut(label, fn):
+        d = copy.deepcopy(base)
+        fn(d)
+        out.append((label, d))
+    mut("scalars as one-element arrays", lambda d: d.update(numLayers=[d["numLayers"]], burnKey=[[d["burnKey"]]], blockHeaderLen=[d["blockHeaderLen"]]))
+    mut("hex and signed strings", lambda d: d.update(revealAmount=hex(int(d["revealAmount"])), numLayers="+%d" % d["numLayers"], byteSecurityRelax=" 0 "))
+    mut("p - 1 and > p", lambda d: d.update(burnExtraCommitment=str(W.P - 1), _proofExtraCommitment=str(W.P + 7), burnKey=2 ** 255 + 12345))
+    mut("negative scalar", lambda d: d.update(_proofExtraCommitment=-5, intendedBalance="-3"))
+    mut("booleans", lambda d: d.update(byteSecurityRelax=False, _proofExtraCommitment=True))
+    mut("byte = 256 / 10000 / 2^31 / 2^40 / negative / string", lambda d: (d["layers"][0].__setitem__(3, 256), d["layers"][1].__setitem__(0, 10000), d["layers"][2].__setitem__(9, 2 ** 31),
+                                                                           d["layers"][3].__setitem__(5, 2 ** 40), d["blockHeader"].__setitem__(7, -1), d["blockHeader"].__setitem__(8, "17")))
+    mut("small input >= 2^31", lambda d: d.update(numLayers=2 ** 31))
+    mut("small input = p - 1", lambda d: d.update(numLeafAddressNibbles=str(W.P - 1)))
+    mut("layerLens as strings", lambda d: d.update(layerLens=[str(x) for x in d["layerLens"]]))
+    mut("flat layers", lambda d: d.update(layers=[x for row in d["layers"] for x in row]))
+    return out
+
+
+def test_native_json_loader_equals_the_python_loader():
+    """pob_pack_json_batch (hand-written parser on host threads) against WitnessCalculator.pack on the parsed dicts: same rows, same
+    forced-failure words, same refusals -- for the fixture's input.json, the loader's edge cases, Spend and a synthetic production batch"""
+    from proof_of_burn_amd import inputs as gen
+    fix = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
+    cases = _loader_cases()
+    texts = [json.dumps(d) for _, d in cases]
+    py = W.pack_inputs(fix, [d for _, d in cases])
+    for threads in (1, 3):
+        nat = W.pack_json(fix, texts, threads=threads)
+        for x, y, what in zip(py, nat, ("fr", "sm", "forced")):
+            bad = [cases[i][0] for i in range(len(cases)) if not np.array_equal(x[i], y[i])]
+            assert not bad, (what, bad)
+    assert py[2][0] == 0 and py[2][6] == W.FAIL_INPUT_RANGE and py[2][7] == W.FAIL_INPUT_RANGE     # out-of-range values fail up front, they do not wrap
+    # the file on disk, byte for byte (whitespace and key order as written by the reference's producer)
+    with open(os.path.join(ROOT, "tests", "golden", "test_pob_input.json"), "rb") as f:
+        raw = f.read()
+    assert all(np.array_equal(x[0], y[0]) for x, y in zip(py, W.pack_json(fix, [raw])))
+    # refusals: both loaders reject, neither truncates
+    base = cases[0][1]
+    for label, fn, exc in (("fraction", lambda d: d["layers"][0].__setitem__(0, 1.7), (TypeError, ValueError)),
+                           ("exponent scalar", lambda d: d.update(numLayers=2e0), (TypeError, ValueError)),
+                           ("null", lambda d: d.update(numLayers=None), (TypeError, ValueError)),
+                           ("garbage string", lambda d: d.update(burnKey="12x"), ValueError),
+                           ("missing key", lambda d: d.pop("numLayers"), KeyError),
+                           ("extra key", lambda d: d.update(bogus=1), KeyError),
+                           ("short array", lambda d: d["layerLens"].pop(), ValueError),
+                           ("two-element scalar", lambda d: d.update(numLayers=[1, 2]), (TypeError, ValueError))):
+        import copy
+        d = copy.deepcopy(base)
+        fn(d)
+        with pytest.raises(exc):
+            W.pack_inputs(fix, [d])
+        with pytest.raises((KeyError, ValueError)):
+            W.pack_json(fix, [json.dumps(d)])
+    # Spend (no small inputs) and the production shape
+    with open(os.path.join(ROOT, "tests", "golden", "test_spend_input.json")) as f:
+        sp = json.load(f)
+    assert all(np.array_equal(x, y) for x, y in zip(W.pack_inputs("Spend(31)", [sp, sp]), W.pack_json("Spend(31)", [json.dumps(sp)] * 2)))
+    main = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
+    batch = gen.synthetic_batch(6, depth=10, seed=0xB0B, distinct_keys=2)
+    assert all(np.array_equal(x, y) for x, y in zip(W.pack_inputs(main, batch.inputs), W.pack_json(main, [json.dumps(d) for d in batch.inputs])))
+
+
+def test_stored_keep_maps():
+    """the compressed O1-style keep maps under circuit_model/data/ (what the device-side reduced emission of the bench and the GPU tests
+    reads): the stored Spend(31) map equals the one derived from the model now; the production map has the recorded size"""
+    from proof_of_burn_amd.circuit_model import circuit, keepmap
+    from proof_of_burn_amd.circuit_model.o1 import reduce_map
+    keep, nw = keepmap.load("Spend(31)")
+    c = circuit("Spend(31)")
+    assert nw == c.n_wires and np.array_equal(keep, reduce_map(c).keep.astype(np.uint32))
+    keep, nw = keepmap.load("ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)")
+    assert nw == 215_907_954 and keep.size == 21_454_032 and keep[0] == 0 and (np.diff(keep.astype(np.int64)) > 0).all()
+    keep, nw = keepmap.load("ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)")
+    assert nw == 64_355_038 and keep[0] == 0 and keep.size < nw // 8
