@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU per step (weak scaling)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: ONE global batch of this many witnesses per step, split over the ranks (BASELINE config 4: 8192)")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("POB_BENCH_PIPELINE", "1")),
+    ap.add_argument("--pipeline", type=int, default=1,
                     help="1: two calculators work on consecutive batches (pob_set_partner): batch k+1's latency-bound generation stages run beside batch k's evaluation")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurements")
     ap.add_argument("--no-single", action="store_true", help="skip the single-calculator steps after the timed region")
+    ap.add_argument("--probe-in-timed-region", action="store_true", help="record the HIP events around the dominant kernel inside the timed steps (default: in extra steps after them)")
+    ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
+    ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
     ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records of the LAST batch (uint8 [N*B, 44]) to this .npy")
     args = ap.parse_args()
 
@@ -110,7 +113,7 @@ def main():
     else:
         B, first0, GB = args.batch, rank * args.batch, world * args.batch
     PIPE = bool(args.pipeline)
-    NB = max(1, args.distinct_batches)
+    NB = 1 if args.dbg_no_upload else max(1, args.distinct_batches)
 
     # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
     t0 = time.time()
@@ -123,6 +126,7 @@ def main():
     # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch); the Python packer beside it
     texts = [[json.dumps(inp).encode() for inp in bt.inputs] for bt in batches]
     pinned = [PinnedInputs(calcs[0], B) for _ in range(NB)]
+    calcs[0].pack_json(texts[0], out=pinned[0])            # (first call: thread start-up, first touch of the texts)
     t0 = time.time()
     for b in range(NB):
         calcs[0].pack_json(texts[b], out=pinned[b])
@@ -140,9 +144,13 @@ def main():
     gathered_ev = [None] * NC
     gather_bad = torch.zeros(1, dtype=torch.int64, device=f"cuda:{dev_index}")      # witnesses of OTHER ranks with a non-clean record, accumulated on the device
     state = {"last_gather": None, "validated": 0, "kchk_ms": [], "h2d_bytes": 0}
+    uploaded = [False] * NC
 
     def validate(c, b):
         """every record of the batch calculator c has just finished: host-visible, checked before the clock stops"""
+        if args.dbg_no_fetch:
+            state["validated"] += B
+            return
         rec = calcs[c].wait_records()
         assert rec.shape[0] == B
         assert not rec["status"].any(), ("a witness failed", np.nonzero(rec["status"])[0][:4], rec["status"][np.nonzero(rec["status"])[0][:4]])
@@ -155,7 +163,8 @@ def main():
     def finish(c):
         """evaluation of calculator c's batch, its records (now with the verdict) to the host and to the other ranks"""
         calcs[c].constraint_check(streams[c].cuda_stream)
-        calcs[c].fetch_records()
+        if not args.dbg_no_fetch:
+            calcs[c].fetch_records()
         if world > 1:
             gs.wait_stream(streams[c])
             with torch.cuda.stream(gs):
@@ -168,8 +177,10 @@ def main():
 
     def start(c, b):
         pin = pinned[b]
-        calcs[c].upload_packed_async(pin.fr, pin.sm, pin.forced)          # H2D from pinned memory on the calculator's upload stream
-        state["h2d_bytes"] += pin.fr.nbytes + pin.sm.nbytes
+        if not (args.dbg_no_upload and uploaded[c]):
+            calcs[c].upload_packed_async(pin.fr, pin.sm, pin.forced)      # H2D from pinned memory on the device's upload stream
+            state["h2d_bytes"] += pin.fr.nbytes + pin.sm.nbytes
+            uploaded[c] = True
         if gathered_ev[c] is not None:
             streams[c].wait_event(gathered_ev[c])                         # the gather of THIS calculator's previous batch has read its records
         calcs[c].generate(streams[c].cuda_stream)
@@ -208,18 +219,30 @@ def main():
     if args.warmup:
         run(args.warmup)
     fence()
-    probing = True
-    for c in calcs:
-        c.probe_check_kernel(True)                        # HIP events around the dominant kernel of every evaluation from here on
+    if args.probe_in_timed_region:
+        probing = True
+        for c in calcs:
+            c.probe_check_kernel(True)                    # HIP events around the dominant kernel of every evaluation from here on
     state.update(validated=0, h2d_bytes=0)
     t0 = time.perf_counter()
     run(args.steps, k0=args.warmup)
     fence()
     dt = time.perf_counter() - t0
+    assert state["validated"] == args.steps * B, "not every batch was validated inside the timed region"
+    h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
+    probe_steps = 0
+    if not args.probe_in_timed_region and not args.dbg_no_fetch:
+        # the dominant kernel as it runs IN the service loop: the same loop for a few more batches with HIP events around each of its launches
+        # (outside the timed region: timing events make the runtime time-stamp every dispatch of the queue)
+        probing = True
+        for c in calcs:
+            c.probe_check_kernel(True)
+        probe_steps = 16
+        run(probe_steps, k0=args.warmup + args.steps)
+        fence()
     probing = False
     for c in calcs:
         c.probe_check_kernel(False)
-    assert state["validated"] == args.steps * B, "not every batch was validated inside the timed region"
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -228,13 +251,12 @@ def main():
         rec_all = state["last_gather"].cpu()
         assert int(rec_all.shape[0]) == GB
         mine = rec_all[first0:first0 + B].numpy() if strong else rec_all[rank * B:(rank + 1) * B].numpy()
-        assert np.array_equal(mine[:, 12:], expect[(args.warmup + args.steps - 1) % NB]), "gathered records differ from this rank's commitments"
+        assert np.array_equal(mine[:, 12:], expect[(args.warmup + args.steps + probe_steps - 1) % NB]), "gathered records differ from this rank's commitments"
         if rank == 0 and args.dump_results:
             np.save(args.dump_results, rec_all.numpy())
     elif rank == 0 and args.dump_results:
-        np.save(args.dump_results, recs[(args.warmup + args.steps - 1) % NC].cpu().numpy())
+        np.save(args.dump_results, recs[(args.warmup + args.steps + probe_steps - 1) % NC].cpu().numpy())
     kchk_in_step = float(np.mean(state["kchk_ms"])) if state["kchk_ms"] else None
-    h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
 
     # ---- the same service loop without the pipeline (one calculator), 10 batches: reported beside `value`, same run, same box
     single = None
@@ -291,7 +313,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
                 "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
-                "measured": "in the timed loop: HIP events on the kernel's stream around each of its launches, mean over the timed steps (pob_probe_check_kernel)" if in_step else "alone",
+                "measured": (("in the timed loop" if args.probe_in_timed_region else f"in {probe_steps} more batches of the same pipelined service loop right after the timed region")
+                             + ": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel)") if in_step else "alone",
                 "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
                 "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
                 "traffic": traffic,

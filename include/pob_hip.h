@@ -53,11 +53,12 @@ const char* pob_strerror(pob_handle h);
  *     ProofOfBurn: numLeafAddressNibbles, layers[L][136*NB], layerLens[L], numLayers, blockHeader[136*HB],
  *                  blockHeaderLen, byteSecurityRelax      (values >= 2^31 must be rejected by the caller:
  *                  every one of them is range-constrained to <= 16 bits in-circuit)
- * Host pointers; the copy to HBM is synchronous.                                                                */
+ * Host pointers; the copy to HBM is synchronous.  The inputs are double-buffered on the device (generation AND evaluation read them): the
+ * batch becomes the current one with the next pob_generate, so it may be uploaded while the previous batch is still being worked on. */
 int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n);
-/* The same for a service loop: the copies are enqueued on `stream` (NULL = the handle's upload stream) behind this handle's previous
- * generation (which reads the input buffers) and the following pob_generate waits for them, so batch k+2 is uploaded while batches
- * k and k+1 are in flight.  The host buffers must be pinned (pob_host_alloc) for the copy to be asynchronous and must stay
+/* The same for a service loop: the copies are enqueued on `stream` (NULL = the handle's upload stream) into the input buffer the current
+ * batch does not use and the following pob_generate waits for them, so batch k+2 is uploaded while batches k and k+1 are in flight.
+ * The host buffers must be pinned (pob_host_alloc) for the copy to be asynchronous and must stay
  * untouched until that pob_generate has been enqueued and its stream has passed the copy (e.g. until the batch's results are in). */
 int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n, void* stream);
 /* The emitted loader itself, natively (reference: loadJson of the emitted calculator; tests/test.py:57-59 and tests/main.py:160-178 write
@@ -105,11 +106,11 @@ int pob_results_device(pob_handle h, void** d_status, void** d_outputs);
 #define POB_RECORD_BYTES 44
 #define POB_NOT_EVALUATED 0xFFFFFFFEu
 int pob_results_records_device(pob_handle h, void** d_records);
-/* Per-batch, host-visible verdicts without stalling the device: pob_results_fetch enqueues the D2H copy of the batch's records into
- * pinned memory owned by the handle, behind the handle's last pob_constraint_check (or pob_generate, if no evaluation was enqueued
- * since); pob_results_wait blocks on THAT copy only (an event of this handle -- a partner handle's work is not waited for) and hands
- * out the records (n x POB_RECORD_BYTES).  Two buffers alternate: the pointer stays valid until the fetch after the next one.
- * The handle's next pob_generate is ordered behind the copy, so the records cannot be overwritten under it.                     */
+/* Per-batch, host-visible verdicts without stalling the device: the kernel that packs the records also writes them straight into pinned
+ * host memory owned by the handle (two buffers alternating per batch: no copy, no copy stream).  pob_results_fetch marks the CURRENT
+ * batch's buffer as the one to read; pob_results_wait blocks until that buffer is written -- an event of this handle, recorded behind its
+ * last pob_constraint_check (or pob_generate, if no evaluation was enqueued since): a partner handle's work is not waited for -- and hands
+ * out the records (n x POB_RECORD_BYTES).  The pointer stays valid until the handle's pob_generate after the next one.            */
 int pob_results_fetch(pob_handle h);
 int pob_results_wait(pob_handle h, const uint8_t** records, uint32_t* n);
 

@@ -1166,8 +1166,7 @@ struct Plan {
                 const uint32_t kk = LB - 31 + 1;
                 record(U_SC_MI, TP + 1, start, i);
                 for (uint32_t lo = 0; lo < kk; lo += SC_RANGE_POS) record(U_SC_RANGE, 6, sc.c_loop, i, lo, std::min<uint32_t>(lo + SC_RANGE_POS, kk));
-                // (POB_SC_SUMS_SPLIT=0: one unit per layer, for A/B runs)
-                const uint32_t sums_step = (getenv("POB_SC_SUMS_SPLIT") && atoi(getenv("POB_SC_SUMS_SPLIT")) == 0) ? kk : 64;
+                const uint32_t sums_step = 64;            // (one unit per layer: 0.12 ms alone but 1-2 ms beside the other batch's evaluation, round 2)
                 for (uint32_t lo = 0; lo < kk; lo += sums_step) record(U_SC_SUMS, 7, sc.c_tail, i, lo, std::min<uint32_t>(lo + sums_step, kk));
             }
         }

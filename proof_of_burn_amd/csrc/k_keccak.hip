@@ -7,20 +7,8 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
 }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
     // (non-temporal loads in the evaluation: 4.35 -> 4.09 ms per launch at batch 1024, 0.785 -> 0.836 of the HBM peak)
-    // experiment switches (A/B on one box): POB_KR_PERSIST_CHECK / POB_KR_PERSIST_GEN = waves per SIMD of the persistent form, 0 = one wavefront per item
-    static const int pc = getenv("POB_KR_PERSIST_CHECK") ? atoi(getenv("POB_KR_PERSIST_CHECK")) : 0;
-    static const int pg = getenv("POB_KR_PERSIST_GEN") ? atoi(getenv("POB_KR_PERSIST_GEN")) : 0;
-    const uint32_t gx = nperms * 24, total = gx * ngroups;
-    const int wps = check ? pc : pg;
-    if (wps > 0 && K.work_counter) {
-        const uint32_t nw = total < 1024u * (uint32_t)wps ? total : 1024u * (uint32_t)wps;
-        hipMemsetAsync(K.work_counter, 0, 4, st);
-        if (check) hipLaunchKernelGGL((k_rounds_persist<true, true>), dim3(nw), dim3(64), 0, st, K, gx, total, K.work_counter);
-        else hipLaunchKernelGGL((k_rounds_persist<false>), dim3(nw), dim3(64), 0, st, K, gx, total, K.work_counter);
-        return;
-    }
-    if (check) hipLaunchKernelGGL((k_rounds<true, true>), dim3(gx, ngroups), dim3(64), 0, st, K);
-    else hipLaunchKernelGGL(k_rounds<false>, dim3(gx, ngroups), dim3(64), 0, st, K);
+    if (check) hipLaunchKernelGGL((k_rounds<true, true>), dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
+    else hipLaunchKernelGGL(k_rounds<false>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
 }
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
     uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;

@@ -308,20 +308,9 @@ template <bool CHECK, bool NT> __device__ __forceinline__ void rounds_item(const
 template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
     rounds_item<CHECK, NT>(A, blockIdx.x, blockIdx.y, threadIdx.x);
 }
-// Persistent form: a FIXED number of wavefronts (waves per SIMD x 1 024 SIMDs) pull items from a counter.  A streaming kernel
-// launched as 32 000 short-lived wavefronts loses its register slots to whatever else is queued each time one of them retires --
-// the latency-bound G kernels that run beside it take the slot and hold it for a long time -- and its bandwidth goes with its
-// occupancy.  Resident wavefronts keep their slots for the whole pass; the kernels beside it get the registers it leaves free.
-template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds_persist(KArgs A, uint32_t gx, uint32_t total, uint32_t* counter) {
-    const uint32_t lane = threadIdx.x;
-    for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1u);
-        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(item, 0, 64));       // lane 0's item, wave-uniform
-        if (item >= total) break;
-        rounds_item<CHECK, NT>(A, item % gx, item / gx, lane);
-    }
-}
+// (A persistent form -- a fixed number of resident wavefronts, 1-4 per SIMD, pulling items from a counter so that the streaming kernel keeps
+//  its register slots while latency-bound kernels run beside it -- was measured in round 3: the evaluation alone 4.09 -> 4.73 ms, in the
+//  pipelined step 7.0 ms either way, the step 14.8 -> 15.2 ms; removed.  profiles/round3_experiments.txt)
 
 // .wtns expansion of a contiguous run of BIT wires for witness `sel` of one group: 8 B in, 32 B out per wire.
 __global__ void __launch_bounds__(256) k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel) {

@@ -30,7 +30,6 @@ struct KArgs {
     const uint32_t* perm_block;
     uint32_t* bad_wire;        // per witness: lowest inconsistent wire (CheckIO)
     uint32_t first, count;
-    uint32_t* work_counter;    // item counter of the persistent round kernels (one word per stream that may run them at a time)
 };
 
 // grid = (nunits, ngroups) wavefronts.  Generation: one kernel per scheduling class (light | SubstringCheck BN254 | the other BN254

@@ -275,7 +275,7 @@ int pob_pack_json_batch(int circuit, const uint64_t* params, int nparams, const 
     if (sh.nsm && !sm) return POB_E_ARG;
     uint32_t nt = threads > 0 ? (uint32_t)threads : std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
-    if (threads <= 0 && nt > (n + 7) / 8) nt = (n + 7) / 8;   // default: at least 8 texts per thread (a thread costs about as much as parsing one text)
+    if (threads <= 0 && nt > (n + 31) / 32) nt = (n + 31) / 32;   // default: at least 32 texts (~4 ms of parsing) per thread -- starting a thread costs about as much as parsing one text
     if (nt > n) nt = n;
     std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu);
     std::vector<std::string> errs(nt);

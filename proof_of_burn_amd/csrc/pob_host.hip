@@ -23,25 +23,34 @@ __global__ void k_init_invlut(uint32_t* lut) {   // canonical inverses of -4096.
     for (int j = 0; j < 8; j++) lut[t * 8 + j] = c.l[j];
 }
 // status/outputs of the batch: commitment FR (Montgomery) -> canonical LE; 0xFFFFFFFF -> 0 (ok)
-// and the same as ONE record per witness {u32 status, u32 check_status, u32 bad_wire, u8 commitment[32]} (44 B): what the host reads
-// per batch and the payload of the multi-GPU result gather.  chk / bad = the evaluator's words (null: not evaluated yet)
-__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, const uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t* records,
-                          const uint32_t* chk, const uint32_t* bad, uint32_t n) {
+// and the same as ONE record per witness {u32 status, u32 check_status, u32 bad_wire, u8 commitment[32]} (44 B), written twice: into device
+// memory (the payload of the multi-GPU result gather) and straight into pinned host memory (what the host reads per batch: no copy, no
+// copy stream).  Runs at the end of the generation (chk == null: verdict = POB_NOT_EVALUATED) and again at the end of the evaluation.
+// The per-witness words the units reduce into with atomicMin (status_raw; chk / bad) are reset here, after they have been read, so that
+// neither pass starts with a memset in front of its first kernel.
+__global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_idx, uint32_t* status_raw, uint32_t* status, uint8_t* outputs, uint32_t* records,
+                          uint32_t* host_records, uint32_t* chk, uint32_t* bad, uint32_t n) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
     const uint32_t g = w / 64, lane = w % 64;
     Fr m;
     for (int k = 0; k < 8; k++) m.l[k] = fr[(uint64_t)g * fr_stride + (uint64_t)out_idx * 512 + k * 64 + lane];
     Fr c = fr_from_mont(m);
-    for (int k = 0; k < 8; k++) ((uint32_t*)(outputs + (uint64_t)w * 32))[k] = c.l[k];
-    uint32_t s = status_raw[w];
-    s = s == 0xFFFFFFFFu ? 0 : s;
-    status[w] = s;
+    uint32_t s, cs = POB_NOT_EVALUATED, bw = POB_NOT_EVALUATED;
+    if (!chk) {                                           // end of the generation
+        s = status_raw[w]; status_raw[w] = 0xFFFFFFFFu;
+        s = s == 0xFFFFFFFFu ? 0 : s;
+        status[w] = s;
+        for (int k = 0; k < 8; k++) ((uint32_t*)(outputs + (uint64_t)w * 32))[k] = c.l[k];
+    } else {                                              // end of the evaluation
+        s = status[w];
+        cs = chk[w]; bw = bad[w];
+        chk[w] = 0xFFFFFFFFu; bad[w] = 0xFFFFFFFFu;
+    }
     uint32_t* rec = records + (uint64_t)w * (POB_RECORD_BYTES / 4);
-    rec[0] = s;
-    rec[1] = chk ? chk[w] : POB_NOT_EVALUATED;
-    rec[2] = bad ? bad[w] : POB_NOT_EVALUATED;
-    for (int k = 0; k < 8; k++) rec[3 + k] = c.l[k];
+    uint32_t* hrec = host_records + (uint64_t)w * (POB_RECORD_BYTES / 4);
+    rec[0] = hrec[0] = s; rec[1] = hrec[1] = cs; rec[2] = hrec[2] = bw;
+    for (int k = 0; k < 8; k++) rec[3 + k] = hrec[3 + k] = c.l[k];
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
@@ -110,9 +119,11 @@ struct pob_ctx {
     UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
-    uint8_t* d_in_fr = nullptr; int32_t* d_in_sm = nullptr;
+    // packed inputs, double-buffered: a batch is uploaded into the buffer the current batch does NOT use (generation AND evaluation read the
+    // inputs), pob_generate switches; ev_in_done[b] = the last generation / evaluation that read buffer b
+    uint8_t* d_in_fr[2] = {nullptr, nullptr}; int32_t* d_in_sm[2] = {nullptr, nullptr}; int in_cur = 0, in_next = 0; uint32_t n_next = 0;
+    hipEvent_t ev_in_done[2] = {nullptr, nullptr}; bool in_done_rec[2] = {false, false};
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
-    uint32_t* d_work = nullptr;                        // item counters of the persistent Keccak round kernels: [0] measurements, [1] evaluation, [2 + i] generation's sponge segment i (segments of different tracks run side by side)
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
     struct Emit {
@@ -151,15 +162,21 @@ struct pob_ctx {
     pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
     hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false, evaluated = false;
     // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
-    hipStream_t s_upload = nullptr, s_fetch = nullptr; hipEvent_t ev_upload = nullptr, ev_fetched[2] = {nullptr, nullptr};
-    hipEvent_t ev_kchk[2] = {nullptr, nullptr};         // timing events around the Keccak round evaluation of the last pob_constraint_check (pob_probe_check_kernel)
-    uint8_t* h_records[2] = {nullptr, nullptr}; int fetch_slot = 0; bool upload_pending = false, fetch_pending = false; uint32_t fetch_n = 0;
+    hipStream_t s_upload = nullptr;                         // = the pool's upload stream
+    hipEvent_t ev_upload = nullptr, ev_rec[2] = {nullptr, nullptr};   // ev_rec[s]: the records of buffer s are written
+    bool kchk_rec = false; hipEvent_t ev_kchk[2] = {nullptr, nullptr};         // timing events around the Keccak round evaluation of the last pob_constraint_check (pob_probe_check_kernel)
+    uint8_t* h_records[2] = {nullptr, nullptr}; int rec_slot = 0, fetch_slot = 0; uint32_t rec_n[2] = {0, 0}; bool upload_pending = false, have_next = false, fetch_pending = false;
 };
+
+static hipStream_t own_stream(pob_ctx* h) {
+    if (!h->stream) { hipSetDevice(h->device); if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) h->stream = nullptr; }
+    return h->stream;
+}
 
 // The side streams are shared by every handle of a device (a handle's launches on them are ordered by events anyway): ROCm multiplexes
 // streams onto GPU_MAX_HW_QUEUES hardware queues and two handles with six streams each fall off that cliff (two calculators in
 // flight ran at 1/30 of the speed).  chk1/chk2 are created on first use (pipeline mode only).
-struct StreamPool { int device = 0, refs = 0; hipStream_t stream2 = nullptr, stream_k = nullptr, track1 = nullptr, track2 = nullptr, chk1 = nullptr, chk2 = nullptr; };
+struct StreamPool { int device = 0, refs = 0; hipStream_t stream2 = nullptr, stream_k = nullptr, track1 = nullptr, track2 = nullptr, chk1 = nullptr, chk2 = nullptr, s_in = nullptr; };
 static std::mutex g_pool_mu;
 static std::vector<StreamPool*> g_pools;
 
@@ -168,6 +185,9 @@ static std::vector<StreamPool*> g_pools;
 static int hw_queues_env() { const char* e = getenv("GPU_MAX_HW_QUEUES"); return e ? atoi(e) : 4; }
 // loaded before the HIP runtime initialises (the usual case for a ctypes / cgo caller): ask for enough queues unless the caller decided otherwise
 __attribute__((constructor)) static void pob_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+struct pob_ctx;
+static hipStream_t own_stream(pob_ctx* h);      // the handle's own stream (callers that pass no stream, emission, test hooks): created on first use
 
 #define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return POB_E_HIP; } } while (0)
 
@@ -208,14 +228,13 @@ static GArgs gargs(pob_ctx* h) {
     A.bits = h->d_bits; A.sm = h->d_sm; A.fr = h->d_fr;
     A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
     A.sb = h->d_sb; A.sb_stride = (uint64_t)h->plan.total.q * 64;
-    A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr; A.in_sm = h->d_in_sm;
+    A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr[h->in_cur]; A.in_sm = h->d_in_sm[h->in_cur];
     A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
     A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
     return A;
 }
-static KArgs kargs(pob_ctx* h, bool check = false) {
+static KArgs kargs(pob_ctx* h) {
     KArgs K; memset(&K, 0, sizeof K);
-    K.work_counter = h->d_work ? h->d_work + (check ? 1 : 0) : nullptr;
     K.bits = (u64*)h->d_bits; K.group_stride = h->plan.total.b; K.sponges = h->d_sponges;
     K.perm_sponge = h->d_perm_sponge; K.perm_block = h->d_perm_block; K.bad_wire = h->d_bad;
     return K;
@@ -284,21 +303,6 @@ int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* 
     int rc;
     try { rc = make_plan(*plan, err, circuit, params, nparams); } catch (const std::exception& e) { fprintf(stderr, "%s\n", e.what()); rc = POB_E_STATE; }
     if (rc == POB_OK) { uint32_t np = 0; for (const SpongeDesc& sd : plan->sponges) np += sd.n; fill_info(*plan, np, 0, info); }
-    if (rc == POB_OK && getenv("POB_PLAN_DUMP")) {          // per (stage, unit kind): units, wires written (planner cost model)
-        std::vector<std::vector<uint64_t>> acc;
-        for (const UnitDesc& u : plan->units) {
-            if (acc.size() <= u.stage) acc.resize(u.stage + 1, std::vector<uint64_t>(2 * 64, 0));
-            acc[u.stage][2 * u.kind]++; acc[u.stage][2 * u.kind + 1] += u.cost;
-        }
-        if (const char* wq = getenv("POB_PLAN_FIND")) {      // which units start closest below wire index wq
-            const uint32_t w = (uint32_t)strtoul(wq, nullptr, 10);
-            for (const UnitDesc& u : plan->units) if (u.cur.w <= w && w - u.cur.w < 200000)
-                fprintf(stderr, "unit kind %u stage %u cur.w %u (+%u) b %u s %u a = %u %u %u %u %u %u\n", u.kind, u.stage, u.cur.w, w - u.cur.w, u.cur.b, u.cur.s, u.a[0], u.a[1], u.a[2], u.a[3], u.a[4], u.a[5]);
-        }
-        for (size_t s = 0; s < acc.size(); s++) for (uint32_t k = 0; k < 64; k++) if (acc[s][2 * k])
-            fprintf(stderr, "stage %3zu kind %2u class %u units %5llu cost %9llu max/unit %8llu\n", s, k, unit_class(k), (unsigned long long)acc[s][2 * k],
-                    (unsigned long long)acc[s][2 * k + 1], (unsigned long long)(acc[s][2 * k + 1] / acc[s][2 * k]));
-    }
     delete plan;
     return rc;
 }
@@ -363,7 +367,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     }
 
     HIPC(hipSetDevice(device));
-    HIPC(hipStreamCreate(&h->stream));
     // the side-track streams get dispatch priority: their few workgroups take the next free slots instead of queueing behind the
     // 30k workgroups of a Keccak expansion running on the caller's stream
     int prio_lo = 0, prio_hi = 0;
@@ -374,9 +377,10 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         for (StreamPool* q : g_pools) if (q->device == device) P = q;
         if (!P) {       // (registered only when every stream exists: a half-built pool must not be found by the next pob_open)
             P = new StreamPool(); P->device = device;
-            hipStream_t* want[6] = {&P->stream2, &P->stream_k, &P->track1, &P->track2, &P->chk1, &P->chk2};
+            // (s_in: the input uploads of every handle of the device -- copies, ordered by events like the rest)
+            hipStream_t* want[7] = {&P->stream2, &P->stream_k, &P->track1, &P->track2, &P->chk1, &P->chk2, &P->s_in};
             hipError_t e = hipSuccess;
-            for (int k = 0; k < 6 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi);
+            for (int k = 0; k < 7 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi);
             if (e != hipSuccess) {
                 for (hipStream_t* q : want) if (*q) hipStreamDestroy(*q);
                 delete P;
@@ -423,13 +427,22 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         HIPC(hipMalloc(&h->d_pow256, tab.size() * sizeof(Fr)));
         HIPC(hipMemcpy(h->d_pow256, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice));
     }
-    HIPC(hipMalloc(&h->d_in_fr, npad * (uint64_t)pl.nfr_in * 32));
-    HIPC(hipMalloc(&h->d_in_sm, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
+    for (int k = 0; k < 2; k++) {
+        HIPC(hipMalloc(&h->d_in_fr[k], npad * (uint64_t)pl.nfr_in * 32));
+        HIPC(hipMalloc(&h->d_in_sm[k], std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
+        HIPC(hipMemset(h->d_in_fr[k], 0, npad * (uint64_t)pl.nfr_in * 32));
+        HIPC(hipMemset(h->d_in_sm[k], 0, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
+        HIPC(hipEventCreateWithFlags(&h->ev_in_done[k], hipEventDisableTiming));
+    }
     HIPC(hipMalloc(&h->d_status_raw, npad * 4)); HIPC(hipMalloc(&h->d_status, npad * 4));
     HIPC(hipMalloc(&h->d_chk, npad * 4)); HIPC(hipMalloc(&h->d_bad, npad * 4));
     HIPC(hipMalloc(&h->d_outputs, npad * 32));
     HIPC(hipMalloc(&h->d_records, npad * POB_RECORD_BYTES));
-    HIPC(hipMalloc(&h->d_work, (2 + h->ksegs.size()) * 4)); HIPC(hipMemset(h->d_work, 0, (2 + h->ksegs.size()) * 4));
+    for (int k = 0; k < 2; k++) {                           // the host's copy of the records: pinned, written by the device directly
+        HIPC(hipHostMalloc((void**)&h->h_records[k], npad * POB_RECORD_BYTES, hipHostMallocDefault));
+        HIPC(hipEventCreateWithFlags(&h->ev_rec[k], hipEventDisableTiming));
+    }
+
     HIPC(hipMemcpy(h->d_units, pl.units.data(), pl.units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_order, h->order.data(), h->order.size() * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(h->d_L, &pl.L, sizeof(CircuitLayout), hipMemcpyHostToDevice));
@@ -439,12 +452,10 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         HIPC(hipMemcpy(h->d_perm_block, perm_block.data(), h->nperms * 4, hipMemcpyHostToDevice));
     }
     HIPC(hipMemcpy(h->d_pos, POS_TABLE_MONT, sizeof(POS_TABLE_MONT), hipMemcpyHostToDevice));
-    HIPC(hipMemset(h->d_in_fr, 0, npad * (uint64_t)pl.nfr_in * 32));
-    HIPC(hipMemset(h->d_in_sm, 0, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
     HIPC(hipMemset(h->d_status_raw, 0xFF, npad * 4)); HIPC(hipMemset(h->d_chk, 0xFF, npad * 4)); HIPC(hipMemset(h->d_bad, 0xFF, npad * 4));
-    hipLaunchKernelGGL(k_init_invlut, dim3((8193 + 63) / 64), dim3(64), 0, h->stream, h->d_inv);
+    hipLaunchKernelGGL(k_init_invlut, dim3((8193 + 63) / 64), dim3(64), 0, h->stream2, h->d_inv);
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipStreamSynchronize(h->stream2));
     return POB_OK;
 }
 
@@ -452,25 +463,24 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_in_fr, h->d_in_sm, h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->d_work, h->em.d_win[0], h->em.d_win[1], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
+                    h->d_inv, h->d_pow256, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < 2; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
         for (hipEvent_t e : {h->em.ev_made[k], h->em.ev_copied[k], h->em.ev_free[k]}) if (e) hipEventDestroy(e);
     }
     hipDeviceSynchronize();                             // (the pool's streams may still carry this handle's work)
-    for (int k = 0; k < 2; k++) { if (h->h_records[k]) hipHostFree(h->h_records[k]); if (h->ev_fetched[k]) hipEventDestroy(h->ev_fetched[k]); }
+    for (int k = 0; k < 2; k++) { if (h->h_records[k]) hipHostFree(h->h_records[k]); if (h->ev_rec[k]) hipEventDestroy(h->ev_rec[k]); }
     if (h->ev_upload) hipEventDestroy(h->ev_upload);
+    for (hipEvent_t e : h->ev_in_done) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_kchk) if (e) hipEventDestroy(e);
-    if (h->s_upload) hipStreamDestroy(h->s_upload);
-    if (h->s_fetch) hipStreamDestroy(h->s_fetch);
     if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
     if (h->pool) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         StreamPool* P = h->pool;
         if (--P->refs == 0) {
-            for (hipStream_t q : {P->stream2, P->stream_k, P->track1, P->track2, P->chk1, P->chk2}) if (q) hipStreamDestroy(q);
+            for (hipStream_t q : {P->stream2, P->stream_k, P->track1, P->track2, P->chk1, P->chk2, P->s_in}) if (q) hipStreamDestroy(q);
             g_pools.erase(std::find(g_pools.begin(), g_pools.end(), P));
             delete P;
         }
@@ -495,26 +505,34 @@ int pob_get_info(pob_handle h, pob_info_t* info) {
     return POB_OK;
 }
 
+// both upload forms write the buffer the current batch does not use; the next pob_generate switches to it
 int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n) {
     if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
-    if (h->gen_done_rec) HIPC(hipEventSynchronize(h->ev_gen_done));        // the previous generation reads the input buffers
-    HIPC(hipMemcpy(h->d_in_fr, fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice));
-    if (h->plan.nsm_in) HIPC(hipMemcpy(h->d_in_sm, sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice));
-    h->n = n; h->generated = false; h->upload_pending = false;
+    const int t = h->in_cur ^ 1;
+    if (h->upload_pending) HIPC(hipEventSynchronize(h->ev_upload));         // an asynchronous upload into the same buffer is still in flight
+    if (h->in_done_rec[t]) HIPC(hipEventSynchronize(h->ev_in_done[t]));     // the batch before the current one read this buffer
+    if (!h->ev_upload) { h->s_upload = h->pool->s_in; HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
+    // (on the handle's own non-blocking stream: a hipMemcpy on the legacy stream would wait for every blocking stream of the process)
+    HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, h->s_upload));
+    if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm[t], sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, h->s_upload));
+    HIPC(hipStreamSynchronize(h->s_upload));
+    h->in_next = t; h->n_next = n; h->upload_pending = false; h->have_next = true;
     return POB_OK;
 }
 
 int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n, void* stream_) {
     if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
-    if (!h->s_upload) { HIPC(hipStreamCreateWithFlags(&h->s_upload, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
+    if (!h->ev_upload) { h->s_upload = h->pool->s_in; HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
     hipStream_t su = stream_ ? (hipStream_t)stream_ : h->s_upload;
-    if (h->gen_done_rec) HIPC(hipStreamWaitEvent(su, h->ev_gen_done, 0));  // the previous generation reads the input buffers
-    HIPC(hipMemcpyAsync(h->d_in_fr, fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
-    if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm, sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, su));
+    const int t = h->in_cur ^ 1;
+    if (h->upload_pending) HIPC(hipStreamWaitEvent(su, h->ev_upload, 0));
+    if (h->in_done_rec[t]) HIPC(hipStreamWaitEvent(su, h->ev_in_done[t], 0));   // the batch before the current one read this buffer (long done in a steady loop)
+    HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
+    if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm[t], sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, su));
     HIPC(hipEventRecord(h->ev_upload, su));
-    h->n = n; h->generated = false; h->upload_pending = true;
+    h->in_next = t; h->n_next = n; h->upload_pending = true; h->have_next = true;
     return POB_OK;
 }
 
@@ -529,18 +547,20 @@ static int enqueue_collect(pob_ctx* h, hipStream_t st, bool evaluated) {
     const uint32_t G = (h->n + 63) / 64;
     const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
     hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs,
-                       h->d_records, evaluated ? h->d_chk : nullptr, evaluated ? h->d_bad : nullptr, G * 64);
+                       h->d_records, (uint32_t*)h->h_records[h->rec_slot], evaluated ? h->d_chk : nullptr, evaluated ? h->d_bad : nullptr, G * 64);
     HIPC(hipGetLastError());
+    HIPC(hipEventRecord(h->ev_rec[h->rec_slot], st)); h->rec_n[h->rec_slot] = h->n;
     return POB_OK;
 }
 
 int pob_generate(pob_handle h, void* stream_) {
-    if (!h || h->n == 0) return POB_E_STATE;
+    if (!h || (h->n == 0 && !h->have_next)) return POB_E_STATE;
     HIPC(hipSetDevice(h->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : own_stream(h);
+    if (h->have_next) { h->in_cur = h->in_next; h->n = h->n_next; h->have_next = false; }      // the uploaded batch becomes the current one (else: the same inputs again)
     const uint32_t G = (h->n + 63) / 64;
     if (h->upload_pending) { HIPC(hipStreamWaitEvent(st, h->ev_upload, 0)); h->upload_pending = false; }
-    if (h->fetch_pending) HIPC(hipStreamWaitEvent(st, h->ev_fetched[h->fetch_slot], 0));    // the previous batch's records are being copied out
+    h->rec_slot ^= 1;                                   // this batch's records go to the other pinned buffer: the previous batch's stay readable
     // pipeline: this generation's latency-bound work starts with the partner's evaluation (= once the partner's generation is complete)
     // (starting ALL of them even earlier, beside the partner's expansion, was measured: no gain -- the chip-filling launches take from the
     //  expansion what they gain).  The first stage and the NARROW tracks forked after it (the burn-address / RLP / account chains: a few
@@ -551,7 +571,6 @@ int pob_generate(pob_handle h, void* stream_) {
     const bool gate_late = gate && h->plan.ntracks > 1;
     auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner) ? h->pool->track2 : h->tracks[t].s_main; };
     if (gate && !gate_late) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
-    HIPC(hipMemsetAsync(h->d_status_raw, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
     const Plan& pl = h->plan;
@@ -583,7 +602,6 @@ int pob_generate(pob_handle h, void* stream_) {
             if (forked) { HIPC(hipEventRecord(ej, sh)); HIPC(hipStreamWaitEvent(sm, ej, 0)); }
             for (const pob_ctx::KSeg& ks : h->ksegs) if (ks.stage == sid) {
                 hipStream_t sk = sm;
-                K.work_counter = h->d_work + 2 + (&ks - h->ksegs.data());
                 K.first = ks.sp_first;
                 launch_k_chain(K, false, ks.sp_count, G, sk);
                 K.first = ks.perm_first;
@@ -613,6 +631,7 @@ int pob_generate(pob_handle h, void* stream_) {
     for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
     { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
     HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
+    HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
     h->generated = true; h->evaluated = false;
     return POB_OK;
 }
@@ -620,7 +639,7 @@ int pob_generate(pob_handle h, void* stream_) {
 int pob_constraint_check(pob_handle h, void* stream_) {
     if (!h || !h->generated) return POB_E_STATE;
     HIPC(hipSetDevice(h->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : own_stream(h);
     const uint32_t G = (h->n + 63) / 64;
     GArgs A = gargs(h);
     // The evaluation has no dependencies between launches: one kernel per family (+ the two Keccak kernels), spread over the
@@ -633,8 +652,6 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
     hipStream_t side[2] = {h->partner ? h->pool->chk1 : h->stream2, h->partner ? h->pool->chk2 : h->stream3};
-    HIPC(hipMemsetAsync(h->d_chk, 0xFF, (uint64_t)h->groups * 64 * 4, st));
-    HIPC(hipMemsetAsync(h->d_bad, 0xFF, (uint64_t)h->groups * 64 * 4, st));
     HIPC(hipEventRecord(h->ev_fork, st));
     for (int k = 0; k < 2; k++) {
         HIPC(hipStreamWaitEvent(side[k], h->ev_fork, 0));
@@ -642,9 +659,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
             for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == fam) { A.first = sg.first; launch_g_check(A, fam, sg.count, G, side[k]); }
     }
     if (!h->plan.sponges.empty()) {
-        KArgs K = kargs(h, true);
+        KArgs K = kargs(h);
         K.first = 0;
-        if (h->ev_kchk[0]) HIPC(hipEventRecord(h->ev_kchk[0], st));          // measurement (pob_probe_check_kernel): the dominant kernel inside the step
+        if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
         launch_k_rounds(K, true, h->nperms, G, st);
         if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
         launch_k_chain(K, true, h->nperms, G, st);
@@ -653,6 +670,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
     { int rc = enqueue_collect(h, st, true); if (rc) return rc; }          // the batch's records, now with the evaluator's verdict
     HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true;
+    HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));                 // (the evaluation reads the packed inputs too: the input units' relations)
     HIPC(hipGetLastError());
     return POB_OK;
 }
@@ -679,28 +697,16 @@ int pob_sync(pob_handle h) {
     // this handle's work only: its last generation / evaluation (the side streams are joined into those events) and its copies
     if (h->gen_done_rec) HIPC(hipEventSynchronize(h->ev_gen_done));
     if (h->check_done_rec && h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
-    if (h->fetch_pending) HIPC(hipEventSynchronize(h->ev_fetched[h->fetch_slot]));
-    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;
 }
 
-// D2H of the batch's records into one of two pinned buffers, behind the handle's last evaluation (or generation); only this handle's
-// events are involved: a partner handle that is generating or evaluating meanwhile is neither waited for nor delayed
+// The records are written straight into pinned host memory by the kernel that packs them (k_collect), into one of two buffers that
+// alternate per batch: "fetching" is remembering which buffer / event belongs to the current batch, waiting is an event of THIS handle
+// only -- a partner handle that is generating or evaluating meanwhile is neither waited for nor delayed.
 int pob_results_fetch(pob_handle h) {
     if (!h || !h->generated) return POB_E_STATE;
-    HIPC(hipSetDevice(h->device));
-    if (!h->s_fetch) {
-        HIPC(hipStreamCreateWithFlags(&h->s_fetch, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
-            HIPC(hipEventCreateWithFlags(&h->ev_fetched[k], hipEventDisableTiming));
-            HIPC(hipHostMalloc((void**)&h->h_records[k], (uint64_t)h->groups * 64 * POB_RECORD_BYTES, hipHostMallocDefault));
-        }
-    }
-    const int slot = h->fetch_slot ^ 1;
-    HIPC(hipStreamWaitEvent(h->s_fetch, h->evaluated ? h->ev_check_done : h->ev_gen_done, 0));
-    HIPC(hipMemcpyAsync(h->h_records[slot], h->d_records, (uint64_t)h->n * POB_RECORD_BYTES, hipMemcpyDeviceToHost, h->s_fetch));
-    HIPC(hipEventRecord(h->ev_fetched[slot], h->s_fetch));
-    h->fetch_slot = slot; h->fetch_pending = true; h->fetch_n = h->n;
+    h->fetch_slot = h->rec_slot; h->fetch_pending = true;
     return POB_OK;
 }
 
@@ -708,9 +714,9 @@ int pob_results_wait(pob_handle h, const uint8_t** records, uint32_t* n) {
     if (!h || !records) return POB_E_ARG;
     if (!h->fetch_pending) { h->err = "pob_results_wait without pob_results_fetch"; return POB_E_STATE; }
     HIPC(hipSetDevice(h->device));
-    HIPC(hipEventSynchronize(h->ev_fetched[h->fetch_slot]));
+    HIPC(hipEventSynchronize(h->ev_rec[h->fetch_slot]));
     *records = h->h_records[h->fetch_slot];
-    if (n) *n = h->fetch_n;
+    if (n) *n = h->rec_n[h->fetch_slot];
     return POB_OK;
 }
 
@@ -750,7 +756,7 @@ static int emit_make_window(pob_ctx* h, uint64_t k) {
     pob_ctx::Emit& E = h->em;
     const int slot = (int)(k & 1);
     const uint64_t w0 = k * E.win_wires, wn = std::min(E.win_wires, E.total - w0);      // positions of the payload (kept wires in reduced mode)
-    hipStream_t st = h->stream;
+    hipStream_t st = own_stream(h);
     HIPC(hipStreamWaitEvent(st, E.ev_free[slot], 0));                       // the copy of the window that used this slot before is done
     // any wire nobody owns stays 0xEE.. (not a field element: the byte compare with the oracle catches it); rocclr's fill kernel took
     // 4.5 ms per 256 MiB window, this one runs at the HBM write rate
@@ -806,8 +812,8 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
     if (E.s_copy) HIPC(hipStreamSynchronize(E.s_copy));
     {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
         uint32_t st_w = 0;
-        HIPC(hipMemcpyAsync(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPC(hipStreamSynchronize(h->stream));
+        HIPC(hipMemcpyAsync(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost, own_stream(h)));
+        HIPC(hipStreamSynchronize(own_stream(h)));
         if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; return POB_E_STATE; }
     }
     if (window_wires == 0) window_wires = 8ull << 20;                       // 8 Mi wires = 256 MiB windows
@@ -839,15 +845,15 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         // launches only the units that can write into it (most windows hold nothing but Keccak round wires)
         const size_t nu = h->plan.units.size();
         if (!E.d_probe) HIPC(hipMalloc(&E.d_probe, nu * 8));
-        HIPC(hipMemsetAsync(E.d_probe, 0, nu * 8, h->stream));
+        HIPC(hipMemsetAsync(E.d_probe, 0, nu * 8, own_stream(h)));
         GArgs A = gargs(h);
         A.emit_sel = 0; A.emit_group = idx / 64; A.emit_w0 = 0; A.emit_wn = (uint32_t)window_wires; A.emit_probe = E.d_probe; A.emit_out = nullptr;
         if (E.red) { A.emit_rbits = E.d_rbits; A.emit_rpre = E.d_rpre; }
-        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, h->stream); }
+        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, own_stream(h)); }
         HIPC(hipGetLastError());
         std::vector<unsigned long long> mask(nu);
-        HIPC(hipMemcpyAsync(mask.data(), E.d_probe, nu * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPC(hipStreamSynchronize(h->stream));
+        HIPC(hipMemcpyAsync(mask.data(), E.d_probe, nu * 8, hipMemcpyDeviceToHost, own_stream(h)));
+        HIPC(hipStreamSynchronize(own_stream(h)));
         std::vector<uint32_t> order;
         E.wsegs.assign(nwin_, {});
         for (uint64_t wi = 0; wi < nwin_; wi++)
@@ -895,7 +901,7 @@ int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uin
         uint32_t acc = 0;
         for (uint64_t i = 0; i < nwords; i++) { pre[i] = acc; acc += (uint32_t)__builtin_popcountll(bits[i]); }
         if (E.s_copy) HIPC(hipStreamSynchronize(E.s_copy));
-        HIPC(hipStreamSynchronize(h->stream));
+        HIPC(hipStreamSynchronize(own_stream(h)));
         if (E.d_rbits) { HIPC(hipFree(E.d_rbits)); E.d_rbits = nullptr; }
         if (E.d_rpre) { HIPC(hipFree(E.d_rpre)); E.d_rpre = nullptr; }
         HIPC(hipMalloc(&E.d_rbits, nwords * 8)); HIPC(hipMalloc(&E.d_rpre, nwords * 4));
@@ -1006,23 +1012,23 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms) {
     if (!h) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
     if (ms) {
-        if (!h->ev_kchk[0] || !h->evaluated) { h->err = "no timed evaluation yet"; return POB_E_STATE; }
+        if (!h->ev_kchk[0] || !h->kchk_rec) { h->err = "no timed evaluation yet"; return POB_E_STATE; }
         HIPC(hipEventSynchronize(h->ev_kchk[1]));
         HIPC(hipEventElapsedTime(ms, h->ev_kchk[0], h->ev_kchk[1]));
     }
     if (enable && !h->ev_kchk[0]) { HIPC(hipEventCreate(&h->ev_kchk[0])); HIPC(hipEventCreate(&h->ev_kchk[1])); }
-    if (!enable) for (hipEvent_t& e : h->ev_kchk) if (e) { hipEventDestroy(e); e = nullptr; }
+    if (!enable) { for (hipEvent_t& e : h->ev_kchk) if (e) { hipEventDestroy(e); e = nullptr; } h->kchk_rec = false; }
     return POB_OK;
 }
 
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* avg_ms) {
     if (!h || !h->generated || iters < 1 || !avg_ms) return POB_E_STATE;
     HIPC(hipSetDevice(h->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : own_stream(h);
     const uint32_t G = (h->n + 63) / 64;
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
-    KArgs K = kargs(h, which == 1); K.first = 0;
+    KArgs K = kargs(h); K.first = 0;
     GArgs A = gargs(h);
     uint32_t* d_sel = nullptr; uint32_t nsel = 0, sel_cls = 0, sel_fam = 0;
     if (which >= 100 && which < 300) {   // 100 + kind: evaluation, 200 + kind: generation of all units of one kind, alone on the device
@@ -1061,8 +1067,8 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask) {
     if (!h || group >= h->groups || bit_index >= h->plan.total.b) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, h->stream, h->d_bits + (uint64_t)group * h->plan.total.b + bit_index, mask);
-    HIPC(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, own_stream(h), h->d_bits + (uint64_t)group * h->plan.total.b + bit_index, mask);
+    HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;
 }
 
@@ -1072,18 +1078,18 @@ int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32
     const Cur t = h->plan.total;
     if (cls == POB_CLASS_BIT) {
         if (index >= t.b) return POB_E_ARG;
-        hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, h->stream, h->d_bits + (uint64_t)group * t.b + index, (uint64_t)(xor_mask & 1u) << lane);
+        hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, own_stream(h), h->d_bits + (uint64_t)group * t.b + index, (uint64_t)(xor_mask & 1u) << lane);
     } else if (cls == POB_CLASS_SM) {
         if (index >= t.s) return POB_E_ARG;
-        hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, h->stream, (uint32_t*)h->d_sm + ((uint64_t)group * t.s + index) * 64 + lane, xor_mask);
+        hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, own_stream(h), (uint32_t*)h->d_sm + ((uint64_t)group * t.s + index) * 64 + lane, xor_mask);
     } else if (cls == POB_CLASS_FR) {
         if (index >= t.f || sub >= 8) return POB_E_ARG;
-        hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, h->stream, h->d_fr + ((uint64_t)group * t.f + index) * 512 + sub * 64 + lane, xor_mask);
+        hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, own_stream(h), h->d_fr + ((uint64_t)group * t.f + index) * 512 + sub * 64 + lane, xor_mask);
     } else if (cls == POB_CLASS_SB) {
         if (index >= t.q) return POB_E_ARG;
-        hipLaunchKernelGGL(k_xor_u8, dim3(1), dim3(1), 0, h->stream, (uint8_t*)h->d_sb + ((uint64_t)group * t.q + index) * 64 + lane, (uint8_t)xor_mask);
+        hipLaunchKernelGGL(k_xor_u8, dim3(1), dim3(1), 0, own_stream(h), (uint8_t*)h->d_sb + ((uint64_t)group * t.q + index) * 64 + lane, (uint8_t)xor_mask);
     } else return POB_E_ARG;
-    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;
 }
 

@@ -319,6 +319,8 @@ class WitnessCalculator:
         self.max_batch = max_batch
         self.n = 0
         self._forced = None
+        self._next = None                    # (n, forced) of an uploaded batch that has not been generated yet
+        self._forced_fetched = None
 
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc):
@@ -361,8 +363,7 @@ class WitnessCalculator:
         fr = np.ascontiguousarray(fr, dtype=np.uint8)
         sm = np.ascontiguousarray(sm, dtype=np.int32)
         self._ck(self.lib.pob_upload_inputs(self.h, fr.ctypes.data, sm.ctypes.data, n))
-        self.n = n
-        self._forced = forced if forced is not None else np.zeros(n, dtype=np.uint32)
+        self._next = (n, np.array(forced, dtype=np.uint32) if forced is not None else np.zeros(n, dtype=np.uint32))
 
     def upload_packed_async(self, fr: np.ndarray, sm: np.ndarray, forced: np.ndarray | None = None, stream: int | None = None):
         """service-loop upload (pob_upload_inputs_async): fr / sm must live in pinned memory (PinnedInputs) and stay untouched until the
@@ -372,11 +373,15 @@ class WitnessCalculator:
             raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
         assert fr.dtype == np.uint8 and sm.dtype == np.int32 and fr.flags.c_contiguous and sm.flags.c_contiguous
         self._ck(self.lib.pob_upload_inputs_async(self.h, fr.ctypes.data, sm.ctypes.data, n, ctypes.c_void_p(stream) if stream else None))
-        self.n = n
-        self._forced = forced if forced is not None else np.zeros(n, dtype=np.uint32)
+        self._next = (n, np.array(forced, dtype=np.uint32) if forced is not None else np.zeros(n, dtype=np.uint32))
 
     def generate(self, stream: int | None = None):
+        """enqueue the generation of the uploaded batch (which becomes the current one: the inputs are double-buffered, a batch may be
+        uploaded while the previous one is still being generated / evaluated / read); without a new upload: the same inputs again"""
         self._ck(self.lib.pob_generate(self.h, ctypes.c_void_p(stream) if stream else None))
+        if self._next is not None:
+            self.n, self._forced = self._next
+            self._next = None
 
     def constraint_check(self, stream: int | None = None):
         self._ck(self.lib.pob_constraint_check(self.h, ctypes.c_void_p(stream) if stream else None))
@@ -391,6 +396,7 @@ class WitnessCalculator:
     def fetch_records(self):
         """enqueue the D2H copy of this batch's result records behind its evaluation (pob_results_fetch); does not block"""
         self._ck(self.lib.pob_results_fetch(self.h))
+        self._forced_fetched = self._forced
 
     def wait_records(self) -> np.ndarray:
         """block on THAT copy only and return the records as a structured array (fields status, check_status, bad_wire, commitment[32]);
@@ -398,7 +404,12 @@ class WitnessCalculator:
         p, n = ctypes.c_void_p(), ctypes.c_uint32()
         self._ck(self.lib.pob_results_wait(self.h, ctypes.byref(p), ctypes.byref(n)))
         buf = (ctypes.c_uint8 * (RECORD_DTYPE.itemsize * n.value)).from_address(p.value)
-        return np.frombuffer(buf, dtype=RECORD_DTYPE)
+        rec = np.frombuffer(buf, dtype=RECORD_DTYPE)
+        f = self._forced_fetched
+        if f is not None and f.any():        # inputs the loader could not represent (FAIL_INPUT_RANGE): failed whatever the device computed
+            rec = rec.copy()
+            rec["status"] = np.where(f != 0, f, rec["status"])
+        return rec
 
     def results(self, with_check: bool = False) -> list[Result]:
         n = self.n

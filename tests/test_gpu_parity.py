@@ -229,7 +229,39 @@ def test_main_instantiation_batch(pkg):
     gpu = calc.witness_payload(5)
     ref = ora.witness_numpy()
     assert np.array_equal(gpu, ref), f"first differing wire {_first_diff(gpu, ref)}"
+    # the reduced (O1-style) witness, expanded and cut on the device: 21.5 M of the 215.9 M wires cross PCIe (two windows of kept wires)
+    from proof_of_burn_amd.circuit_model import keepmap
+    keep, nw = keepmap.load(main)
+    assert nw == calc.nwitness
+    red = calc.witness_payload_reduced(5, keep, window_wires=1 << 24)
+    assert np.array_equal(red.reshape(-1, 32), ref.reshape(-1, 32)[keep]), "reduced payload differs from the oracle's kept wires"
+    assert np.array_equal(calc.witness_payload(5), ref)          # and the O0 payload again (the per-window unit lists are per map)
     calc.close()
+
+
+def test_reduced_witness_on_the_device(pkg, tmp_path):
+    """SURVEY 8f-3 on the device (pob_emit_begin_reduced / pob_write_wtns_reduced): Spend(31) and the fixture instantiation, reduced payload ==
+    the oracle's payload at the kept wires, through one window and through many; the .wtns header carries the kept count.
+    (Which representative circom's own --O1 keeps is not pinned -- no circom here; the map is data, circuit_model/o1.py.)"""
+    import struct
+    from proof_of_burn_amd.circuit_model import keepmap
+    for main, suite, case in (("Spend(31)", "test_spend", 0), (POB_FIX, "test_proof_of_burn", 3)):
+        s = _suite(suite)
+        keep, nw = keepmap.load(main)
+        calc = pkg.WitnessCalculator(main, max_batch=4)
+        res = calc.calculate([c["input"] for c in s["cases"]][:4] if main == "Spend(31)" else [s["cases"][case]["input"]] * 2)
+        idx = case if main == "Spend(31)" else 1
+        assert res[idx].ok and nw == calc.nwitness
+        ref = O.run(main, s["cases"][case]["input"]).witness_numpy().reshape(-1, 32)[keep]
+        assert np.array_equal(calc.witness_payload_reduced(idx, keep).reshape(-1, 32), ref)
+        assert np.array_equal(calc.witness_payload_reduced(idx, keep, window_wires=len(keep) // 7 + 1).reshape(-1, 32), ref)
+        path = str(tmp_path / "red.wtns")
+        calc.write_wtns_reduced(idx, path, keep)
+        data = np.fromfile(path, dtype=np.uint8)
+        assert struct.unpack("<I", data[60:64].tobytes())[0] == len(keep) and np.array_equal(data[76:].reshape(-1, 32), ref)
+        with pytest.raises(RuntimeError):
+            calc.witness_payload_reduced(idx, keep[1:])           # wire 0 must be kept
+        calc.close()
 
 
 def _mutations(base, rng):
@@ -299,13 +331,16 @@ def test_failure_sets_match_oracle(pkg, depth):
     calc = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
     res = calc.calculate([c[1] for c in cases], check=True)
     n_fail = 0
-    for (label, inp), r in zip(cases, res):
-        exp = O.run_main(POB_FIX, inp)
+    for i, ((label, inp), r) in enumerate(zip(cases, res)):
+        ora = O.run(POB_FIX, inp)
+        exp = None if ora.failed else ora.outputs()
         got = r.outputs if r.ok else None
         assert got == exp, f"{label}: GPU {got} vs oracle {exp} ({r.message()})"
         n_fail += exp is None
         if r.ok:
             assert r.check_status == 0 and r.bad_wire is None, label
+            gpu, ref = calc.witness_payload(i), ora.witness_numpy()      # every valid mutation: the whole payload, not only the output
+            assert np.array_equal(gpu, ref), f"{label}: first differing wire {_first_diff(gpu, ref)}"
     assert exp is not None or n_fail > 0
     assert 15 < n_fail < len(cases) - 5          # the mutation set really exercises both outcomes
     calc.close()
@@ -358,13 +393,20 @@ def test_two_ranks_on_one_gpu_equal_a_single_rank_run(pkg, tmp_path):
     equal a single-rank run of the same 1024 seeds (the two ranks in bench.py's default two-calculator pipeline, the single rank
     without it).  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
     a, b = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
-    two = _run_bench(["--gpus", "2", "--batch", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-results", a],
-                     {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
-    one = _run_bench(["--gpus", "1", "--batch", "1024", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pipeline", "0", "--dump-results", b])
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    quick = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single"]
+    two = _run_bench(["--gpus", "2", "--batch", "512", "--dump-results", a] + quick, {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
+    one = _run_bench(["--gpus", "1", "--batch", "1024", "--pipeline", "0", "--dump-results", b] + quick)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak" and two["config"]["rccl_ranks"] == 2
+    assert two["config"]["validated_witnesses"] == 3 * 512 and one["config"]["validated_witnesses"] == 3 * 1024
     ra, rb = np.load(a), np.load(b)
-    assert ra.shape == rb.shape == (1024, 36) and np.array_equal(ra, rb)
-    assert not ra[:, :4].any()                      # every status 0
+    assert ra.shape == rb.shape == (1024, 44) and np.array_equal(ra, rb)
+    assert not ra[:, :4].any() and (ra[:, 4:12] == 0xFF).all()       # every status 0, every verdict clean
+    # BASELINE config 4 as written: ONE global batch split over the ranks (strong scaling), uneven split included
+    c = str(tmp_path / "strong.npy")
+    st = _run_bench(["--gpus", "2", "--total-batch", "1023", "--dump-results", c] + quick, {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
+    rc = np.load(c)
+    assert st["scaling"] == "strong" and rc.shape == (1023, 44) and not rc[:, :4].any() and (rc[:, 4:12] == 0xFF).all()
+    assert st["config"]["validated_witnesses"] == 3 * 512 and len({bytes(x) for x in rc[:, 12:]}) == 1023       # (rank 0's slice: 512 of the 1023; all commitments differ)
 
 
 def test_max_depth_config5_payload_and_bench(pkg):
@@ -383,7 +425,8 @@ def test_max_depth_config5_payload_and_bench(pkg):
     ref = ora.witness_numpy()
     assert np.array_equal(gpu, ref), f"first differing wire {_first_diff(gpu, ref)}"
     calc.close()
-    line = _run_bench(["--gpus", "1", "--depth", "16", "--batch", "128", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--distinct-keys", "2"])
+    line = _run_bench(["--gpus", "1", "--depth", "16", "--batch", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single",
+                       "--distinct-keys", "2", "--distinct-batches", "2"])
     assert "16-layer" in line["config"]["workload"] and line["value"] > 0
 
 
@@ -430,3 +473,97 @@ def test_pow_search_gpu_matches_host(pkg):
         assert key == start + t1
         assert pkg.keccak256(o2.raw + postfix)[:zb] == bytes(zb)
         assert gen.pow_search(start, reveal, extra, zb, device=0) == key
+
+
+def test_reading_a_batch_does_not_stall_the_partner(pkg):
+    """the service loop's read path: pob_results_fetch / pob_results_wait of batch k go through the handle's OWN events -- when the wait
+    returns, the partner calculator's generation of batch k+1 (enqueued before) is still running, i.e. nothing synchronised the device;
+    and the legacy pob_results of the same batch gives the same answer afterwards"""
+    import torch
+    from proof_of_burn_amd import inputs as gen, witness as W
+    main = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
+    B = 512
+    batch = gen.synthetic_batch(B, depth=10, seed=0xB0B, distinct_keys=4)
+    a, b = pkg.WitnessCalculator(main, max_batch=B), pkg.WitnessCalculator(main, max_batch=B)
+    a.set_partner(b)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    pin = pkg.PinnedInputs(a, B)
+    a.pack_json([json.dumps(d) for d in batch.inputs], out=pin)
+    still_running = 0
+    for rnd in range(3):
+        a.upload_packed_async(pin.fr, pin.sm, pin.forced); a.generate(sa.cuda_stream)
+        b.upload_packed_async(pin.fr, pin.sm, pin.forced)
+        a.constraint_check(sa.cuda_stream); a.fetch_records()
+        b.generate(sb.cuda_stream)                      # its round expansion follows the end of a's evaluation
+        done_b = torch.cuda.Event(); done_b.record(sb)
+        rec = a.wait_records()                          # returns when a's records are on the host ...
+        still_running += 0 if done_b.query() else 1     # ... while b is still generating
+        assert not rec["status"].any() and (rec["check_status"] == W.CLEAN).all() and (rec["bad_wire"] == W.CLEAN).all()
+        assert [int.from_bytes(c.tobytes(), "little") for c in rec["commitment"]] == batch.commitments
+        b.constraint_check(sb.cuda_stream); b.fetch_records()
+        recb = b.wait_records()
+        assert np.array_equal(recb["commitment"], rec["commitment"]) and (recb["check_status"] == W.CLEAN).all()
+    assert still_running == 3, "waiting for a batch's records synchronised the partner's generation"
+    res = a.results(with_check=True)
+    assert [r.outputs[0] for r in res] == batch.commitments and all(r.check_status == 0 and r.bad_wire is None for r in res)
+    pin.free(); a.close(); b.close()
+
+
+def test_rccl_world_of_one_gathers_the_device_records(pkg, tmp_path):
+    """multi-GPU readiness without a node: the `nccl` backend (= RCCL on ROCm) initialised with world size 1 in a fresh process, the
+    calculator's device-resident record tensor (a zero-copy __cuda_array_interface__ view of library memory) pushed through
+    all_gather_into_tensor on a side stream: RCCL loads, accepts the view and returns the records"""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl1.py"
+    script.write_text(f"""
+import json, os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", GPU_MAX_HW_QUEUES="16")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from proof_of_burn_amd import WitnessCalculator, distributed as D, witness as W
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+s = next(x for x in json.load(open(os.path.join({ROOT!r}, "tests", "golden", "suites.json"))) if x["name"] == "test_spend")
+calc = WitnessCalculator("Spend(31)", max_batch=8)
+inputs = [c["input"] for c in s["cases"]]
+res = calc.calculate(inputs, check=True)
+rec = D.device_records(calc, len(inputs))
+gs = torch.cuda.Stream()
+with torch.cuda.stream(gs):
+    out = torch.empty_like(rec)
+    dist.all_gather_into_tensor(out, rec.contiguous())
+gs.synchronize()
+st, outs = D.unpack_records(out.cpu())
+cs, bw = D.unpack_verdicts(out.cpu())
+for i, r in enumerate(res):
+    assert int(st[i]) == r.status
+    if r.ok:
+        assert int.from_bytes(bytes(outs[i].tolist()), "little") == r.outputs[0] and int(cs[i]) == D.CLEAN and int(bw[i]) == D.CLEAN
+print("rccl ranks", dist.get_world_size(), dist.get_backend())
+dist.destroy_process_group()
+calc.close()
+""")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ranks 1 nccl" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_seeded_differential_fixture_instantiation(pkg):
+    """64 random VALID proofs of depths 2..4 on the fixture instantiation (seeded): outputs, clean evaluator and the WHOLE canonical payload
+    of every one of them against the oracle"""
+    from proof_of_burn_amd import inputs as gen
+    params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
+    inputs, commitments = [], []
+    for depth, n, seed in ((2, 21, 1001), (3, 21, 2002), (4, 22, 3003)):
+        bt = gen.synthetic_batch(n, depth=depth, seed=seed, distinct_keys=3, params=params)
+        inputs += bt.inputs; commitments += bt.commitments
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=64)
+    res = calc.calculate(inputs, check=True)
+    for i, (r, c) in enumerate(zip(res, commitments)):
+        assert r.ok and r.outputs == [c] and r.check_status == 0 and r.bad_wire is None, (i, r)
+        ora = O.run(POB_FIX, inputs[i])
+        assert not ora.failed and ora.outputs() == [c]
+        gpu, ref = calc.witness_payload(i), ora.witness_numpy()
+        assert np.array_equal(gpu, ref), f"witness {i}: first differing wire {_first_diff(gpu, ref)}"
+    calc.close()

@@ -69,20 +69,17 @@ def test_from_account_proof_rebuilds_the_reference_fixture():
 
 
 def test_pack_vectorised_equals_elementwise():
-    """WitnessCalculator.pack: the numpy fast path and the per-element (string / huge int) path agree"""
+    """the Python loader (witness.pack_inputs): the numpy fast path and the per-element (string / huge int) path agree"""
     import numpy as np
     from proof_of_burn_amd import witness as W
     params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
     b = G.synthetic_batch(2, depth=2, seed=3, distinct_keys=1, params=params)
 
-    class Fake:                      # pack() only needs the shapes
-        name, L, NB, HB = "ProofOfBurn", 4, 4, 5
-        class info:
-            n_fr_inputs, n_sm_inputs = 6, 1 + 4 * 544 + 4 + 1 + 680 + 2
-    a = W.WitnessCalculator.pack(Fake, b.inputs)
+    main = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
+    a = W.pack_inputs(main, b.inputs)
     slow = [dict(d, layers=[[str(x) for x in row] for row in d["layers"]], blockHeader=[hex(x) for x in d["blockHeader"]]) for d in b.inputs]
-    c = W.WitnessCalculator.pack(Fake, slow)
+    c = W.pack_inputs(main, slow)
     for x, y in zip(a, c):
         assert np.array_equal(x, y)
     big = dict(b.inputs[0]); big["layerLens"] = list(big["layerLens"]); big["layerLens"][3] = 2 ** 40
-    assert W.WitnessCalculator.pack(Fake, [big])[2][0] == W.FAIL_INPUT_RANGE
+    assert W.pack_inputs(main, [big])[2][0] == W.FAIL_INPUT_RANGE
