@@ -5,8 +5,14 @@ declared components of circomlib: the statement that assigns their last input --
 MultiAND: ands[0], ands[1], and2)."""
 from __future__ import annotations
 
+import os
+
 from .. import poseidon_host as PH
 from .core import P, Template
+
+# The one numbering switch of the three statements of the O0 layout (csrc/policy.hpp POB_DECL_ORDER; the oracle's ORACLE_DECL_ORDER):
+# 1 = the two circomlib templates whose children are DECLARED in another order than they are initialised follow the declaration order.
+DECL_ORDER = os.environ.get("POB_DECL_ORDER", "0")[:1] == "1"
 
 
 class XOR(Template):           # out <== a + b - 2*a*b
@@ -96,7 +102,10 @@ class MultiAND(Template):
             self.assign(a["a"].lc, inp[0]); self.assign(a["b"].lc, inp[1]); self.assign(out.lc, a["out"].lc)
         else:
             n1, n2 = n // 2, n - n // 2
-            m0 = self.comp("ands[0]", MultiAND.get(n1)); m1 = self.comp("ands[1]", MultiAND.get(n2)); a2 = self.comp("and2", AND.get())
+            if DECL_ORDER:                   # and2 is DECLARED first (circomlib gates.circom); default: initialisation order, see DECL_ORDER
+                a2 = self.comp("and2", AND.get()); m0 = self.comp("ands[0]", MultiAND.get(n1)); m1 = self.comp("ands[1]", MultiAND.get(n2))
+            else:
+                m0 = self.comp("ands[0]", MultiAND.get(n1)); m1 = self.comp("ands[1]", MultiAND.get(n2)); a2 = self.comp("and2", AND.get())
             for i in range(n1):
                 self.assign(m0["in"][i], inp[i])
             for i in range(n2):
@@ -157,7 +166,10 @@ class AliasCheck(Template):    # compConstant(p - 1).out === 0
 class Num2Bits_strict(Template):
     def build(self):
         out = self.output("out", 254); inp = self.input("in")
-        n2b = self.comp("n2b", Num2Bits.get(254)); ac = self.comp("aliasCheck", AliasCheck.get())
+        if DECL_ORDER:                       # aliasCheck is DECLARED first (circomlib bitify.circom)
+            ac = self.comp("aliasCheck", AliasCheck.get()); n2b = self.comp("n2b", Num2Bits.get(254))
+        else:
+            n2b = self.comp("n2b", Num2Bits.get(254)); ac = self.comp("aliasCheck", AliasCheck.get())
         self.assign(n2b["in"].lc, inp.lc)
         for i in range(254):
             self.assign(out[i], n2b["out"][i])

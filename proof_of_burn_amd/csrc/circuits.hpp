@@ -126,12 +126,13 @@ struct RaRefs {
 struct SpongeDesc { uint32_t n, stage, src_b, kin_b, fin_b, fs_b, abs_b, kin_w, fin_w, fs_w, abs_w, src_w; };
 struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[8]; uint32_t cost, flags; };
 
-#define SC_RANGE_POS 32          // positions of SubstringCheck's existence loop per unit (one batch inversion each; <= 64)
+#define SC_RANGE_POS 64          // positions of SubstringCheck's existence loop per unit (one batch inversion each; <= 64: the zero flags are one 64-bit word)
 #define MAX_KB 72
 #define MAX_SC 64
 // everything a unit body needs besides the policy; lives in device memory, read-only on the device
 struct CircuitLayout {
     int circuit;                  // 0 = ProofOfBurn, 1 = Spend
+    uint32_t decl_order;          // policy.hpp POB_DECL_ORDER: the numbering variant this layout was planned with (the device policies follow it)
     PobParams pob; SpendParams spend;
     PobMain pm; SpendMain sm;
     Fr prefix[3];                 // POSEIDON_PREFIX + 0/1/2 (constants.circom:3-14), Montgomery
@@ -488,7 +489,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             p.put(sb.sum, 0);
             p.require(p.ballot((uint32_t)select < N), FAILCODE(T_SELECTOR, 43));      // sum isEq === 1  <=>  0 <= select < N
         }
-        { B m[7] = {0, 0, 0, 0, 0, 0, 0}; p.cur = R.c_mand; CountP q; q.cur = p.cur; MultiANDg<CountP, 7>::run(q, m); R.c_end = q.cur; }
+        { B m[7] = {0, 0, 0, 0, 0, 0, 0}; p.cur = R.c_mand; CountP q; q.cur = p.cur; q.decl_order = p.decl_order; MultiANDg<CountP, 7>::run(q, m); R.c_end = q.cur; }
         p.cur = R.c_end;
         if (P::is_count) L.lds[d.a[0]] = R;
     } break;
@@ -733,14 +734,14 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             still = still && b == 0; lead += still;
         }
         A.c_cb = p.cur;
-        { CountP q; q.cur = p.cur; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
+        { CountP q; q.cur = p.cur; q.decl_order = p.decl_order; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
         p.cur = A.c_lt;
         B single = p.put(A.isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
         p.put(A.isz, gIsZeroF(p, x));
         const S length = P::is_gen ? (S)N - lead : p.get(A.len);
         p.put(A.frb, gMux1SF(p, 0x80 + length, x, single));
         A.c_concat = p.cur;
-        { CountP q; q.cur = p.cur; S cl; gConcat(q, 4 + N, 66, A.pn, 0, A.sc, 0, cl); A.c_end = q.cur; }
+        { CountP q; q.cur = p.cur; q.decl_order = p.decl_order; S cl; gConcat(q, 4 + N, 66, A.pn, 0, A.sc, 0, cl); A.c_end = q.cur; }
         p.cur = A.c_end;
         if (P::is_count) L.ra = A;
     } break;
@@ -963,6 +964,7 @@ struct Plan {
                 : kind == CK_N2BE ? (UNIT_GEN | UNIT_CHECK)                                            // ... and the generator too
                 : kind == U_POS_WIDE ? UNIT_GEN
                 : kind == U_POB_POSEIDONS ? (UNIT_CHECK | UNIT_EMIT)                                   // generation: nothing but the two U_POS_WIDE blocks
+                : kind == U_POB_INPUT ? UNIT_EMIT                                                      // generation / evaluation: the tile-transposing k_inputs kernel (pob_host.hip)
                 : (UNIT_GEN | UNIT_CHECK | UNIT_EMIT);
         units.push_back(d);
         if (stage > max_stage) max_stage = stage;
@@ -1077,7 +1079,7 @@ struct Plan {
     }
     void plan_pob(const PobParams& prm) {
         memset(&L, 0, sizeof L);
-        L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0;
+        L.circuit = 0; L.pob = prm; L.nkb = 0; max_stage = 0; L.decl_order = p.decl_order;
         L.fp_n2be32 = n2be_footprint(32); L.fp_n2beN = n2be_footprint(prm.amountBytes);
         // track 1 (TB): everything that hangs off the main inputs only -- range checks, Poseidons, BurnAddressHash, ProofOfWorkChecker,
         // RlpMerklePatriciaTrieLeaf -- runs beside the layer/header Keccak sponges of the main track and is joined before main stage 5
@@ -1216,7 +1218,7 @@ struct Plan {
     }
     void plan_spend(const SpendParams& prm) {
         memset(&L, 0, sizeof L);
-        L.circuit = 1; L.spend = prm; L.nkb = 0; max_stage = 0; ntracks = 1;
+        L.circuit = 1; L.spend = prm; L.nkb = 0; max_stage = 0; ntracks = 1; L.decl_order = p.decl_order;
         L.fp_n2be32 = n2be_footprint(32); L.fp_n2beN = n2be_footprint(prm.maxAmountBytes);
         L.pob = PobParams{1, 1, 1, 0, prm.maxAmountBytes, 0, fr_zero(), fr_zero()};
         SpendMain& M = L.sm;

@@ -26,6 +26,7 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
         p.m.rs_sb = __builtin_amdgcn_make_buffer_rsrc(sbp, 0, (int)(A.sb_stride > 0xFFFFFFFFull ? 0xFFFFFFFFull : A.sb_stride), 0x00020000);
     }
     p.m.pos_tab = A.pos_tab;
+    p.decl_order = A.L->decl_order;
     if constexpr (P::is_gen) p.status = 0;
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.unit = A.order[A.first + blockIdx.x]; }

@@ -170,6 +170,13 @@ template <class P, int N> struct MultiANDg {
         B v[N];
 #pragma unroll
         for (int k = 0; k < N; k++) v[k] = p.put(i + k, in[k]);
+        if (p.decl_order) {                                   // and2 = AND() [out | a, b] in front of ands[0], ands[1]
+            BitRef a2 = p.bits(3);
+            B a = MultiANDg<P, N / 2>::run(p, v);
+            B b = MultiANDg<P, N - N / 2>::run(p, v + N / 2);
+            a = p.put(a2 + 1, a); b = p.put(a2 + 2, b);
+            return p.put(o, p.put(a2, a & b));
+        }
         B a = MultiANDg<P, N / 2>::run(p, v);
         B b = MultiANDg<P, N - N / 2>::run(p, v + N / 2);
         return p.put(o, gAND(p, a, b));
@@ -249,9 +256,17 @@ template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in, BV* vout = nullp
     BitRef o = p.bits(254); FrRef i = p.frs(1);
     F x = p.put(i, in);
     BV v; F c;
-    gNum2BitsF(p, 254, x, &v, &c);
-    bv_put(p, o, 254, v);
-    gAliasCheck(p, v, c);
+    if (p.decl_order) {                                       // aliasCheck in front of n2b
+        c = fr_from_mont(x);
+        v = bv_from_canon(p, c, 254);
+        gAliasCheck(p, v, c);
+        gNum2BitsF(p, 254, x, &v, &c);
+        bv_put(p, o, 254, v);
+    } else {
+        gNum2BitsF(p, 254, x, &v, &c);
+        bv_put(p, o, 254, v);
+        gAliasCheck(p, v, c);
+    }
     if (vout) *vout = v;
     if (cout) *cout = c;
     return o;

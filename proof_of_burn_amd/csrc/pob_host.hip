@@ -52,6 +52,29 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
     rec[0] = hrec[0] = s; rec[1] = hrec[1] = cs; rec[2] = hrec[2] = bw;
     for (int k = 0; k < 8; k++) rec[3 + k] = hrec[3 + k] = c.l[k];
 }
+// The main component's small inputs (proof_of_burn.circom:43-72: numLeafAddressNibbles, layers[][], layerLens[], numLayers, blockHeader[], ...):
+// packed rows [witness][nsm] -> the input wires' SM rows [wire][64 witnesses], 64 x 64 tiles through LDS so that both sides are coalesced
+// 256-byte accesses.  As lane = witness units (U_POB_INPUT) every lane read its own 43 KB-strided row: 0.09 ms alone, 1.8-2 ms beside the
+// other batch's round expansion -- at the head of every narrow chain of the generation.  CHECK: the stored rows against the inputs
+// (the relation `wire === input`, the evaluator's U_POB_INPUT).  grid = (ceil(nsm / 64), groups).
+extern __shared__ uint32_t g_lds[];
+template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32_t* in_sm, uint32_t nsm, int32_t* sm, uint64_t sm_stride, uint32_t s0, uint32_t w0, uint32_t* bad_wire) {
+    int32_t* t = (int32_t*)g_lds;                         // [64 witnesses][65]
+    const uint32_t lane = threadIdx.x, k0 = blockIdx.x * 64, g = blockIdx.y;
+    const int32_t* src = in_sm + (uint64_t)g * 64 * nsm;
+    for (uint32_t w = 0; w < 64; w++) t[w * 65 + lane] = (k0 + lane < nsm) ? src[(uint64_t)w * nsm + k0 + lane] : 0;
+    __syncthreads();
+    int32_t* dst = sm + (uint64_t)g * sm_stride + (uint64_t)(s0 + k0) * 64;
+    const uint32_t nk = nsm - k0 < 64 ? nsm - k0 : 64;
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t kk = 0; kk < nk; kk++) {
+        const int32_t v = t[lane * 65 + kk];
+        if (CHECK) { if (dst[kk * 64 + lane] != v && bad == 0xFFFFFFFFu) bad = w0 + k0 + kk; }
+        else dst[kk * 64 + lane] = v;
+    }
+    if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
+}
+static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st);
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
 // emission window pre-fill (0xEE..: not a field element, so a wire nobody owns is caught by the byte compare); rocclr's fill kernel
@@ -217,6 +240,13 @@ static void launch_g_emit(const GArgs& A, uint32_t cls, uint32_t nunits, hipStre
     if (cls == 3) launch_g_emit_sc(A, nunits, 1, st); else if (cls) launch_g_emit_heavy(A, nunits, 1, st); else launch_g_emit_light(A, nunits, 1, st);
 }
 
+static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st) {
+    if (h->circuit != POB_CIRCUIT_PROOF_OF_BURN || !h->plan.nsm_in) return;
+    const SmRef r0 = h->plan.L.pm.numLeafAddressNibbles;  // the small inputs are contiguous SM ranks / wire indices from here (declaration order)
+    const dim3 grid((h->plan.nsm_in + 63) / 64, G);
+    if (check) hipLaunchKernelGGL(k_inputs<true>, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
+    else hipLaunchKernelGGL(k_inputs<false>, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
+}
 static Fr limbs_to_mont(const uint64_t* l) {
     Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
     return fr_to_mont(c);
@@ -627,6 +657,7 @@ int pob_generate(pob_handle h, void* stream_) {
         }
         return POB_OK;
     };
+    launch_inputs(h, false, G, st);                       // the small inputs' wires (tile transpose): ahead of stage 0, whose forks wait for the stream
     { int rc = run_track(0); if (rc) return rc; }
     for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
     { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
@@ -655,6 +686,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipEventRecord(h->ev_fork, st));
     for (int k = 0; k < 2; k++) {
         HIPC(hipStreamWaitEvent(side[k], h->ev_fork, 0));
+        if (k == 1) launch_inputs(h, true, G, side[k]);
         for (uint32_t fam : side_plan[k])
             for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == fam) { A.first = sg.first; launch_g_check(A, fam, sg.count, G, side[k]); }
     }

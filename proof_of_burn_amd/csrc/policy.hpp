@@ -49,8 +49,21 @@ enum : uint32_t {
 };
 #define FAILCODE(tpl, line) (((uint32_t)(tpl) << 12) | (uint32_t)(line))
 
+// Two circomlib templates instantiate a child in a different order than they DECLARE it (Num2Bits_strict: aliasCheck is declared first,
+// n2b initialised first; MultiAND(n > 2): and2 is declared first, initialised last).  Which of the two orders circom's --O0 numbering
+// follows is not pinned here (no circom).  Default: initialisation order.  POB_DECL_ORDER=1 in the environment (read once,
+// when the first circuit is planned) flips BOTH statements -- together with ORACLE_DECL_ORDER=1 for the oracle and the circuit model
+// (which reads the same POB_DECL_ORDER), so that a circom user can re-diff a real .sym / .wtns with one knob.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define POB_DECL_ORDER_DEFAULT 0u                     // (device policies copy the flag from the circuit layout)
+#else
+#include <stdlib.h>
+static inline uint32_t pob_decl_order_env() { static const uint32_t v = (getenv("POB_DECL_ORDER") && getenv("POB_DECL_ORDER")[0] == '1') ? 1u : 0u; return v; }
+#define POB_DECL_ORDER_DEFAULT pob_decl_order_env()
+#endif
 struct PolBase {
     Cur cur;
+    uint32_t decl_order = POB_DECL_ORDER_DEFAULT;
     HD BitRef bits(uint32_t n) { BitRef r = {cur.w, cur.b}; cur.w += n; cur.b += n; return r; }
     HD SmRef sms(uint32_t n) { SmRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
     HD SiRef sis(uint32_t n) { SiRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
