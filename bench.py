@@ -229,6 +229,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     assert state["validated"] == args.steps * B, "not every batch was validated inside the timed region"
+    validated_timed = state["validated"]
     h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
     probe_steps = 0
     if not args.probe_in_timed_region and not args.dbg_no_fetch:
@@ -419,7 +420,7 @@ def main():
                        "wires_per_witness": int(info.n_witness), "resident_bytes_per_witness": int(info.group_bytes // 64),
                        "canonical_bytes_per_witness": int(info.n_witness) * 32,
                        "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {B} (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                       "validated_witnesses": state["validated"], "h2d_bytes_per_step": int(h2d_per_step),
+                       "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input_synthesis_s_per_batch": round(t_synth, 2),
                        "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),

@@ -171,7 +171,7 @@ struct pob_ctx {
     struct KSeg { uint32_t stage, sp_first, sp_count, perm_first, perm_count; hipEvent_t ev_done; };
     std::vector<KSeg> ksegs;                           // ev_done: recorded behind the segment's sponge kernels in pob_generate
     hipStream_t stream_k = nullptr;                                     // the main track's round expansion in pipeline mode (pob_generate)
-    hipEvent_t ev_rounds_fork = nullptr;
+    hipEvent_t ev_rounds_fork = nullptr, ev_g_done = nullptr, ev_k_done = nullptr;   // pipeline: the G side of a generation is enqueued / the Keccak evaluation on the streaming stream is done
     // side tracks (Plan::track_fork/track_join): streams of the device's pool (StreamPool below), own fork/join events, start and end events
     // (ROCm multiplexes streams onto few hardware queues: a lone handle keeps to the caller's stream + 4 of the pool's --
     //  stream2, track 1's (also track 6), track 2's (also track 3, which runs before it anyway), the round expansion's; a track's BN254 and light
@@ -424,6 +424,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     h->stream2 = h->pool->stream2; h->stream_k = h->pool->stream_k;
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_g_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_k_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_gen_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_check_done, hipEventDisableTiming));
     for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -518,6 +519,8 @@ void pob_close(pob_handle h) {
     if (h->ev_gen_done) hipEventDestroy(h->ev_gen_done);
     if (h->ev_check_done) hipEventDestroy(h->ev_check_done);
     if (h->ev_rounds_fork) hipEventDestroy(h->ev_rounds_fork);
+    if (h->ev_g_done) hipEventDestroy(h->ev_g_done);
+    if (h->ev_k_done) hipEventDestroy(h->ev_k_done);
     for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
     for (pob_ctx::Track& T : h->tracks) {
@@ -639,8 +642,10 @@ int pob_generate(pob_handle h, void* stream_) {
                     // nothing in the generation reads a KeccakfRound block's wires (k_chain wrote every state a later stage uses): the
                     // main track's HBM-streaming expansion leaves the track here and is only joined before the results are collected
                     HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->stream_k, h->ev_rounds_fork, 0));
-                    // pipeline: the write-saturating expansion does not run beside the partner's evaluation (it follows it)
-                    if (h->partner && h->partner->check_done_rec) HIPC(hipStreamWaitEvent(h->stream_k, h->partner->ev_check_done, 0));
+                    // pipeline: the write-saturating expansion does not run beside the partner's evaluation, it follows it -- IN ORDER on the
+                    // device's one streaming stream, where the partner's Keccak evaluation was enqueued before (pob_constraint_check): the two
+                    // HBM-saturating kernels of the two batches alternate on one hardware queue without an event hand-over between them
+                    // (0.3 ms per phase change when the evaluation ran on the caller's stream and the expansion waited for its end through an event)
                     sk = h->stream_k; pending.push_back(ks.ev_done);
                 }
                 launch_k_rounds(K, false, ks.perm_count, G, sk);
@@ -659,6 +664,7 @@ int pob_generate(pob_handle h, void* stream_) {
     };
     launch_inputs(h, false, G, st);                       // the small inputs' wires (tile transpose): ahead of stage 0, whose forks wait for the stream
     { int rc = run_track(0); if (rc) return rc; }
+    HIPC(hipEventRecord(h->ev_g_done, st));              // every stage of the G side is enqueued behind this point of st (the joined tracks included)
     for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
     { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
     HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
@@ -693,10 +699,16 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     if (!h->plan.sponges.empty()) {
         KArgs K = kargs(h);
         K.first = 0;
-        if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
-        launch_k_rounds(K, true, h->nperms, G, st);
-        if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
-        launch_k_chain(K, true, h->nperms, G, st);
+        // pipeline: on the device's streaming stream, directly behind this batch's round expansion (in order: no event between the two) and
+        // ahead of the partner's next expansion; it needs the G side of the generation (its tail runs beside the expansion), not the
+        // result collection on the caller's stream.  A lone handle: on the caller's stream.
+        hipStream_t sk = h->partner ? h->stream_k : st;
+        if (sk != st) HIPC(hipStreamWaitEvent(sk, h->ev_g_done, 0));
+        if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
+        launch_k_rounds(K, true, h->nperms, G, sk);
+        if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
+        launch_k_chain(K, true, h->nperms, G, sk);
+        if (sk != st) { HIPC(hipEventRecord(h->ev_k_done, sk)); HIPC(hipStreamWaitEvent(st, h->ev_k_done, 0)); }
     }
     HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
     HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
