@@ -7,6 +7,8 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
 }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
     // (non-temporal loads in the evaluation: 4.35 -> 4.09 ms per launch at batch 1024, 0.785 -> 0.836 of the HBM peak)
+    // (compiled for 3 / 4 waves per SIMD -- 168 VGPRs + 64 B scratch / 128 + 152 B -- it is slower alone (4.4-4.7 / 4.6-5.2 ms vs 4.09) and in the step
+    //  (13.3-13.7 / 13.7-14.0 ms vs 13.15-13.2): profiles/round3_experiments.txt)
     if (check) hipLaunchKernelGGL((k_rounds<true, true>), dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
     else hipLaunchKernelGGL(k_rounds<false>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
 }

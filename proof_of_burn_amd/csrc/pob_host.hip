@@ -410,6 +410,8 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             // (s_in: the input uploads of every handle of the device -- copies, ordered by events like the rest)
             hipStream_t* want[7] = {&P->stream2, &P->stream_k, &P->track1, &P->track2, &P->chk1, &P->chk2, &P->s_in};
             hipError_t e = hipSuccess;
+            // (the streaming stream at the lowest priority; normal priority measured the same step, the highest lets the round evaluation
+            //  finish in 5.1 ms instead of 7.6 but the step grows from 13.2 to 14.8 ms: the G kernels it displaces are needed next)
             for (int k = 0; k < 7 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi);
             if (e != hipSuccess) {
                 for (hipStream_t* q : want) if (*q) hipStreamDestroy(*q);

@@ -190,23 +190,34 @@ def synthetic_batch(n: int, depth: int = 10, seed: int = 0xB0B, distinct_keys: i
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Real account proof -> input.json (reference tests/main.py:65-178, which obtains the proof from a JSON-RPC node)
 def rlp_decode(data: bytes):
-    """minimal RLP decoder: bytes -> nested lists of bytes (yellow paper app. B; the reference uses the `rlp` package)"""
+    """minimal RLP decoder: bytes -> nested lists of bytes (yellow paper app. B; the reference uses the `rlp` package).  Every declared
+    length is checked against the buffer: a truncated or over-long encoding raises ValueError, nothing is silently cut by slicing"""
+    data = bytes(data)
+
+    def take(pos, n, what):
+        if pos + n > len(data):
+            raise ValueError(f"RLP: {what} of {n} bytes at offset {pos} overruns the {len(data)}-byte buffer")
+        return data[pos:pos + n]
+
     def item(pos):
+        if pos >= len(data):
+            raise ValueError("RLP: unexpected end of input")
         b0 = data[pos]
         if b0 < 0x80:
             return data[pos:pos + 1], pos + 1
         if b0 < 0xB8:
             n = b0 - 0x80
-            return data[pos + 1:pos + 1 + n], pos + 1 + n
+            return take(pos + 1, n, "string"), pos + 1 + n
         if b0 < 0xC0:
             ll = b0 - 0xB7
-            n = int.from_bytes(data[pos + 1:pos + 1 + ll], "big")
-            return data[pos + 1 + ll:pos + 1 + ll + n], pos + 1 + ll + n
+            n = int.from_bytes(take(pos + 1, ll, "length"), "big")
+            return take(pos + 1 + ll, n, "string"), pos + 1 + ll + n
         if b0 < 0xF8:
             n, start = b0 - 0xC0, pos + 1
         else:
             ll = b0 - 0xF7
-            n, start = int.from_bytes(data[pos + 1:pos + 1 + ll], "big"), pos + 1 + ll
+            n, start = int.from_bytes(take(pos + 1, ll, "length"), "big"), pos + 1 + ll
+        take(start, n, "list payload")
         out, p = [], start
         while p < start + n:
             x, p = item(p)
@@ -223,7 +234,12 @@ def rlp_decode(data: bytes):
 def leaf_address_nibbles(leaf_node: bytes) -> int:
     """number of address-hash nibbles stored in the leaf of an account proof = `numLeafAddressNibbles`
     (reference tests/main.py:69-82: hex-prefix flag 2 -> even, 3 -> odd path)"""
-    key = rlp_decode(leaf_node)[0]
+    node = rlp_decode(leaf_node)
+    if not isinstance(node, list) or len(node) != 2 or not isinstance(node[0], bytes):
+        raise ValueError("last proof node is not a leaf (a leaf is a 2-item list [hex-prefix key, value])")
+    key = node[0]
+    if len(key) == 0:
+        raise ValueError("last proof node has an empty key")
     flag = key[0] >> 4
     if flag == 2:
         return 2 * (len(key) - 1)

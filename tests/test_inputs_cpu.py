@@ -83,3 +83,16 @@ def test_pack_vectorised_equals_elementwise():
         assert np.array_equal(x, y)
     big = dict(b.inputs[0]); big["layerLens"] = list(big["layerLens"]); big["layerLens"][3] = 2 ** 40
     assert W.pack_inputs(main, [big])[2][0] == W.FAIL_INPUT_RANGE
+
+
+def test_rlp_decode_checks_every_length():
+    """truncated / over-long encodings and malformed leaves raise instead of being cut by slicing"""
+    import pytest
+    good = G.rlp([G.hex_prefix_leaf([1, 2, 3]), b"value"])
+    assert G.rlp_decode(good) == [G.hex_prefix_leaf([1, 2, 3]), b"value"] and G.leaf_address_nibbles(good) == 3
+    for bad in (good[:-1], good + b"\x00", bytes([0xB8]), bytes([0x85, 1, 2]), bytes([0xC5, 0x83, 1]), bytes([0xF8, 0x40, 1, 2]), b""):
+        with pytest.raises(ValueError):
+            G.rlp_decode(bad)
+    for node in (G.rlp([b"", b"v"]), G.rlp([b"\x20", b"a", b"b"]), G.rlp(b"\x20\x12"), G.rlp([[b"\x20"], b"v"]), G.rlp([b"\x10", b"v"])):
+        with pytest.raises(ValueError):
+            G.leaf_address_nibbles(node)
