@@ -327,17 +327,6 @@ template <class P> GD void kb_post(P& p, const KBRefs& r) {
     p.cur = cur_add(r.c_post, Cur{512 + 32 * 9, 512 + 32 * 8, 32, 0}, 1);
 }
 
-// Selector(N) block at cursor c (selector.circom:21-46): [out | vals[N], select | isEq[N], sum[N+1]] || IsEqual x N
-struct SelBlk { SmRef o, vals, sel; BitRef isEq; SmRef sum; Cur kids; };
-HD SelBlk sel_blk(Cur c, uint32_t N) {
-    SelBlk s;
-    s.o = SmRef{c.w, c.s}; s.vals = SmRef{c.w + 1, c.s + 1}; s.sel = SmRef{c.w + 1 + N, c.s + 1 + N};
-    s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum = SmRef{c.w + 2 + 2 * N, c.s + 2 + N};
-    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f, c.q};
-    return s;
-}
-HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; }
-
 // ---------------------------------------------------------------------------- unit bodies
 // ONE switch over every unit kind; a kernel instantiates it with the MASK of the families it serves and the other cases
 // compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
@@ -410,6 +399,19 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const Cur fp = {9 * n + 3, 3 * n, 6 * n + 3, 0};
         S select = p.get(M.numLayers) - 1;
         for (uint32_t j = d.a[0]; j < d.a[1]; j++) {
+            if constexpr (P::is_check) {              // arraysT[j][i] === arrays[i][j] === layers[i][j], eight layers' loads in flight
+                for (uint32_t i0 = 0; i0 < n; i0 += 8) {
+                    SmRef ra[8], rt[8];
+#pragma unroll
+                    for (uint32_t t = 0; t < 8; t++) { const uint32_t i = i0 + t < n ? i0 + t : n - 1; ra[t] = L.ll.arr + (i * q + j); rt[t] = L.ll.T + (j * n + i); }
+                    const SmLoaded<8> ha = sm_load(p, ra), ht = sm_load(p, rt);
+                    S src[8];
+#pragma unroll
+                    for (uint32_t t = 0; t < 8; t++) src[t] = p.get(M.layers + ((i0 + t < n ? i0 + t : n - 1) * q + j));
+                    sm_commit(p, ra, ha, src);
+                    sm_commit(p, rt, ht, ha.s);
+                }
+            } else
             for (uint32_t i = 0; i < n; i++) p.put(L.ll.T + (j * n + i), p.put(L.ll.arr + (i * q + j), p.get(M.layers + (i * q + j))));
             p.cur = cur_add(L.ll.c_sel0, fp, j);
             S v = p.put(L.ll.out + j, gSelectorS(p, n, L.ll.T + j * n, select));
@@ -501,7 +503,8 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         S acc;
         if (P::is_gen) { const uint32_t us = (uint32_t)select; acc = us < lo ? p.get_lane(R.src, us) : 0; }
         else acc = p.get(sb.sum + lo);
-        for (uint32_t i = lo; i < hi; i++) {
+        if constexpr (P::is_check) acc = sel_check_range<P, 4>(p, sb, R.src, select, lo, hi, acc, nullptr);      // (the evaluator: four entries' loads in flight)
+        else for (uint32_t i = lo; i < hi; i++) {
             const S v = p.put(sb.vals + i, p.get(R.src + i));
             p.cur = cur_add(sb.kids, FP_ISEQ_S, i);
             const B e = p.put(sb.isEq + i, gIsEqualS(p, select, (S)i));

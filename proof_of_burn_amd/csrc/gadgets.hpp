@@ -574,11 +574,72 @@ template <class P> GD void gDivide(P& p, int N, S a, S b, S& q, S& r) {
 }
 
 // ============================================================================ circuits/utils/selector.circom
+// Selector(N) block at cursor c (selector.circom:21-46): [out | vals[N], select | isEq[N], sum[N+1]] || IsEqual x N
+struct SelBlk { SmRef o, vals, sel; BitRef isEq; SmRef sum; Cur kids; };
+HD SelBlk sel_blk(Cur c, uint32_t N) {
+    SelBlk s;
+    s.o = SmRef{c.w, c.s}; s.vals = SmRef{c.w + 1, c.s + 1}; s.sel = SmRef{c.w + 1 + N, c.s + 1 + N};
+    s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum = SmRef{c.w + 2 + 2 * N, c.s + 2 + N};
+    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f, c.q};
+    return s;
+}
+HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; }
+#define FP_ISEQ_S_ (Cur{6, 2, 4, 0})          // IsEqual [out | in[2]] + IsZero [out | in | inv]
+// The evaluator's Selector entries [lo, hi) of the block `sb`: the same relations as the loop of gSelectorS / U_LD_SELR, on the same STORED
+// operands and in the same order, but with the loads of C entries (6 SM rows + the IsZero hint + 3 BIT words each) in flight together -- a
+// relation at a time (CheckP::put loads, waits, compares) an entry is nine serial memory round trips, and the leaf detectors alone have
+// 37 000 entries per witness.  acc = the stored sum[lo]; returns the stored sum[hi]; *cnt counts the entries whose stored isEq is set.
+template <class P, int C> GD S sel_check_range(P& p, const SelBlk& sb, SmRef src, S select, uint32_t lo, uint32_t hi, S acc, S* cnt) {
+    for (uint32_t i0 = lo; i0 < hi; i0 += C) {
+        SmRef rr[6 * C]; SiRef ri[C]; BitRef rb[3 * C];
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)C; q++) {
+            const uint32_t i = i0 + q < hi ? i0 + q : hi - 1;              // (a ragged tail repeats the last entry)
+            const Cur c = cur_add(sb.kids, FP_ISEQ_S_, i);
+            rr[6 * q] = src + i; rr[6 * q + 1] = sb.vals + i; rr[6 * q + 2] = SmRef{c.w + 1, c.s}; rr[6 * q + 3] = SmRef{c.w + 2, c.s + 1};
+            rr[6 * q + 4] = SmRef{c.w + 4, c.s + 2}; rr[6 * q + 5] = sb.sum + (i + 1);
+            ri[q] = SiRef{c.w + 5, c.s + 3};
+            rb[3 * q] = BitRef{c.w, c.b}; rb[3 * q + 1] = BitRef{c.w + 3, c.b + 1}; rb[3 * q + 2] = sb.isEq + i;
+        }
+        const SmLoaded<6 * C> h = sm_load(p, rr);
+        S inv[C]; B bw[3 * C];
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)C; q++) inv[q] = p.hint_inv(ri[q], 0);
+#pragma unroll
+        for (uint32_t q = 0; q < 3 * (uint32_t)C; q++) bw[q] = p.get(rb[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)C; q++) {
+            if (i0 + q >= hi) break;
+            const uint32_t i = i0 + q;
+            const S vals = h.s[6 * q + 1], in0 = h.s[6 * q + 2], in1 = h.s[6 * q + 3], x = h.s[6 * q + 4], sum = h.s[6 * q + 5], k = inv[q];
+            p.mark(vals != h.s[6 * q], rr[6 * q + 1].w);                                      // vals[i] <== src[i]
+            p.mark(in0 != select, rr[6 * q + 2].w); p.mark(in1 != (S)i, rr[6 * q + 3].w);      // IsEqual.in
+            p.mark(x != (S)((uint32_t)in1 - (uint32_t)in0), rr[6 * q + 4].w);                  // IsZero.in <== in[1] - in[0]
+            p.require(p.ballot(k == 0 || k == x), FAILCODE(T_ISZERO, 30));
+            const B zo = bw[3 * q + 1], eo = bw[3 * q], e = bw[3 * q + 2];
+            p.mark(((zo ^ p.ballot(k == 0)) >> p.lane_id()) & 1, rb[3 * q + 1].w);             // IsZero.out <== -in*inv + 1
+            p.require(p.ballot(x == 0) | ~zo, FAILCODE(T_ISZERO, 31));
+            p.mark(((eo ^ zo) >> p.lane_id()) & 1, rb[3 * q].w);                               // IsEqual.out <== isz.out
+            p.mark(((e ^ eo) >> p.lane_id()) & 1, rb[3 * q + 2].w);                            // isEq[i] <== eq.out
+            const bool hit = p.bit(e);
+            if (cnt) *cnt += hit;
+            p.mark(sum != acc + (hit ? vals : 0), rr[6 * q + 5].w);                            // sum[i+1] <== sum[i] + isEq[i] * vals[i]
+            acc = sum;
+        }
+        p.pin();
+    }
+    return acc;
+}
 // Selector(n) :21-46  [out | vals[n], select | isEq[n], sum[n+1]] || IsEqual([select, i]) x n;  sum isEq === 1
 template <class P> GD S gSelectorS(P& p, int n, SmRef src, S select) {
+    const Cur blk = p.cur;
     SmRef o = p.sms(1), vals = p.sms(n), sel = p.sms(1); BitRef isEq = p.bits(n); SmRef sum = p.sms(n + 1);
     select = p.put(sel, select);
     S acc = p.put(sum, 0), cnt = 0;
+    if constexpr (P::is_check) {
+        acc = sel_check_range<P, 4>(p, sel_blk(blk, (uint32_t)n), src, select, 0, (uint32_t)n, acc, &cnt);
+        p.cur = cur_add(p.cur, FP_ISEQ_S_, (uint32_t)n);
+    } else
     for (int i = 0; i < n; i++) {
         S v = p.put(vals + i, p.get(src + i));
         B e = p.put(isEq + i, gIsEqualS(p, select, (S)i));

@@ -602,6 +602,8 @@ int pob_generate(pob_handle h, void* stream_) {
     //  dozen wavefronts, next to no bandwidth) do start at once, i.e. beside the partner's expansion (+1.2 % on average of nine A/B pairs);
     //  the main track from its second stage on and the wide pre-work track wait for the partner's generation to be complete.  Track 4 is
     //  then enqueued AHEAD of the wide track 5, whose stream it normally shares: it moves to track 2's.
+    // (a strictly PHASED schedule -- evaluation kernel alone | the G work of both batches | expansion alone -- was measured too: the evaluation
+    //  kernel then runs at 0.77 of the HBM peak inside the step, but the G phase takes 5.3 ms by itself and the step 14.87 ms instead of 13.5)
     const bool gate = h->partner && h->partner->gen_done_rec;
     const bool gate_late = gate && h->plan.ntracks > 1;
     auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner) ? h->pool->track2 : h->tracks[t].s_main; };
