@@ -19,7 +19,7 @@ extern "C" {
 
 typedef struct pob_ctx* pob_handle;
 
-enum { POB_CIRCUIT_PROOF_OF_BURN = 0, POB_CIRCUIT_SPEND = 1 };
+enum { POB_CIRCUIT_PROOF_OF_BURN = 0, POB_CIRCUIT_SPEND = 1, POB_CIRCUIT_GADGET = 2 };
 enum { POB_OK = 0, POB_E_ARG = -1, POB_E_HIP = -2, POB_E_NOMEM = -3, POB_E_STATE = -4, POB_E_IO = -5 };
 
 typedef struct {
@@ -37,13 +37,22 @@ typedef struct {
  * params: template parameters as canonical 4x64-bit LE limbs each:
  *   ProofOfBurn: maxNumLayers, maxNodeBlocks, maxHeaderBlocks, minLeafAddressNibbles, amountBytes,
  *                powMinimumZeroBytes, maxIntendedBalance, maxActualBalance   (proof_of_burn.circom:34)
- *   Spend:       maxAmountBytes                                              (spend.circom:32)        */
+ *   Spend:       maxAmountBytes                                              (spend.circom:32)
+ *   POB_CIRCUIT_GADGET: a gadget-level main -- what the reference's test harness builds with `component main = T(params);`
+ *                around ONE template (tests/test.py:24-33, the 54 non-circuit entries of tests/test.py:146-201):
+ *                params[0] = pob_gadget_template("T"), params[1..] = T's template parameters.  Inputs: the main's input signals in
+ *                declaration order, field-valued ones in fr_inputs, the others (bytes, lengths, selectors: int32) in sm_inputs --
+ *                pob_plan_info gives the two counts; outputs: wires 1 .. n_outputs of the witness (pob_emit_begin / pob_write_wtns),
+ *                which is where the reference's harness reads them (tests/test.py:40-47); pob_results' commitment is zero.          */
 int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint32_t max_batch, pob_handle* out);
 void pob_close(pob_handle h);
 int pob_get_info(pob_handle h, pob_info_t* info);
 /* Layout planner only (no GPU touched): wire / class counts of an instantiation, e.g. to size buffers. */
 int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* info);
 const char* pob_strerror(pob_handle h);
+/* template name (as written after `component main =`, e.g. "SubstringCheck") -> id for params[0] of POB_CIRCUIT_GADGET; *nparams = the
+ * number of template parameters it takes.  -1: not a template of the reference's circuits/utils. */
+int pob_gadget_template(const char* name, int* nparams);
 
 /* Replaces the emitted loader (loadJson; reference tests/test.py:57-59 writes input.json).  Witness-major:
  *   fr_inputs[n][n_fr_inputs][32]  canonical LE field elements, circuit declaration order of the FR-class inputs

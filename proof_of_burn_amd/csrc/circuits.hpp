@@ -36,12 +36,14 @@ enum UnitKind : uint32_t {
     // generation-only unit (UNIT_GEN): the Poseidon(a0 - 1) block at cur with the state spread over lanes (poseidon_wide.hpp);
     // a1 = prefix index, a2..a4 = FR ranks of inputs 1.., a5 = FR rank subtracted from the last input, a6 = FR rank of the caller's copy
     U_POS_WIDE,
+    // gadget-level mains (gadget_mains.hpp): a0 = template, a1..a4 = its parameters | the packed inputs of a main planned from split units
+    U_GM, U_GM_INPUT,
     U_KIND_COUNT
 };
 enum : uint32_t { UNIT_GEN = 1, UNIT_CHECK = 2, UNIT_EMIT = 4 };      // UnitDesc.flags: generation / constraint evaluation / .wtns emission
 // Kernel FAMILIES: every family is compiled as a kernel of its own (own register allocation -- one kernel over every unit kind
 // spilled ~1.9 k VGPRs in the evaluator); generation merges families into the classes of its stage scheduler.
-enum Fam : uint32_t { F_MISC = 0, F_RANGE, F_SELROW, F_LD, F_RL, F_SC, F_POS, F_N2B, F_COUNT };
+enum Fam : uint32_t { F_MISC = 0, F_RANGE, F_SELROW, F_LD, F_RL, F_SC, F_POS, F_N2B, F_GM, F_COUNT };      // F_GM: gadget-level mains (kernels of their own, g_*_gm.hip)
 #define FAM_BIT(f) (1u << (f))
 #define FAM_LIGHT (FAM_BIT(F_MISC) | FAM_BIT(F_RANGE) | FAM_BIT(F_SELROW) | FAM_BIT(F_LD) | FAM_BIT(F_RL))
 #define FAM_HEAVY (FAM_BIT(F_POS) | FAM_BIT(F_N2B))
@@ -53,6 +55,7 @@ HD constexpr uint32_t fam_of(uint32_t k) {
          : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B || k == CK_SR_COLS || k == CK_SL_ROWS) ? F_RL
          : (k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE) ? F_SC
          : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG || k == U_POS_WIDE) ? F_POS
+         : (k == U_GM || k == U_GM_INPUT) ? F_GM
          : (k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_N2B || k == U_PC_POST || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == CK_N2BE) ? F_N2B
          : F_MISC;
 }
@@ -131,7 +134,8 @@ struct UnitDesc { uint32_t kind, stage; Cur cur; uint32_t a[8]; uint32_t cost, f
 #define MAX_SC 64
 // everything a unit body needs besides the policy; lives in device memory, read-only on the device
 struct CircuitLayout {
-    int circuit;                  // 0 = ProofOfBurn, 1 = Spend
+    int circuit;                  // 0 = ProofOfBurn, 1 = Spend, 2 = a gadget-level main (gm)
+    struct { uint32_t tid, nfr_in, nsm_in, nout; } gm;
     uint32_t decl_order;          // policy.hpp POB_DECL_ORDER: the numbering variant this layout was planned with (the device policies follow it)
     PobParams pob; SpendParams spend;
     PobMain pm; SpendMain sm;
@@ -327,6 +331,8 @@ template <class P> GD void kb_post(P& p, const KBRefs& r) {
     p.cur = cur_add(r.c_post, Cur{512 + 32 * 9, 512 + 32 * 8, 32, 0}, 1);
 }
 
+#include "gadget_mains.hpp"
+
 // ---------------------------------------------------------------------------- unit bodies
 // ONE switch over every unit kind; a kernel instantiates it with the MASK of the families it serves and the other cases
 // compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
@@ -341,6 +347,8 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
     (void)M; (void)LB; (void)HBy;
     p.cur = d.cur;
     switch (d.kind) {
+    UCASE(U_GM) { gm_run(p, d, L); } break;
+    UCASE(U_GM_INPUT) { gm_input(p, d); } break;
     UCASE(U_POB_INPUT) {   // SM main inputs [a0, a1) from the packed batch buffer (declaration order = contiguous SM ranks)
         for (uint32_t k = d.a[0]; k < d.a[1]; k++) { SmRef r = {M.numLeafAddressNibbles.w + k, M.numLeafAddressNibbles.i + k}; p.put(r, p.input_sm(k)); }
     } break;
@@ -378,7 +386,8 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const int N = L.pc.N;
         for (int j = 0; j < N; j++) {
             SmRef src;
-            if (L.circuit == 0) src = j == 0 ? M.blockRoot : j == 1 ? M.nullifierBytes : j == 2 ? M.remainingCoinBytes : j == 3 ? M.revealAmountBytes : j == 4 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
+            if (L.circuit == 2) src = L.pc.in + 32 * j;      // PublicCommitment(N) as the main: in[][] holds the packed inputs already (U_GM_INPUT)
+            else if (L.circuit == 0) src = j == 0 ? M.blockRoot : j == 1 ? M.nullifierBytes : j == 2 ? M.remainingCoinBytes : j == 3 ? M.revealAmountBytes : j == 4 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
             else src = j == 0 ? L.sm.coinBytes : j == 1 ? L.sm.withdrawnBalanceBytes : j == 2 ? L.sm.remainingCoinBytes : L.sm.extraCommitmentBytes;
             for (int i = 0; i < 32; i++) p.put(L.pc.in + (32 * j + i), p.get(src + i));
         }
@@ -716,7 +725,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         SmRef f = gFitS(p, 32, 31, L.pc.hash);
         copy_n(p, L.pc.reduced, f, (int)(31));
         F c = p.put(L.pc.out, gBigEndianBytes2NumF(p, 31, L.pc.reduced));
-        p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
+        if (L.circuit != 2) p.put(L.circuit == 0 ? M.commitment : L.sm.commitment, c);
     } break;
     UCASE(U_RL_ACC) {             // RlpEmptyAccount/RlpInteger, field-element part: Num2BigEndianBytes(N)(balance), LessThan(8N), IsZero, Mux1
                                  // (integer.circom:83,88-90); CountBytes/ShiftLeft and the byte assembly run as light units B and C
@@ -967,6 +976,7 @@ struct Plan {
                 : kind == CK_N2BE ? (UNIT_GEN | UNIT_CHECK)                                            // ... and the generator too
                 : kind == U_POS_WIDE ? UNIT_GEN
                 : kind == U_POB_POSEIDONS ? (UNIT_CHECK | UNIT_EMIT)                                   // generation: nothing but the two U_POS_WIDE blocks
+                : kind == U_GM_INPUT ? (UNIT_GEN | UNIT_CHECK)                                           // (the wires belong to the units of the template and are emitted there)
                 : kind == U_POB_INPUT ? UNIT_EMIT                                                      // generation / evaluation: the tile-transposing k_inputs kernel (pob_host.hip)
                 : (UNIT_GEN | UNIT_CHECK | UNIT_EMIT);
         units.push_back(d);
@@ -1040,13 +1050,13 @@ struct Plan {
         unit(U_KB_POST, range_stage + 2, kb);
         if (range_stage + 1 > max_stage) max_stage = range_stage + 1;
     }
-    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst, uint32_t len_input = 0) {
+    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst, uint32_t len_input = 0, bool has_dst = true) {
         L.kbs[kb].mb = mb;
         const Cur start = p.cur;
         unit(U_KB_HEAD, stage, kb, len.w, len.i, len_input);
         const uint32_t m = 136 * mb;
         for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage + 1, start, kb, src.w, src.i, lo, std::min(lo + 16, m));
-        keccak_tail(kb, stage + 1, dst, true);
+        keccak_tail(kb, stage + 1, dst, has_dst);
     }
     // byte-range units of a KeccakBytes whose head ran inside another unit at `head_stage`
     void kb_ranges(uint32_t kb, uint32_t stage, SmRef src) {
@@ -1062,6 +1072,28 @@ struct Plan {
         expect_cursor("LeafDetector", p.cur, chk.cur);
         for (uint32_t k = 0; k < 4; k++) for (uint32_t lo = 0; lo < N; lo += 34) record(U_LD_SELR, stage + 1, p.cur, inst, k, lo, std::min(lo + 34, N));
         record(U_LD_TAIL, stage + 2, p.cur, inst);
+    }
+    // BurnAddressHash (burn_address.circom:67-84): pre | byte ranges +1 | sponge +2 | selector rows, post +3 | Bytes2Nibbles +4.  As a MAIN
+    // (circuit 2) the template's own input wires play the part of the parent's burnKey / revealAmount / burnExtraCommitment.
+    void burn_address_hash(uint32_t pre_stage) {
+        L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
+        L.bah.kb = L.nkb++;
+        if (L.circuit == 2) { L.pm.burnKey = L.bah.in; L.pm.revealAmount = L.bah.in + 1; L.pm.burnExtraCommitment = L.bah.in + 2; L.pm.addressHashNibbles = L.bah.nibbles; }
+        unit(U_BAH_PRE, pre_stage);
+        kb_ranges(L.bah.kb, pre_stage + 1, L.bah.block);
+        keccak_tail(L.bah.kb, pre_stage + 1, L.bah.hash, true);
+        unit(U_BAH_POST, pre_stage + 4);
+    }
+    // ProofOfWorkChecker (proof_of_work.circom:54-81), same stages.  As a main: minimumZeroBytes is an input (powZero = 0 + the stored input wire)
+    void proof_of_work_checker(uint32_t pre_stage) {
+        L.pw.in = p.frs(3); L.pw.mzb = p.sms(1); L.pw.keyBytes = p.sms(32); L.pw.raBytes = p.sms(32); L.pw.becBytes = p.sms(32); L.pw.eip = p.sms(8);
+        L.pw.hin = p.sms(104); L.pw.block = p.sms(136); L.pw.keccak = p.sms(32); L.pw.sbz = p.bits(32);
+        L.pw.kb = L.nkb++;
+        if (L.circuit == 2) { L.pm.burnKey = L.pw.in; L.pm.revealAmount = L.pw.in + 1; L.pm.burnExtraCommitment = L.pw.in + 2; L.pm.byteSecurityRelax = L.pw.mzb; }
+        unit(U_POW_PRE, pre_stage);
+        kb_ranges(L.pw.kb, pre_stage + 1, L.pw.block);
+        keccak_tail(L.pw.kb, pre_stage + 1, L.pw.keccak, true);
+        unit(U_POW_POST, pre_stage + 4);
     }
     void public_commitment(int N, uint32_t pre_stage) {   // public_commitment.circom:18-42
         L.pc.N = N; L.pc.nb = N * 32 / 136 + ((N * 32) % 136 != 0);
@@ -1129,14 +1161,7 @@ struct Plan {
         // the composites that continue from their outputs follow in TB + 2, with the Num2BigEndianBytes blocks beside them (CK_N2BE).
         unit(U_POB_POSEIDONS, TB + 2, 0);
         unit(U_POB_POSEIDONS, TB + 2, 1);
-        {   // BurnAddressHash :119
-            L.bah.nibbles = p.sms(64); L.bah.in = p.frs(3); L.bah.addressBytes = p.sms(20); L.bah.block = p.sms(136); L.bah.hash = p.sms(32);
-            L.bah.kb = L.nkb++;
-            unit(U_BAH_PRE, TB + 2);
-            kb_ranges(L.bah.kb, TB + 3, L.bah.block);
-            keccak_tail(L.bah.kb, TB + 3, L.bah.hash, true);      // sponge TB+4, rows/post TB+5
-            unit(U_BAH_POST, TB + 6);
-        }
+        burn_address_hash(TB + 2);                             // :119
         L.kb_hdr = L.nkb++;
         keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot, M.blockHeaderLen.i - in0 + 1);       // :122
         for (int j = 0; j < 5; j++) unit(U_POB_N2B, TN + 1, j);                                    // :132-136
@@ -1206,18 +1231,82 @@ struct Plan {
             record_composite(U_RL_B, TR + 2, R.c_mux);
             p.cur = chk.cur;
         }
-        {   // ProofOfWorkChecker :211
-            L.pw.in = p.frs(3); L.pw.mzb = p.sms(1); L.pw.keyBytes = p.sms(32); L.pw.raBytes = p.sms(32); L.pw.becBytes = p.sms(32); L.pw.eip = p.sms(8);
-            L.pw.hin = p.sms(104); L.pw.block = p.sms(136); L.pw.keccak = p.sms(32); L.pw.sbz = p.bits(32);
-            L.pw.kb = L.nkb++;
-            unit(U_POW_PRE, TB + 2);                              // (inputs only; in step with BurnAddressHash so that the two sponges share their launches)
-            kb_ranges(L.pw.kb, TB + 3, L.pw.block);
-            keccak_tail(L.pw.kb, TB + 3, L.pw.keccak, true);
-            unit(U_POW_POST, TB + 6);
-        }
+        proof_of_work_checker(TB + 2);                         // :211 (inputs only; in step with BurnAddressHash so that the two sponges share their launches)
         unit(U_POB_FINAL, 10);
         total = p.cur;
         estimate_costs();
+    }
+    // A gadget-level main (gadget_mains.hpp; reference tests/test.py:146-201): template `tid` with parameters prm[0..nprm).  Returns null or
+    // the reason the instantiation is refused.  Mains without a sponge are ONE unit (stage 1); the four Keccak mains are planned from the split
+    // units of the production circuits, with the template's own input wires written from the packed inputs by a U_GM_INPUT unit first.
+    const char* plan_gadget(uint32_t tid, const int* prm, int nprm) {
+        memset(&L, 0, sizeof L);
+        L.circuit = 2; L.nkb = 0; max_stage = 0; ntracks = 1; L.decl_order = p.decl_order;
+        L.pob = PobParams{1, 1, 1, 0, 31, 0, fr_zero(), fr_zero()};
+        L.fp_n2be32 = n2be_footprint(32); L.fp_n2beN = n2be_footprint(31);
+        L.gm.tid = tid;
+        const GmName* nm = nullptr;
+        for (const GmName& g : GM_NAMES) if (g.id == tid) nm = &g;
+        if (!nm) return "unknown gadget template";
+        if (nprm != nm->nparams) return "wrong number of template parameters";
+        const int a = nprm > 0 ? prm[0] : 0, b = nprm > 1 ? prm[1] : 0, c = nprm > 2 ? prm[2] : 0, d = nprm > 3 ? prm[3] : 0;
+        auto in = [](long v, long lo, long hi) { return v >= lo && v <= hi; };
+        bool ok = true;
+        switch (tid) {
+        case GM_CONCAT_FIXED4: ok = in(a, 0, 4096) && in(b, 0, 4096) && in(c, 0, 4096) && in(d, 0, 4096) && a + b + c + d >= 1; break;
+        case GM_PUBLIC_COMMITMENT: ok = in(a, 1, 16); break;
+        case GM_POSEIDON: ok = in(a, 2, 4); break;
+        case GM_DIVIDE: case GM_ASSERT_LESS_EQ_THAN: case GM_ASSERT_LESS_THAN: case GM_ASSERT_GREATER_EQ_THAN: case GM_IS_IN_RANGE: ok = in(a, 1, 30); break;   // int32 signals
+        case GM_SUBSTRING_CHECK: ok = in(b, 1, 31) && in(a, b, 4096); break;
+        case GM_SHIFT_LEFT: ok = in(a, 1, 256); break;
+        case GM_SHIFT_RIGHT: ok = in(a, 1, 4096) && in(b, 0, 4096) && in((long)a * (b + 1), 1, 1 << 20); break;
+        case GM_MASK: case GM_SELECTOR: case GM_BYTES2NIBBLES: case GM_NIBBLES2BYTES: case GM_ASSERT_BYTE_STRING: case GM_FILTER: case GM_REVERSE:
+        case GM_COUNT_BYTES: ok = in(a, 1, 4096); break;
+        case GM_CONCAT: ok = in(a, 1, 2048) && in(b, 1, 2048); break;
+        case GM_SELECTOR_ARRAY_1D: ok = in(a, 1, 4096) && in(b, 1, 4096) && in((long)a * b, 1, 1 << 16); break;
+        case GM_SELECTOR_ARRAY_2D: ok = in(a, 1, 4096) && in(b, 1, 4096) && in(c, 1, 4096) && in((long)a * b * c, 1, 1 << 16); break;
+        case GM_BIG_ENDIAN_BYTES2NUM: case GM_LITTLE_ENDIAN_BYTES2NUM: case GM_RLP_INTEGER: case GM_RLP_EMPTY_ACCOUNT: ok = in(a, 1, 31); break;
+        case GM_NUM2BIG_ENDIAN_BYTES: case GM_NUM2LITTLE_ENDIAN_BYTES: ok = in(a, 1, 32); break;
+        case GM_NUM2BITS_SAFE: ok = in(a, 1, 256); break;
+        case GM_PAD: ok = in(a, 1, 4096) && in(b, 1, 4096) && in((long)a * b, 1, 4096); break;
+        case GM_KECCAK_BYTES: ok = in(a, 1, 32); break;
+        case GM_ASSERT_BITS: ok = in(a, 1, 253); break;
+        case GM_FIT: ok = in(a, 1, 4096) && in(b, 1, 4096); break;
+        case GM_FLATTEN: case GM_RESHAPE: ok = in(a, 1, 4096) && in(b, 1, 4096) && in((long)a * b, 1, 1 << 16); break;
+        case GM_TRUNCATED_ADDRESS_HASH: ok = in(a, 1, 32); break;
+        case GM_LEAF_DETECTOR: ok = in(a, 3, 4096); break;
+        case GM_RLP_MPT_LEAF: ok = in(a, 1, 32) && in(b, 1, 31); break;
+        default: break;
+        }
+        if (!ok) return "template parameters outside the range the gadget-main path supports";
+        p.cur = Cur{1, 0, 0, 0, 0};                     // wire 0 = constant 1; the main component's block starts at wire 1
+        nfr_in = nsm_in = 0;
+        if (tid == GM_KECCAK_BYTES) {                  // keccak.circom:454-489  [out[32] | in[136 mb], inLen | ...]
+            const uint32_t m = 136u * (uint32_t)a;
+            const SmRef own_in = {1 + 32, 32}, own_len = own_in + m;
+            L.nkb = 1;
+            keccak_bytes(0, a, 1, own_in, own_len, SmRef{0, 0}, m + 1, false);
+            const KBRefs& r = L.kbs[0];
+            if (r.in.w != own_in.w || r.in.i != own_in.i || r.inLen.w != own_len.w || r.inLen.i != own_len.i) throw std::runtime_error("layout planner: KeccakBytes main inputs");
+            record(U_GM_INPUT, 1, Cur{1, 0, 0, 0, 0}, 0, 0, 0, own_in.w, own_in.i, m + 1);
+            L.gm.nfr_in = 0; L.gm.nsm_in = m + 1; L.gm.nout = 32;
+        } else if (tid == GM_PUBLIC_COMMITMENT) {      // public_commitment.circom:18-42  [out | in[N][32] | ...]
+            public_commitment(a, 2);
+            record(U_GM_INPUT, 1, Cur{1, 0, 0, 0, 0}, 0, 0, 0, L.pc.in.w, L.pc.in.i, 32u * (uint32_t)a);
+            L.gm.nfr_in = 0; L.gm.nsm_in = 32u * (uint32_t)a; L.gm.nout = 1;
+        } else if (tid == GM_BURN_ADDRESS_HASH) {      // burn_address.circom:67-84  [addressHashNibbles[64] | burnKey, revealAmount, burnExtraCommitment | ...]
+            burn_address_hash(2);                       // (the Poseidon block runs as a U_POS_WIDE unit in stage 1, behind the inputs of stage 0)
+            record(U_GM_INPUT, 0, Cur{1, 0, 0, 0, 0}, L.bah.in.w, L.bah.in.i, 3, 0, 0, 0);
+            L.gm.nfr_in = 3; L.gm.nsm_in = 0; L.gm.nout = 64;
+        } else if (tid == GM_PROOF_OF_WORK_CHECKER) {  // proof_of_work.circom:54-81  [ | burnKey, revealAmount, burnExtraCommitment, minimumZeroBytes | ...]
+            proof_of_work_checker(2);
+            record(U_GM_INPUT, 0, Cur{1, 0, 0, 0, 0}, L.pw.in.w, L.pw.in.i, 3, L.pw.mzb.w, L.pw.mzb.i, 1);
+            L.gm.nfr_in = 3; L.gm.nsm_in = 1; L.gm.nout = 0;
+        } else unit(U_GM, 1, tid, (uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d);
+        nfr_in = L.gm.nfr_in; nsm_in = L.gm.nsm_in;
+        total = p.cur;
+        estimate_costs();
+        return nullptr;
     }
     void plan_spend(const SpendParams& prm) {
         memset(&L, 0, sizeof L);

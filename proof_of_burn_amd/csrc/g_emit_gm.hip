@@ -1,0 +1,3 @@
+// gadget-level mains (gadget_mains.hpp; reference tests/test.py:146-201): one kernel over the whole template list, not on the production path
+#include "g_units.hpp"
+POB_DEFINE_G_LAUNCH(launch_g_emit_gm, GmPol<EmitP>, FAM_BIT(F_GM), 1)

@@ -1152,6 +1152,35 @@ template <class P> GD B gLeafDetector(P& p, int N, SmRef src, S layerLen) {
     return p.put(o, MultiANDg<P, 7>::run(p, m));
 }
 
+// ============================================================================ circuits/utils/keccak.circom:412-446
+// Pad(maxBlocks, blockSize) as a template of its own (KeccakBytes' instance is cut into the kb_head / kb_range units of circuits.hpp)
+// [out[m], numBlocks | in[m], inLen | div, rem, filter[m+1], isEq[m], isLast[m]] || Divide(16), AssertLessEqThan(16), IsEqual([i, inLen]) x m,
+// IsEqual([i, numBlocks*blockSize - 1]) x m;  out[i] = in[i]*filter[i+1] + isEq[i] + 0x80*isLast[i]
+template <class P> GD SmRef gPad(P& p, int mb, int bs, SmRef src, S inLen, S& numBlocks) {
+    const int m = mb * bs;
+    SmRef o = p.sms(m), nbr = p.sms(1), in = p.sms(m), il = p.sms(1), dv = p.sms(1), rm = p.sms(1); BitRef flt = p.bits(m + 1), isEq = p.bits(m), isLast = p.bits(m);
+    copy_n(p, in, src, m);
+    inLen = p.put(il, inLen);
+    S q, r;
+    gDivide(p, 16, inLen, (S)bs, q, r);
+    q = p.put(dv, q); p.put(rm, r);
+    const S nb = p.put(nbr, q + 1);
+    gAssertLessEqThanS(p, 16, nb, (S)mb);
+    B f = p.put(flt, ~(B)0);
+    for (int i = 0; i < m; i++) {
+        const B e = p.put(isEq + i, gIsEqualS(p, (S)i, inLen));
+        f = p.put(flt + i + 1, f & ~e);
+    }
+    const S last = (S)((uint32_t)nb * (uint32_t)bs - 1u);
+    for (int i = 0; i < m; i++) {
+        const B l = p.put(isLast + i, gIsEqualS(p, (S)i, last));
+        const S v = p.get(in + i);
+        p.put(o + i, (p.bit(p.get(flt + i + 1)) ? v : 0) + (S)p.bit(p.get(isEq + i)) + (p.bit(l) ? 0x80 : 0));
+    }
+    numBlocks = nb;
+    return o;
+}
+
 // ============================================================================ circuits/utils/burn_address.circom:47-58
 // BurnAddress  [addressBytes[20] | burnKey, revealAmount, burnExtraCommitment | hash, hashBytes[32]] || Poseidon(4), Num2BigEndianBytes(32), Fit(32,20)
 template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix0, const F& bk, const F& ra, const F& bec, Cur fp_n2be32, const PosSrc& psrc, F* hash_canon = nullptr) {

@@ -50,6 +50,10 @@ void launch_g_check_n2b(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipSt
 void launch_g_emit_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_emit_heavy(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_emit_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+// gadget-level mains (gadget_mains.hpp): generation / evaluation / emission of family F_GM on the policies that resolve input references
+void launch_g_gen_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_check_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_emit_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);

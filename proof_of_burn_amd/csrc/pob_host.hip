@@ -33,8 +33,8 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
     const uint32_t g = w / 64, lane = w % 64;
-    Fr m;
-    for (int k = 0; k < 8; k++) m.l[k] = fr[(uint64_t)g * fr_stride + (uint64_t)out_idx * 512 + k * 64 + lane];
+    Fr m = fr_zero();
+    if (out_idx != 0xFFFFFFFFu) for (int k = 0; k < 8; k++) m.l[k] = fr[(uint64_t)g * fr_stride + (uint64_t)out_idx * 512 + k * 64 + lane];
     Fr c = fr_from_mont(m);
     uint32_t s, cs = POB_NOT_EVALUATED, bw = POB_NOT_EVALUATED;
     if (!chk) {                                           // end of the generation
@@ -216,10 +216,12 @@ static hipStream_t own_stream(pob_ctx* h);      // the handle's own stream (call
 
 // generation scheduling class: 0 = light, 1 = BN254 (byte conversions, range checks, the composites around the Poseidon blocks),
 // 3 = SubstringCheck BN254, 4 = Poseidon blocks with the state spread over lanes (poseidon_wide.hpp)
-#define N_GEN_CLASSES 5
-static uint32_t unit_class(uint32_t kind) { return kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : unit_is_heavy(kind) ? 1 : 0; }
+// 5 = gadget-level mains (gadget_mains.hpp)
+#define N_GEN_CLASSES 6
+static uint32_t unit_class(uint32_t kind) { return fam_of(kind) == F_GM ? 5 : kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : unit_is_heavy(kind) ? 1 : 0; }
 static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
-    if (cls == 4) launch_pos_wide(A, nunits, ngroups, st);
+    if (cls == 5) launch_g_gen_gm(A, nunits, ngroups, st);
+    else if (cls == 4) launch_pos_wide(A, nunits, ngroups, st);
     else if (cls == 3) launch_g_gen_sc(A, nunits, ngroups, st);
     else if (cls == 1) launch_g_gen_n2b(A, nunits, ngroups, st);
     else launch_g_gen_light(A, nunits, ngroups, st);
@@ -233,11 +235,12 @@ static void launch_g_check(const GArgs& A, uint32_t fam, uint32_t nunits, uint32
     case F_RL: launch_g_check_rl(A, nunits, ngroups, st); break;
     case F_SC: launch_g_check_sc(A, nunits, ngroups, st); break;
     case F_POS: launch_g_check_pos(A, nunits, ngroups, st); break;
+    case F_GM: launch_g_check_gm(A, nunits, ngroups, st); break;
     default: launch_g_check_n2b(A, nunits, ngroups, st); break;
     }
 }
 static void launch_g_emit(const GArgs& A, uint32_t cls, uint32_t nunits, hipStream_t st) {
-    if (cls == 3) launch_g_emit_sc(A, nunits, 1, st); else if (cls) launch_g_emit_heavy(A, nunits, 1, st); else launch_g_emit_light(A, nunits, 1, st);
+    if (cls == 5) launch_g_emit_gm(A, nunits, 1, st); else if (cls == 3) launch_g_emit_sc(A, nunits, 1, st); else if (cls) launch_g_emit_heavy(A, nunits, 1, st); else launch_g_emit_light(A, nunits, 1, st);
 }
 
 static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st) {
@@ -305,6 +308,13 @@ static int make_plan(Plan& plan, std::string& err, int circuit, const uint64_t* 
         if (nparams != 1 || !small_param(params, 1, 31, &mab)) { err = "Spend takes maxAmountBytes in 1..31"; return POB_E_ARG; }
         SpendParams sp; sp.maxAmountBytes = mab;
         plan.plan_spend(sp);
+    } else if (circuit == POB_CIRCUIT_GADGET) {
+        // params[0] = the template (pob_gadget_template), params[1..] = its template parameters
+        int tid = 0, prm[4] = {0, 0, 0, 0};
+        if (nparams < 1 || nparams > 5 || !small_param(params, 1, GM_TEMPLATE_COUNT - 1, &tid)) { err = "gadget main: params[0] must be a template id (pob_gadget_template)"; return POB_E_ARG; }
+        for (int k = 1; k < nparams; k++) if (!small_param(params + 4 * k, 0, 1 << 20, &prm[k - 1])) { err = "gadget main: template parameter out of range"; return POB_E_ARG; }
+        const char* why = plan.plan_gadget((uint32_t)tid, prm, nparams - 1);
+        if (why) { err = std::string("gadget main: ") + why; return POB_E_ARG; }
     } else { err = "unknown circuit"; return POB_E_ARG; }
     const Cur t = plan.total;
     if (t.b >= (1u << 29) || t.s >= (1u << 24) || t.f >= (1u << 21) || t.q >= (1u << 26)) {
@@ -314,7 +324,7 @@ static int make_plan(Plan& plan, std::string& err, int circuit, const uint64_t* 
 }
 static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_info_t* info) {
     info->n_witness = pl.total.w; info->n_bit = pl.total.b; info->n_sm = pl.total.s; info->n_fr = pl.total.f;
-    info->n_fr_inputs = pl.nfr_in; info->n_sm_inputs = pl.nsm_in; info->n_outputs = 1;
+    info->n_fr_inputs = pl.nfr_in; info->n_sm_inputs = pl.nsm_in; info->n_outputs = pl.L.circuit == 2 ? pl.L.gm.nout : 1;
     info->n_units = (uint32_t)pl.units.size(); info->n_sponges = (uint32_t)pl.sponges.size(); info->n_perms = nperms;
     { std::vector<char> used(pl.max_stage + 1, 0); for (const UnitDesc& u : pl.units) if (u.flags & UNIT_GEN) used[u.stage] = 1; for (const SpongeDesc& s : pl.sponges) used[s.stage] = 1;
       info->n_stages = 0; for (char c : used) info->n_stages += c; }
@@ -335,6 +345,12 @@ int pob_plan_info(int circuit, const uint64_t* params, int nparams, pob_info_t* 
     if (rc == POB_OK) { uint32_t np = 0; for (const SpongeDesc& sd : plan->sponges) np += sd.n; fill_info(*plan, np, 0, info); }
     delete plan;
     return rc;
+}
+
+int pob_gadget_template(const char* name, int* nparams) {
+    if (!name) return -1;
+    for (const GmName& g : GM_NAMES) if (!strcmp(g.name, name)) { if (nparams) *nparams = g.nparams; return (int)g.id; }
+    return -1;
 }
 
 const char* pob_strerror(pob_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -382,7 +398,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         }
     }
     h->nperms = (uint32_t)perm_sponge.size();
-    for (uint32_t cls = 0; cls < 4; cls++) {             // emission: every generation unit once, grouped by class
+    for (uint32_t cls = 0; cls < N_GEN_CLASSES; cls++) {  // emission: every emitting unit once, grouped by class
         pob_ctx::Seg sg{0, cls, (uint32_t)h->order.size(), 0};
         for (uint32_t u = 0; u < pl.units.size(); u++) if ((pl.units[u].flags & UNIT_EMIT) && unit_class(pl.units[u].kind) == cls) h->order.push_back(u);
         sg.count = (uint32_t)h->order.size() - sg.first;
@@ -439,9 +455,9 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     }
     h->stream3 = h->pool->track1;
     const uint64_t G = h->groups, npad = G * 64;
-    HIPC(hipMalloc(&h->d_bits, G * (uint64_t)pl.total.b * 8));
+    HIPC(hipMalloc(&h->d_bits, G * (uint64_t)std::max(pl.total.b, 1u) * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
-    HIPC(hipMalloc(&h->d_fr, G * (uint64_t)pl.total.f * 2048));
+    HIPC(hipMalloc(&h->d_fr, G * (uint64_t)std::max(pl.total.f, 1u) * 2048));
     HIPC(hipMalloc(&h->d_sb, std::max<uint64_t>(G * (uint64_t)pl.total.q * 64, 64)));
     HIPC(hipMalloc(&h->d_units, pl.units.size() * sizeof(UnitDesc)));
     HIPC(hipMalloc(&h->d_order, h->order.size() * sizeof(uint32_t)));
@@ -461,9 +477,9 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         HIPC(hipMemcpy(h->d_pow256, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice));
     }
     for (int k = 0; k < 2; k++) {
-        HIPC(hipMalloc(&h->d_in_fr[k], npad * (uint64_t)pl.nfr_in * 32));
+        HIPC(hipMalloc(&h->d_in_fr[k], std::max<uint64_t>(npad * (uint64_t)pl.nfr_in * 32, 32)));
         HIPC(hipMalloc(&h->d_in_sm[k], std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
-        HIPC(hipMemset(h->d_in_fr[k], 0, npad * (uint64_t)pl.nfr_in * 32));
+        HIPC(hipMemset(h->d_in_fr[k], 0, std::max<uint64_t>(npad * (uint64_t)pl.nfr_in * 32, 32)));
         HIPC(hipMemset(h->d_in_sm[k], 0, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
         HIPC(hipEventCreateWithFlags(&h->ev_in_done[k], hipEventDisableTiming));
     }
@@ -542,14 +558,14 @@ int pob_get_info(pob_handle h, pob_info_t* info) {
 
 // both upload forms write the buffer the current batch does not use; the next pob_generate switches to it
 int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n) {
-    if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
+    if (!h || n == 0 || n > h->max_batch || (h->plan.nfr_in && !fr_inputs) || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
     const int t = h->in_cur ^ 1;
     if (h->upload_pending) HIPC(hipEventSynchronize(h->ev_upload));         // an asynchronous upload into the same buffer is still in flight
     if (h->in_done_rec[t]) HIPC(hipEventSynchronize(h->ev_in_done[t]));     // the batch before the current one read this buffer
     if (!h->ev_upload) { h->s_upload = h->pool->s_in; HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
     // (on the handle's own non-blocking stream: a hipMemcpy on the legacy stream would wait for every blocking stream of the process)
-    HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, h->s_upload));
+    if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, h->s_upload));
     if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm[t], sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, h->s_upload));
     HIPC(hipStreamSynchronize(h->s_upload));
     h->in_next = t; h->n_next = n; h->upload_pending = false; h->have_next = true;
@@ -557,14 +573,14 @@ int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_
 }
 
 int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_inputs, uint32_t n, void* stream_) {
-    if (!h || n == 0 || n > h->max_batch || !fr_inputs || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
+    if (!h || n == 0 || n > h->max_batch || (h->plan.nfr_in && !fr_inputs) || (h->plan.nsm_in && !sm_inputs)) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
     if (!h->ev_upload) { h->s_upload = h->pool->s_in; HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
     hipStream_t su = stream_ ? (hipStream_t)stream_ : h->s_upload;
     const int t = h->in_cur ^ 1;
     if (h->upload_pending) HIPC(hipStreamWaitEvent(su, h->ev_upload, 0));
     if (h->in_done_rec[t]) HIPC(hipStreamWaitEvent(su, h->ev_in_done[t], 0));   // the batch before the current one read this buffer (long done in a steady loop)
-    HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
+    if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
     if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm[t], sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, su));
     HIPC(hipEventRecord(h->ev_upload, su));
     h->in_next = t; h->n_next = n; h->upload_pending = true; h->have_next = true;
@@ -580,7 +596,8 @@ void pob_host_free(void* p) { if (p) hipHostFree(p); }
 // status / outputs of the batch and its result records; `evaluated`: the evaluator's verdict is part of the record
 static int enqueue_collect(pob_ctx* h, hipStream_t st, bool evaluated) {
     const uint32_t G = (h->n + 63) / 64;
-    const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->plan.L.sm.commitment.i;
+    // (a gadget-level main has no commitment: its outputs are the witness' first wires, read through the emitter)
+    const uint32_t out_idx = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? h->plan.L.pm.commitment.i : h->circuit == POB_CIRCUIT_SPEND ? h->plan.L.sm.commitment.i : 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_collect, dim3((G * 64 + 255) / 256), dim3(256), 0, st, h->d_fr, (uint64_t)h->plan.total.f * 512, out_idx, h->d_status_raw, h->d_status, h->d_outputs,
                        h->d_records, (uint32_t*)h->h_records[h->rec_slot], evaluated ? h->d_chk : nullptr, evaluated ? h->d_bad : nullptr, G * 64);
     HIPC(hipGetLastError());
@@ -689,7 +706,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     // plan (30 configurations, profiles/round2_scheduling_experiments.txt): the Keccak evaluation after the families costs 8.1 ms per
     // pass, beside them 5.8; starting it before the END of the generation (per sponge segment, beside the generation's tail) gains
     // nothing -- the tail is latency-bound on the same memory system and stretches by what the evaluation saves.
-    static const uint32_t side_plan[2][4] = {{F_N2B, F_SC, F_LD, F_RANGE}, {F_RL, F_POS, F_MISC, F_SELROW}};
+    static const uint32_t side_plan[2][5] = {{F_N2B, F_SC, F_LD, F_RANGE, F_GM}, {F_RL, F_POS, F_MISC, F_SELROW, F_COUNT}};      // (F_GM: gadget-level mains only; F_COUNT: no family)
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
     hipStream_t side[2] = {h->partner ? h->pool->chk1 : h->stream2, h->partner ? h->pool->chk2 : h->stream3};

@@ -557,4 +557,14 @@ struct EmitP : DevPol {
         if (m.lane < n) { B s = run_ld_off(i << 3); Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); }
     }
 };
+
+// Gadget-level mains (gadget_mains.hpp: the reference's test wrappers around single templates, tests/test.py:146-201): the main component
+// IS the template, so its SM input arrays are not wires of a parent but the packed inputs.  A reference with w >= GM_INPUT_W stands for
+// "packed SM input i"; the policies the gadget-main kernels run resolve it in get() / get_lane(), everything else is the base policy.
+#define GM_INPUT_W 0xFFF00000u
+template <class Base> struct GmPol : Base {
+    using Base::get;
+    __device__ __forceinline__ S get(SmRef r) { return r.w >= GM_INPUT_W ? this->input_sm(r.i) : Base::get(r); }
+    __device__ __forceinline__ S get_lane(SmRef base, uint32_t k) { return base.w >= GM_INPUT_W ? this->input_sm(base.i + k) : Base::get_lane(base, k); }
+};
 #endif  // __HIPCC__

@@ -1,7 +1,7 @@
 """`run(main, test_cases)` with the signature and semantics of the reference harness (tests/test.py:6-75),
-executed on the HIP calculator instead of `circom -c` + the emitted binary.  Supports the two circuits that
-have a `component main` in the reference (ProofOfBurn(...), Spend(...)); gadget-level mains are covered by
-the CPU oracle in tests/ (they are not on the GPU hot path).
+executed on the HIP calculator instead of `circom -c` + the emitted binary.  Every entry of the reference's list
+(tests/test.py:146-201) runs: the two circuits with a `component main` (ProofOfBurn(...), Spend(...)) and the 54
+gadget-level mains the harness wraps around one template of circuits/utils (csrc/gadget_mains.hpp).
 """
 from .witness import WitnessCalculator
 

@@ -36,6 +36,79 @@ _TPL = {1: "Num2Bits", 2: "IsZero", 3: "AliasCheck", 4: "AssertLessThan", 5: "As
         7: "Divide", 8: "Selector", 9: "ProofOfWorkChecker", 10: "ProofOfBurn", 11: "input", 12: "CompConstant", 13: "misc"}
 FAIL_INPUT_RANGE = (11 << 12) | 1
 
+# Gadget-level mains (reference tests/test.py:146-201: `component main = T(params);` around one template of circuits/utils): the main's
+# input signals in declaration order as (name, class, number of elements); class "f" = field-valued (packed as 32-byte canonical values),
+# "s" = byte / length / selector signals the HIP gadgets compute in int32.  csrc/gadget_mains.hpp reads them in this order.
+GADGET_INPUTS = {
+    "EIP7503": lambda p: [],
+    "ConcatFixed4": lambda p: [("a", "s", p[0]), ("b", "s", p[1]), ("c", "s", p[2]), ("d", "s", p[3])],
+    "ProofOfWorkChecker": lambda p: [("burnKey", "f", 1), ("revealAmount", "f", 1), ("burnExtraCommitment", "f", 1), ("minimumZeroBytes", "s", 1)],
+    "PublicCommitment": lambda p: [("in", "s", 32 * p[0])],
+    "Poseidon": lambda p: [("inputs", "f", p[0])],
+    "Divide": lambda p: [("a", "s", 1), ("b", "s", 1)],
+    "SubstringCheck": lambda p: [("mainInput", "s", p[0]), ("mainLen", "s", 1), ("subInput", "s", p[1])],
+    "ShiftLeft": lambda p: [("in", "s", p[0]), ("count", "s", 1)],
+    "ShiftRight": lambda p: [("in", "s", p[0]), ("count", "s", 1)],
+    "Mask": lambda p: [("in", "s", p[0]), ("count", "s", 1)],
+    "Concat": lambda p: [("a", "s", p[0]), ("aLen", "s", 1), ("b", "s", p[1]), ("bLen", "s", 1)],
+    "Selector": lambda p: [("vals", "s", p[0]), ("select", "s", 1)],
+    "SelectorArray1D": lambda p: [("arrays", "s", p[0] * p[1]), ("select", "s", 1)],
+    "SelectorArray2D": lambda p: [("arrays", "s", p[0] * p[1] * p[2]), ("select", "s", 1)],
+    "BigEndianBytes2Num": lambda p: [("in", "s", p[0])],
+    "LittleEndianBytes2Num": lambda p: [("in", "s", p[0])],
+    "Bytes2Nibbles": lambda p: [("in", "s", p[0])],
+    "Nibbles2Bytes": lambda p: [("nibbles", "s", 2 * p[0])],
+    "Num2BigEndianBytes": lambda p: [("in", "f", 1)],
+    "Num2LittleEndianBytes": lambda p: [("in", "f", 1)],
+    "Num2BitsSafe": lambda p: [("in", "f", 1)],
+    "Pad": lambda p: [("in", "s", p[0] * p[1]), ("inLen", "s", 1)],
+    "KeccakBytes": lambda p: [("in", "s", 136 * p[0]), ("inLen", "s", 1)],
+    "BurnAddress": lambda p: [("burnKey", "f", 1), ("revealAmount", "f", 1), ("burnExtraCommitment", "f", 1)],
+    "BurnAddressHash": lambda p: [("burnKey", "f", 1), ("revealAmount", "f", 1), ("burnExtraCommitment", "f", 1)],
+    "AssertBits": lambda p: [("in", "f", 1)],
+    "AssertByteString": lambda p: [("in", "s", p[0])],
+    "AssertLessEqThan": lambda p: [("a", "s", 1), ("b", "s", 1)],
+    "AssertLessThan": lambda p: [("a", "s", 1), ("b", "s", 1)],
+    "AssertGreaterEqThan": lambda p: [("a", "s", 1), ("b", "s", 1)],
+    "Filter": lambda p: [("in", "s", 1)],
+    "Fit": lambda p: [("in", "s", p[0])],
+    "Reverse": lambda p: [("in", "s", p[0])],
+    "Flatten": lambda p: [("in", "s", p[0] * p[1])],
+    "Reshape": lambda p: [("in", "s", p[0] * p[1])],
+    "RlpInteger": lambda p: [("in", "f", 1)],
+    "CountBytes": lambda p: [("bytes", "s", p[0])],
+    "RlpEmptyAccount": lambda p: [("balance", "f", 1)],
+    "TruncatedAddressHash": lambda p: [("addressHashNibbles", "s", 2 * p[0]), ("addressHashNibblesLen", "s", 1)],
+    "IsInRange": lambda p: [("lower", "s", 1), ("value", "s", 1), ("upper", "s", 1)],
+    "LeafDetector": lambda p: [("layer", "s", p[0]), ("layerLen", "s", 1)],
+    "RlpMerklePatriciaTrieLeaf": lambda p: [("addressHashNibbles", "s", 2 * p[0]), ("addressHashNibblesLen", "s", 1), ("balance", "f", 1)],
+}
+
+
+def circuit_of(name: str, params):
+    """(circuit id, parameter list) for pob_plan_info / pob_open: the two production circuits, or a gadget-level main (template id first)"""
+    if name == "ProofOfBurn":
+        return 0, list(params)
+    if name == "Spend":
+        return 1, list(params)
+    if name not in GADGET_INPUTS:
+        raise NotImplementedError(f"{name} is not a template of the reference's circuits")
+    npar = ctypes.c_int()
+    tid = load_library().pob_gadget_template(name.encode(), ctypes.byref(npar))
+    if tid < 0:
+        raise NotImplementedError(f"{name}: unknown to libpob_hip.so")
+    if npar.value != len(params):
+        raise ValueError(f"{name} takes {npar.value} template parameters, got {len(params)}")
+    return 2, [tid] + list(params)
+
+
+def _limbs(params):
+    arr = (ctypes.c_uint64 * (4 * max(len(params), 1)))()
+    for i, v in enumerate(params):
+        for k in range(4):
+            arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return arr
+
 
 class PobInfo(ctypes.Structure):
     _fields_ = [("n_witness", ctypes.c_uint64), ("n_bit", ctypes.c_uint64), ("n_sm", ctypes.c_uint64), ("n_fr", ctypes.c_uint64),
@@ -69,6 +142,8 @@ def load_library() -> ctypes.CDLL:
     lib.pob_plan_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.POINTER(PobInfo)]
     lib.pob_strerror.argtypes = [vp]
     lib.pob_strerror.restype = ctypes.c_char_p
+    lib.pob_gadget_template.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    lib.pob_gadget_template.restype = ctypes.c_int
     lib.pob_upload_inputs.argtypes = [vp, vp, vp, ctypes.c_uint32]
     lib.pob_upload_inputs_async.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
     lib.pob_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
@@ -109,7 +184,7 @@ def load_library() -> ctypes.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ["pob_plan_info", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
+EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
                     "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
@@ -121,15 +196,11 @@ def plan_info(main: str) -> PobInfo:
 
 
 def plan_info_of(name: str, params) -> PobInfo:
-    circuit = {"ProofOfBurn": 0, "Spend": 1}[name]
-    arr = (ctypes.c_uint64 * (4 * len(params)))()
-    for i, v in enumerate(params):
-        for k in range(4):
-            arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    circuit, cparams = circuit_of(name, params)
     info = PobInfo()
-    rc = load_library().pob_plan_info(circuit, arr, len(params), ctypes.byref(info))
+    rc = load_library().pob_plan_info(circuit, _limbs(cparams), len(cparams), ctypes.byref(info))
     if rc != 0:
-        raise ValueError(f"pob_plan_info rc={rc}")
+        raise ValueError(f"pob_plan_info rc={rc}: unsupported instantiation {name}{tuple(params)}")
     return info
 
 
@@ -189,6 +260,8 @@ def pack_inputs(main, inputs: Sequence[dict], info: PobInfo | None = None):
     cannot hold as int64 (strings, huge ints -- the loader's mod-p path) fall back to per-element parsing.  Needs no GPU."""
     name, params = _main_of(main)
     info = info or plan_info_of(name, params)
+    if name not in ("ProofOfBurn", "Spend"):
+        return _pack_gadget_inputs(name, params, inputs, info)
     n = len(inputs)
     nfr, nsm = info.n_fr_inputs, info.n_sm_inputs
     fr = np.zeros((n, nfr, 32), dtype=np.uint8)
@@ -237,6 +310,42 @@ def pack_inputs(main, inputs: Sequence[dict], info: PobInfo | None = None):
             col += cnt
         assert col == nsm
     return fr, sm, forced
+
+
+def _pack_gadget_inputs(name, params, inputs: Sequence[dict], info: PobInfo):
+    """the loader for a gadget-level main: every input signal of the template must be present with its declared number of elements
+    (the emitted loader aborts otherwise: KeyError / ValueError here); values are reduced mod p like loadJson does.  An "s" signal whose
+    value does not fit int32 cannot be represented by the HIP gadgets: NotImplementedError (loud, never a wrong answer)."""
+    spec = GADGET_INPUTS[name](params)
+    n = len(inputs)
+    nfr = sum(c for _, k, c in spec if k == "f")
+    nsm = sum(c for _, k, c in spec if k == "s")
+    if (nfr, nsm) != (info.n_fr_inputs, info.n_sm_inputs):
+        raise RuntimeError(f"{name}: the loader's input table ({nfr} field / {nsm} small) disagrees with the planner ({info.n_fr_inputs} / {info.n_sm_inputs})")
+    fr = np.zeros((n, max(nfr, 1), 32), dtype=np.uint8)
+    sm = np.zeros((n, max(nsm, 1)), dtype=np.int32)
+    want = {nm for nm, _, _ in spec}
+    for w, d in enumerate(inputs):
+        keys = set(d.keys())
+        if keys != want:
+            raise KeyError(f"input {w}: missing {sorted(want - keys)} unexpected {sorted(keys - want)}")
+        cf = cs = 0
+        for nm, kind, cnt in spec:
+            vals = []
+            _flat(d[nm], vals)
+            if len(vals) != cnt:
+                raise ValueError(f"input {w}: {nm} has {len(vals)} elements, {name} expects {cnt}")
+            for v in vals:
+                if kind == "f":
+                    fr[w, cf] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+                    cf += 1
+                else:
+                    sv = v if v < (1 << 31) else v - P          # small negative values arrive as p - |v|
+                    if not -(1 << 31) <= sv < (1 << 31):
+                        raise NotImplementedError(f"input {w}: {nm} = {v} does not fit the int32 class the HIP gadget path keeps this signal in")
+                    sm[w, cs] = sv
+                    cs += 1
+    return fr, sm, np.zeros(n, dtype=np.uint32)
 
 
 def pack_json(main, texts: Sequence[bytes | str], threads: int = 0, out: "PinnedInputs | None" = None, info: PobInfo | None = None):
@@ -301,16 +410,12 @@ class WitnessCalculator:
             self.L, self.NB, self.HB = params[0], params[1], params[2]
         elif name == "Spend":
             circuit = 1
-        else:
-            raise NotImplementedError(f"the HIP calculator implements the two `component main` circuits (ProofOfBurn, Spend); got {name}")
         self.lib = load_library()
+        circuit, cparams = circuit_of(name, params)       # (a gadget-level main: circuit 2, template id in front of the parameters)
+        self.is_gadget = circuit == 2
         self.device = device
-        arr = (ctypes.c_uint64 * (4 * len(params)))()
-        for i, v in enumerate(params):
-            for k in range(4):
-                arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
         self.h = ctypes.c_void_p()
-        rc = self.lib.pob_open(device, circuit, arr, len(params), max_batch, ctypes.byref(self.h))
+        rc = self.lib.pob_open(device, circuit, _limbs(cparams), len(cparams), max_batch, ctypes.byref(self.h))
         if rc != 0:
             msg = self.lib.pob_strerror(self.h).decode() if self.h else "pob_open failed"
             raise RuntimeError(f"pob_open: {msg} (rc={rc})")
@@ -422,7 +527,10 @@ class WitnessCalculator:
         res = []
         for i in range(n):
             st = int(self._forced[i]) or int(status[i])
-            out = None if st else [int.from_bytes(outs[i].tobytes(), "little")]
+            if self.is_gadget:                 # the main's outputs are the first wires of its witness (tests/test.py:40-47)
+                out = None if st else self.output_signals(i)
+            else:
+                out = None if st else [int.from_bytes(outs[i].tobytes(), "little")]
             r = Result(st, out)
             if with_check:
                 r.check_status = 0 if chk[i] == 0xFFFFFFFF else int(chk[i])
@@ -439,6 +547,17 @@ class WitnessCalculator:
         if check:
             self.constraint_check()
         return self.results(with_check=check)
+
+    def output_signals(self, idx: int) -> list:
+        """witness[1 .. nOutputs] of witness idx, read through the emitter's first window (what the reference's patched main.cpp prints)"""
+        nout = int(self.info.n_outputs)
+        if nout == 0:
+            return []
+        for w0, view in self.witness_windows(idx, max(nout + 1, min(self.nwitness, 1 << 16))):
+            assert w0 == 0 and view.size >= 32 * (nout + 1)
+            b = view[32:32 * (nout + 1)].tobytes()
+            return [int.from_bytes(b[32 * k:32 * k + 32], "little") for k in range(nout)]
+        raise RuntimeError("empty witness")
 
     def witness_payload(self, idx: int = 0) -> np.ndarray:
         """canonical 32-byte LE values of witness `idx` (the .wtns section 2 payload) as a uint8 array"""
