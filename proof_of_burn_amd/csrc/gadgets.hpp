@@ -13,7 +13,9 @@
 #include <type_traits>
 #include "policy.hpp"
 
-#if defined(__HIPCC__) && (defined(__HIP_DEVICE_COMPILE__) || defined(POB_HOSTSIM))
+#if defined(POB_GM_KERNELS) && defined(__HIPCC__)
+#define GD __host__ __device__ inline            // the gadget-level mains' kernels (g_*_gm.hip): 40 templates in one switch, off the production path -- called, not inlined (compile time)
+#elif defined(__HIPCC__) && (defined(__HIP_DEVICE_COMPILE__) || defined(POB_HOSTSIM))
 #define GD __host__ __device__ __forceinline__   // the policy object must stay in registers: one non-inlined callee taking P& forces it (and every p.cur/p.m access) through memory
 #elif defined(__HIPCC__)
 #define GD __host__ __device__ inline            // host pass (layout planner): no forced inlining -- it only made the planner's translation unit slow to compile
