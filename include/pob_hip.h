@@ -144,6 +144,11 @@ int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires);
  * of the reduced payload (first_wire / n_wires count kept wires).  The map is uploaded once per (handle, keep pointer contents).   */
 int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uint64_t n_keep, uint64_t window_wires);
 int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires);
+/* Announce the witness that will be emitted AFTER the current (or the next) one, with the same payload kind and window size: its first
+ * window -- the one that holds most gadget wires and takes longest to expand -- is then expanded while the current witness' last windows are
+ * still being copied, and the pob_emit_begin* / pob_write_wtns* call for it continues from there (three window slots per handle).  Without
+ * it every witness pays its first expansion un-overlapped (6 of 134 ms for the production circuit).  POB_E_STATE: next_idx failed an assert. */
+int pob_emit_queue(pob_handle h, uint32_t next_idx);
 /* Measurement: `count` witnesses from `first_idx` on, back to back through the window pipeline into pinned host memory.          */
 int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes);
 /* The same with an optional reduced map (keep != NULL: pob_emit_begin_reduced).  The first witness a handle emits at a window size

@@ -150,9 +150,16 @@ struct pob_ctx {
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
     struct Emit {
-        uint8_t* d_win[2] = {nullptr, nullptr}; uint8_t* h_pin[2] = {nullptr, nullptr};
-        hipStream_t s_copy = nullptr; hipEvent_t ev_made[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+        // THREE window slots: one with the caller, one being copied, one being expanded -- so that the first window of the NEXT witness
+        // (pob_emit_queue) is expanded while the last windows of the current one are still on their way to the host
+        enum { NSLOT = 3 };
+        uint8_t* d_win[NSLOT] = {nullptr, nullptr, nullptr}; uint8_t* h_pin[NSLOT] = {nullptr, nullptr, nullptr};
+        hipStream_t s_copy = nullptr; hipEvent_t ev_made[NSLOT] = {nullptr, nullptr, nullptr}, ev_copied[NSLOT] = {nullptr, nullptr, nullptr}, ev_free[NSLOT] = {nullptr, nullptr, nullptr};
         uint64_t win_wires = 0, alloc_wires = 0, next_make = 0, next_take = 0, nwin = 0; uint32_t idx = 0; bool active = false;
+        uint32_t first_slot = 0;                        // slot of the current witness' window 0 (window k: (first_slot + k) % NSLOT)
+        int64_t queued_idx = -1; bool pre_made = false; // pob_emit_queue: the witness the next pob_emit_begin* will ask for / its window 0 is made
+        std::vector<uint32_t> status_host; uint64_t status_gen = 0;      // the batch's generation statuses, fetched once per generation
+        const uint32_t* map_ptr = nullptr; uint64_t map_sample = 0;     // reduced: address / sampled fingerprint of the caller's map at its last full validation
         struct Run { uint32_t w, b, n; };
         std::vector<Run> runs;                          // the Keccak-owned BIT runs (wire index, BIT rank, count), sorted by wire index
         // which G units write into which window (found by one probe pass per window size): a window launches only those
@@ -179,7 +186,7 @@ struct pob_ctx {
     struct Track { hipStream_t s_main = nullptr, s_heavy = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_end = nullptr; };
     Track tracks[Plan::MAX_TRACKS];
     uint32_t nperms = 0;
-    bool generated = false;
+    bool generated = false; uint64_t gen_count = 0;
     // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
     // waits for the end of that evaluation; the evaluation then uses the pool's two evaluation streams
     pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
@@ -512,9 +519,9 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
+                    h->d_inv, h->d_pow256, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
         for (hipEvent_t e : {h->em.ev_made[k], h->em.ev_copied[k], h->em.ev_free[k]}) if (e) hipEventDestroy(e);
     }
@@ -690,7 +697,7 @@ int pob_generate(pob_handle h, void* stream_) {
     { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
     HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
     HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
-    h->generated = true; h->evaluated = false;
+    h->generated = true; h->evaluated = false; h->gen_count++;
     return POB_OK;
 }
 
@@ -817,9 +824,8 @@ int pob_results_records_device(pob_handle h, void** d_records) {
 // the production instantiation) never exists on the device as a whole: it is expanded window by window from the compact resident
 // vector, each window goes D2H into pinned memory on a copy stream while the next one is being expanded and the caller consumes
 // the previous one.
-static int emit_make_window(pob_ctx* h, uint64_t k) {
+static int emit_make_window(pob_ctx* h, uint32_t idx, uint64_t k, int slot) {
     pob_ctx::Emit& E = h->em;
-    const int slot = (int)(k & 1);
     const uint64_t w0 = k * E.win_wires, wn = std::min(E.win_wires, E.total - w0);      // positions of the payload (kept wires in reduced mode)
     hipStream_t st = own_stream(h);
     HIPC(hipStreamWaitEvent(st, E.ev_free[slot], 0));                       // the copy of the window that used this slot before is done
@@ -828,7 +834,7 @@ static int emit_make_window(pob_ctx* h, uint64_t k) {
     hipLaunchKernelGGL(k_fill_ee, dim3(2048), dim3(256), 0, st, (uint4*)E.d_win[slot], wn * 2);
     if (w0 == 0) { const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}; HIPC(hipMemcpyAsync(E.d_win[slot], one, 32, hipMemcpyHostToDevice, st)); }   // wire 0 = 1 (always kept)
     GArgs A = gargs(h);
-    A.emit_out = E.d_win[slot]; A.emit_sel = E.idx % 64; A.emit_group = E.idx / 64; A.emit_w0 = (uint32_t)w0; A.emit_wn = (uint32_t)wn;
+    A.emit_out = E.d_win[slot]; A.emit_sel = idx % 64; A.emit_group = idx / 64; A.emit_w0 = (uint32_t)w0; A.emit_wn = (uint32_t)wn;
     if (E.red) { A.emit_rbits = E.d_rbits; A.emit_rpre = E.d_rpre; }
     if (E.probe_win == E.win_wires && E.probe_map == E.map_id && k < E.wsegs.size()) {      // only the units that write into this window
         A.order = E.d_order;
@@ -836,18 +842,18 @@ static int emit_make_window(pob_ctx* h, uint64_t k) {
     } else {
         for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, st); }
     }
-    const u64* Gp = (const u64*)h->d_bits + (uint64_t)(E.idx / 64) * h->plan.total.b;
+    const u64* Gp = (const u64*)h->d_bits + (uint64_t)(idx / 64) * h->plan.total.b;
     // the Keccak kernels' wires: contiguous BIT runs cut to the window (reduced: cut to the window's wire range, runs without a kept wire skipped)
     const uint64_t wire_lo = E.red ? E.keep[w0] : w0, wire_hi = E.red ? (uint64_t)E.keep[w0 + wn - 1] + 1 : w0 + wn;
     for (const pob_ctx::Emit::Run& r : E.runs) {
         const uint64_t lo = std::max<uint64_t>(r.w, wire_lo), hi = std::min<uint64_t>((uint64_t)r.w + r.n, wire_hi);
         if (lo >= hi) continue;
-        if (!E.red) launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), E.idx % 64, st);
+        if (!E.red) launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), idx % 64, st);
         else {
             const auto a = std::lower_bound(E.keep.begin() + w0, E.keep.begin() + w0 + wn, (uint32_t)lo), b = std::lower_bound(a, E.keep.begin() + w0 + wn, (uint32_t)hi);
             if (a == b) continue;                                           // (a round block whose wires are all dropped costs nothing)
             const uint64_t lo2 = *a, hi2 = (uint64_t)*(b - 1) + 1;
-            launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), E.idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
+            launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
         }
     }
     HIPC(hipGetLastError());
@@ -868,24 +874,53 @@ static uint64_t fnv64(const void* p, size_t n) {
     return hsh ? hsh : 1;
 }
 
+// fingerprint of 1 024 evenly spaced 16-entry blocks of a map (and its ends): recognises the map a caller passes again and again -- the full
+// hash of a production map (86 MB) costs 9 ms per witness, a third of a reduced emission
+static uint64_t fnv64_sampled(const uint32_t* keep, uint64_t n) {
+    uint64_t hsh = fnv64(keep, std::min<uint64_t>(n, 64) * 4) ^ fnv64(keep + (n > 64 ? n - 64 : 0), std::min<uint64_t>(n, 64) * 4);
+    if (n > (1u << 15)) for (uint64_t b = 0; b < 1024; b++) hsh = (hsh * 1099511628211ull) ^ fnv64(keep + (n / 1024) * b, 64);
+    return hsh ? hsh : 1;
+}
+// the generation statuses of the current batch on the host (one D2H per generation): no witness is emitted for a failed input
+static int emit_statuses(pob_ctx* h) {
+    pob_ctx::Emit& E = h->em;
+    if (E.status_gen == h->gen_count && E.status_host.size() == h->n) return POB_OK;
+    HIPC(hipEventSynchronize(h->ev_gen_done));
+    E.status_host.resize(h->n);
+    HIPC(hipMemcpyAsync(E.status_host.data(), h->d_status, (size_t)h->n * 4, hipMemcpyDeviceToHost, own_stream(h)));
+    HIPC(hipStreamSynchronize(own_stream(h)));
+    E.status_gen = h->gen_count;
+    return POB_OK;
+}
+
 // common part of pob_emit_begin / pob_emit_begin_reduced: E.red / E.map_id / E.total are set
 static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
     pob_ctx::Emit& E = h->em;
-    // this handle's work only (a partner handle may be busy): the generation of the batch, and the copies of a previous witness
+    const int NS = pob_ctx::Emit::NSLOT;
+    // this handle's work only (a partner handle may be busy): the generation of the batch
     HIPC(hipEventSynchronize(h->ev_gen_done));
     if (h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
-    if (E.s_copy) HIPC(hipStreamSynchronize(E.s_copy));
     {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
-        uint32_t st_w = 0;
-        HIPC(hipMemcpyAsync(&st_w, h->d_status + idx, 4, hipMemcpyDeviceToHost, own_stream(h)));
-        HIPC(hipStreamSynchronize(own_stream(h)));
-        if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; return POB_E_STATE; }
+        int rc = emit_statuses(h); if (rc) return rc;
+        const uint32_t st_w = E.status_host[idx];
+        if (st_w != 0) { h->err = "witness " + std::to_string(idx) + " failed an assert (status " + std::to_string(st_w) + "): nothing to emit"; E.queued_idx = -1; E.pre_made = false; return POB_E_STATE; }
     }
     if (window_wires == 0) window_wires = 8ull << 20;                       // 8 Mi wires = 256 MiB windows
     window_wires = std::min<uint64_t>(window_wires, E.total);
+    const uint64_t nwin_ = (E.total + window_wires - 1) / window_wires;
+    // the witness announced with pob_emit_queue, same payload and window size: its first window has been expanded (and is being copied)
+    // behind the previous witness' last windows already -- continue from there, nothing to wait for
+    if (E.pre_made && E.queued_idx == (int64_t)idx && E.win_wires == window_wires && E.nwin == nwin_ && E.probe_map == E.map_id && E.status_gen == h->gen_count) {
+        E.first_slot = (E.first_slot + (uint32_t)E.nwin) % NS;
+        E.idx = idx; E.next_make = 1; E.next_take = 0; E.active = true; E.queued_idx = -1; E.pre_made = false;
+        return POB_OK;
+    }
+    if (E.pre_made || E.queued_idx == (int64_t)idx) E.queued_idx = -1;      // (an announcement made BEFORE this begin, for the witness after this one, stays)
+    E.pre_made = false;
+    if (E.s_copy) HIPC(hipStreamSynchronize(E.s_copy));                    // the copies of a previous witness (an abandoned emission, a discarded first window)
     if (!E.s_copy) {
         HIPC(hipStreamCreateWithPriority(&E.s_copy, hipStreamNonBlocking, 0));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < NS; k++) {
             HIPC(hipEventCreateWithFlags(&E.ev_made[k], hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
             HIPC(hipEventCreateWithFlags(&E.ev_free[k], hipEventDisableTiming));
         }
@@ -896,7 +931,7 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         std::sort(E.runs.begin(), E.runs.end(), [](const pob_ctx::Emit::Run& a, const pob_ctx::Emit::Run& b) { return a.w < b.w; });
     }
     if (E.alloc_wires < window_wires) {                                     // (re)allocated only when a larger window is asked for: K witnesses reuse the buffers
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < NS; k++) {
             if (E.d_win[k]) { HIPC(hipFree(E.d_win[k])); E.d_win[k] = nullptr; }
             if (E.h_pin[k]) { HIPC(hipHostFree(E.h_pin[k])); E.h_pin[k] = nullptr; }
             HIPC(hipMalloc(&E.d_win[k], window_wires * 32));
@@ -904,7 +939,6 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         }
         E.alloc_wires = window_wires;
     }
-    const uint64_t nwin_ = (E.total + window_wires - 1) / window_wires;
     if ((E.probe_win != window_wires || E.probe_map != E.map_id) && nwin_ <= 64) {
         // probe pass: every G unit runs once with the emitter's stores replaced by "mark window position / window_wires"; a window then
         // launches only the units that can write into it (most windows hold nothing but Keccak round wires)
@@ -932,10 +966,10 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         HIPC(hipMalloc(&E.d_order, std::max<size_t>(order.size(), 1) * 4));
         if (!order.empty()) HIPC(hipMemcpy(E.d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
         E.probe_win = window_wires; E.probe_map = E.map_id;
-    }
-    for (int k = 0; k < 2; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
-    E.win_wires = window_wires; E.nwin = nwin_; E.idx = idx; E.next_make = 0; E.next_take = 0; E.active = true;
-    for (; E.next_make < std::min<uint64_t>(1, E.nwin); E.next_make++) { int rc = emit_make_window(h, E.next_make); if (rc) return rc; }
+    } else if (nwin_ > 64) { E.probe_win = 0; E.probe_map = E.map_id; }       // (too many windows for the probe's 64-bit masks: every unit runs for every window)
+    for (int k = 0; k < NS; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
+    E.win_wires = window_wires; E.nwin = nwin_; E.idx = idx; E.next_make = 0; E.next_take = 0; E.first_slot = 0; E.active = true;
+    for (; E.next_make < std::min<uint64_t>(1, E.nwin); E.next_make++) { int rc = emit_make_window(h, idx, E.next_make, (int)((E.first_slot + E.next_make) % NS)); if (rc) return rc; }
     return POB_OK;
 }
 
@@ -953,7 +987,10 @@ int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uin
     HIPC(hipSetDevice(h->device));
     pob_ctx::Emit& E = h->em;
     const uint64_t W = h->plan.total.w;
-    const uint64_t id = fnv64(keep, n_keep * 4) ^ (n_keep << 1);
+    // the map the caller passed last time (same address, same length, same sampled fingerprint) is not hashed / validated again
+    const uint64_t sample = fnv64_sampled(keep, n_keep);
+    const bool same = E.map_id && keep == E.map_ptr && E.keep.size() == n_keep && sample == E.map_sample;
+    const uint64_t id = same ? E.map_id : (fnv64(keep, n_keep * 4) ^ (n_keep << 1));
     if (id != E.map_id || E.keep.size() != n_keep) {
         // a new map: validate (wire 0 first, strictly increasing, inside the circuit), build the bitmap and the per-word ranks, upload
         if (keep[0] != 0 || keep[n_keep - 1] >= W) { h->err = "reduced map: keep[0] must be wire 0 and every index must be < nWitness"; return POB_E_ARG; }
@@ -973,7 +1010,9 @@ int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uin
         HIPC(hipMemcpy(E.d_rbits, bits.data(), nwords * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(E.d_rpre, pre.data(), nwords * 4, hipMemcpyHostToDevice));
         E.keep.assign(keep, keep + n_keep);
+        E.queued_idx = -1; E.pre_made = false;
     }
+    E.map_ptr = keep; E.map_sample = sample;
     E.red = true; E.map_id = id; E.total = n_keep;
     return emit_start(h, idx, window_wires);
 }
@@ -984,11 +1023,35 @@ int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint
     if (!E.active) { h->err = "pob_emit_next without pob_emit_begin"; return POB_E_STATE; }
     if (E.next_take == E.nwin) { E.active = false; *data = nullptr; *first_wire = E.total; *n_wires = 0; return POB_OK; }
     HIPC(hipSetDevice(h->device));
-    // the window handed out by the previous call is released now: its slot takes the window after the one returned here
-    if (E.next_make < E.nwin && E.next_make <= E.next_take + 1) { int rc = emit_make_window(h, E.next_make); if (rc) return rc; E.next_make++; }
+    const int NS = pob_ctx::Emit::NSLOT;
+    // the window handed out by the previous call is released now.  Two windows beyond the one returned here are kept in the making: one is
+    // being copied while the caller works on this one, the next one is being expanded
+    while (E.next_make < E.nwin && E.next_make <= E.next_take + 2) {
+        int rc = emit_make_window(h, E.idx, E.next_make, (int)((E.first_slot + E.next_make) % NS)); if (rc) return rc;
+        E.next_make++;
+    }
+    // ... and when this witness has no more windows to make, the first window of the witness announced with pob_emit_queue
+    if (E.next_make == E.nwin && E.nwin - E.next_take <= 2 && E.queued_idx >= 0 && !E.pre_made) {
+        int rc = emit_make_window(h, (uint32_t)E.queued_idx, 0, (int)((E.first_slot + E.nwin) % NS)); if (rc) return rc;
+        E.pre_made = true;
+    }
     const uint64_t k = E.next_take++;
-    HIPC(hipEventSynchronize(E.ev_copied[k & 1]));
-    *data = E.h_pin[k & 1]; *first_wire = k * E.win_wires; *n_wires = std::min(E.win_wires, E.total - k * E.win_wires);
+    const int slot = (int)((E.first_slot + k) % NS);
+    HIPC(hipEventSynchronize(E.ev_copied[slot]));
+    *data = E.h_pin[slot]; *first_wire = k * E.win_wires; *n_wires = std::min(E.win_wires, E.total - k * E.win_wires);
+    return POB_OK;
+}
+
+int pob_emit_queue(pob_handle h, uint32_t next_idx) {
+    if (!h) return POB_E_ARG;
+    pob_ctx::Emit& E = h->em;
+    if (!h->generated) { h->err = "nothing generated"; return POB_E_STATE; }
+    if (next_idx >= h->n) { h->err = "witness index out of range"; return POB_E_STATE; }
+    if (E.pre_made) return POB_OK;                      // (a first window is on its way already: one announcement at a time)
+    HIPC(hipSetDevice(h->device));
+    { int rc = emit_statuses(h); if (rc) return rc; }
+    if (E.status_host[next_idx] != 0) { h->err = "witness " + std::to_string(next_idx) + " failed an assert: nothing to emit"; return POB_E_STATE; }
+    E.queued_idx = next_idx;
     return POB_OK;
 }
 
@@ -1054,6 +1117,7 @@ int pob_emit_measure_ex(pob_handle h, uint32_t first_idx, uint32_t count, uint64
     for (uint32_t i = 0; i < count; i++) {
         int rc = keep ? pob_emit_begin_reduced(h, first_idx + i, keep, n_keep, window_wires) : pob_emit_begin(h, first_idx + i, window_wires);
         if (rc) return rc;
+        if (i + 1 < count) { rc = pob_emit_queue(h, first_idx + i + 1); if (rc) return rc; }
         for (;;) {
             const uint8_t* p; uint64_t w0, wn;
             rc = pob_emit_next(h, &p, &w0, &wn);

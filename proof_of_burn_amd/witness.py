@@ -168,6 +168,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_write_wtns.argtypes = [vp, ctypes.c_uint32, ctypes.c_char_p]
     lib.pob_emit_begin.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
     lib.pob_emit_next.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.pob_emit_queue.argtypes = [vp, ctypes.c_uint32]
     lib.pob_emit_measure.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_time_kernel.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.pob_probe_check_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
@@ -187,7 +188,7 @@ def load_library() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -594,6 +595,10 @@ class WitnessCalculator:
                 return
             buf = (ctypes.c_uint8 * (32 * wn.value)).from_address(p.value)
             yield w0.value, np.frombuffer(buf, dtype=np.uint8)
+
+    def emit_queue(self, next_idx: int):
+        """announce the witness emitted after the current / next one (pob_emit_queue): its first window is expanded behind the current one's last"""
+        self._ck(self.lib.pob_emit_queue(self.h, next_idx))
 
     def witness_payload_reduced(self, idx: int, keep, window_wires: int = 0) -> np.ndarray:
         """the reduced payload (32 B per kept wire) as one array"""

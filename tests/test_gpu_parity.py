@@ -611,3 +611,37 @@ def test_gadget_mains_seeded_differential(pkg):
         total += nok
     assert not bad, bad[:4]
     assert total > 1500
+
+
+def test_queued_emission_equals_one_at_a_time(pkg):
+    """two witnesses in flight (pob_emit_queue, three rotating window slots): every window of every witness equals what the same witness
+    gives emitted alone -- which test_reference_suite_proof_of_burn_and_wtns compares with the oracle -- for the O0 and the reduced payload"""
+    import hashlib
+    s = _suite("test_proof_of_burn")
+    ok_cases = [c["input"] for c in s["cases"] if c["expected"] is not None]
+    inputs = [ok_cases[i % len(ok_cases)] for i in range(5)]
+    inputs[2] = dict(inputs[2]); inputs[2]["burnExtraCommitment"] = "12345"      # (a different witness: fails the PoW or not, either is fine)
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=5)
+    res = calc.calculate(inputs)
+    good = [i for i, r in enumerate(res) if r.ok]
+    assert len(good) >= 3
+    W = calc.nwitness
+    keep = np.arange(0, W, 7, dtype=np.uint32)
+
+    def digest(idx, win, kp, queue_next=None):
+        h, pos = hashlib.sha256(), 0
+        for w0, view in calc.witness_windows(idx, window_wires=win, keep=kp):
+            if w0 == 0 and queue_next is not None:
+                calc.emit_queue(queue_next)
+            assert w0 == pos
+            h.update(view.tobytes()); pos += view.size // 32
+        assert pos == (W if kp is None else kp.size)
+        return h.hexdigest()
+
+    for kp in (None, keep):
+        for win in (4 << 20, 3_000_001):
+            alone = {i: digest(i, win, kp) for i in good}
+            seq = good + good[::-1]
+            got = [digest(i, win, kp, queue_next=seq[k + 1] if k + 1 < len(seq) else None) for k, i in enumerate(seq)]
+            assert got == [alone[i] for i in seq], (kp is not None, win)
+    calc.close()

@@ -54,6 +54,24 @@ def test_spend_suite_wtns_and_evaluator(pkg, tmp_path):
         pos += view.size // 32
     assert pos == calc.nwitness
     assert np.array_equal(calc.witness_payload(3), O.run("Spend(31)", s["cases"][3]["input"]).witness_numpy())
+    # two witnesses in flight (pob_emit_queue): witness 3's first window is expanded behind witness 0's last ones, three window slots rotate
+    ref3 = O.run("Spend(31)", s["cases"][3]["input"]).witness_numpy().copy()
+    for win in (100_000, 1_000_000, 1_700_000, 5_000_000):
+        calc.emit_queue(3)                                   # announced before the emission it follows ...
+        for idx, want in ((0, ref), (3, ref3), (0, ref)):
+            pos = 0
+            for w0, view in calc.witness_windows(idx, window_wires=win):
+                if idx == 3 and w0 == 0:
+                    calc.emit_queue(0)                       # ... or while it runs
+                assert w0 == pos and np.array_equal(view, want[32 * w0:32 * w0 + view.size]), (win, idx, w0)
+                pos += view.size // 32
+            assert pos == calc.nwitness
+    calc.emit_queue(0)                                       # an announcement that is not followed: the prepared window is dropped
+    assert np.array_equal(calc.witness_payload(3), ref3) and np.array_equal(calc.witness_payload(3), ref3)
+    bad_idx = next(i for i, r in enumerate(res) if not r.ok)
+    with pytest.raises(RuntimeError):
+        calc.emit_queue(bad_idx)                             # no witness for a failed input, announced or not
+    assert np.array_equal(calc.witness_payload(0), ref)
     path = str(tmp_path / "w.wtns")
     calc.write_wtns(0, path)
     ora = O.run("Spend(31)", s["cases"][0]["input"])
