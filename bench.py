@@ -136,7 +136,8 @@ def main():
     t_pack_py = (time.time() - t0) / min(B, 128) * B
     assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].sm, pinned[0].forced))), "native loader differs from the Python loader"
     expect = [np.array([list(c.to_bytes(32, "little")) for c in bt.commitments], dtype=np.uint8) for bt in batches]
-    streams = [torch.cuda.Stream(device=dev_index) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
+    # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
+    streams = [torch.cuda.Stream(device=dev_index, priority=-1) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
     recs = [D.device_records(calcs[c], B) for c in range(NC)]
     if PIPE:
         calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])

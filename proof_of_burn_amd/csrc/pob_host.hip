@@ -199,7 +199,12 @@ struct pob_ctx {
 };
 
 static hipStream_t own_stream(pob_ctx* h) {
-    if (!h->stream) { hipSetDevice(h->device); if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) h->stream = nullptr; }
+    if (!h->stream) {       // (high priority like the side tracks: when the caller passes no stream this one carries the generation's main track)
+        int lo = 0, hi = 0;
+        hipSetDevice(h->device);
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) hi = 0;
+        if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi) != hipSuccess) h->stream = nullptr;
+    }
     return h->stream;
 }
 
@@ -435,7 +440,9 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             hipError_t e = hipSuccess;
             // (the streaming stream at the lowest priority; normal priority measured the same step, the highest lets the round evaluation
             //  finish in 5.1 ms instead of 7.6 but the step grows from 13.2 to 14.8 ms: the G kernels it displaces are needed next)
-            for (int k = 0; k < 7 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi);
+            // (the evaluation families' two streams at the LOW priority like the streaming stream -- the device has two levels: their chip-filling launches
+            //  have slack, the next batch's generation chain that shares the read phase with them does not: 13.31 -> 13.20 ms per step, five interleaved pairs)
+            for (int k = 0; k < 7 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, (k == 1 || k == 4 || k == 5) ? prio_lo : prio_hi);
             if (e != hipSuccess) {
                 for (hipStream_t* q : want) if (*q) hipStreamDestroy(*q);
                 delete P;

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 3, call 20: selector rows beyond the hash on a late side track -- five interleaved pairs (evaluation families low, callers high)
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+for rep in 1 2 3 4 5; do for lr in 0 1; do
+  POB_CHK_PRIO=2 POB_BENCH_PRIO=-1 POB_LATE_ROWS=$lr timeout 300 python bench.py --gpus 1 --steps 100 --warmup 6 --no-cpu-baseline --no-emission --no-single > gpurun_out/r3p_l${lr}_$rep.json 2> gpurun_out/r3p_l${lr}_$rep.err
+  python - <<PY
+import json
+d=json.loads(open("gpurun_out/r3p_l${lr}_$rep.json").read().strip().splitlines()[-1])
+print("late_rows=$lr rep=$rep", d["ms_per_step"], d["value"], "kchk", d["roofline"]["avg_ms"])
+PY
+done; done 2>&1 | tee gpurun_out/r3p_summary.txt
