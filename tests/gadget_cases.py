@@ -108,6 +108,15 @@ def _rand_inputs(name, params, rng: random.Random):
     return d
 
 
+# the templates at the sizes the production circuit instantiates them with (and the largest the gadget-main path takes), beyond the reference's small cases
+LARGE_MAINS = ["SubstringCheck(136, 31)", "RlpMerklePatriciaTrieLeaf(32, 31)", "Selector(16)", "SelectorArray1D(16, 136)", "SelectorArray2D(5, 4, 16)",
+               "Concat(36, 103)", "ShiftLeft(64)", "ShiftRight(103, 36)", "Pad(4, 136)", "TruncatedAddressHash(32)", "Num2BigEndianBytes(31)", "Num2LittleEndianBytes(32)",
+               "Poseidon(4)", "KeccakBytes(4)", "PublicCommitment(4)", "Divide(30)", "IsInRange(30)", "Mask(139)", "CountBytes(31)", "Fit(32, 31)", "Fit(104, 136)",
+               "AssertBits(253)", "AssertByteString(136)", "Num2BitsSafe(255)", "Num2BitsSafe(253)", "LittleEndianBytes2Num(31)", "BigEndianBytes2Num(31)",
+               "Bytes2Nibbles(32)", "Nibbles2Bytes(33)", "RlpInteger(31)", "RlpEmptyAccount(31)", "LeafDetector(136)", "Filter(64)", "Reverse(31)", "Flatten(6, 32)",
+               "AssertLessEqThan(30)", "AssertLessThan(16)", "AssertGreaterEqThan(16)", "ConcatFixed4(32, 32, 32, 8)"]
+
+
 def differential(pkg, s, n: int = 48, seed: int = 11) -> list:
     """n seeded random inputs of the suite's main against the oracle: same accept / reject decision, same outputs, same payload"""
     from proof_of_burn_amd.witness import parse_main

@@ -645,3 +645,16 @@ def test_queued_emission_equals_one_at_a_time(pkg):
             got = [digest(i, win, kp, queue_next=seq[k + 1] if k + 1 < len(seq) else None) for k, i in enumerate(seq)]
             assert got == [alone[i] for i in seq], (kp is not None, win)
     calc.close()
+
+
+def test_gadget_mains_at_production_sizes(pkg):
+    """the templates at the parameters the production circuit uses (SubstringCheck(136, 31), RlpMerklePatriciaTrieLeaf(32, 31), KeccakBytes(4) ...):
+    24 seeded random inputs each against the oracle -- decision, outputs, evaluator, full payload"""
+    from tests import gadget_cases as GC
+    bad, total = [], 0
+    for main in GC.LARGE_MAINS:
+        b, nok = GC.differential(pkg, {"main": main}, n=24, seed=5)
+        bad += b
+        total += nok
+    assert not bad, bad[:4]
+    assert total > 400
