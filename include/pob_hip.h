@@ -24,12 +24,12 @@ enum { POB_OK = 0, POB_E_ARG = -1, POB_E_HIP = -2, POB_E_NOMEM = -3, POB_E_STATE
 
 typedef struct {
     uint64_t n_witness;          /* W: O0 wires incl. the constant-1 wire (= nWitness of the .wtns)            */
-    uint64_t n_bit, n_sm, n_fr;  /* wires per storage class (policy.hpp)                                        */
+    uint64_t n_bit, n_sm, n_fr;  /* wires per storage class (policy.hpp); n_bit + n_sm + n_fr + n_derived + 1 = n_witness */
     uint32_t n_fr_inputs, n_sm_inputs, n_outputs;
     uint32_t n_units, n_sponges, n_perms, n_stages, max_batch;
     uint64_t group_bytes;        /* HBM-resident bytes of the compact witness vector per 64 witnesses           */
     uint64_t keccak_bit_wires;   /* wires handled by the bit-sliced Keccak kernels                              */
-    uint64_t n_sb;               /* wires of the int8 class (operands of the Keccak output selectors' IsEqual gadgets) */
+    uint64_t n_derived;          /* wires that are not stored: operands of the Keccak output selectors' IsEqual gadgets, rebuilt from numBlocks by the emitter */
 } pob_info_t;
 
 /* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference
@@ -170,9 +170,9 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
 /* Test hook for the constraint evaluator: corrupt ONE stored value of ONE witness (lane `lane` of group `group`) of storage class
  * `cls` at storage index `index` (the wire's rank within its class): BIT: flips the bit if xor_mask & 1; SM: int32 ^= xor_mask;
- * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask; SB: int8 ^= xor_mask.  IsZero.inv wires live in the SM / SB slabs as their
- * operand code, so poking those indices pokes the hint.                                                                          */
-enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2, POB_CLASS_SB = 3 };
+ * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask.  IsZero.inv wires of SM operands live in the SM slab as their operand code, so
+ * poking those indices pokes the hint.  (Derived wires -- pob_info_t.n_derived -- have no storage to corrupt.)                    */
+enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2 };
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
 /* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the
  * first Poseidon block); "pad.div.out" / "pad.div.rem" / "pad.iseq.inv" of KeccakBytes instance k (the Divide hint of

@@ -265,7 +265,7 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
 // IsEqual (comparators.circom): [out | in[2]] || IsZero [out | in | inv]
 template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
     const uint32_t n1 = N1 ? (uint32_t)N1 : r.mb + 1, n = j1 - j0, ln = p.lane_id();
-    const uint32_t fw = 9 * n1 + 3, fb = 5 * n1 + 2, fq = 4 * n1 + 1;       // footprint of one selector: wires, BIT, SB (no SM)
+    const uint32_t fw = 9 * n1 + 3, fb = 5 * n1 + 2, fq = 4 * n1 + 1;       // footprint of one selector: wires, BIT, derived (no SM)
     const Cur c0 = p.cur;
     const uint32_t idx = row * 64 + j0 + ln;
     const S blocks = p.get(r.numBlocks);
@@ -309,16 +309,16 @@ template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t r
             if (r.has_dst) p.put(r.dst + i, o);
         }
     }
-    // SM side of the n selectors: select, and per IsEqual child in[0] = select, in[1] = k, IsZero.in = k - select, IsZero.inv.
-    // Every selector carries the same rows, so each kind of wire is swept over the selectors with many loads in flight.
-    sb_rows_same<P, 16>(p, c0.w + n1 + 1, c0.q, fw, fq, n, blocks);
+    // The non-BIT side of the n selectors -- select, and per IsEqual child in[0] = select, in[1] = k, IsZero.in = k - select, IsZero.inv: the same four
+    // per-witness values for every selector, all functions of numBlocks -- are DERIVED wires (policy.hpp): only the emitter writes them.
+    derived_rows_same(p, c0.w + n1 + 1, fw, n, blocks);
     for (uint32_t k = 0; k < n1; k++) {
-        const uint32_t cw = c0.w + 3 * n1 + 3 + 6 * k, cq = c0.q + 1 + 4 * k;
+        const uint32_t cw = c0.w + 3 * n1 + 3 + 6 * k;
         const S x = (S)(k - (uint32_t)blocks);
-        sb_rows_same<P, 16>(p, cw + 1, cq, fw, fq, n, blocks);
-        sb_rows_same<P, 16>(p, cw + 2, cq + 1, fw, fq, n, (S)k);
-        sb_rows_same<P, 16>(p, cw + 4, cq + 2, fw, fq, n, x);
-        sbi_rows_same<P, 16>(p, cw + 5, cq + 3, fw, fq, n, x);
+        derived_rows_same(p, cw + 1, fw, n, blocks);
+        derived_rows_same(p, cw + 2, fw, n, (S)k);
+        derived_rows_same(p, cw + 4, fw, n, x);
+        derived_rows_same(p, cw + 5, fw, n, x, true);
     }
     p.cur = cur_add(c0, Cur{fw, fb, 0, 0, fq}, n);
 }

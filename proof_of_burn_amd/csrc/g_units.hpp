@@ -12,7 +12,6 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
     p.m.bits = A.bits + (uint64_t)g * A.bits_stride;
     p.m.sm = A.sm + (uint64_t)g * A.sm_stride;
     p.m.fr = A.fr + (uint64_t)g * A.fr_stride;
-    int8_t* sbp = A.sb + (uint64_t)g * A.sb_stride;
     p.m.inv_lut = A.inv_lut; p.m.pow256 = A.pow256; p.m.npow256 = A.npow256;
     p.m.nfr_in = A.nfr_in; p.m.nsm_in = A.nsm_in;
     p.m.in_fr = A.in_fr + (uint64_t)g * 64 * A.nfr_in * 32;
@@ -23,7 +22,6 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
         p.m.rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.m.bits, 0, (int)(nb > 0xFFFFFFFFull ? 0xFFFFFFFFull : nb), 0x00020000);
         p.m.rs_sm = __builtin_amdgcn_make_buffer_rsrc(p.m.sm, 0, (int)(ns > 0xFFFFFFFFull ? 0xFFFFFFFFull : ns), 0x00020000);
         p.m.rs_fr = __builtin_amdgcn_make_buffer_rsrc(p.m.fr, 0, (int)(nf > 0xFFFFFFFFull ? 0xFFFFFFFFull : nf), 0x00020000);
-        p.m.rs_sb = __builtin_amdgcn_make_buffer_rsrc(sbp, 0, (int)(A.sb_stride > 0xFFFFFFFFull ? 0xFFFFFFFFull : A.sb_stride), 0x00020000);
     }
     p.m.pos_tab = A.pos_tab;
     p.decl_order = A.L->decl_order;

@@ -13,7 +13,6 @@ struct GArgs {
     CircuitLayout* L;                                  // read-only on the device (only the host planner writes reference tables)
     uint64_t* bits; int32_t* sm; uint32_t* fr;
     uint64_t bits_stride, sm_stride, fr_stride;       // elements per group
-    int8_t* sb; uint64_t sb_stride;                    // SB slab (int8 rows), bytes per group
     const uint32_t* pos_tab; const uint32_t* inv_lut; const uint32_t* pow256; uint32_t npow256;
     const uint8_t* in_fr; const int32_t* in_sm; uint32_t nfr_in, nsm_in;
     uint32_t* status; uint32_t* chk_status; uint32_t* bad_wire;

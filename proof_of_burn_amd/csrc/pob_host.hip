@@ -83,7 +83,6 @@ __global__ void __launch_bounds__(256) k_fill_ee(uint4* p, uint64_t n16) {
     const uint4 v = make_uint4(0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
-__global__ void k_xor_u8(uint8_t* p, uint8_t mask) { *p ^= mask; }
 
 // ---- proof-of-work search (input producer, reference tests/main.py:47-56): thread t hashes key = start + t
 __device__ __forceinline__ uint64_t pow_rotl(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
@@ -138,7 +137,7 @@ struct pob_ctx {
     std::string err;
     hipStream_t stream = nullptr;
     // device memory
-    uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr; int8_t* d_sb = nullptr;
+    uint64_t* d_bits = nullptr; int32_t* d_sm = nullptr; uint32_t* d_fr = nullptr;
     UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
@@ -272,7 +271,6 @@ static GArgs gargs(pob_ctx* h) {
     A.units = h->d_units; A.order = h->d_order; A.L = h->d_L;
     A.bits = h->d_bits; A.sm = h->d_sm; A.fr = h->d_fr;
     A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
-    A.sb = h->d_sb; A.sb_stride = (uint64_t)h->plan.total.q * 64;
     A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr[h->in_cur]; A.in_sm = h->d_in_sm[h->in_cur];
     A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
     A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
@@ -329,8 +327,8 @@ static int make_plan(Plan& plan, std::string& err, int circuit, const uint64_t* 
         if (why) { err = std::string("gadget main: ") + why; return POB_E_ARG; }
     } else { err = "unknown circuit"; return POB_E_ARG; }
     const Cur t = plan.total;
-    if (t.b >= (1u << 29) || t.s >= (1u << 24) || t.f >= (1u << 21) || t.q >= (1u << 26)) {
-        err = "instantiation exceeds the layout's offset limits (BIT < 2^29, SM < 2^24, FR < 2^21, SB < 2^26 wires)"; return POB_E_ARG;
+    if (t.b >= (1u << 29) || t.s >= (1u << 24) || t.f >= (1u << 21) || t.q >= (1u << 30)) {
+        err = "instantiation exceeds the layout's offset limits (BIT < 2^29, SM < 2^24, FR < 2^21 wires)"; return POB_E_ARG;
     }
     return POB_OK;
 }
@@ -341,8 +339,8 @@ static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_i
     { std::vector<char> used(pl.max_stage + 1, 0); for (const UnitDesc& u : pl.units) if (u.flags & UNIT_GEN) used[u.stage] = 1; for (const SpongeDesc& s : pl.sponges) used[s.stage] = 1;
       info->n_stages = 0; for (char c : used) info->n_stages += c; }
     info->max_batch = max_batch;
-    info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048 + (uint64_t)pl.total.q * 64;
-    info->n_sb = pl.total.q;
+    info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;      // (derived wires take no storage)
+    info->n_derived = pl.total.q;
     info->keccak_bit_wires = 0;
     for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
 }
@@ -472,7 +470,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)std::max(pl.total.b, 1u) * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
     HIPC(hipMalloc(&h->d_fr, G * (uint64_t)std::max(pl.total.f, 1u) * 2048));
-    HIPC(hipMalloc(&h->d_sb, std::max<uint64_t>(G * (uint64_t)pl.total.q * 64, 64)));
     HIPC(hipMalloc(&h->d_units, pl.units.size() * sizeof(UnitDesc)));
     HIPC(hipMalloc(&h->d_order, h->order.size() * sizeof(uint32_t)));
     HIPC(hipMalloc(&h->d_L, sizeof(CircuitLayout)));
@@ -525,7 +522,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
 void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
-    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_sb, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
+    void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
                     h->d_inv, h->d_pow256, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
@@ -1221,9 +1218,6 @@ int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32
     } else if (cls == POB_CLASS_FR) {
         if (index >= t.f || sub >= 8) return POB_E_ARG;
         hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, own_stream(h), h->d_fr + ((uint64_t)group * t.f + index) * 512 + sub * 64 + lane, xor_mask);
-    } else if (cls == POB_CLASS_SB) {
-        if (index >= t.q) return POB_E_ARG;
-        hipLaunchKernelGGL(k_xor_u8, dim3(1), dim3(1), 0, own_stream(h), (uint8_t*)h->d_sb + ((uint64_t)group * t.q + index) * 64 + lane, (uint8_t)xor_mask);
     } else return POB_E_ARG;
     HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;

@@ -12,8 +12,12 @@
 //   SI   wires (IsZero.inv of an SM operand): stored in the SM array as the operand k itself; the
 //        wire's value is k^-1 mod p (0 for k = 0), decoded through a table when a .wtns is emitted.
 //   FR   wires (genuine field elements): 8 x uint32 limb planes [wire][limb][64 lanes], Montgomery form.
-//   SB   wires (operands of the Keccak output selectors' IsEqual gadgets: |value| <= 33 in a valid witness, half of all
-//        non-BIT wires): int8 [wire][64 lanes] (64 B rows); IsZero.inv among them is stored as its operand like SI.
+//   DV   wires (DERIVED: the operands of the Keccak output selectors' IsEqual gadgets -- select, in[0], in[1], IsZero.in, IsZero.inv of
+//        Selector(n+1) x 1600 per KeccakBytes, half of all non-BIT wires): every one is a function of that sponge's numBlocks (an SM wire) and
+//        of constants, so they are NOT stored: the emitter rebuilds them (EmitP::derived), generation and evaluation skip them (their
+//        relations hold by construction; that the rebuilt values are the right ones is what the payload comparison with the oracle checks).
+//        Rounds 1-2 stored them as an int8 class (SB): 0.7 GB written and 0.7 GB read per batch of 1 024 through 64-byte stores that left
+//        the selector-row kernels store-issue-bound -- dropping the class took 0.33 ms off a 13.0 ms step.
 //
 // Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
 // run of same-class wires (e.g. a whole Keccak-f block, 2 506 944 BIT wires) is contiguous in HBM.
@@ -34,13 +38,12 @@ typedef uint64_t B;   // BIT value: lane mask over the 64 witnesses of the group
 typedef int32_t S;    // SM value of this lane's witness
 typedef Fr F;         // FR value (Montgomery) of this lane's witness
 
-struct Cur { uint32_t w, b, s, f, q; };   // next free: wire index, BIT rank, SM rank, FR rank, SB rank
+struct Cur { uint32_t w, b, s, f, q; };   // next free: wire index, BIT rank, SM rank, FR rank; q = derived wires so far (no storage)
 HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k, a.q + d.q * k}; return r; }
 struct BitRef { uint32_t w, i; HD BitRef operator+(uint32_t k) const { BitRef r = {w + k, i + k}; return r; } };
 struct SmRef  { uint32_t w, i; HD SmRef  operator+(uint32_t k) const { SmRef  r = {w + k, i + k}; return r; } };
 struct SiRef  { uint32_t w, i; HD SiRef  operator+(uint32_t k) const { SiRef  r = {w + k, i + k}; return r; } };
 struct FrRef  { uint32_t w, i; HD FrRef  operator+(uint32_t k) const { FrRef  r = {w + k, i + k}; return r; } };
-struct SbRef  { uint32_t w, i; HD SbRef  operator+(uint32_t k) const { SbRef  r = {w + k, i + k}; return r; } };   // SB class (int8 rows)
 
 // failure codes: (template id << 12) | source line of the failing assert / === in the reference circuits
 enum : uint32_t {
@@ -68,7 +71,6 @@ struct PolBase {
     HD SmRef sms(uint32_t n) { SmRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
     HD SiRef sis(uint32_t n) { SiRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
     HD FrRef frs(uint32_t n) { FrRef r = {cur.w, cur.f}; cur.w += n; cur.f += n; return r; }
-    HD SbRef sbs(uint32_t n) { SbRef r = {cur.w, cur.q}; cur.w += n; cur.q += n; return r; }
     HD void skip_bits(uint32_t n) { cur.w += n; cur.b += n; }
 };
 
@@ -98,9 +100,8 @@ struct CountP : PolBase {
     HD B get(BitRef) { return 0; }
     HD S get(SmRef) { return 0; }
     HD S get_lane(SmRef, uint32_t) { return 0; }
-    HD S get(SbRef) { return 0; }
-    HD S put(SbRef, S v) { nput++; return v; }
-    HD S hint_inv(SbRef, S v) { nput++; return v; }
+    HD void derived(uint32_t, S) {}               // a DERIVED wire (see the header): value v / the inverse of x; only the emitter does anything
+    HD void derived_inv(uint32_t, S) {}
     HD F get(FrRef) { return fr_zero(); }
     HD void raw_put(FrRef, const F&) {}
     HD B ballot(bool) { return 0; }
@@ -262,38 +263,11 @@ template <class P, int N> HD __attribute__((always_inline)) void fr_commit(P& p,
         for (int k = 0; k < N; k++) p.put(r[k], v[k]);
     }
 }
-// the SB-class versions of sm_rows_same / si_rows_same
-template <class P, int BATCH> HD __attribute__((always_inline)) void sb_rows_same(P& p, uint32_t w0, uint32_t q0, uint32_t dw, uint32_t dq, uint32_t n, S v) {
-    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
-        S got[BATCH];
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-            const uint32_t t = t0 + q < n ? t0 + q : n - 1;
-            const SbRef r = {w0 + t * dw, q0 + t * dq};
-            if constexpr (P::is_check) got[q] = p.get(r); else got[q] = p.put(r, v);
-        }
-        if constexpr (P::is_check) {
-#pragma unroll
-            for (int q = 0; q < BATCH; q++) { const uint32_t t = t0 + q < n ? t0 + q : n - 1; p.mark(got[q] != v, w0 + t * dw); }
-        }
-    }
-}
-template <class P, int BATCH> HD __attribute__((always_inline)) void sbi_rows_same(P& p, uint32_t w0, uint32_t q0, uint32_t dw, uint32_t dq, uint32_t n, S x) {
-    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
-        S kk[BATCH];
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-            const uint32_t t = t0 + q < n ? t0 + q : n - 1;
-            kk[q] = p.hint_inv(SbRef{w0 + t * dw, q0 + t * dq}, x);
-        }
-        if constexpr (!P::is_gen) {
-            bool ok30 = true, ok31 = true;
-#pragma unroll
-            for (int q = 0; q < BATCH; q++) { ok30 = ok30 && (kk[q] == 0 || kk[q] == x); ok31 = ok31 && (x == 0 || kk[q] != 0); }
-            p.require(p.ballot(ok30), FAILCODE(T_ISZERO, 30));
-            p.require(p.ballot(ok31), FAILCODE(T_ISZERO, 31));
-        }
-    }
+// n DERIVED wires w0 + t*dw, t < n, that all carry the value v (inv: the field inverse of v, 0 for 0): nothing but the emitter touches them
+template <class P> HD __attribute__((always_inline)) void derived_rows_same(P& p, uint32_t w0, uint32_t dw, uint32_t n, S v, bool inv = false) {
+    if constexpr (P::is_emit) {
+        for (uint32_t t = 0; t < n; t++) { if (inv) p.derived_inv(w0 + t * dw, v); else p.derived(w0 + t * dw, v); }
+    } else { (void)p; (void)w0; (void)dw; (void)n; (void)v; (void)inv; }
 }
 // N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
 template <class P, class R, class V, int N> HD __attribute__((always_inline)) void put_batch(P& p, const R (&r)[N], const V (&v)[N]) {
@@ -327,7 +301,7 @@ struct DevMem {
     uint32_t lane;
     // buffer resources over the three slabs: a wire access is `buffer_load/store v, v_lane_offset, s[rsrc], s_wire_offset offen`
     // -- the per-wire part of the address stays scalar, no 64-bit per-lane address arithmetic (or registers) per access
-    __amdgpu_buffer_rsrc_t rs_bits, rs_sm, rs_fr, rs_sb;
+    __amdgpu_buffer_rsrc_t rs_bits, rs_sm, rs_fr;
     uint32_t lane4;     // lane * 4
 };
 typedef int pob_v2i __attribute__((ext_vector_type(2)));
@@ -341,9 +315,8 @@ struct DevPol : PolBase {
     __device__ __forceinline__ B ld(BitRef r) { return m.bits[r.i]; }
     __device__ __forceinline__ S ld(SmRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ S ld(SiRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
-    __device__ __forceinline__ S ld(SbRef r) { return (S)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(m.rs_sb, (int)m.lane, (int)(POB_UNI(r.i) << 6), 0); }
-    __device__ __forceinline__ void st(SbRef r, S v) { __builtin_amdgcn_raw_buffer_store_b8((char)v, m.rs_sb, (int)m.lane, (int)(POB_UNI(r.i) << 6), 0); }
-    __device__ __forceinline__ S get(SbRef r) { return ld(r); }
+    __device__ __forceinline__ void derived(uint32_t, S) {}
+    __device__ __forceinline__ void derived_inv(uint32_t, S) {}
     __device__ __forceinline__ F ld(FrRef r) {
         F v; const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
@@ -418,8 +391,6 @@ struct GenP : DevPol {
     __device__ __forceinline__ S hint(SmRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ F hint(FrRef r, const F& v) { st(r, v); return v; }
     __device__ __forceinline__ S hint_inv(SiRef r, S v) { st(r, v); return v; }
-    __device__ __forceinline__ S put(SbRef r, S v) { st(r, v); return v; }
-    __device__ __forceinline__ S hint_inv(SbRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
@@ -463,8 +434,6 @@ struct CheckP : DevPol {
     __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
     __device__ __forceinline__ S hint_inv(SiRef r, S) { return ld(r); }
-    __device__ __forceinline__ S put(SbRef r, S v) { const S s = ld(r); mark(s != v, r.w); return s; }
-    __device__ __forceinline__ S hint_inv(SbRef r, S) { return ld(r); }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     // lane-distributed runs: a run's difference is folded into `rdiff` when the NEXT run's load has been issued (one load is
@@ -535,8 +504,8 @@ struct EmitP : DevPol {
     __device__ __forceinline__ B hint(BitRef r, B v) { return put(r, v); }
     __device__ __forceinline__ S hint(SmRef r, S v) { return put(r, v); }
     __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
-    __device__ __forceinline__ S put(SbRef r, S) { S s = ld(r); if (m.lane == sel) w32(r.w, small(s)); return s; }
-    __device__ __forceinline__ S hint_inv(SbRef r, S) { S k = ld(r); emit_inv(r.w, k); return k; }
+    __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
+    __device__ __forceinline__ void derived_inv(uint32_t w, S x) { emit_inv(w, x); }
     __device__ __forceinline__ S hint_inv(SiRef r, S) { S k = ld(r); emit_inv(r.w, k); return k; }
     __device__ __forceinline__ void emit_inv(uint32_t w, S k) {
         if (m.lane == sel) {

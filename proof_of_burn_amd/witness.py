@@ -115,7 +115,7 @@ class PobInfo(ctypes.Structure):
                 ("n_fr_inputs", ctypes.c_uint32), ("n_sm_inputs", ctypes.c_uint32), ("n_outputs", ctypes.c_uint32),
                 ("n_units", ctypes.c_uint32), ("n_sponges", ctypes.c_uint32), ("n_perms", ctypes.c_uint32),
                 ("n_stages", ctypes.c_uint32), ("max_batch", ctypes.c_uint32),
-                ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64), ("n_sb", ctypes.c_uint64)]
+                ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64), ("n_derived", ctypes.c_uint64)]
 
 
 # one result record (include/pob_hip.h POB_RECORD_BYTES = 44)
@@ -630,10 +630,10 @@ class WitnessCalculator:
         return float(ms.value) if read else None
 
     # ------------------------------------------------------------------ test hooks of the constraint evaluator
-    CLASS_BIT, CLASS_SM, CLASS_FR, CLASS_SB = 0, 1, 2, 3
+    CLASS_BIT, CLASS_SM, CLASS_FR = 0, 1, 2
 
     def class_sizes(self) -> dict:
-        return {self.CLASS_BIT: int(self.info.n_bit), self.CLASS_SM: int(self.info.n_sm), self.CLASS_FR: int(self.info.n_fr), self.CLASS_SB: int(self.info.n_sb)}
+        return {self.CLASS_BIT: int(self.info.n_bit), self.CLASS_SM: int(self.info.n_sm), self.CLASS_FR: int(self.info.n_fr)}
 
     def poke(self, cls: int, index: int, lane: int, xor_mask: int = 1, sub: int = 0, group: int = 0):
         """XOR one stored value of one witness of the resident vector (storage class, rank in the class, lane)"""

@@ -4,15 +4,15 @@ reduced sizes, on the CPU through the HIP-on-fibers shim (`tests/test_hostsim_cp
 Method: a batch of 64 IDENTICAL valid witnesses = one group (one wavefront, lane = witness).  One pass pokes a DIFFERENT stored
 wire in each of the lanes 1..63 and leaves lane 0 alone; then one evaluation must flag exactly the poked lanes -- a failing lane
 never disturbs another, and lane 0 is the control.  Storage classes: BIT (1 bit), SM (int32 rows: bytes, lengths, and the
-IsZero.inv hints stored as their operand), SB (int8 rows of the Keccak output selectors' IsEqual gadgets), FR (8 x 32-bit limb
+IsZero.inv hints stored as their operand), FR (8 x 32-bit limb
 planes, Montgomery: Poseidon state, SubstringCheck M[] / exists operands, balances).
 """
 from __future__ import annotations
 
 import numpy as np
 
-BIT, SM, FR, SB = 0, 1, 2, 3
-NAMES = {BIT: "BIT", SM: "SM", FR: "FR", SB: "SB"}
+BIT, SM, FR = 0, 1, 2
+NAMES = {BIT: "BIT", SM: "SM", FR: "FR"}
 
 
 def _flagged(r) -> bool:
@@ -40,8 +40,6 @@ def sweep(calc, cls: int, indices, rng, lanes_per_pass: int = 63):
                 sub, mask = int(rng.integers(0, 8)), 1 << int(rng.integers(0, 28))
             elif cls == SM:
                 sub, mask = 0, 1 << int(rng.integers(0, 4))
-            elif cls == SB:
-                sub, mask = 0, 1 << int(rng.integers(0, 3))
             else:
                 sub, mask = 0, 1
             calc.poke(cls, idx, lane, mask, sub)
