@@ -29,7 +29,7 @@ typedef struct {
     uint32_t n_units, n_sponges, n_perms, n_stages, max_batch;
     uint64_t group_bytes;        /* HBM-resident bytes of the compact witness vector per 64 witnesses           */
     uint64_t keccak_bit_wires;   /* wires handled by the bit-sliced Keccak kernels                              */
-    uint64_t n_derived;          /* wires that are not stored: operands of the Keccak output selectors' IsEqual gadgets, rebuilt from numBlocks by the emitter */
+    uint64_t n_derived;          /* wires that are not stored: the operand wires of IsZero / IsEqual over small operands, rebuilt by the emitter (policy.hpp) */
 } pob_info_t;
 
 /* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference
@@ -170,13 +170,12 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
 /* Test hook for the constraint evaluator: corrupt ONE stored value of ONE witness (lane `lane` of group `group`) of storage class
  * `cls` at storage index `index` (the wire's rank within its class): BIT: flips the bit if xor_mask & 1; SM: int32 ^= xor_mask;
- * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask.  IsZero.inv wires of SM operands live in the SM slab as their operand code, so
- * poking those indices pokes the hint.  (Derived wires -- pob_info_t.n_derived -- have no storage to corrupt.)                    */
+ * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask.  (Derived wires -- pob_info_t.n_derived: the operand wires of IsZero / IsEqual
+ * over small operands -- have no storage to corrupt.)                                                                              */
 enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2 };
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
 /* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the
- * first Poseidon block); "pad.div.out" / "pad.div.rem" / "pad.iseq.inv" of KeccakBytes instance k (the Divide hint of
- * divide.circom:23-24 and an IsZero.inv hint); ProofOfBurn only: "sc.M" / "sc.exists" / "sc.isz.inv" [k] of layer 1's SubstringCheck. */
+ * first Poseidon block); "pad.div.out" / "pad.div.rem" of KeccakBytes instance k (the Divide hint of divide.circom:23-24); ProofOfBurn only: "sc.M" / "sc.exists" / "sc.isz.inv" [k] of layer 1's SubstringCheck. */
 int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire);
 
 /* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */

@@ -65,7 +65,7 @@ struct PobParams { int L, NB, HB, minNib, amountBytes, powZero; Fr maxIntended, 
 struct SpendParams { int maxAmountBytes; };
 
 // footprints {wires, BIT, SM, FR} of fixed-size components
-#define FP_ISEQ_S (Cur{6, 2, 4, 0})          // IsEqual [out | in[2]] + IsZero [out | in | inv]
+#define FP_ISEQ_S (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv] over small operands: two BIT outputs, four DERIVED operand wires (policy.hpp)
 #define FP_ISEQ_F (Cur{6, 2, 0, 4})
 #define FP_N2B8 (Cur{9, 8, 1, 0})
 
@@ -188,9 +188,12 @@ template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
     r.c_loop = p.cur;
     p.cur = cur_add(cur_add(cur_add(p.cur, FP_ISEQ_S, 2 * m), FP_N2B8, m), Cur{16u * m, 16u * m, 0, 0}, 1);   // -> Keccak(mb)
 }
-// SM / SI wires of an IsEqual([a, b]) child at cursor c (its two BIT wires are written by the caller as part of a run):
-// rr/vv get in[0], in[1], IsZero.in; returns the IsZero.inv reference and operand
-#define ISEQ_SM_REFS(c) SmRef{(c).w + 1, (c).s}, SmRef{(c).w + 2, (c).s + 1}, SmRef{(c).w + 4, (c).s + 2}
+// the four derived operand wires of an IsEqual([a, b]) child at cursor c (its two BIT wires are written by the caller as part of a run)
+template <class P> HD void iseq_derived(P& p, Cur c, S a, S b) {
+    p.derived(c.w + 1, a); p.derived(c.w + 2, b);
+    const S x = (S)((uint32_t)b - (uint32_t)a);
+    p.derived(c.w + 4, x); p.derived_inv(c.w + 5, x);
+}
 template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t lo, uint32_t hi) {
     const uint32_t m = 136 * r.mb, cnt = hi - lo, ln = p.lane_id();     // cnt <= 16 bytes
     const S inLen = p.get(r.inLen), nb = p.get(r.numBlocks);
@@ -203,19 +206,15 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
     for (uint32_t t = 0; t < cnt; t++) {
         const uint32_t i = lo + t;
         const Cur ce = cur_add(cE, FP_ISEQ_S, i), cl = cur_add(cL, FP_ISEQ_S, i);
-        const SmRef rr[11] = {r.in + i, r.pad_in + i, ISEQ_SM_REFS(ce), ISEQ_SM_REFS(cl), r.pad_o + i, r.padded + i, SmRef{cN.w + 9 * i + 8, cN.s + i}};
-        const SmLoaded<11> h = sm_load(p, rr);
+        const SmRef rr[5] = {r.in + i, r.pad_in + i, r.pad_o + i, r.padded + i, SmRef{cN.w + 9 * i + 8, cN.s + i}};
+        const SmLoaded<5> h = sm_load(p, rr);
         const S v = p.get(src + i);
         const S xe = (S)((uint32_t)inLen - i), xl = (S)((uint32_t)last - i);
-        const S ke = p.hint_inv(SiRef{ce.w + 5, ce.s + 3}, xe), kl = p.hint_inv(SiRef{cl.w + 5, cl.s + 3}, xl);
-        if constexpr (!P::is_gen) {
-            p.require(p.ballot((ke == 0 || ke == xe) && (kl == 0 || kl == xl)), FAILCODE(T_ISZERO, 30));
-            p.require(p.ballot((xe == 0 || ke != 0) && (xl == 0 || kl != 0)), FAILCODE(T_ISZERO, 31));
-        }
+        iseq_derived(p, ce, (S)i, inLen); iseq_derived(p, cl, (S)i, last);      // IsEqual([i, inLen]), IsEqual([i, numBlocks*136 - 1]): operand wires derived
         const B e = p.ballot(xe == 0), l = p.ballot(xl == 0);
         f &= ~e;
         const S pv = (p.bit(f) ? v : 0) + (S)p.bit(e) + (p.bit(l) ? 0x80 : 0);
-        const S vv[11] = {v, v, (S)i, inLen, xe, (S)i, last, xl, pv, pv, pv};
+        const S vv[5] = {v, v, pv, pv, pv};
         sm_commit(p, rr, h, vv);
         p.require(p.ballot((uint32_t)pv < 256u), FAILCODE(T_NUM2BITS, 38));
         runE = p.run_set(runE, t, e); runL = p.run_set(runL, t, l); runF = p.run_set(runF, t, f);
@@ -405,7 +404,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
     } break;
     UCASE(U_POB_LASTLAYER_RANGE) {   // selectors [a0, a1) of SelectorArray1D (selector.circom:62-77); Selector(n) footprint {9n+3, 3n, 6n+3, 0}
         const uint32_t n = prm.L, q = LB;
-        const Cur fp = {9 * n + 3, 3 * n, 6 * n + 3, 0};
+        const Cur fp = sel_fp(n);
         S select = p.get(M.numLayers) - 1;
         for (uint32_t j = d.a[0]; j < d.a[1]; j++) {
             if constexpr (P::is_check) {              // arraysT[j][i] === arrays[i][j] === layers[i][j], eight layers' loads in flight
@@ -825,7 +824,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             sc.c_loop = p.cur;
             p.cur = cur_add(cur_add(p.cur, FP_ISEQ_S, kk), FP_ISEQ_F, kk);
             sc.c_tail = p.cur;
-            p.cur = cur_add(p.cur, Cur{3, 1, 2, 0}, 1);            // the final IsZero
+            p.cur = cur_add(p.cur, Cur{3, 1, 0, 0, 2}, 1);         // the final IsZero (in, inv: derived)
             if (P::is_count) L.scs[i] = sc;
         }
     } break;
@@ -1171,7 +1170,7 @@ struct Plan {
             L.ll.out = p.sms(LB); L.ll.arr = p.sms(Ln * LB); L.ll.sel = p.sms(1); L.ll.T = p.sms(LB * Ln);
             unit(U_POB_LASTLAYER, TP + 1);
             L.ll.c_sel0 = p.cur;
-            const Cur fp = {9u * Ln + 3, 3u * Ln, 6u * Ln + 3, 0};
+            const Cur fp = sel_fp((uint32_t)Ln);
             for (uint32_t j = 0; j < (uint32_t)LB; j += 4) record(U_POB_LASTLAYER_RANGE, TP + 1, p.cur, j, std::min<uint32_t>(j + 4, LB));
             p.cur = cur_add(p.cur, fp, LB);
             expect_cursor("SelectorArray1D", p.cur, chk.cur);

@@ -90,15 +90,11 @@ template <class P> HD S gBits2Num8(P& p, BitRef src) {
 
 // ============================================================================ circomlib: comparators.circom
 // IsZero  [out | in | inv];  inv <-- in!=0 ? 1/in : 0;  out <== -in*inv+1;  in*out === 0
+// Small operands: `in` and `inv` are DERIVED wires (policy.hpp) -- the emitter rebuilds them from the caller's operand; out = [in == 0].
 template <class P> HD B gIsZeroS(P& p, S in) {
-    BitRef o = p.bits(1); SmRef i = p.sms(1); SiRef v = p.sis(1);
-    S x = p.put(i, in);
-    S k = p.hint_inv(v, x);                               // stored code k means the field element k^-1
-    // out = 1 - x/k must be representable as the stored bit: k == 0 (out = 1) or k == x (out = 0)
-    p.require(p.ballot(k == 0 || k == x), FAILCODE(T_ISZERO, 30));
-    B out = p.put(o, p.ballot(k == 0));
-    p.require(p.ballot(x == 0) | ~out, FAILCODE(T_ISZERO, 31));   // in*out === 0
-    return out;
+    BitRef o = p.bits(1); const uint32_t w = p.dvs(2);
+    p.derived(w, in); p.derived_inv(w + 1, in);
+    return p.put(o, p.ballot(in == 0));
 }
 template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) {
     BitRef o = p.bits(1); FrRef i = p.frs(1); FrRef v = p.frs(1);
@@ -114,10 +110,10 @@ template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) 
     p.require(p.ballot(fr_is_zero(x)) | ~out, FAILCODE(T_ISZERO, 31));
     return out;
 }
-// IsEqual  [out | in[2]] || IsZero(in[1]-in[0])
+// IsEqual  [out | in[2]] || IsZero(in[1]-in[0])      (small operands: in[] are derived wires)
 template <class P> HD B gIsEqualS(P& p, S a, S b) {
-    BitRef o = p.bits(1); SmRef in = p.sms(2);
-    a = p.put(in, a); b = p.put(in + 1, b);
+    BitRef o = p.bits(1); const uint32_t w = p.dvs(2);
+    p.derived(w, a); p.derived(w + 1, b);
     return p.put(o, gIsZeroS(p, (S)((uint32_t)b - (uint32_t)a)));
 }
 template <class P> GD B gIsEqualF(P& p, const F& a, const F& b, bool inv_is_stored = false) {
@@ -585,47 +581,38 @@ HD SelBlk sel_blk(Cur c, uint32_t N) {
     s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f, c.q};
     return s;
 }
-HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 6 * N + 3, 0}; return r; }
-#define FP_ISEQ_S_ (Cur{6, 2, 4, 0})          // IsEqual [out | in[2]] + IsZero [out | in | inv]
+HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 2 * N + 3, 0, 4 * N}; return r; }      // (the N IsEqual children: 2 BIT + 4 derived wires each)
+#define FP_ISEQ_S_ (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv]: two BIT outputs, four derived operand wires
 // The evaluator's Selector entries [lo, hi) of the block `sb`: the same relations as the loop of gSelectorS / U_LD_SELR, on the same STORED
-// operands and in the same order, but with the loads of C entries (6 SM rows + the IsZero hint + 3 BIT words each) in flight together -- a
-// relation at a time (CheckP::put loads, waits, compares) an entry is nine serial memory round trips, and the leaf detectors alone have
-// 37 000 entries per witness.  acc = the stored sum[lo]; returns the stored sum[hi]; *cnt counts the entries whose stored isEq is set.
+// operands and in the same order, but with the loads of C entries (3 SM rows + 3 BIT words each) in flight together -- a relation at a time
+// (CheckP::put loads, waits, compares) an entry is six serial memory round trips, and the leaf detectors alone have 37 000 entries per witness.  acc = the stored sum[lo]; returns the stored sum[hi]; *cnt counts the entries whose stored isEq is set.
 template <class P, int C> GD S sel_check_range(P& p, const SelBlk& sb, SmRef src, S select, uint32_t lo, uint32_t hi, S acc, S* cnt) {
     for (uint32_t i0 = lo; i0 < hi; i0 += C) {
-        SmRef rr[6 * C]; SiRef ri[C]; BitRef rb[3 * C];
+        SmRef rr[3 * C]; BitRef rb[3 * C];
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)C; q++) {
             const uint32_t i = i0 + q < hi ? i0 + q : hi - 1;              // (a ragged tail repeats the last entry)
             const Cur c = cur_add(sb.kids, FP_ISEQ_S_, i);
-            rr[6 * q] = src + i; rr[6 * q + 1] = sb.vals + i; rr[6 * q + 2] = SmRef{c.w + 1, c.s}; rr[6 * q + 3] = SmRef{c.w + 2, c.s + 1};
-            rr[6 * q + 4] = SmRef{c.w + 4, c.s + 2}; rr[6 * q + 5] = sb.sum + (i + 1);
-            ri[q] = SiRef{c.w + 5, c.s + 3};
+            rr[3 * q] = src + i; rr[3 * q + 1] = sb.vals + i; rr[3 * q + 2] = sb.sum + (i + 1);
             rb[3 * q] = BitRef{c.w, c.b}; rb[3 * q + 1] = BitRef{c.w + 3, c.b + 1}; rb[3 * q + 2] = sb.isEq + i;
         }
-        const SmLoaded<6 * C> h = sm_load(p, rr);
-        S inv[C]; B bw[3 * C];
-#pragma unroll
-        for (uint32_t q = 0; q < (uint32_t)C; q++) inv[q] = p.hint_inv(ri[q], 0);
+        const SmLoaded<3 * C> h = sm_load(p, rr);
+        B bw[3 * C];
 #pragma unroll
         for (uint32_t q = 0; q < 3 * (uint32_t)C; q++) bw[q] = p.get(rb[q]);
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)C; q++) {
             if (i0 + q >= hi) break;
             const uint32_t i = i0 + q;
-            const S vals = h.s[6 * q + 1], in0 = h.s[6 * q + 2], in1 = h.s[6 * q + 3], x = h.s[6 * q + 4], sum = h.s[6 * q + 5], k = inv[q];
-            p.mark(vals != h.s[6 * q], rr[6 * q + 1].w);                                      // vals[i] <== src[i]
-            p.mark(in0 != select, rr[6 * q + 2].w); p.mark(in1 != (S)i, rr[6 * q + 3].w);      // IsEqual.in
-            p.mark(x != (S)((uint32_t)in1 - (uint32_t)in0), rr[6 * q + 4].w);                  // IsZero.in <== in[1] - in[0]
-            p.require(p.ballot(k == 0 || k == x), FAILCODE(T_ISZERO, 30));
+            const S vals = h.s[3 * q + 1], sum = h.s[3 * q + 2];
+            p.mark(vals != h.s[3 * q], rr[3 * q + 1].w);                                      // vals[i] <== src[i]
             const B zo = bw[3 * q + 1], eo = bw[3 * q], e = bw[3 * q + 2];
-            p.mark(((zo ^ p.ballot(k == 0)) >> p.lane_id()) & 1, rb[3 * q + 1].w);             // IsZero.out <== -in*inv + 1
-            p.require(p.ballot(x == 0) | ~zo, FAILCODE(T_ISZERO, 31));
+            p.mark(((zo ^ p.ballot(select == (S)i)) >> p.lane_id()) & 1, rb[3 * q + 1].w);     // IsZero.out = [i - select == 0] (its operand wires are derived)
             p.mark(((eo ^ zo) >> p.lane_id()) & 1, rb[3 * q].w);                               // IsEqual.out <== isz.out
             p.mark(((e ^ eo) >> p.lane_id()) & 1, rb[3 * q + 2].w);                            // isEq[i] <== eq.out
             const bool hit = p.bit(e);
             if (cnt) *cnt += hit;
-            p.mark(sum != acc + (hit ? vals : 0), rr[6 * q + 5].w);                            // sum[i+1] <== sum[i] + isEq[i] * vals[i]
+            p.mark(sum != acc + (hit ? vals : 0), rr[3 * q + 2].w);                            // sum[i+1] <== sum[i] + isEq[i] * vals[i]
             acc = sum;
         }
         p.pin();
@@ -687,7 +674,7 @@ template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count, bool spl
     gAssertLessEqThanS(p, 16, count, (S)n);
     if constexpr (P::is_count) { if (split) p.note(NOTE_SHIFTLEFT, (uint32_t)n, blk, p.cur.w, p.cur.b, p.cur.s); }
     if constexpr (P::is_check) {
-        if (split) { p.cur = cur_add(p.cur, Cur{6, 2, 4, 0, 0}, (uint32_t)(n * n)); return o; }
+        if (split) { p.cur = cur_add(p.cur, FP_ISEQ_S_, (uint32_t)(n * n)); return o; }
     }
     for (int i = 0; i < n; i++) {
         S acc = 0;
@@ -706,7 +693,7 @@ template <class P> GD void gShiftLeftRows(P& p, int n, Cur blk, Cur ciseq, uint3
     const S count = p.get(cn);
     for (uint32_t i = i0; i < i1; i++) {
         S acc = 0;
-        p.cur = cur_add(ciseq, Cur{6, 2, 4, 0, 0}, i * (uint32_t)n);
+        p.cur = cur_add(ciseq, FP_ISEQ_S_, i * (uint32_t)n);
         for (uint32_t j = 0; j < (uint32_t)n; j++) {
             B e = p.put(isEq + (i * n + j), gIsEqualS(p, (S)i, (S)((S)j - count)));
             acc += p.put(temp + (i * n + j), p.bit(e) ? p.get(in + j) : 0);

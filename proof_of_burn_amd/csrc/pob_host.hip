@@ -1237,10 +1237,9 @@ int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t
         return POB_E_ARG;
     }
     if (n == "commitment") { const FrRef r = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? L.pm.commitment : L.sm.commitment; return set(POB_CLASS_FR, r.i, r.w); }
-    if (n == "pad.div.out" || n == "pad.div.rem" || n == "pad.iseq.inv") {       // of KeccakBytes instance k
+    if (n == "pad.div.out" || n == "pad.div.rem") {       // of KeccakBytes instance k
         if (k >= L.nkb) return POB_E_ARG;
         const KBRefs& r = L.kbs[k];
-        if (n == "pad.iseq.inv") return set(POB_CLASS_SM, r.c_loop.s + 3, r.c_loop.w + 5);      // IsEqual([0, inLen]).IsZero.inv (stored as its operand)
         const uint32_t o = n == "pad.div.rem" ? 1 : 0;
         return set(POB_CLASS_SM, r.c_div.s + o, r.c_div.w + o);
     }

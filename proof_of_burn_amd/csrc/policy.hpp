@@ -9,15 +9,16 @@
 //        CDNA wave lane-mask (VCC/EXEC), so gate logic on BIT wires is one 64-bit scalar op for 64
 //        witnesses and a comparison result becomes a wire with one v_cmp (ballot).
 //   SM   wires (bytes, lengths, small signed differences): int32 [wire][64 lanes] (256 B rows).
-//   SI   wires (IsZero.inv of an SM operand): stored in the SM array as the operand k itself; the
-//        wire's value is k^-1 mod p (0 for k = 0), decoded through a table when a .wtns is emitted.
 //   FR   wires (genuine field elements): 8 x uint32 limb planes [wire][limb][64 lanes], Montgomery form.
-//   DV   wires (DERIVED: the operands of the Keccak output selectors' IsEqual gadgets -- select, in[0], in[1], IsZero.in, IsZero.inv of
-//        Selector(n+1) x 1600 per KeccakBytes, half of all non-BIT wires): every one is a function of that sponge's numBlocks (an SM wire) and
-//        of constants, so they are NOT stored: the emitter rebuilds them (EmitP::derived), generation and evaluation skip them (their
-//        relations hold by construction; that the rebuilt values are the right ones is what the payload comparison with the oracle checks).
-//        Rounds 1-2 stored them as an int8 class (SB): 0.7 GB written and 0.7 GB read per batch of 1 024 through 64-byte stores that left
-//        the selector-row kernels store-issue-bound -- dropping the class took 0.33 ms off a 13.0 ms step.
+//   DV   wires (DERIVED): the operand wires of every IsZero / IsEqual gadget over small operands -- IsEqual.in[0], in[1], IsZero.in,
+//        IsZero.inv -- are functions of the two values the CALLER hands the gadget (values of other stored wires, loop indices,
+//        constants).  They are NOT stored: the emitter rebuilds them from the same expressions (EmitP::derived / derived_inv: value,
+//        field inverse with 0 -> 0), generation and evaluation skip them and define / check the gadget's BIT outputs as [a == b]
+//        directly (their relations hold by construction; that the rebuilt values are the right ones is what the payload comparison
+//        with the oracle checks).  These are the selectors' IsEqual([select, i]) of the leaf detectors, SelectorArray1D and the
+//        Keccak outputs, Pad's IsEqual([i, inLen]), ShiftLeft's n^2 IsEqual, SubstringCheck's isLastIndex: 1.0 M of the 1.36 M non-BIT
+//        wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors' as an int8 class of their own,
+//        IsZero.inv as its operand code).
 //
 // Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
 // run of same-class wires (e.g. a whole Keccak-f block, 2 506 944 BIT wires) is contiguous in HBM.
@@ -42,7 +43,6 @@ struct Cur { uint32_t w, b, s, f, q; };   // next free: wire index, BIT rank, SM
 HD Cur cur_add(Cur a, Cur d, uint32_t k) { Cur r = {a.w + d.w * k, a.b + d.b * k, a.s + d.s * k, a.f + d.f * k, a.q + d.q * k}; return r; }
 struct BitRef { uint32_t w, i; HD BitRef operator+(uint32_t k) const { BitRef r = {w + k, i + k}; return r; } };
 struct SmRef  { uint32_t w, i; HD SmRef  operator+(uint32_t k) const { SmRef  r = {w + k, i + k}; return r; } };
-struct SiRef  { uint32_t w, i; HD SiRef  operator+(uint32_t k) const { SiRef  r = {w + k, i + k}; return r; } };
 struct FrRef  { uint32_t w, i; HD FrRef  operator+(uint32_t k) const { FrRef  r = {w + k, i + k}; return r; } };
 
 // failure codes: (template id << 12) | source line of the failing assert / === in the reference circuits
@@ -69,7 +69,7 @@ struct PolBase {
     uint32_t decl_order = POB_DECL_ORDER_DEFAULT;
     HD BitRef bits(uint32_t n) { BitRef r = {cur.w, cur.b}; cur.w += n; cur.b += n; return r; }
     HD SmRef sms(uint32_t n) { SmRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
-    HD SiRef sis(uint32_t n) { SiRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
+    HD uint32_t dvs(uint32_t n) { const uint32_t w = cur.w; cur.w += n; cur.q += n; return w; }     // n derived wires: no storage, the first one's wire index
     HD FrRef frs(uint32_t n) { FrRef r = {cur.w, cur.f}; cur.w += n; cur.f += n; return r; }
     HD void skip_bits(uint32_t n) { cur.w += n; cur.b += n; }
 };
@@ -96,7 +96,6 @@ struct CountP : PolBase {
     HD B hint(BitRef, B v) { nput++; return v; }
     HD S hint(SmRef, S v) { nput++; return v; }
     HD F hint(FrRef, const F& v) { nput += 8; return v; }
-    HD S hint_inv(SiRef, S v) { nput++; return v; }
     HD B get(BitRef) { return 0; }
     HD S get(SmRef) { return 0; }
     HD S get_lane(SmRef, uint32_t) { return 0; }
@@ -156,24 +155,6 @@ template <class P, int BATCH> HD __attribute__((always_inline)) void sm_rows_sam
         }
         const SmLoaded<BATCH> h = sm_load(p, rr);
         sm_commit(p, rr, h, vv);
-    }
-}
-// same for IsZero.inv wires of operand x (comparators.circom:30-31 on the stored code)
-template <class P, int BATCH> HD __attribute__((always_inline)) void si_rows_same(P& p, uint32_t w0, uint32_t s0, uint32_t dw, uint32_t ds, uint32_t n, S x) {
-    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
-        S kk[BATCH];
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-            const uint32_t t = t0 + q < n ? t0 + q : n - 1;
-            kk[q] = p.hint_inv(SiRef{w0 + t * dw, s0 + t * ds}, x);
-        }
-        if constexpr (!P::is_gen) {
-            bool ok30 = true, ok31 = true;
-#pragma unroll
-            for (int q = 0; q < BATCH; q++) { ok30 = ok30 && (kk[q] == 0 || kk[q] == x); ok31 = ok31 && (x == 0 || kk[q] != 0); }
-            p.require(p.ballot(ok30), FAILCODE(T_ISZERO, 30));
-            p.require(p.ballot(ok31), FAILCODE(T_ISZERO, 31));
-        }
     }
 }
 // Lane-distributed bit vector of up to 256 BIT wires: bit 64q + k lives in lane k of r[q] as that wire's 64-witness mask.  A
@@ -314,7 +295,6 @@ struct DevPol : PolBase {
     __device__ __forceinline__ uint32_t lane_id() { return m.lane; }
     __device__ __forceinline__ B ld(BitRef r) { return m.bits[r.i]; }
     __device__ __forceinline__ S ld(SmRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
-    __device__ __forceinline__ S ld(SiRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void derived(uint32_t, S) {}
     __device__ __forceinline__ void derived_inv(uint32_t, S) {}
     __device__ __forceinline__ F ld(FrRef r) {
@@ -327,7 +307,6 @@ struct DevPol : PolBase {
     // measured 1.5x slower on the selector-row stage)
     __device__ __forceinline__ void st(BitRef r, B v) { if (m.lane == 0) m.bits[r.i] = v; POB_WAVE_FENCE(); }
     __device__ __forceinline__ void st(SmRef r, S v) { __builtin_amdgcn_raw_buffer_store_b32(v, m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
-    __device__ __forceinline__ void st(SiRef r, S v) { __builtin_amdgcn_raw_buffer_store_b32(v, m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void st(FrRef r, const F& v) {
         const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
@@ -390,7 +369,6 @@ struct GenP : DevPol {
     __device__ __forceinline__ B hint(BitRef r, B v) { st(r, v); return v; }
     __device__ __forceinline__ S hint(SmRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ F hint(FrRef r, const F& v) { st(r, v); return v; }
-    __device__ __forceinline__ S hint_inv(SiRef r, S v) { st(r, v); return v; }
     __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
@@ -433,7 +411,6 @@ struct CheckP : DevPol {
     __device__ __forceinline__ B hint(BitRef r, B) { return ld(r); }
     __device__ __forceinline__ S hint(SmRef r, S) { return ld(r); }
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
-    __device__ __forceinline__ S hint_inv(SiRef r, S) { return ld(r); }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     // lane-distributed runs: a run's difference is folded into `rdiff` when the NEXT run's load has been issued (one load is
@@ -506,7 +483,6 @@ struct EmitP : DevPol {
     __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
     __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
     __device__ __forceinline__ void derived_inv(uint32_t w, S x) { emit_inv(w, x); }
-    __device__ __forceinline__ S hint_inv(SiRef r, S) { S k = ld(r); emit_inv(r.w, k); return k; }
     __device__ __forceinline__ void emit_inv(uint32_t w, S k) {
         if (m.lane == sel) {
             F c;

@@ -157,11 +157,11 @@ def test_constraint_evaluator_detects_sm_sb_fr_pokes(pkg, which):
     SubstringCheck M[] / IsEqual operands and inverses.  Then the named wires, one at a time, with the reported wire checked."""
     if which == "spend":
         s = _suite("test_spend"); main = "Spend(31)"
-        named = [("poseidon", k) for k in (1, 77, 200, 413, 640, 900)] + [("pad.div.out", 0), ("pad.div.rem", 0), ("pad.iseq.inv", 0), ("commitment", 0)]
+        named = [("poseidon", k) for k in (1, 77, 200, 413, 640, 900)] + [("pad.div.out", 0), ("pad.div.rem", 0), ("commitment", 0)]
     else:
         s = _suite("test_proof_of_burn"); main = POB_FIX
         named = ([("poseidon", k) for k in (5, 300, 800)] + [("sc.M", k) for k in (0, 17, 300, 544)] + [("sc.exists", k) for k in (0, 5, 513)] +
-                 [("sc.isz.inv", k) for k in (0, 40, 513)] + [("pad.div.out", k) for k in (0, 1, 3)] + [("pad.div.rem", 2), ("pad.iseq.inv", 2), ("commitment", 0)])
+                 [("sc.isz.inv", k) for k in (0, 40, 513)] + [("pad.div.out", k) for k in (0, 1, 3)] + [("pad.div.rem", 2), ("commitment", 0)])
     calc = EC.open_identical_batch(pkg, main, s["cases"][0]["input"])
     missed, done = EC.uniform_sweep(calc, {EC.SM: 1200, EC.FR: 400, EC.BIT: 300})
     assert done["SM"] >= 1000 and done["FR"] >= 300
