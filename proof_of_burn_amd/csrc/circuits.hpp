@@ -66,7 +66,7 @@ struct SpendParams { int maxAmountBytes; };
 
 // footprints {wires, BIT, SM, FR} of fixed-size components
 #define FP_ISEQ_S (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv] over small operands: two BIT outputs, four DERIVED operand wires (policy.hpp)
-#define FP_ISEQ_F (Cur{6, 2, 0, 4})
+#define FP_ISEQ_F (Cur{6, 2, 0, 0, 4})       // ... over field elements with derived operand wires (gIsEqualFd)
 #define FP_N2B8 (Cur{9, 8, 1, 0})
 
 // references to main's own wires (proof_of_burn.circom:41-72 in/out, :113-200 intermediates)
@@ -870,54 +870,41 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const uint32_t lo = d.a[1], hi = d.a[2], sl = 31;
         const S mainLen = p.get(sc.ml);
         const F subNum = p.get(sc.num);
-        // FR wires of position i's IsEqual(exists): 0 = in[0], 1 = in[1], 2 = isz.in, 3 = isz.inv
-        auto fref = [&](uint32_t i, uint32_t which) {
-            Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i + 1), FP_ISEQ_F, i);
-            FrRef r = {c.w + 1 + which + (which >= 2 ? 1u : 0u), c.f + which};
-            return r;
-        };
         // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
         const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
+        const uint32_t ln = p.lane_id(), cnt = hi - lo;                      // cnt <= 32
         B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
-        if constexpr (P::is_gen) {
-            // One forward pass writes IsEqual(exists).in[0..1] and IsZero.in for good and leaves the running product of the non-zero
-            // operands in the IsZero.inv slot; one inversion (Montgomery's trick); one backward pass turns the slots into inverses.
-            F run = fr_one_mont();
-            B exm = 0;                                   // bit i - lo (per witness): operand i is zero  (hi - lo <= 64)
-            F ma = p.get(sc.M + lo + sl), mb = p.get(sc.M + lo);
-            for (uint32_t i = lo; i < hi; i++) {
-                // the next position's M operands are requested BEFORE this position's stores are issued: a load queued behind stores
-                // completes only after them (one in-order counter), which would put a store round trip into every iteration
-                const uint32_t in = i + 1 < hi ? i + 1 : i;
-                const F na = p.get(sc.M + in + sl), nb = p.get(sc.M + in);
-                const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_sub(ma, mb), dd = fr_sub(t2, t1);
-                ma = na; mb = nb;
-                p.raw_put(fref(i, 0), t1); p.raw_put(fref(i, 1), t2); p.raw_put(fref(i, 2), dd); p.raw_put(fref(i, 3), run);
-                const bool z = fr_is_zero(dd);
-                if (z) exm |= (B)1 << (i - lo); else run = fr_mul(run, dd);
+        // Per position: IsEqual([i, lastIndex]) and IsEqual([subNum * 256^i, M[i+sl] - M[i]]) -- 12 wires: 4 BIT outputs (IsEqual.out, IsZero.out
+        // twice) and 8 DERIVED operand wires (policy.hpp), i.e. nothing but bits is stored: exists[i] = [t1 == t2] needs no inverse (rounds 1-2
+        // stored the four field-element operands and ran a Montgomery batch inversion per unit through the witness' own slots: 2.3 GB per batch).
+        // The bits leave as lane-distributed runs: isLastIndex[], allowed[], exists[] (one wire per position) and the children's outputs
+        // (four per position, consecutive BIT ranks: 16 positions per run).
+        B runIsl = 0, runAlw = 0, runEx = 0, runC0 = 0, runC1 = 0;
+        F ma = p.get(sc.M + lo + sl), mb = p.get(sc.M + lo);
+        for (uint32_t t = 0; t < cnt; t++) {
+            const uint32_t i = lo + t, in = i + 1 < hi ? i + 1 : i;
+            const F na = p.get(sc.M + in + sl), nb = p.get(sc.M + in);         // (the next position's operands are requested before this one's product)
+            const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_sub(ma, mb);
+            ma = na; mb = nb;
+            const B e = p.ballot(fr_eq(t1, t2)), last = p.ballot(i == lastIdx);
+            allowed &= ~last;
+            runIsl = p.run_set(runIsl, t, last); runAlw = p.run_set(runAlw, t, allowed); runEx = p.run_set(runEx, t, e);
+            const uint32_t k = 4 * (t & 15);
+            if (t < 16) runC0 = p.run_set(p.run_set(p.run_set(p.run_set(runC0, k, last), k + 1, last), k + 2, e), k + 3, e);
+            else runC1 = p.run_set(p.run_set(p.run_set(p.run_set(runC1, k, last), k + 1, last), k + 2, e), k + 3, e);
+            if constexpr (P::is_emit) {
+                const Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
+                iseq_derived(p, c, (S)i, (S)lastIdx);
+                const F dd = fr_sub(t2, t1);
+                p.derived_fr(c.w + 7, t1); p.derived_fr(c.w + 8, t2); p.derived_fr(c.w + 10, dd); p.derived_fr_inv(c.w + 11, dd);
             }
-            F inv = fr_inv_inl(run);
-            for (uint32_t i = hi; i-- > lo;) {
-                const bool z = (exm >> (i - lo)) & 1;
-                const F pre = p.get(fref(i, 3));
-                p.raw_put(fref(i, 3), z ? fr_zero() : fr_mul(inv, pre));
-                if (!z) inv = fr_mul(inv, p.get(fref(i, 2)));
-            }
-            for (uint32_t i = lo; i < hi; i++) {         // the BIT / SM wires: IsEqual(isLastIndex), allowed, exists and the two IsEqual(exists) outputs
-                p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
-                B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
-                allowed = p.put(sc.alw + i + 1, allowed & ~last);
-                const B e = p.ballot((exm >> (i - lo)) & 1);
-                BitRef eo = p.bits(1); p.frs(2); BitRef zo = p.bits(1); p.frs(2);
-                p.put(sc.ex + i, p.put(eo, p.put(zo, e)));
-            }
-        } else {
-            for (uint32_t i = lo; i < hi; i++) {
-                p.cur = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
-                B last = p.put(sc.isl + i, gIsEqualS(p, (S)i, (S)lastIdx));
-                allowed = p.put(sc.alw + i + 1, allowed & ~last);
-                p.put(sc.ex + i, gIsEqualF(p, fr_mul(subNum, p.k256(i)), fr_sub(p.get(sc.M + i + sl), p.get(sc.M + i)), true));
-            }
+        }
+        p.run_put(cnt, sc.isl.w + lo + ln, sc.isl.i + lo + ln, runIsl);
+        p.run_put(cnt, sc.alw.w + lo + 1 + ln, sc.alw.i + lo + 1 + ln, runAlw);
+        p.run_put(cnt, sc.ex.w + lo + ln, sc.ex.i + lo + ln, runEx);
+        for (uint32_t h2 = 0; h2 < 2 && 16 * h2 < cnt; h2++) {               // children: position lo + 16*h2 + lane/4, output lane%4 (wire offsets 0, 3, 6, 9)
+            const uint32_t n = (cnt - 16 * h2 < 16 ? cnt - 16 * h2 : 16) * 4, i = lo + 16 * h2 + (ln >> 2), wh = ln & 3;
+            p.run_put(n, sc.c_loop.w + 12 * i + 3 * wh, sc.c_loop.b + 4 * i + wh, h2 ? runC1 : runC0);
         }
     } break;
     UCASE(CK_POS_SEG) {          // segment a1 of the Poseidon(a0 - 1) block at cur, from the stored state wires before it

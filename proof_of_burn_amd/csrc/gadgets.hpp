@@ -121,6 +121,15 @@ template <class P> GD B gIsEqualF(P& p, const F& a, const F& b, bool inv_is_stor
     F x = p.put(in, a), y = p.put(in + 1, b);
     return p.put(o, gIsZeroF(p, fr_sub(y, x), inv_is_stored));
 }
+// IsEqual over field elements with DERIVED operand wires (policy.hpp): [out | in[2]] || IsZero [out | in | inv]; out = [a == b], the four
+// field-element wires are rebuilt by the emitter (the inverse with one exponentiation per emitted wire -- emission is for sampled witnesses)
+template <class P> GD B gIsEqualFd(P& p, const F& a, const F& b) {
+    BitRef o = p.bits(1); const uint32_t w = p.dvs(2); BitRef zo = p.bits(1); const uint32_t wz = p.dvs(2);
+    const F d = fr_sub(b, a);
+    if constexpr (P::is_emit) { p.derived_fr(w, a); p.derived_fr(w + 1, b); p.derived_fr(wz, d); p.derived_fr_inv(wz + 1, d); }
+    const B z = p.ballot(fr_is_zero(d));
+    return p.put(o, p.put(zo, z));
+}
 // LessThan(n)  [out | in[2]] || Num2Bits(n+1)(in0 + 2^n - in1);  out <== 1 - bit n
 template <class P> GD B gLessThanS(P& p, int n, S a, S b) {
     BitRef o = p.bits(1); SmRef in = p.sms(2);
@@ -948,36 +957,14 @@ template <class P> GD B gSubstringCheck(P& p, int mm, int sl, SmRef mainSrc, S m
             pw = fr_mul(pw, c256);
         }
     }
-    // per i the loop below instantiates IsEqualS (2 BIT, 4 SM) then IsEqualF (2 BIT, 4 FR: in0, in1, isz.in, isz.inv)
-    const FrRef f0 = {p.cur.w + 7, p.cur.f};         // first IsEqualF.in[0]: 6 wires of IsEqualS + IsEqualF.out precede it
-    if (P::is_gen) {
-        // Montgomery batch inversion of the k operands d_i = (M[i+sl]-M[i]) - sub*256^i, using the witness' own
-        // isz.in / isz.inv slots as scratch: pass 1 stores d_i and the running product, pass 2 walks back.
-        F pw = fr_one_mont(), run = fr_one_mont();
-        for (int i = 0; i < k; i++) {
-            F d = fr_sub(fr_sub(p.get(M + i + sl), p.get(M + i)), fr_mul(subNum, pw));
-            FrRef din = {f0.w + 12 * i + 3, f0.i + 4 * i + 2}, dinv = {din.w + 1, din.i + 1};
-            p.raw_put(din, d);
-            p.raw_put(dinv, run);                       // product of the non-zero d_j, j < i
-            if (!fr_is_zero(d)) run = fr_mul(run, d);
-            pw = fr_mul(pw, c256);
-        }
-        F inv = fr_inv(run);
-        for (int i = k - 1; i >= 0; i--) {
-            FrRef din = {f0.w + 12 * i + 3, f0.i + 4 * i + 2}, dinv = {din.w + 1, din.i + 1};
-            F d = p.get(din), pre = p.get(dinv);
-            bool z = fr_is_zero(d);
-            p.raw_put(dinv, z ? fr_zero() : fr_mul(inv, pre));
-            if (!z) inv = fr_mul(inv, d);
-        }
-    }
+    // per i the loop below instantiates IsEqual([i, lastIndex]) and IsEqual(exists): two BIT outputs and four derived operand wires each
     B allowed = p.put(alw, ~(B)0);
     S sum = p.put(sums, 0);
     F pw = fr_one_mont();
     for (int i = 0; i < k; i++) {
         B last = p.put(isl + i, gIsEqualS(p, (S)i, (S)(mainLen - sl + 1)));                 // :87
         allowed = p.put(alw + i + 1, allowed & ~last);
-        B e = p.put(ex + i, gIsEqualF(p, fr_mul(subNum, pw), fr_sub(p.get(M + i + sl), p.get(M + i)), true));   // :91
+        B e = p.put(ex + i, gIsEqualFd(p, fr_mul(subNum, pw), fr_sub(p.get(M + i + sl), p.get(M + i))));   // :91
         sum = p.put(sums + i + 1, sum + (S)p.bit(allowed & e));
         pw = fr_mul(pw, c256);
     }

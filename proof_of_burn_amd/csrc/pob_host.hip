@@ -1248,10 +1248,6 @@ int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t
         const uint32_t mm = 136u * (uint32_t)L.pob.NB, kk = mm - 31 + 1;
         if (n == "sc.M" && k <= mm) return set(POB_CLASS_FR, sc.M.i + k, sc.M.w + k);
         if (n == "sc.exists" && k < kk) return set(POB_CLASS_BIT, sc.ex.i + k, sc.ex.w + k);
-        if (n == "sc.isz.inv" && k < kk) {   // IsEqual(exists[k]).IsZero.inv: FR wires of position k are in0, in1, isz.in, isz.inv
-            const Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, k + 1), FP_ISEQ_F, k);
-            return set(POB_CLASS_FR, c.f + 3, c.w + 5);
-        }
     }
     return POB_E_ARG;
 }

@@ -16,8 +16,9 @@
 //        field inverse with 0 -> 0), generation and evaluation skip them and define / check the gadget's BIT outputs as [a == b]
 //        directly (their relations hold by construction; that the rebuilt values are the right ones is what the payload comparison
 //        with the oracle checks).  These are the selectors' IsEqual([select, i]) of the leaf detectors, SelectorArray1D and the
-//        Keccak outputs, Pad's IsEqual([i, inLen]), ShiftLeft's n^2 IsEqual, SubstringCheck's isLastIndex: 1.0 M of the 1.36 M non-BIT
-//        wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors' as an int8 class of their own,
+//        Keccak outputs, Pad's IsEqual([i, inLen]), ShiftLeft's n^2 IsEqual, SubstringCheck's isLastIndex -- and, over field elements, the
+//        IsEqual(exists) of SubstringCheck's 7 710 positions (gIsEqualFd: 30 840 FR wires whose inverses needed a batch inversion per 32
+//        positions): 1.06 M of the 1.36 M non-BIT wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors' as an int8 class of their own,
 //        IsZero.inv as its operand code).
 //
 // Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
@@ -101,6 +102,8 @@ struct CountP : PolBase {
     HD S get_lane(SmRef, uint32_t) { return 0; }
     HD void derived(uint32_t, S) {}               // a DERIVED wire (see the header): value v / the inverse of x; only the emitter does anything
     HD void derived_inv(uint32_t, S) {}
+    HD void derived_fr(uint32_t, const F&) {}     // ... with a field-element value (Montgomery) / the field inverse of x (0 for 0)
+    HD void derived_fr_inv(uint32_t, const F&) {}
     HD F get(FrRef) { return fr_zero(); }
     HD void raw_put(FrRef, const F&) {}
     HD B ballot(bool) { return 0; }
@@ -297,6 +300,8 @@ struct DevPol : PolBase {
     __device__ __forceinline__ S ld(SmRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void derived(uint32_t, S) {}
     __device__ __forceinline__ void derived_inv(uint32_t, S) {}
+    __device__ __forceinline__ void derived_fr(uint32_t, const F&) {}
+    __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&) {}
     __device__ __forceinline__ F ld(FrRef r) {
         F v; const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
@@ -483,6 +488,8 @@ struct EmitP : DevPol {
     __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
     __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
     __device__ __forceinline__ void derived_inv(uint32_t w, S x) { emit_inv(w, x); }
+    __device__ __forceinline__ void derived_fr(uint32_t w, const F& v) { if (m.lane == sel) w32(w, fr_from_mont(v)); }
+    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) w32(w, fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv_fermat(x))); }
     __device__ __forceinline__ void emit_inv(uint32_t w, S k) {
         if (m.lane == sel) {
             F c;

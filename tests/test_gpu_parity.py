@@ -161,7 +161,7 @@ def test_constraint_evaluator_detects_sm_sb_fr_pokes(pkg, which):
     else:
         s = _suite("test_proof_of_burn"); main = POB_FIX
         named = ([("poseidon", k) for k in (5, 300, 800)] + [("sc.M", k) for k in (0, 17, 300, 544)] + [("sc.exists", k) for k in (0, 5, 513)] +
-                 [("sc.isz.inv", k) for k in (0, 40, 513)] + [("pad.div.out", k) for k in (0, 1, 3)] + [("pad.div.rem", 2), ("commitment", 0)])
+                 [("pad.div.out", k) for k in (0, 1, 3)] + [("pad.div.rem", 2), ("commitment", 0)])
     calc = EC.open_identical_batch(pkg, main, s["cases"][0]["input"])
     missed, done = EC.uniform_sweep(calc, {EC.SM: 1200, EC.FR: 400, EC.BIT: 300})
     assert done["SM"] >= 1000 and done["FR"] >= 300
