@@ -67,7 +67,7 @@ struct SpendParams { int maxAmountBytes; };
 // footprints {wires, BIT, SM, FR} of fixed-size components
 #define FP_ISEQ_S (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv] over small operands: two BIT outputs, four DERIVED operand wires (policy.hpp)
 #define FP_ISEQ_F (Cur{6, 2, 0, 0, 4})       // ... over field elements with derived operand wires (gIsEqualFd)
-#define FP_N2B8 (Cur{9, 8, 1, 0})
+#define FP_N2B8 (Cur{9, 8, 0, 0, 1})         // Num2Bits(8) [out[8] | in] of KeccakBytes' byte loop: `in` derived
 
 // references to main's own wires (proof_of_burn.circom:41-72 in/out, :113-200 intermediates)
 struct PobMain {
@@ -87,8 +87,9 @@ struct SpendMain {   // spend.circom:33-38, :43-49
 };
 // KeccakBytes own wires, Pad's own wires, and the Keccak/Final/SelectorArray2D wires its G units touch
 struct KBRefs {
-    SmRef out, in, inLen, padded, numBlocks; BitRef inBitsArray, inBits, inBlocks, outBits, outBytes;
-    SmRef pad_o, pad_nb, pad_in, pad_il, pad_dv, pad_rm; BitRef pad_flt, pad_isEq, pad_isLast;
+    SmRef out, in, inLen, numBlocks; BitRef inBitsArray, inBits, inBlocks, outBits, outBytes;
+    uint32_t padded_w, pad_o_w, pad_in_w;          // padded[m], Pad.out[m], Pad.in[m]: derived wires (functions of the byte, inLen, numBlocks)
+    SmRef pad_nb, pad_il, pad_dv, pad_rm; BitRef pad_flt, pad_isEq, pad_isLast;
     Cur c_loop;                       // first IsEqual of Pad's isEq loop; then m isLast IsEquals, m Num2Bits(8), Flatten(m,8)
     Cur c_div;                        // Pad's Divide(16) block: [out, rem | a, b] ...  (divide.circom:17-33)
     BitRef k_out, k_in; SmRef k_blocks; BitRef k_finalState, f_out, f_in; SmRef f_blocks; BitRef f_s;
@@ -143,7 +144,7 @@ struct CircuitLayout {
     struct { SmRef nibbles; FrRef in; SmRef addressBytes, block, hash; uint32_t kb; } bah;
     struct { FrRef out; SmRef in, flat, block, hash, reduced; uint32_t kb; int N, nb; } pc;
     struct { FrRef in; SmRef mzb, keyBytes, raBytes, becBytes, eip, hin, block, keccak; BitRef sbz; uint32_t kb; } pw;
-    struct { SmRef out, arr, sel, T; Cur c_sel0; } ll;                   // SelectorArray1D(L, 136*NB) of :142
+    struct { SmRef out; uint32_t arr_w, sel_w, T_w; Cur c_sel0; } ll;    // SelectorArray1D(L, 136*NB) of :142 (arrays / select / arraysT: derived wires)
     RlRefs rl;
     RaRefs ra;
     uint32_t kb_hdr, kb_layer0, nkb, nsc;
@@ -170,11 +171,11 @@ HD PosOff pos_off(int t) {
 template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
     const uint32_t m = 136 * mb;
     r.mb = mb;
-    r.out = p.sms(32); r.in = p.sms(m); r.inLen = p.sms(1); r.padded = p.sms(m); r.numBlocks = p.sms(1);
+    r.out = p.sms(32); r.in = p.sms(m); r.inLen = p.sms(1); r.padded_w = p.dvs(m); r.numBlocks = p.sms(1);
     r.inBitsArray = p.bits(8 * m); r.inBits = p.bits(8 * m); r.inBlocks = p.bits(8 * m); r.outBits = p.bits(256); r.outBytes = p.bits(256);
     inLen = p.put(r.inLen, inLen);
     gAssertLessThanS(p, 16, inLen, (S)m);
-    r.pad_o = p.sms(m); r.pad_nb = p.sms(1); r.pad_in = p.sms(m); r.pad_il = p.sms(1); r.pad_dv = p.sms(1); r.pad_rm = p.sms(1);
+    r.pad_o_w = p.dvs(m); r.pad_nb = p.sms(1); r.pad_in_w = p.dvs(m); r.pad_il = p.sms(1); r.pad_dv = p.sms(1); r.pad_rm = p.sms(1);
     r.pad_flt = p.bits(m + 1); r.pad_isEq = p.bits(m); r.pad_isLast = p.bits(m);
     inLen = p.put(r.pad_il, inLen);
     S q, rem;
@@ -206,16 +207,13 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
     for (uint32_t t = 0; t < cnt; t++) {
         const uint32_t i = lo + t;
         const Cur ce = cur_add(cE, FP_ISEQ_S, i), cl = cur_add(cL, FP_ISEQ_S, i);
-        const SmRef rr[5] = {r.in + i, r.pad_in + i, r.pad_o + i, r.padded + i, SmRef{cN.w + 9 * i + 8, cN.s + i}};
-        const SmLoaded<5> h = sm_load(p, rr);
-        const S v = p.get(src + i);
+        const S v = p.put(r.in + i, p.get(src + i));
         const S xe = (S)((uint32_t)inLen - i), xl = (S)((uint32_t)last - i);
         iseq_derived(p, ce, (S)i, inLen); iseq_derived(p, cl, (S)i, last);      // IsEqual([i, inLen]), IsEqual([i, numBlocks*136 - 1]): operand wires derived
         const B e = p.ballot(xe == 0), l = p.ballot(xl == 0);
         f &= ~e;
         const S pv = (p.bit(f) ? v : 0) + (S)p.bit(e) + (p.bit(l) ? 0x80 : 0);
-        const S vv[5] = {v, v, pv, pv, pv};
-        sm_commit(p, rr, h, vv);
+        p.derived(r.pad_in_w + i, v); p.derived(r.pad_o_w + i, pv); p.derived(r.padded_w + i, pv); p.derived(cN.w + 9 * i + 8, pv);   // (derived copies)
         p.require(p.ballot((uint32_t)pv < 256u), FAILCODE(T_NUM2BITS, 38));
         runE = p.run_set(runE, t, e); runL = p.run_set(runL, t, l); runF = p.run_set(runF, t, f);
         runPairE = p.run_set(p.run_set(runPairE, 2 * t, e), 2 * t + 1, e);
@@ -358,9 +356,9 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         gAssertLessThanS(p, 16, p.get(M.blockHeaderLen), (S)(HBy * 8));
         for (int i = 0; i < 32; i++) p.put(M.stateRoot + i, p.get(M.blockHeader + 91 + i));
     } break;
-    UCASE(U_ABS_RANGE) {          // cur = first AssertBits(8) child; a = own_in (w,i), src (w,i), lo, hi
-        SmRef own = {d.a[0], d.a[1]}, src = {d.a[2], d.a[3]};
-        abs_range(p, d.cur, own, src, d.a[4], d.a[5]);
+    UCASE(U_ABS_RANGE) {          // cur = first AssertBits(8) child; a = first wire of the own in[], -, src (w,i), lo, hi
+        SmRef src = {d.a[2], d.a[3]};
+        abs_range(p, d.cur, d.a[0], src, d.a[4], d.a[5]);
     } break;
     UCASE(U_BAH_POST) {           // :82 Bytes2Nibbles(32) + main.addressHashNibbles (:119)
         SmRef nb = gBytes2Nibbles(p, 32, L.bah.hash);
@@ -400,29 +398,18 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         if (P::is_count) L.kbs[L.pc.kb] = r;
     } break;
     UCASE(U_POB_LASTLAYER) {      // :142-143 SelectorArray1D(L, LB): the select input; selectors run as range units
-        p.put(L.ll.sel, p.get(M.numLayers) - 1);
+        p.derived(L.ll.sel_w, p.get(M.numLayers) - 1);
     } break;
-    UCASE(U_POB_LASTLAYER_RANGE) {   // selectors [a0, a1) of SelectorArray1D (selector.circom:62-77); Selector(n) footprint {9n+3, 3n, 6n+3, 0}
+    UCASE(U_POB_LASTLAYER_RANGE) {   // selectors [a0, a1) of SelectorArray1D (selector.circom:62-77): selector j reads column j of layers[][] directly
         const uint32_t n = prm.L, q = LB;
         const Cur fp = sel_fp(n);
         S select = p.get(M.numLayers) - 1;
         for (uint32_t j = d.a[0]; j < d.a[1]; j++) {
-            if constexpr (P::is_check) {              // arraysT[j][i] === arrays[i][j] === layers[i][j], eight layers' loads in flight
-                for (uint32_t i0 = 0; i0 < n; i0 += 8) {
-                    SmRef ra[8], rt[8];
-#pragma unroll
-                    for (uint32_t t = 0; t < 8; t++) { const uint32_t i = i0 + t < n ? i0 + t : n - 1; ra[t] = L.ll.arr + (i * q + j); rt[t] = L.ll.T + (j * n + i); }
-                    const SmLoaded<8> ha = sm_load(p, ra), ht = sm_load(p, rt);
-                    S src[8];
-#pragma unroll
-                    for (uint32_t t = 0; t < 8; t++) src[t] = p.get(M.layers + ((i0 + t < n ? i0 + t : n - 1) * q + j));
-                    sm_commit(p, ra, ha, src);
-                    sm_commit(p, rt, ht, ha.s);
-                }
-            } else
-            for (uint32_t i = 0; i < n; i++) p.put(L.ll.T + (j * n + i), p.put(L.ll.arr + (i * q + j), p.get(M.layers + (i * q + j))));
+            if constexpr (P::is_emit) {               // arrays[i][j] and arraysT[j][i]: derived copies of layers[i][j]
+                for (uint32_t i = 0; i < n; i++) { const S v = p.get(M.layers + (i * q + j)); p.derived(L.ll.arr_w + i * q + j, v); p.derived(L.ll.T_w + j * n + i, v); }
+            }
             p.cur = cur_add(L.ll.c_sel0, fp, j);
-            S v = p.put(L.ll.out + j, gSelectorS(p, n, L.ll.T + j * n, select));
+            S v = p.put(L.ll.out + j, gSelectorS(p, n, M.layers + j, select, q));
             p.put(M.lastLayer + j, v);
         }
     } break;
@@ -495,32 +482,26 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         R.c_eq[3] = cur_add(R.c_eq[2], FP_ISEQ_S, 1); R.c_mand = cur_add(R.c_eq[3], FP_ISEQ_S, 1);
         for (uint32_t k = 0; k < 4; k++) {
             const SelBlk sb = sel_blk(R.c_sel[k], N);
-            const S select = p.put(sb.sel, 2 + kl + (S)k);
-            p.put(sb.sum, 0);
+            const S select = 2 + kl + (S)k;
+            p.derived(sb.sel_w, select); p.derived(sb.sum_w, 0);
             p.require(p.ballot((uint32_t)select < N), FAILCODE(T_SELECTOR, 43));      // sum isEq === 1  <=>  0 <= select < N
         }
         { B m[7] = {0, 0, 0, 0, 0, 0, 0}; p.cur = R.c_mand; CountP q; q.cur = p.cur; q.decl_order = p.decl_order; MultiANDg<CountP, 7>::run(q, m); R.c_end = q.cur; }
         p.cur = R.c_end;
         if (P::is_count) L.lds[d.a[0]] = R;
     } break;
-    UCASE(U_LD_SELR) {            // entries [a2, a3) of selector a1 of LeafDetector a0; sum[i] = [select < i] * vals[select]
+    UCASE(U_LD_SELR) {            // entries [a2, a3) of selector a1 of LeafDetector a0: bits only (gadgets.hpp sel_range); the last range also writes out
         const LdRefs& R = L.lds[d.a[0]];
         const uint32_t N = LB, which = d.a[1], lo = d.a[2], hi = d.a[3];
         const SelBlk sb = sel_blk(R.c_sel[which], N);
         const S select = 2 + p.get(R.keyLen) + (S)which;
-        S acc;
-        if (P::is_gen) { const uint32_t us = (uint32_t)select; acc = us < lo ? p.get_lane(R.src, us) : 0; }
-        else acc = p.get(sb.sum + lo);
-        if constexpr (P::is_check) acc = sel_check_range<P, 4>(p, sb, R.src, select, lo, hi, acc, nullptr);      // (the evaluator: four entries' loads in flight)
-        else for (uint32_t i = lo; i < hi; i++) {
-            const S v = p.put(sb.vals + i, p.get(R.src + i));
-            p.cur = cur_add(sb.kids, FP_ISEQ_S, i);
-            const B e = p.put(sb.isEq + i, gIsEqualS(p, select, (S)i));
-            acc = p.put(sb.sum + i + 1, acc + (p.bit(e) ? v : 0));
-        }
+        const uint32_t us = (uint32_t)select;
+        S out = 0;
+        if (P::is_emit || hi == N) out = us < N ? p.get_lane(R.src, us) : 0;
+        sel_range(p, sb, R.src, 1, select, out, lo, hi);
         if (hi == N) {
             const SmRef dst = which == 0 ? R.valueWrapperPrefix : which == 1 ? R.valueWrapperLen : which == 2 ? R.valuePrefix : R.valueLen;
-            p.put(dst, p.put(sb.o, acc));
+            p.put(dst, p.put(sb.o, out));
         }
     } break;
     UCASE(U_LD_TAIL) {            // :280-293 the four IsEquals after the selectors, MultiAND(7), isLeaf
@@ -814,7 +795,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
             sc.c_abs_sub = p.cur;
             gAssertByteString(p, sl, sc.si);
-            sc.abs_main_in = p.sms(mm);
+            sc.abs_main_in = SmRef{p.dvs(mm), 0};
             sc.c_abs_main = p.cur;
             p.cur = cur_add(p.cur, FP_ABITS8, mm);
             sc.c_after_abs = p.cur;
@@ -1004,9 +985,9 @@ struct Plan {
     // AssertByteString(N)(src) as range units; p.cur = start of the AssertByteString block
     void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32) {
         CountP chk; chk.cur = p.cur; gAssertByteString(chk, (int)N, src);
-        SmRef own = p.sms(N);
+        const uint32_t own_w = p.dvs(N);
         const Cur c0 = p.cur;
-        for (uint32_t lo = 0; lo < N; lo += chunk) record(U_ABS_RANGE, stage, c0, own.w, own.i, src.w, src.i, lo, std::min(lo + chunk, N));
+        for (uint32_t lo = 0; lo < N; lo += chunk) record(U_ABS_RANGE, stage, c0, own_w, 0, src.w, src.i, lo, std::min(lo + chunk, N));
         p.cur = cur_add(c0, FP_ABITS8, N);
         expect_cursor("AssertByteString", p.cur, chk.cur);
     }
@@ -1154,7 +1135,7 @@ struct Plan {
         public_commitment(6, TQ + 1);                                                           // :137  (track 6: pre 1, ranges 2, sponge 3, rows/post 4, commitment 5)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
             CountP chk; chk.cur = p.cur; gSelectorArray1D(chk, Ln, LB, M.layers, 0);
-            L.ll.out = p.sms(LB); L.ll.arr = p.sms(Ln * LB); L.ll.sel = p.sms(1); L.ll.T = p.sms(LB * Ln);
+            L.ll.out = p.sms(LB); L.ll.arr_w = p.dvs(Ln * LB); L.ll.sel_w = p.dvs(1); L.ll.T_w = p.dvs(LB * Ln);
             unit(U_POB_LASTLAYER, TP + 1);
             L.ll.c_sel0 = p.cur;
             const Cur fp = sel_fp((uint32_t)Ln);

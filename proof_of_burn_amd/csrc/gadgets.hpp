@@ -454,10 +454,11 @@ template <class P> GD void gAssertBitsF(P& p, int nb, const F& in) {
     gNum2BitsF(p, nb, x, &v);
     bv_put(p, bits, nb, v);
 }
-#define FP_ABITS8 (Cur{18, 16, 2, 0})        // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]
+#define FP_ABITS8 (Cur{18, 16, 0, 0, 2})     // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]: 16 stored bits, the two `in` copies derived
 // ---------------------------------------------------------------------------- AssertByteString(N) in ranges (assert.circom:26-31)
-// own in[N] is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8
-template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint32_t lo, uint32_t hi) {
+// own in[N] (first wire own_w) is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8.  The three copies of the byte -- own
+// in[i], AssertBits.in, Num2Bits.in -- are DERIVED wires (policy.hpp): only the 16 bits per byte are stored
+template <class P> GD void abs_range(P& p, Cur c0, uint32_t own_w, SmRef src, uint32_t lo, uint32_t hi) {
     // per byte i: own in[i]; AssertBits(8) [in | bits[8]] || Num2Bits(8) [out[8] | in] at c0 + i*FP_ABITS8.  The 16 BIT wires of a
     // byte are consecutive in BIT rank (bits[8] then out[8]), so 4 bytes make one lane-distributed run of 64 wires.
     const uint32_t ln = p.lane_id();
@@ -467,11 +468,8 @@ template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint
         for (uint32_t t = 0; t < cnt; t++) {
             const uint32_t i = i0 + t;
             const Cur c = cur_add(c0, FP_ABITS8, i);
-            const SmRef rr[3] = {own_in + i, SmRef{c.w, c.s}, SmRef{c.w + 17, c.s + 1}};
-            const SmLoaded<3> h = sm_load(p, rr);
             const S v = p.get(src + i);
-            const S vv[3] = {v, v, v};
-            sm_commit(p, rr, h, vv);
+            p.derived(own_w + i, v); p.derived(c.w, v); p.derived(c.w + 17, v);
             p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
@@ -487,10 +485,10 @@ template <class P> GD void abs_range(P& p, Cur c0, SmRef own_in, SmRef src, uint
 
 // AssertByteString(N) :26-31  [ | in[N]] || AssertBits(8) x N
 template <class P> GD void gAssertByteString(P& p, int N, SmRef src) {
-    SmRef in = p.sms(N);
+    const uint32_t in_w = p.dvs(N);
     const Cur c0 = p.cur;
-    abs_range(p, c0, in, src, 0, (uint32_t)N);
-    p.cur = Cur{c0.w + 18u * N, c0.b + 16u * N, c0.s + 2u * N, c0.f, c0.q};
+    abs_range(p, c0, in_w, src, 0, (uint32_t)N);
+    p.cur = cur_add(c0, FP_ABITS8, (uint32_t)N);
 }
 // AssertLessThan(B) :40-47 / AssertLessEqThan :56-63 / AssertGreaterEqThan :72-79   [ | a, b | out]; out === 1
 template <class P> GD void gAssertLessThanS(P& p, int nb, S a, S b) {
@@ -581,72 +579,63 @@ template <class P> GD void gDivide(P& p, int N, S a, S b, S& q, S& r) {
 }
 
 // ============================================================================ circuits/utils/selector.circom
-// Selector(N) block at cursor c (selector.circom:21-46): [out | vals[N], select | isEq[N], sum[N+1]] || IsEqual x N
-struct SelBlk { SmRef o, vals, sel; BitRef isEq; SmRef sum; Cur kids; };
+// Selector(N) block at cursor c (selector.circom:21-46): [out | vals[N], select | isEq[N], sum[N+1]] || IsEqual([select, i]) x N;  sum isEq === 1.
+// STORED: out (one SM wire) and the 3N bits (isEq[], the children's IsEqual.out / IsZero.out).  DERIVED (policy.hpp): vals[] (copies of the
+// source), select, sum[i+1] = [select <= i] * out, the children's operand wires -- the emitter rebuilds them.
+struct SelBlk { SmRef o; uint32_t vals_w, sel_w, sum_w; BitRef isEq; Cur kids; };
 HD SelBlk sel_blk(Cur c, uint32_t N) {
     SelBlk s;
-    s.o = SmRef{c.w, c.s}; s.vals = SmRef{c.w + 1, c.s + 1}; s.sel = SmRef{c.w + 1 + N, c.s + 1 + N};
-    s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum = SmRef{c.w + 2 + 2 * N, c.s + 2 + N};
-    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 2 * N + 3, c.f, c.q};
+    s.o = SmRef{c.w, c.s}; s.vals_w = c.w + 1; s.sel_w = c.w + 1 + N;
+    s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum_w = c.w + 2 + 2 * N;
+    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 1, c.f, c.q + 2 * N + 2};
     return s;
 }
-HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 2 * N + 3, 0, 4 * N}; return r; }      // (the N IsEqual children: 2 BIT + 4 derived wires each)
+HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 1, 0, 6 * N + 2}; return r; }
 #define FP_ISEQ_S_ (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv]: two BIT outputs, four derived operand wires
-// The evaluator's Selector entries [lo, hi) of the block `sb`: the same relations as the loop of gSelectorS / U_LD_SELR, on the same STORED
-// operands and in the same order, but with the loads of C entries (3 SM rows + 3 BIT words each) in flight together -- a relation at a time
-// (CheckP::put loads, waits, compares) an entry is six serial memory round trips, and the leaf detectors alone have 37 000 entries per witness.  acc = the stored sum[lo]; returns the stored sum[hi]; *cnt counts the entries whose stored isEq is set.
-template <class P, int C> GD S sel_check_range(P& p, const SelBlk& sb, SmRef src, S select, uint32_t lo, uint32_t hi, S acc, S* cnt) {
-    for (uint32_t i0 = lo; i0 < hi; i0 += C) {
-        SmRef rr[3 * C]; BitRef rb[3 * C];
-#pragma unroll
-        for (uint32_t q = 0; q < (uint32_t)C; q++) {
-            const uint32_t i = i0 + q < hi ? i0 + q : hi - 1;              // (a ragged tail repeats the last entry)
-            const Cur c = cur_add(sb.kids, FP_ISEQ_S_, i);
-            rr[3 * q] = src + i; rr[3 * q + 1] = sb.vals + i; rr[3 * q + 2] = sb.sum + (i + 1);
-            rb[3 * q] = BitRef{c.w, c.b}; rb[3 * q + 1] = BitRef{c.w + 3, c.b + 1}; rb[3 * q + 2] = sb.isEq + i;
-        }
-        const SmLoaded<3 * C> h = sm_load(p, rr);
-        B bw[3 * C];
-#pragma unroll
-        for (uint32_t q = 0; q < 3 * (uint32_t)C; q++) bw[q] = p.get(rb[q]);
-#pragma unroll
-        for (uint32_t q = 0; q < (uint32_t)C; q++) {
-            if (i0 + q >= hi) break;
-            const uint32_t i = i0 + q;
-            const S vals = h.s[3 * q + 1], sum = h.s[3 * q + 2];
-            p.mark(vals != h.s[3 * q], rr[3 * q + 1].w);                                      // vals[i] <== src[i]
-            const B zo = bw[3 * q + 1], eo = bw[3 * q], e = bw[3 * q + 2];
-            p.mark(((zo ^ p.ballot(select == (S)i)) >> p.lane_id()) & 1, rb[3 * q + 1].w);     // IsZero.out = [i - select == 0] (its operand wires are derived)
-            p.mark(((eo ^ zo) >> p.lane_id()) & 1, rb[3 * q].w);                               // IsEqual.out <== isz.out
-            p.mark(((e ^ eo) >> p.lane_id()) & 1, rb[3 * q + 2].w);                            // isEq[i] <== eq.out
-            const bool hit = p.bit(e);
-            if (cnt) *cnt += hit;
-            p.mark(sum != acc + (hit ? vals : 0), rr[3 * q + 2].w);                            // sum[i+1] <== sum[i] + isEq[i] * vals[i]
-            acc = sum;
-        }
-        p.pin();
-    }
-    return acc;
+// four derived operand wires of an IsEqual([a, b]) child whose first wire is w
+template <class P> HD void iseq_derived_w(P& p, uint32_t w, S a, S b) {
+    p.derived(w + 1, a); p.derived(w + 2, b);
+    const S x = (S)((uint32_t)b - (uint32_t)a);
+    p.derived(w + 4, x); p.derived_inv(w + 5, x);
 }
-// Selector(n) :21-46  [out | vals[n], select | isEq[n], sum[n+1]] || IsEqual([select, i]) x n;  sum isEq === 1
-template <class P> GD S gSelectorS(P& p, int n, SmRef src, S select) {
-    const Cur blk = p.cur;
-    SmRef o = p.sms(1), vals = p.sms(n), sel = p.sms(1); BitRef isEq = p.bits(n); SmRef sum = p.sms(n + 1);
-    select = p.put(sel, select);
-    S acc = p.put(sum, 0), cnt = 0;
-    if constexpr (P::is_check) {
-        acc = sel_check_range<P, 4>(p, sel_blk(blk, (uint32_t)n), src, select, 0, (uint32_t)n, acc, &cnt);
-        p.cur = cur_add(p.cur, FP_ISEQ_S_, (uint32_t)n);
-    } else
-    for (int i = 0; i < n; i++) {
-        S v = p.put(vals + i, p.get(src + i));
-        B e = p.put(isEq + i, gIsEqualS(p, select, (S)i));
-        bool hit = p.bit(e);
-        cnt += hit;
-        acc = p.put(sum + i + 1, acc + (hit ? v : 0));
+// entries [lo, hi) of the Selector block sb over src[i * stride]: the bits as lane-distributed runs (32 entries: isEq[], and the children's two
+// outputs each as one run of 64), the derived wires for the emitter.  out = the selected value (src[select]).
+template <class P> GD void sel_range(P& p, const SelBlk& sb, SmRef src, uint32_t stride, S select, S out, uint32_t lo, uint32_t hi) {
+    const uint32_t ln = p.lane_id();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 32) {
+        const uint32_t n = hi - i0 < 32 ? hi - i0 : 32;
+        B runE = 0, runK = 0;
+        for (uint32_t t = 0; t < n; t++) {
+            const B e = p.ballot((uint32_t)select == i0 + t);
+            runE = p.run_set(runE, t, e);
+            runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
+        }
+        p.run_put(n, sb.isEq.w + i0 + ln, sb.isEq.i + i0 + ln, runE);
+        p.run_put(2 * n, sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), sb.kids.b + 2 * i0 + ln, runK);
+        if constexpr (P::is_emit) {
+            for (uint32_t t = 0; t < n; t++) {
+                const uint32_t i = i0 + t;
+                p.derived(sb.vals_w + i, p.get(src + i * stride));
+                iseq_derived_w(p, sb.kids.w + 6 * i, select, (S)i);
+                p.derived(sb.sum_w + i + 1, (uint32_t)select <= i ? out : 0);
+            }
+        }
     }
-    p.require(p.ballot(cnt == 1), FAILCODE(T_SELECTOR, 43));
-    return p.put(o, acc);
+}
+// the head of a Selector block: out, select, sum[0], the range check (sum isEq === 1  <=>  0 <= select < N); returns the selected value
+template <class P> GD S sel_head(P& p, const SelBlk& sb, uint32_t N, SmRef src, uint32_t stride, S select) {
+    const uint32_t us = (uint32_t)select;
+    p.require(p.ballot(us < N), FAILCODE(T_SELECTOR, 43));
+    p.derived(sb.sel_w, select); p.derived(sb.sum_w, 0);
+    return p.put(sb.o, us < N ? p.get_lane(src, us * stride) : 0);
+}
+// Selector(n) :21-46 over src[i * stride]
+template <class P> GD S gSelectorS(P& p, int n, SmRef src, S select, uint32_t stride = 1) {
+    const SelBlk sb = sel_blk(p.cur, (uint32_t)n);
+    p.cur = cur_add(p.cur, sel_fp((uint32_t)n), 1);
+    const S out = sel_head(p, sb, (uint32_t)n, src, stride, select);
+    sel_range(p, sb, src, stride, select, out, 0, (uint32_t)n);
+    return out;
 }
 // same template on BIT-valued data (Final's SelectorArray2D over Keccak states): all-mask arithmetic
 template <class P> GD B gSelectorB(P& p, int n, BitRef src, S select) {
@@ -662,12 +651,15 @@ template <class P> GD B gSelectorB(P& p, int n, BitRef src, S select) {
     p.require(any & ~multi, FAILCODE(T_SELECTOR, 43));
     return p.put(o, acc);
 }
-// SelectorArray1D(n, q) :62-77  [out[q] | arrays[n][q], select | arraysT[q][n]] || Selector(n) x q
+// SelectorArray1D(n, q) :62-77  [out[q] | arrays[n][q], select | arraysT[q][n]] || Selector(n) x q.  arrays[][], select and the transposed
+// copy are derived wires (copies of the source); selector j reads its column of the source directly (stride q)
 template <class P> GD SmRef gSelectorArray1D(P& p, int n, int q, SmRef src, S select) {
-    SmRef o = p.sms(q), arr = p.sms(n * q), sel = p.sms(1), T = p.sms(q * n);
-    select = p.put(sel, select);
-    for (int i = 0; i < n; i++) for (int j = 0; j < q; j++) p.put(T + (j * n + i), p.put(arr + (i * q + j), p.get(src + (i * q + j))));
-    for (int j = 0; j < q; j++) p.put(o + j, gSelectorS(p, n, T + j * n, select));
+    SmRef o = p.sms(q); const uint32_t arr_w = p.dvs(n * q), sel_w = p.dvs(1), T_w = p.dvs(q * n);
+    if constexpr (P::is_emit) {
+        p.derived(sel_w, select);
+        for (int i = 0; i < n; i++) for (int j = 0; j < q; j++) { const S v = p.get(src + (i * q + j)); p.derived(arr_w + i * q + j, v); p.derived(T_w + j * n + i, v); }
+    }
+    for (int j = 0; j < q; j++) p.put(o + j, gSelectorS(p, n, src + j, select, (uint32_t)q));
     return o;
 }
 
