@@ -175,7 +175,7 @@ int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_
 enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2 };
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
 /* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the
- * first Poseidon block); "pad.div.out" / "pad.div.rem" of KeccakBytes instance k (the Divide hint of divide.circom:23-24); ProofOfBurn only: "sc.M" / "sc.exists" [k] of layer 1's SubstringCheck. */
+ * first Poseidon block); "pad.div.out" / "pad.div.rem" of KeccakBytes instance k (the Divide hint of divide.circom:23-24); ProofOfBurn only: "sc.exists" [k] of layer 1's SubstringCheck. */
 int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire);
 
 /* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */

@@ -101,7 +101,7 @@ struct KBRefs {
 };
 // SubstringCheck instance (substring_check.circom:24-100)
 struct ScRefs {
-    BitRef out; SmRef mi, ml, si; FrRef num, M; BitRef ex, isl, alw; SmRef sums; BitRef dne;
+    BitRef out; uint32_t mi_w; SmRef ml, si; FrRef num; uint32_t M_w; BitRef ex, isl, alw; SmRef sums; BitRef dne;     // mainInput[] / M[]: derived wires
     Cur c_abs_sub, c_abs_main, c_after_abs, c_loop, c_tail;
     SmRef abs_main_in;
 };
@@ -789,8 +789,8 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         if (i > 0) {
             ScRefs sc = L.scs[i];
             const int mm = LB, sl = 31, kk = mm - sl + 1;
-            sc.out = p.bits(1); sc.mi = p.sms(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
-            sc.num = p.frs(1); sc.M = p.frs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
+            sc.out = p.bits(1); sc.mi_w = p.dvs(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
+            sc.num = p.frs(1); sc.M_w = p.dvs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
             const S mainLen = p.get(sc.ml);                  // mainInput[] / mainLen are written by U_SC_MI (inputs only: pre-work track)
             for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
             sc.c_abs_sub = p.cur;
@@ -811,10 +811,10 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
     } break;
     UCASE(U_SC_MI) {              // SubstringCheck's own copies of its inputs: mainInput[mm] <== layers[i-1], mainLen <== layerLens[i-1] (:25-26)
         const ScRefs& sc = L.scs[d.a[0]];
-        copy_n(p, sc.mi, M.layers + ((d.a[0] - 1) * LB), LB);
+        if constexpr (P::is_emit) { for (int k = 0; k < LB; k++) p.derived(sc.mi_w + k, p.get(M.layers + ((d.a[0] - 1) * LB + k))); }      // (derived copies)
         p.put(sc.ml, p.get(M.layerLens + (d.a[0] - 1)));
     } break;
-    UCASE(U_SC_M) {               // M[k+1] <== mainInput[k]*256^k + M[k]  (substring_check.circom:45-49) for k in [a1, a2); reads the source
+    UCASE(U_SC_M) {               // EMISSION ONLY (M[] are derived wires): M[k+1] <== mainInput[k]*256^k + M[k]  (substring_check.circom:45-49) for k in [a1, a2); reads the source
                                  // bytes; 256^k comes from a table in "double Montgomery" form so that byte * 256^k is ONE Montgomery
                                  // product.  The prefix M[a1] is rebuilt from the bytes below a1, 31 at a time (31 bytes packed into limbs
                                  // are one canonical value: one product per 31 bytes), so the 17 ranges of a layer run side by side.
@@ -840,10 +840,11 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
                 }
             }
         }
-        if (lo == 0) p.put(sc.M, fr_zero());
+        if (lo == 0) p.derived_fr(sc.M_w, fr_zero());
         for (uint32_t k = lo; k < hi; k++) {
             Fr b1 = {{(uint32_t)p.get(src + k), 0, 0, 0, 0, 0, 0, 0}};
-            acc = p.put(sc.M + k + 1, fr_add(fr_mul(b1, p.k256r(k)), acc));
+            acc = fr_add(fr_mul(b1, p.k256r(k)), acc);
+            p.derived_fr(sc.M_w + k + 1, acc);
         }
     } break;
     UCASE(U_SC_RANGE) {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
@@ -851,23 +852,24 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const uint32_t lo = d.a[1], hi = d.a[2], sl = 31;
         const S mainLen = p.get(sc.ml);
         const F subNum = p.get(sc.num);
+        const Fr subC = fr_from_mont(subNum);
+        const SmRef src = M.layers + ((d.a[0] - 1) * LB);
         // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
         const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
         const uint32_t ln = p.lane_id(), cnt = hi - lo;                      // cnt <= 32
         B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
         // Per position: IsEqual([i, lastIndex]) and IsEqual([subNum * 256^i, M[i+sl] - M[i]]) -- 12 wires: 4 BIT outputs (IsEqual.out, IsZero.out
-        // twice) and 8 DERIVED operand wires (policy.hpp), i.e. nothing but bits is stored: exists[i] = [t1 == t2] needs no inverse (rounds 1-2
-        // stored the four field-element operands and ran a Montgomery batch inversion per unit through the witness' own slots: 2.3 GB per batch).
+        // twice) and 8 DERIVED operand wires (policy.hpp), i.e. nothing but bits is stored, and exists[i] needs no field arithmetic: it is
+        // [subNum == the 31 bytes from position i] on a sliding window (gadgets.hpp sc_window; rounds 1-2 stored M[] and the four field-element
+        // operands and ran a Montgomery batch inversion per unit through the witness' own slots: 2.3 GB per batch).
         // The bits leave as lane-distributed runs: isLastIndex[], allowed[], exists[] (one wire per position) and the children's outputs
         // (four per position, consecutive BIT ranks: 16 positions per run).
         B runIsl = 0, runAlw = 0, runEx = 0, runC0 = 0, runC1 = 0;
-        F ma = p.get(sc.M + lo + sl), mb = p.get(sc.M + lo);
+        Fr win = sc_window(p, src, lo, sl);
         for (uint32_t t = 0; t < cnt; t++) {
-            const uint32_t i = lo + t, in = i + 1 < hi ? i + 1 : i;
-            const F na = p.get(sc.M + in + sl), nb = p.get(sc.M + in);         // (the next position's operands are requested before this one's product)
-            const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_sub(ma, mb);
-            ma = na; mb = nb;
-            const B e = p.ballot(fr_eq(t1, t2)), last = p.ballot(i == lastIdx);
+            const uint32_t i = lo + t;
+            const S nxt = i + sl < (uint32_t)LB ? p.get(src + (i + sl)) : 0;    // (the byte that enters the window next is requested before this position's compares)
+            const B e = p.ballot(fr_eq(win, subC)), last = p.ballot(i == lastIdx);
             allowed &= ~last;
             runIsl = p.run_set(runIsl, t, last); runAlw = p.run_set(runAlw, t, allowed); runEx = p.run_set(runEx, t, e);
             const uint32_t k = 4 * (t & 15);
@@ -876,9 +878,9 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             if constexpr (P::is_emit) {
                 const Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
                 iseq_derived(p, c, (S)i, (S)lastIdx);
-                const F dd = fr_sub(t2, t1);
-                p.derived_fr(c.w + 7, t1); p.derived_fr(c.w + 8, t2); p.derived_fr(c.w + 10, dd); p.derived_fr_inv(c.w + 11, dd);
+                iseqf_derived(p, c.w + 6, fr_mul(subNum, p.k256(i)), fr_mul(fr_to_mont(win), p.k256(i)));
             }
+            sc_window_step(win, sl, (uint32_t)nxt);
         }
         p.run_put(cnt, sc.isl.w + lo + ln, sc.isl.i + lo + ln, runIsl);
         p.run_put(cnt, sc.alw.w + lo + 1 + ln, sc.alw.i + lo + 1 + ln, runAlw);
@@ -942,6 +944,7 @@ struct Plan {
         d.flags = (kind == CK_POS_SEG || kind == CK_SR_COLS || kind == CK_SL_ROWS) ? UNIT_CHECK      // sub-blocks the evaluator runs on their own
                 : kind == CK_N2BE ? (UNIT_GEN | UNIT_CHECK)                                            // ... and the generator too
                 : kind == U_POS_WIDE ? UNIT_GEN
+                : kind == U_SC_M ? UNIT_EMIT                                                           // (M[]: derived wires, rebuilt by the emitter only)
                 : kind == U_POB_POSEIDONS ? (UNIT_CHECK | UNIT_EMIT)                                   // generation: nothing but the two U_POS_WIDE blocks
                 : kind == U_GM_INPUT ? (UNIT_GEN | UNIT_CHECK)                                           // (the wires belong to the units of the template and are emitted there)
                 : kind == U_POB_INPUT ? UNIT_EMIT                                                      // generation / evaluation: the tile-transposing k_inputs kernel (pob_host.hip)

@@ -123,12 +123,20 @@ template <class P> GD B gIsEqualF(P& p, const F& a, const F& b, bool inv_is_stor
 }
 // IsEqual over field elements with DERIVED operand wires (policy.hpp): [out | in[2]] || IsZero [out | in | inv]; out = [a == b], the four
 // field-element wires are rebuilt by the emitter (the inverse with one exponentiation per emitted wire -- emission is for sampled witnesses)
-template <class P> GD B gIsEqualFd(P& p, const F& a, const F& b) {
-    BitRef o = p.bits(1); const uint32_t w = p.dvs(2); BitRef zo = p.bits(1); const uint32_t wz = p.dvs(2);
-    const F d = fr_sub(b, a);
-    if constexpr (P::is_emit) { p.derived_fr(w, a); p.derived_fr(w + 1, b); p.derived_fr(wz, d); p.derived_fr_inv(wz + 1, d); }
-    const B z = p.ballot(fr_is_zero(d));
+template <class P> GD B gIsEqualFz(P& p, B z, uint32_t* w0) {              // the block with out = z given; *w0 = its first wire (for iseqf_derived)
+    *w0 = p.cur.w;
+    BitRef o = p.bits(1); p.dvs(2); BitRef zo = p.bits(1); p.dvs(2);
     return p.put(o, p.put(zo, z));
+}
+template <class P> GD void iseqf_derived(P& p, uint32_t w0, const F& a, const F& b) {
+    const F d = fr_sub(b, a);
+    p.derived_fr(w0 + 1, a); p.derived_fr(w0 + 2, b); p.derived_fr(w0 + 4, d); p.derived_fr_inv(w0 + 5, d);
+}
+template <class P> GD B gIsEqualFd(P& p, const F& a, const F& b) {
+    uint32_t w0;
+    const B out = gIsEqualFz(p, p.ballot(fr_is_zero(fr_sub(b, a))), &w0);
+    if constexpr (P::is_emit) iseqf_derived(p, w0, a, b);
+    return out;
 }
 // LessThan(n)  [out | in[2]] || Num2Bits(n+1)(in0 + 2^n - in1);  out <== 1 - bit n
 template <class P> GD B gLessThanS(P& p, int n, S a, S b) {
@@ -929,23 +937,47 @@ template <class P> GD SmRef gNibbles2Bytes(P& p, int n, SmRef src) {
 // [out | mainInput[mm], mainLen, subInput[sl] | subInputNum, M[mm+1], exists[k], isLastIndex[k], allowed[k+1], sums[k+1], doesNotExist]
 // || AssertByteString(sl), AssertByteString(mm), AssertLessEqThan(16) x2, LittleEndianBytes2Num(sl), {IsEqual, IsEqual} x k, IsZero
 // The MPT layer-inclusion check: M[i+1] = mainInput[i]*256^i + M[i]; exists[i] = (sub*256^i == M[i+sl]-M[i]).
+// exists[i] needs NO field arithmetic: M[i+sl] - M[i] = 256^i * W_i with W_i = the sl bytes from position i as a little-endian integer (< 2^248 < p
+// for bytes, which AssertByteString(mainInput) enforces), so  subNum * 256^i == M[i+sl] - M[i]  <=>  subNum == W_i : a sliding window of sl bytes
+// against the canonical subNum.  mainInput[] (a copy), M[] and the IsEqual operands are DERIVED wires (policy.hpp): the emitter rebuilds them.
+template <class P> GD Fr sc_window(P& p, SmRef src, uint32_t i, uint32_t sl) {      // bytes [i, i + sl) little-endian, canonical limbs (sl <= 31)
+    Fr w = fr_zero();
+#pragma unroll
+    for (uint32_t k = 0; k < 31; k++) {
+        const S b = p.get(src + (i + (k < sl ? k : sl - 1)));
+        if (k < sl) w.l[k >> 2] |= ((uint32_t)b & 0xffu) << (8 * (k & 3));
+    }
+    return w;
+}
+HD void sc_window_step(Fr& w, uint32_t sl, uint32_t nb) {                          // drop the lowest byte, append nb as byte sl - 1
+#pragma unroll
+    for (int j = 0; j < 7; j++) w.l[j] = (w.l[j] >> 8) | (w.l[j + 1] << 24);
+    w.l[7] >>= 8;
+    const uint32_t pos = sl - 1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((pos >> 2) == (uint32_t)j) w.l[j] |= (nb & 0xffu) << (8 * (pos & 3));
+}
 template <class P> GD B gSubstringCheck(P& p, int mm, int sl, SmRef mainSrc, S mainLen, SmRef subSrc) {
     const int k = mm - sl + 1;
-    BitRef o = p.bits(1); SmRef mi = p.sms(mm), ml = p.sms(1), si = p.sms(sl);
-    FrRef num = p.frs(1), M = p.frs(mm + 1); BitRef ex = p.bits(k), isl = p.bits(k), alw = p.bits(k + 1); SmRef sums = p.sms(k + 1); BitRef dne = p.bits(1);
-    copy_n(p, mi, mainSrc, (int)(mm));
+    BitRef o = p.bits(1); const uint32_t mi_w = p.dvs(mm); SmRef ml = p.sms(1), si = p.sms(sl);
+    FrRef num = p.frs(1); const uint32_t M_w = p.dvs(mm + 1); BitRef ex = p.bits(k), isl = p.bits(k), alw = p.bits(k + 1); SmRef sums = p.sms(k + 1); BitRef dne = p.bits(1);
     mainLen = p.put(ml, mainLen);
     copy_n(p, si, subSrc, (int)(sl));
     gAssertByteString(p, sl, si);
-    gAssertByteString(p, mm, mi);
+    gAssertByteString(p, mm, mainSrc);
     gAssertLessEqThanS(p, 16, mainLen, (S)mm);
     gAssertLessEqThanS(p, 16, (S)sl, mainLen);
-    F subNum = p.put(num, gLittleEndianBytes2NumF(p, sl, si));
+    const F subNum = p.put(num, gLittleEndianBytes2NumF(p, sl, si));
+    const Fr subC = fr_from_mont(subNum);
     const F c256 = fr_from_i64(256);
-    {   // M[] prefix sums (:45-49)
-        F pw = fr_one_mont(), acc = p.put(M, fr_zero());
+    if constexpr (P::is_emit) {   // mainInput[] copies and the M[] prefix sums (:45-49)
+        F pw = fr_one_mont(), acc = fr_zero();
+        p.derived_fr(M_w, acc);
         for (int i = 0; i < mm; i++) {
-            acc = p.put(M + i + 1, fr_add(fr_mul(fr_from_i64(p.get(mi + i)), pw), acc));
+            const S b = p.get(mainSrc + i);
+            p.derived(mi_w + i, b);
+            acc = fr_add(fr_mul(fr_from_i64(b), pw), acc);
+            p.derived_fr(M_w + i + 1, acc);
             pw = fr_mul(pw, c256);
         }
     }
@@ -953,12 +985,16 @@ template <class P> GD B gSubstringCheck(P& p, int mm, int sl, SmRef mainSrc, S m
     B allowed = p.put(alw, ~(B)0);
     S sum = p.put(sums, 0);
     F pw = fr_one_mont();
+    Fr win = sc_window(p, mainSrc, 0, (uint32_t)sl);
     for (int i = 0; i < k; i++) {
+        const S nxt = i + sl < mm ? p.get(mainSrc + (i + sl)) : 0;
         B last = p.put(isl + i, gIsEqualS(p, (S)i, (S)(mainLen - sl + 1)));                 // :87
         allowed = p.put(alw + i + 1, allowed & ~last);
-        B e = p.put(ex + i, gIsEqualFd(p, fr_mul(subNum, pw), fr_sub(p.get(M + i + sl), p.get(M + i))));   // :91
+        uint32_t w0;
+        B e = p.put(ex + i, gIsEqualFz(p, p.ballot(fr_eq(win, subC)), &w0));               // :91
+        if constexpr (P::is_emit) { iseqf_derived(p, w0, fr_mul(subNum, pw), fr_mul(fr_to_mont(win), pw)); pw = fr_mul(pw, c256); }
         sum = p.put(sums + i + 1, sum + (S)p.bit(allowed & e));
-        pw = fr_mul(pw, c256);
+        sc_window_step(win, (uint32_t)sl, (uint32_t)nxt);
     }
     B none = p.put(dne, gIsZeroS(p, sum));
     return p.put(o, ~none);

@@ -1246,7 +1246,6 @@ int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t
     if (h->circuit == POB_CIRCUIT_PROOF_OF_BURN && L.nsc > 1) {                  // SubstringCheck of layer 1 (substring_check.circom:45-49, :91)
         const ScRefs& sc = L.scs[1];
         const uint32_t mm = 136u * (uint32_t)L.pob.NB, kk = mm - 31 + 1;
-        if (n == "sc.M" && k <= mm) return set(POB_CLASS_FR, sc.M.i + k, sc.M.w + k);
         if (n == "sc.exists" && k < kk) return set(POB_CLASS_BIT, sc.ex.i + k, sc.ex.w + k);
     }
     return POB_E_ARG;

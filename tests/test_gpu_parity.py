@@ -160,7 +160,7 @@ def test_constraint_evaluator_detects_sm_sb_fr_pokes(pkg, which):
         named = [("poseidon", k) for k in (1, 77, 200, 413, 640, 900)] + [("pad.div.out", 0), ("pad.div.rem", 0), ("commitment", 0)]
     else:
         s = _suite("test_proof_of_burn"); main = POB_FIX
-        named = ([("poseidon", k) for k in (5, 300, 800)] + [("sc.M", k) for k in (0, 17, 300, 544)] + [("sc.exists", k) for k in (0, 5, 513)] +
+        named = ([("poseidon", k) for k in (5, 300, 800)] + [("sc.exists", k) for k in (0, 5, 513)] +
                  [("pad.div.out", k) for k in (0, 1, 3)] + [("pad.div.rem", 2), ("commitment", 0)])
     calc = EC.open_identical_batch(pkg, main, s["cases"][0]["input"])
     missed, done = EC.uniform_sweep(calc, {EC.SM: 1200, EC.FR: 400, EC.BIT: 300})
@@ -445,11 +445,12 @@ def test_gpu_witness_satisfies_the_independent_r1cs(pkg):
     calc = pkg.WitnessCalculator(POB_FIX, max_batch=1)
     assert calc.calculate(s["cases"][0]["input"])[0].ok
     assert CK.check_witness(c, CK.Witness(calc.witness_payload(0))) == []
-    for name, k in (("poseidon", 300), ("sc.M", 17), ("pad.div.out", 1)):
+    for name, k in (("poseidon", 300), ("sc.exists", 5), ("pad.div.out", 1)):
         cls, idx, wire = calc.debug_ref(name, k)
-        calc.poke(cls, idx, 0, 4)
+        mask = 1 if cls == 0 else 4                      # (BIT class: the bit itself)
+        calc.poke(cls, idx, 0, mask)
         bad = CK.check_witness(c, CK.Witness(calc.witness_payload(0)))
-        calc.poke(cls, idx, 0, 4)
+        calc.poke(cls, idx, 0, mask)
         assert bad and all(wire in wires for _, wires in bad), (name, wire, bad[:3])
     calc.close()
     # (the production instantiation's 215.9 M rows x 6.9 GB payload go through the same code: `python -m proof_of_burn_amd.circuit_model
