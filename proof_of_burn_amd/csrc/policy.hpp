@@ -10,16 +10,18 @@
 //        witnesses and a comparison result becomes a wire with one v_cmp (ballot).
 //   SM   wires (bytes, lengths, small signed differences): int32 [wire][64 lanes] (256 B rows).
 //   FR   wires (genuine field elements): 8 x uint32 limb planes [wire][limb][64 lanes], Montgomery form.
-//   DV   wires (DERIVED): the operand wires of every IsZero / IsEqual gadget over small operands -- IsEqual.in[0], in[1], IsZero.in,
-//        IsZero.inv -- are functions of the two values the CALLER hands the gadget (values of other stored wires, loop indices,
-//        constants).  They are NOT stored: the emitter rebuilds them from the same expressions (EmitP::derived / derived_inv: value,
-//        field inverse with 0 -> 0), generation and evaluation skip them and define / check the gadget's BIT outputs as [a == b]
-//        directly (their relations hold by construction; that the rebuilt values are the right ones is what the payload comparison
-//        with the oracle checks).  These are the selectors' IsEqual([select, i]) of the leaf detectors, SelectorArray1D and the
-//        Keccak outputs, Pad's IsEqual([i, inLen]), ShiftLeft's n^2 IsEqual, SubstringCheck's isLastIndex -- and, over field elements, the
-//        IsEqual(exists) of SubstringCheck's 7 710 positions (gIsEqualFd: 30 840 FR wires whose inverses needed a batch inversion per 32
-//        positions): 1.06 M of the 1.36 M non-BIT wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors' as an int8 class of their own,
-//        IsZero.inv as its operand code).
+//   DV   wires (DERIVED): every wire that is a function of stored wires / inputs / constants within its unit and that no other unit
+//        reads.  They are NOT stored (p.dvs(n) allocates wire indices only): the emitter rebuilds them from the same expressions
+//        (EmitP::derived / derived_inv / derived_fr / derived_fr_inv: value, field inverse with 0 -> 0), generation and evaluation
+//        skip them and define / check the gadgets' BIT outputs directly (their relations hold by construction; that the rebuilt
+//        values are the right ones is what the payload comparison with the oracle checks).  These are
+//          * the operand wires of every IsZero / IsEqual gadget (in[0], in[1], IsZero.in, IsZero.inv): the selectors' IsEqual([select, i])
+//            of the leaf detectors, SelectorArray1D and the Keccak outputs, Pad's IsEqual([i, inLen]), ShiftLeft's n^2 IsEqual,
+//            SubstringCheck's isLastIndex and -- over field elements -- its IsEqual(exists) (gIsEqualFd);
+//          * copies: Selector.vals[], SelectorArray1D.arrays / arraysT, Pad's and AssertByteString's byte copies, SubstringCheck.mainInput[];
+//          * running sums that are functions of stored wires: Selector.sum[], SubstringCheck.M[];
+//        1.29 M of the 1.36 M non-BIT wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors'
+//        as an int8 class of their own, IsZero.inv as its operand code, M[] and the IsEqual(exists) operands as field elements).
 //
 // Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
 // run of same-class wires (e.g. a whole Keccak-f block, 2 506 944 BIT wires) is contiguous in HBM.
