@@ -865,6 +865,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         // The bits leave as lane-distributed runs: isLastIndex[], allowed[], exists[] (one wire per position) and the children's outputs
         // (four per position, consecutive BIT ranks: 16 positions per run).
         B runIsl = 0, runAlw = 0, runEx = 0, runC0 = 0, runC1 = 0;
+        F ddL = fr_zero();                                                   // (emitter: lane t <- position lo + t's IsZero operand of the emitted witness)
         Fr win = sc_window(p, src, lo, sl);
         for (uint32_t t = 0; t < cnt; t++) {
             const uint32_t i = lo + t;
@@ -878,9 +879,16 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             if constexpr (P::is_emit) {
                 const Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
                 iseq_derived(p, c, (S)i, (S)lastIdx);
-                iseqf_derived(p, c.w + 6, fr_mul(subNum, p.k256(i)), fr_mul(fr_to_mont(win), p.k256(i)));
+                const F t1 = fr_mul(subNum, p.k256(i)), t2 = fr_mul(fr_to_mont(win), p.k256(i)), dd = fr_sub(t2, t1);
+                p.derived_fr(c.w + 7, t1); p.derived_fr(c.w + 8, t2); p.derived_fr(c.w + 10, dd);
+                const F ds = p.bcast_sel(dd);
+                if (ln == t) ddL = ds;
             }
             sc_window_step(win, sl, (uint32_t)nxt);
+        }
+        if constexpr (P::is_emit) {      // the cnt inverses of the emitted witness: one per lane, ONE inversion time per unit (a lane at a time they were 10 ms per unit)
+            const F inv = fr_is_zero(ddL) ? fr_zero() : fr_inv(ddL);
+            if (ln < cnt) p.w32(cur_add(cur_add(sc.c_loop, FP_ISEQ_S, lo + ln), FP_ISEQ_F, lo + ln).w + 11, fr_from_mont(inv));
         }
         p.run_put(cnt, sc.isl.w + lo + ln, sc.isl.i + lo + ln, runIsl);
         p.run_put(cnt, sc.alw.w + lo + 1 + ln, sc.alw.i + lo + 1 + ln, runAlw);

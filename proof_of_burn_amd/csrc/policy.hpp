@@ -491,7 +491,14 @@ struct EmitP : DevPol {
     __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
     __device__ __forceinline__ void derived_inv(uint32_t w, S x) { emit_inv(w, x); }
     __device__ __forceinline__ void derived_fr(uint32_t w, const F& v) { if (m.lane == sel) w32(w, fr_from_mont(v)); }
-    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) w32(w, fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv_fermat(x))); }
+    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) w32(w, fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv(x))); }
+    // the selected witness' value in every lane (a unit that has many inverses to rebuild spreads them over the lanes: circuits.hpp U_SC_RANGE)
+    __device__ __forceinline__ F bcast_sel(const F& v) {
+        F r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], (int)sel);
+        return r;
+    }
     __device__ __forceinline__ void emit_inv(uint32_t w, S k) {
         if (m.lane == sel) {
             F c;
