@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 3, call 25: the SB class (operands of the Keccak output selectors' IsEqual gadgets) as DERIVED wires (not stored) -- unit times and interleaved pairs
+# (two-build A/B: needs libpob_hip_base.so / libpob_hip_<variant>.so copied next to libpob_hip.so and, in witness.py for the run only,
+#  LIB_PATH = os.environ.get("POB_LIB_EXPERIMENT") or ...; the product reads no such variable)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/proof_of_burn_amd/csrc/libpob_hip_base.so; D=$GRAFT_REPO_ROOT/proof_of_burn_amd/csrc/libpob_hip_sbd.so
 for v in base sbd; do

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 3, call 27: derived operand wires, this build against the one before -- tests, unit times, interleaved pairs against the build before
+# (two-build A/B: needs libpob_hip_base.so / libpob_hip_<variant>.so copied next to libpob_hip.so and, in witness.py for the run only,
+#  LIB_PATH = os.environ.get("POB_LIB_EXPERIMENT") or ...; the product reads no such variable)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT/gpurun_out
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "spend_wtns or proof_of_burn_and_wtns or main_instantiation_batch or gadget_mains_payload or failure_sets or corruption_sweep" 2>&1 | tail -4
 for v in base dv; do
