@@ -739,7 +739,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
         launch_k_rounds(K, true, h->nperms, G, sk);
         if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
-        launch_k_chain(K, true, h->nperms, G, sk);
+        // (pipeline: the narrow sponge-chain evaluation -- 84 wavefronts per group, 0.18 ms -- on an evaluation stream beside the families, not in
+        //  order between the two chip-filling kernels of the streaming stream, where the machine idled for its duration: -0.02 ms, three interleaved pairs)
+        launch_k_chain(K, true, h->nperms, G, h->partner ? side[1] : sk);
         if (sk != st) { HIPC(hipEventRecord(h->ev_k_done, sk)); HIPC(hipStreamWaitEvent(st, h->ev_k_done, 0)); }
     }
     HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
