@@ -66,6 +66,15 @@ def test_spend_suite_wtns_and_evaluator(pkg, tmp_path):
                 assert w0 == pos and np.array_equal(view, want[32 * w0:32 * w0 + view.size]), (win, idx, w0)
                 pos += view.size // 32
             assert pos == calc.nwitness
+    keep = np.arange(0, calc.nwitness, 5, dtype=np.uint32)   # ... and the reduced payload through the same three slots
+    for idx, want, nxt in ((0, ref, 3), (3, ref3, 0), (0, ref, None)):
+        pos = 0
+        for w0, view in calc.witness_windows(idx, window_wires=90_000, keep=keep):
+            if w0 == 0 and nxt is not None:
+                calc.emit_queue(nxt)
+            assert w0 == pos and np.array_equal(view.reshape(-1, 32), want.reshape(-1, 32)[keep[w0:w0 + view.size // 32]]), (idx, w0)
+            pos += view.size // 32
+        assert pos == keep.size
     calc.emit_queue(0)                                       # an announcement that is not followed: the prepared window is dropped
     assert np.array_equal(calc.witness_payload(3), ref3) and np.array_equal(calc.witness_payload(3), ref3)
     bad_idx = next(i for i, r in enumerate(res) if not r.ok)
