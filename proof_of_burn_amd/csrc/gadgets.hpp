@@ -116,11 +116,6 @@ template <class P> HD B gIsEqualS(P& p, S a, S b) {
     p.derived(w, a); p.derived(w + 1, b);
     return p.put(o, gIsZeroS(p, (S)((uint32_t)b - (uint32_t)a)));
 }
-template <class P> GD B gIsEqualF(P& p, const F& a, const F& b, bool inv_is_stored = false) {
-    BitRef o = p.bits(1); FrRef in = p.frs(2);
-    F x = p.put(in, a), y = p.put(in + 1, b);
-    return p.put(o, gIsZeroF(p, fr_sub(y, x), inv_is_stored));
-}
 // IsEqual over field elements with DERIVED operand wires (policy.hpp): [out | in[2]] || IsZero [out | in | inv]; out = [a == b], the four
 // field-element wires are rebuilt by the emitter (the inverse with one exponentiation per emitted wire -- emission is for sampled witnesses)
 template <class P> GD B gIsEqualFz(P& p, B z, uint32_t* w0) {              // the block with out = z given; *w0 = its first wire (for iseqf_derived)
@@ -549,20 +544,9 @@ template <class P> GD SmRef gFitS(P& p, int M, int N, SmRef src) {
     for (int i = M; i < N; i++) p.put(o + i, 0);
     return o;
 }
-template <class P> GD BitRef gFitB(P& p, int M, int N, BitRef src) {
-    BitRef o = p.bits(N), in = p.bits(M);
-    copy_n(p, in, src, M); copy_n(p, o, src, M < N ? M : N);
-    for (int i = M; i < N; i++) p.put(o + i, 0);
-    return o;
-}
 // Flatten(M,N) :64-72 and Reshape(M,N) :79-87 are the identity on row-major data  [out[MN] | in[MN]]
 template <class P> GD SmRef gFlattenS(P& p, int n, SmRef src) {
     SmRef o = p.sms(n), in = p.sms(n);
-    { copy_n(p, in, src, (int)(n)); copy_n(p, o, src, (int)(n)); }
-    return o;
-}
-template <class P> GD BitRef gFlattenB(P& p, int n, BitRef src) {
-    BitRef o = p.bits(n), in = p.bits(n);
     { copy_n(p, in, src, (int)(n)); copy_n(p, o, src, (int)(n)); }
     return o;
 }
@@ -644,20 +628,6 @@ template <class P> GD S gSelectorS(P& p, int n, SmRef src, S select, uint32_t st
     const S out = sel_head(p, sb, (uint32_t)n, src, stride, select);
     sel_range(p, sb, src, stride, select, out, 0, (uint32_t)n);
     return out;
-}
-// same template on BIT-valued data (Final's SelectorArray2D over Keccak states): all-mask arithmetic
-template <class P> GD B gSelectorB(P& p, int n, BitRef src, S select) {
-    BitRef o = p.bits(1), vals = p.bits(n); SmRef sel = p.sms(1); BitRef isEq = p.bits(n), sum = p.bits(n + 1);
-    select = p.put(sel, select);
-    B acc = p.put(sum, 0), any = 0, multi = 0;
-    for (int i = 0; i < n; i++) {
-        B v = p.put(vals + i, p.get(src + i));
-        B e = p.put(isEq + i, gIsEqualS(p, select, (S)i));
-        multi |= any & e; any |= e;
-        acc = p.put(sum + i + 1, acc | (e & v));
-    }
-    p.require(any & ~multi, FAILCODE(T_SELECTOR, 43));
-    return p.put(o, acc);
 }
 // SelectorArray1D(n, q) :62-77  [out[q] | arrays[n][q], select | arraysT[q][n]] || Selector(n) x q.  arrays[][], select and the transposed
 // copy are derived wires (copies of the source); selector j reads its column of the source directly (stride q)

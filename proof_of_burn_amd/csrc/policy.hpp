@@ -149,19 +149,6 @@ template <class P, int N> HD __attribute__((always_inline)) void sm_commit(P& p,
         for (int k = 0; k < N; k++) p.put(r[k], v[k]);
     }
 }
-// n SM wires (w0 + t*dw, s0 + t*ds), t < n, that all carry the same per-witness value v: BATCH evaluator loads in flight
-template <class P, int BATCH> HD __attribute__((always_inline)) void sm_rows_same(P& p, uint32_t w0, uint32_t s0, uint32_t dw, uint32_t ds, uint32_t n, S v) {
-    for (uint32_t t0 = 0; t0 < n; t0 += BATCH) {
-        SmRef rr[BATCH]; S vv[BATCH];
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-            const uint32_t t = t0 + q < n ? t0 + q : n - 1;          // a ragged tail repeats the last wire
-            rr[q] = SmRef{w0 + t * dw, s0 + t * ds}; vv[q] = v;
-        }
-        const SmLoaded<BATCH> h = sm_load(p, rr);
-        sm_commit(p, rr, h, vv);
-    }
-}
 // Lane-distributed bit vector of up to 256 BIT wires: bit 64q + k lives in lane k of r[q] as that wire's 64-witness mask.  A
 // decomposition (Num2Bits and everything copied from it) is built ONCE from the witnesses' canonical values and then written /
 // verified as runs -- no wire of it is ever read back.
@@ -255,15 +242,6 @@ template <class P> HD __attribute__((always_inline)) void derived_rows_same(P& p
         for (uint32_t t = 0; t < n; t++) { if (inv) p.derived_inv(w0 + t * dw, v); else p.derived(w0 + t * dw, v); }
     } else { (void)p; (void)w0; (void)dw; (void)n; (void)v; (void)inv; }
 }
-// N independent wires written (generation) / verified (evaluation: loads batched ahead of the compares) together
-template <class P, class R, class V, int N> HD __attribute__((always_inline)) void put_batch(P& p, const R (&r)[N], const V (&v)[N]) {
-    if constexpr (P::is_check) p.put_batch(r, v);
-    else {
-#pragma unroll
-        for (int k = 0; k < N; k++) p.put(r[k], v[k]);
-    }
-}
-
 #ifdef __HIPCC__
 // A BIT wire is shared by the 64 lanes of its wavefront (one lane stores the mask, every lane may load it later).  On the GPU the
 // wavefront executes in lockstep, so a later load sees the store; the CPU test shim (tests/hostsim) runs the lanes as independent
@@ -436,21 +414,6 @@ struct CheckP : DevPol {
         pend_s = s; pend_x = m.lane < n ? x : 0; pend_w = w;   // ... and expect 0
     }
     __device__ __forceinline__ void run_flush() { run_resolve(); pend_s = pend_x = 0; }
-    // N independent wires at once: all loads are issued before the first compare (one wait instead of N)
-    template <int N> __device__ __forceinline__ void put_batch(const BitRef (&r)[N], const B (&v)[N]) {
-        B s[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) s[k] = ld(r[k]);
-#pragma unroll
-        for (int k = 0; k < N; k++) mark(((s[k] ^ v[k]) >> m.lane) & 1, r[k].w);
-    }
-    template <int N> __device__ __forceinline__ void put_batch(const SmRef (&r)[N], const S (&v)[N]) {
-        S s[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) s[k] = ld(r[k]);
-#pragma unroll
-        for (int k = 0; k < N; k++) mark(s[k] != v[k], r[k].w);
-    }
 };
 
 // .wtns emitter for ONE witness of the group (lane `sel`): canonical 32-byte LE value at wire index.
