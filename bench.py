@@ -310,7 +310,7 @@ def main():
     #                                + the round input/output states it is checked against.
     t_chk = calcs[0].time_kernel(1, iters=5, stream=stream0)
     t_gen = calcs[0].time_kernel(0, iters=5, stream=stream0)
-    round_bytes = (102656 + 2 * 1600) * 8
+    round_bytes = (76 + 2 * 25) * 64 * 8                  # the 76 stored gate-output arrays of a round block + midRound[r] + midRound[r+1] (keccak_kernels.hpp)
     launch_bytes = info.n_perms * 24 * round_bytes * groups
     alone = launch_bytes / (t_chk * 1e-3) / 1e9
     in_step = launch_bytes / (kchk_in_step * 1e-3) / 1e9 if kchk_in_step else None
@@ -345,7 +345,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
                 "bytes_per_launch": launch_bytes,
-                "gen_kernel": {"kernel": "k_rounds<GEN>, alone", "achieved": round(info.n_perms * 24 * (102656 + 1600) * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
+                "gen_kernel": {"kernel": "k_rounds<GEN>, alone", "achieved": round(info.n_perms * 24 * (76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)},
                 "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,
                                "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),

@@ -24,12 +24,21 @@ enum { POB_OK = 0, POB_E_ARG = -1, POB_E_HIP = -2, POB_E_NOMEM = -3, POB_E_STATE
 
 typedef struct {
     uint64_t n_witness;          /* W: O0 wires incl. the constant-1 wire (= nWitness of the .wtns)            */
-    uint64_t n_bit, n_sm, n_fr;  /* wires per storage class (policy.hpp); n_bit + n_sm + n_fr + n_derived + 1 = n_witness */
+    uint64_t n_bit, n_sm, n_fr;  /* STORED wires per storage class (policy.hpp); n_bit + n_sm + n_fr + n_derived + n_alias + 1 = n_witness */
     uint32_t n_fr_inputs, n_sm_inputs, n_outputs;
     uint32_t n_units, n_sponges, n_perms, n_stages, max_batch;
     uint64_t group_bytes;        /* HBM-resident bytes of the compact witness vector per 64 witnesses           */
     uint64_t keccak_bit_wires;   /* wires handled by the bit-sliced Keccak kernels                              */
-    uint64_t n_derived;          /* wires that are not stored: the operand wires of IsZero / IsEqual over small operands, rebuilt by the emitter (policy.hpp) */
+    uint64_t n_derived;          /* wires that are not stored because they are FUNCTIONS of stored wires / inputs / constants inside their unit and
+                                    no other unit reads them (policy.hpp DV): the operand wires in[0], in[1], IsZero.in, IsZero.inv of every IsZero /
+                                    IsEqual (over small operands and, in SubstringCheck, over field elements), copies (Selector.vals[],
+                                    SelectorArray1D.arrays / arraysT, Pad's and AssertByteString's byte copies, SubstringCheck.mainInput[]) and running
+                                    sums (Selector.sum[], SubstringCheck.M[]).  Generation and evaluation skip them; the emitter rebuilds them from
+                                    the same expressions                                                                                              */
+    uint64_t n_alias;            /* wires of the Keccak round blocks that are not stored because they ARE another wire: copies of a stored gate
+                                    output / of the round's input or output state, possibly at a rotated bit position (ShL / ShR / RhoPi) or negated
+                                    (NotArray), or constants (shifted-out positions, round constants).  76 of the 1 604 arrays of a KeccakfRound
+                                    block are stored (keccak_kernels.hpp); the emitter expands the others through one table                          */
 } pob_info_t;
 
 /* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference
@@ -89,7 +98,11 @@ void pob_host_free(void* p);
  * `stream` (a hipStream_t, NULL = the handle's own stream) for the n uploaded inputs.  Asynchronous.              */
 int pob_generate(pob_handle h, void* stream);
 /* Per-gate constraint evaluator over the resident witness vector (north star; the reference checks inline,
- * e.g. assert.circom:46,62,78, divide.circom:32): re-reads every wire, asynchronous.                             */
+ * e.g. assert.circom:46,62,78, divide.circom:32): re-reads every STORED wire and checks it against its defining expression evaluated on
+ * STORED operands, and every `===`; asynchronous.  Wires without storage are not read: a derived wire's (n_derived) relations hold by
+ * construction in whatever the emitter writes for it, an alias wire's (n_alias) copy constraint holds structurally, and every non-copy
+ * gate that consumes one is evaluated on the stored wire it stands for.  pob_emit_begin*'s self-check (POB_EMIT_SELFCHECK) evaluates the
+ * derived / alias wires' own relations on the values as written.                                                  */
 int pob_constraint_check(pob_handle h, void* stream);
 int pob_sync(pob_handle h);
 /* Two-batch pipeline (no counterpart in the reference, whose calculator runs one witness per process, Makefile:4-5): links two
@@ -170,8 +183,8 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
 /* Test hook for the constraint evaluator: corrupt ONE stored value of ONE witness (lane `lane` of group `group`) of storage class
  * `cls` at storage index `index` (the wire's rank within its class): BIT: flips the bit if xor_mask & 1; SM: int32 ^= xor_mask;
- * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask.  (Derived wires -- pob_info_t.n_derived: the operand wires of IsZero / IsEqual
- * over small operands -- have no storage to corrupt.)                                                                              */
+ * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask.  (Derived and alias wires -- pob_info_t.n_derived / n_alias -- have no storage
+ * to corrupt: corrupting the stored wire they are a function / a copy of changes them with it.)                                    */
 enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2 };
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
 /* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the

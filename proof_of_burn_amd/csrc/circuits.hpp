@@ -19,6 +19,17 @@
 #define KECCAKF_WIRES (43200u + 24u * KECCAKF_ROUND_WIRES)        // 2 506 944
 #define ABSORB_OWN 5888u                                            // out, s, block[17], aux
 #define ABSORB_WIRES (ABSORB_OWN + 17u * 384u + KECCAKF_WIRES)     // 2 519 360
+// Storage of an Absorb block (round 4).  Its own wires, its 17 XorArrays and Keccakf's own wires (out, in, midRound[25]) are stored 1:1
+// (AB_DIRECT BIT ranks in wire order).  Of the 102 656 wires of a KeccakfRound block only the KR_STORED = 76 arrays of 64 that are OUTPUTS
+// OF A GATE and not the round's output state are stored (20 Xor5 partials, 5 D, 25 theta, 25 chi-AND, chi.out[0] before iota); every other
+// wire of the block is an ALIAS: a copy of a stored wire / of midRound[r] / of midRound[r+1], possibly at a rotated bit position or
+// negated (NotArray), or a constant (shifted-out positions, round constants).  keccak_kernels.hpp states which (one walker), the emitter
+// expands through that table.
+#define KR_STORED 76u
+#define KR_BITS (KR_STORED * 64u)                                   // 4 864 BIT ranks per round block
+#define AB_DIRECT (ABSORB_OWN + 17u * 384u + 43200u)               // 55 616
+#define ABSORB_BITS (AB_DIRECT + 24u * KR_BITS)                    // 172 352
+#define ABSORB_ALIAS (ABSORB_WIRES - ABSORB_BITS)                  // 2 347 008 alias wires per permutation
 
 enum UnitKind : uint32_t {
     U_POB_INPUT = 1, U_POB_RANGE, U_POB_LAYER_ASSERT, U_POB_HDR_ASSERT, U_POB_POSEIDONS, U_BAH_PRE, U_BAH_POST,
@@ -250,7 +261,7 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
     r.k_out = p.bits(256); r.k_in = p.bits(n * 1088); r.k_blocks = p.sms(1); r.k_finalState = p.bits(1600);
     r.f_out = p.bits(1600); r.f_in = p.bits(n * 1088); r.f_blocks = p.sms(1); r.f_s = p.bits((n + 1) * 1600);
     r.abs_w = p.cur.w; r.abs_b = p.cur.b;
-    p.skip_bits(n * ABSORB_WIRES);
+    p.skip_alias(n * ABSORB_WIRES, n * ABSORB_BITS);
     r.sel_out = p.bits(1600); r.sel_arrays = p.bits((n + 1) * 1600); r.sel_select = p.sms(1); r.sel_T = p.bits(1600 * (n + 1));
 }
 // selectors [j0, j1) of row `row` of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs;

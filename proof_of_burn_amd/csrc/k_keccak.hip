@@ -21,3 +21,13 @@ void launch_k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t
     uint32_t blocks = (count + 255) / 256; if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_emit_bits_red, dim3(blocks), dim3(256), 0, st, G, out, wire0, bit_base, count, sel, rbits, rpre, k0, kn);
 }
+void launch_k_emit_absorb(const u64* G, uint8_t* out, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab, hipStream_t st) {
+    uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_emit_absorb, dim3(blocks), dim3(256), 0, st, G, out, ab, o0, count, sel, tab);
+}
+void launch_k_emit_absorb_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab, const unsigned long long* rbits,
+                              const uint32_t* rpre, uint32_t k0, uint32_t kn, hipStream_t st) {
+    uint32_t blocks = (count + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_emit_absorb_red, dim3(blocks), dim3(256), 0, st, G, out, wire0, ab, o0, count, sel, tab, rbits, rpre, k0, kn);
+}
+bool keccak_alias_table_host(uint16_t* tab) { return keccak_round_alias_table(tab); }

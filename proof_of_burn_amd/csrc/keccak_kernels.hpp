@@ -29,26 +29,18 @@ __host__ __device__ constexpr int krot_(int i) {
 }
 #define KROT(i) krot_(i)
 
-struct GenIO {
-    u64* base; uint32_t lane;
-    __device__ __forceinline__ void arr(uint32_t off, u64 v) const { base[off + lane] = v; }
-    // (measured alternatives: transposing the triples through LDS into three coalesced 512-byte stores is 2 % slower, non-temporal
-    //  stores are 45 % slower -- the 24-byte-stride stores merge in L2 and the kernel sits at the HBM write rate)
-    __device__ __forceinline__ void gate(uint32_t off, u64 o, u64 a, u64 b) const {   // XOR/AND/OR component k: (out, a, b)
-        u64* q = base + off + 3 * lane; q[0] = o; q[1] = a; q[2] = b;
-    }
-};
-// NT: non-temporal loads -- the round evaluation streams 27 GB through the L2s once and never re-reads a line; without the hint it
-// evicts the working sets of the latency-bound G families that run beside it
-template <bool NT> struct CheckIOT {
-    const u64* base; uint32_t lane; u64 bad;
-    __device__ __forceinline__ u64 ldw(const u64* p) const { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
-    __device__ __forceinline__ void arr(uint32_t off, u64 v) { bad |= ldw(base + off + lane) ^ v; }
-    __device__ __forceinline__ void gate(uint32_t off, u64 o, u64 a, u64 b) {
-        const u64* q = base + off + 3 * lane; bad |= (ldw(q) ^ o) | (ldw(q + 1) ^ a) | (ldw(q + 2) ^ b);
-        POB_OPAQUE(bad);                     // opaque point: stops LLVM from reassociating one 4800-term OR tree (compile time)
-    }
-};
+// ---- what a KeccakfRound block stores (round 4; circuits.hpp KR_STORED).  A wire of the block is named by a 14-bit code
+//      (slot << 7) | (bit position << 1) | negated:  slot KS_IN + i  = midRound[r][i]        (Keccakf's own wires, written by k_chain)
+//                                                    slot KS_ST + s  = stored array s of the round block (the 76 gate outputs below)
+//                                                    slot KS_OUT + i = midRound[r+1][i]
+//                                                    KS_ZERO (negated: the constant 1), KS_RC: bit `position` of the round constant
+enum : uint32_t { KS_IN = 0, KS_ST = 25, KS_OUT = 101, KS_ZERO = 126, KS_RC = 127 };
+// stored arrays: Xor5 x: ab, abc, abcd, out = 4x .. 4x+3 | D x: out = 20 + x | Theta out[idx] = 25 + idx | stepChi i: AndArray out = 50 + i | stepChi 0 out = 75
+#define KSL_X5(x, k) (4u * (x) + (k))
+#define KSL_D(x) (20u + (x))
+#define KSL_TH(i) (25u + (i))
+#define KSL_AND(i) (50u + (i))
+#define KSL_CHI0 75u
 
 // value held by lane (lane - r) mod 64  (rotl by r in bit-position space)
 __device__ __forceinline__ u64 lane_rotl(u64 v, int r, uint32_t lane) {
@@ -57,8 +49,71 @@ __device__ __forceinline__ u64 lane_rotl(u64 v, int r, uint32_t lane) {
     return ((u64)hi << 32) | lo;
 }
 
+// Device side of the walker: V = the 64-witness mask of bit position `lane`.  arr / gate (the alias wires) are nothing here.
+struct DevIOBase {
+    typedef u64 V;
+    uint32_t lane;
+    __device__ __forceinline__ V rotl(V v, int r) const { return lane_rotl(v, r, lane); }
+    __device__ __forceinline__ V keep_ge(V v, int s) const { return (int)lane >= s ? v : 0; }
+    __device__ __forceinline__ V keep_lt(V v, int s) const { return (int)lane < s ? v : 0; }
+    __device__ __forceinline__ V or_disjoint(V, V, V whole) const { return whole; }       // (a | b with disjoint supports = the unmasked rotation)
+    __device__ __forceinline__ V not_(V v) const { return ~v; }
+    __device__ __forceinline__ V rc(int r) const { return ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL; }
+    __device__ __forceinline__ void arr(uint32_t, V) const {}
+    __device__ __forceinline__ void gate(uint32_t, V, V, V) const {}
+};
+// generation: the 76 gate outputs are stored; the round's output state is midRound[r+1], which k_chain wrote
+struct GenIO : DevIOBase {
+    u64* st; const u64* in_;             // the round's stored arrays / midRound[r]
+    __device__ __forceinline__ V in(int i) const { return in_[64 * i + lane]; }
+    __device__ __forceinline__ V gx(uint32_t s, V a, V b) const { const V v = a ^ b; st[64 * s + lane] = v; return v; }
+    __device__ __forceinline__ V ga(uint32_t s, V a, V b) const { const V v = a & b; st[64 * s + lane] = v; return v; }
+    __device__ __forceinline__ V gxo(int, V a, V b) const { return a ^ b; }
+};
+// constraint evaluation: every gate's STORED output against the gate function of its STORED operands; the stored value is what the next
+// gate sees.  NT: non-temporal loads (the evaluation streams the vector through the L2s once and never re-reads a line)
+template <bool NT> struct CheckIOT : DevIOBase {
+    const u64* st; const u64* in_; const u64* out_; u64 bad;
+    __device__ __forceinline__ u64 ldw(const u64* p) const { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+    __device__ __forceinline__ V in(int i) const { return ldw(in_ + 64 * i + lane); }
+    __device__ __forceinline__ V gx(uint32_t s, V a, V b) { const V v = ldw(st + 64 * s + lane); bad |= v ^ a ^ b; return v; }
+    __device__ __forceinline__ V ga(uint32_t s, V a, V b) { const V v = ldw(st + 64 * s + lane); bad |= v ^ (a & b); return v; }
+    __device__ __forceinline__ V gxo(int i, V a, V b) { const V v = ldw(out_ + 64 * i + lane); bad |= v ^ a ^ b; return v; }
+};
+// host side: V = the 64 codes of an array; the walk fills the alias table of the block (one per library, shared by every round: the only
+// round-dependent wires are the round constants, coded KS_RC)
+struct SymV { uint16_t e[64]; };
+struct SymIO {
+    typedef SymV V;
+    uint16_t* tab; bool ok;
+    static uint16_t enc(uint32_t slot, uint32_t k, uint32_t neg = 0) { return (uint16_t)((slot << 7) | (k << 1) | neg); }
+    static V all(uint32_t slot) { V v; for (uint32_t k = 0; k < 64; k++) v.e[k] = enc(slot, k); return v; }
+    V in(int i) { return all(KS_IN + (uint32_t)i); }
+    V gx(uint32_t s, const V&, const V&) { return all(KS_ST + s); }
+    V ga(uint32_t s, const V&, const V&) { return all(KS_ST + s); }
+    V gxo(int i, const V&, const V&) { return all(KS_OUT + (uint32_t)i); }
+    V rotl(const V& v, int r) { V o; for (int k = 0; k < 64; k++) o.e[k] = v.e[(k - r) & 63]; return o; }
+    V keep_ge(const V& v, int s) { V o; for (int k = 0; k < 64; k++) o.e[k] = k >= s ? v.e[k] : enc(KS_ZERO, 0); return o; }
+    V keep_lt(const V& v, int s) { V o; for (int k = 0; k < 64; k++) o.e[k] = k < s ? v.e[k] : enc(KS_ZERO, 0); return o; }
+    V or_disjoint(const V& a, const V& b, const V& whole) {
+        V o;
+        for (int k = 0; k < 64; k++) {
+            const uint16_t z = enc(KS_ZERO, 0);
+            if (a.e[k] != z && b.e[k] != z) ok = false;               // an OrArray whose operands overlap would be a gate of its own
+            o.e[k] = a.e[k] != z ? a.e[k] : b.e[k];
+            if (o.e[k] != whole.e[k]) ok = false;
+        }
+        return o;
+    }
+    V not_(const V& v) { V o; for (int k = 0; k < 64; k++) o.e[k] = v.e[k] ^ 1; return o; }
+    V rc(int) { V v; for (uint32_t k = 0; k < 64; k++) v.e[k] = enc(KS_RC, k); return v; }
+    void arr(uint32_t off, const V& v) { for (uint32_t k = 0; k < 64; k++) set(off + k, v.e[k]); }
+    void gate(uint32_t off, const V& o, const V& a, const V& b) { for (uint32_t k = 0; k < 64; k++) { set(off + 3 * k, o.e[k]); set(off + 3 * k + 1, a.e[k]); set(off + 3 * k + 2, b.e[k]); } }
+    void set(uint32_t w, uint16_t e) { if (w >= KECCAKF_ROUND_WIRES || tab[w] != 0xFFFFu) ok = false; else tab[w] = e; }     // every wire exactly once
+};
+
 // XorArray/OrArray/AndArray(64) block: [out | a | b | 64 x (o,a,b)]
-template <class IO> __device__ __forceinline__ void garr(IO& io, uint32_t off, u64 o, u64 a, u64 b) {
+template <class IO> HD void garr(IO& io, uint32_t off, const typename IO::V& o, const typename IO::V& a, const typename IO::V& b) {
     io.arr(off, o); io.arr(off + 64, a); io.arr(off + 128, b); io.gate(off + 192, o, a, b);
 }
 
@@ -79,24 +134,28 @@ __device__ __forceinline__ void round_native(u64* a, int r, uint32_t lane) {
     a[0] ^= ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL;
 }
 
-// KeccakfRound(r) keccak.circom:290-297: every wire of the block at `io.base`, from the round input `in`.
-template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64* in, int r, u64* out) {
-    const uint32_t lane = io.lane;
-    u64 th[25], rp[25], ch[25];
+// KeccakfRound(r) keccak.circom:290-297: every wire of the block, in O0 order, from the round input midRound[r].  The GATES (io.gx / io.ga /
+// io.gxo: XorArray / AndArray outputs) are what generation stores and the evaluator checks; every io.arr / io.gate names an alias wire
+// (offset within the block, value) and is compiled to nothing on the device.
+template <class IO> HD void round_walk(IO& io, int r) {
+    typedef typename IO::V V;
+    V in[25], th[25], rp[25], ch[25], out[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) in[i] = io.in(i);
     // ---- own: out@0 in@1600 theta@3200 rhopi@4800 chi@6400
 #pragma unroll
     for (int i = 0; i < 25; i++) io.arr(1600 + 64 * i, in[i]);
     // ---- Theta @8000 (:151-170): out@0 in@1600 c@3200 d@3520 | Xor5 x5 @3840 (2112 each) | D x5 @14400 (1408 each) | XorArray x25 @21440
     {
         const uint32_t T = 8000;
-        u64 C[5], Dv[5];
+        V C[5], Dv[5];
 #pragma unroll
         for (int i = 0; i < 25; i++) io.arr(T + 1600 + 64 * i, in[i]);
 #pragma unroll
         for (int x = 0; x < 5; x++) {   // Xor5(64) :58-70  [out | a,b,c,d,e | xor_ab, xor_abc, xor_abcd] || XorArray x4
             const uint32_t X = T + 3840 + 2112 * x;
-            const u64 a = in[x], b = in[5 + x], c = in[10 + x], d = in[15 + x], e = in[20 + x];
-            const u64 ab = a ^ b, abc = ab ^ c, abcd = abc ^ d, o = abcd ^ e;
+            const V a = in[x], b = in[5 + x], c = in[10 + x], d = in[15 + x], e = in[20 + x];
+            const V ab = io.gx(KSL_X5(x, 0), a, b), abc = io.gx(KSL_X5(x, 1), ab, c), abcd = io.gx(KSL_X5(x, 2), abc, d), o = io.gx(KSL_X5(x, 3), abcd, e);
             io.arr(X, o); io.arr(X + 64, a); io.arr(X + 128, b); io.arr(X + 192, c); io.arr(X + 256, d); io.arr(X + 320, e);
             io.arr(X + 384, ab); io.arr(X + 448, abc); io.arr(X + 512, abcd);
             garr(io, X + 576, ab, a, b); garr(io, X + 960, abc, ab, c); garr(io, X + 1344, abcd, abc, d); garr(io, X + 1728, o, abcd, e);
@@ -105,9 +164,10 @@ template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64
 #pragma unroll
         for (int x = 0; x < 5; x++) {   // D :135-144  [out | a, b | aux0, aux1, aux2] || ShL(64,1), ShR(64,63), OrArray, XorArray
             const uint32_t Dd = T + 14400 + 1408 * x;
-            const u64 a = C[(x + 1) % 5], b = C[(x + 4) % 5];
-            const u64 rot = lane_rotl(a, 1, lane);
-            const u64 aux0 = lane >= 1 ? rot : 0, aux1 = lane < 1 ? rot : 0, aux2 = aux0 | aux1, o = b ^ aux2;
+            const V a = C[(x + 1) % 5], b = C[(x + 4) % 5];
+            const V rot = io.rotl(a, 1);
+            const V aux0 = io.keep_ge(rot, 1), aux1 = io.keep_lt(rot, 1), aux2 = io.or_disjoint(aux0, aux1, rot);
+            const V o = io.gx(KSL_D(x), b, aux2);
             io.arr(Dd, o); io.arr(Dd + 64, a); io.arr(Dd + 128, b); io.arr(Dd + 192, aux0); io.arr(Dd + 256, aux1); io.arr(Dd + 320, aux2);
             io.arr(Dd + 384, aux0); io.arr(Dd + 448, a);          // ShL(64,1)  [out | in]
             io.arr(Dd + 512, aux1); io.arr(Dd + 576, a);          // ShR(64,63)
@@ -119,7 +179,7 @@ template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64
 #pragma unroll
             for (int j = 0; j < 5; j++) {   // :165-169, i outer, j inner
                 const int idx = i + 5 * j;
-                const u64 o = in[idx] ^ Dv[i];
+                const V o = io.gx(KSL_TH(idx), in[idx], Dv[i]);
                 garr(io, T + 21440 + 384 * (i * 5 + j), o, in[idx], Dv[i]);
                 th[idx] = o; io.arr(T + 64 * idx, o);
             }
@@ -137,11 +197,11 @@ template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64
         for (int i = 0; i < 24; i++) {
             const uint32_t S_ = Rb + 3200 + 896 * i;
             const int shl = ((i + 1) * (i + 2) / 2) % 64;
-            const u64 a = th[KROT(i)];
-            const u64 rot = lane_rotl(a, shl, lane);
-            const u64 aux0 = (int)lane < shl ? rot : 0;          // ShR(64, 64-shl): out[k] = a[k + 64 - shl]
-            const u64 aux1 = (int)lane >= shl ? rot : 0;         // ShL(64, shl):    out[k] = a[k - shl]
-            const u64 o = aux0 | aux1;
+            const V a = th[KROT(i)];
+            const V rot = io.rotl(a, shl);
+            const V aux0 = io.keep_lt(rot, shl);                 // ShR(64, 64-shl): out[k] = a[k + 64 - shl]
+            const V aux1 = io.keep_ge(rot, shl);                 // ShL(64, shl):    out[k] = a[k - shl]
+            const V o = io.or_disjoint(aux0, aux1, rot);
             io.arr(S_, o); io.arr(S_ + 64, a); io.arr(S_ + 128, aux0); io.arr(S_ + 192, aux1);
             io.arr(S_ + 256, aux0); io.arr(S_ + 320, a);
             io.arr(S_ + 384, aux1); io.arr(S_ + 448, a);
@@ -160,8 +220,9 @@ template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64
         for (int i = 0; i < 25; i++) {
             const uint32_t C_ = Cb + 3200 + 1280 * i;
             const int y = i / 5 * 5;
-            const u64 a = rp[i], b = rp[y + (i + 1) % 5], c = rp[y + (i + 2) % 5];
-            const u64 bx = ~b, bc = bx & c, o = a ^ bc;
+            const V a = rp[i], b = rp[y + (i + 1) % 5], c = rp[y + (i + 2) % 5];
+            const V bx = io.not_(b), bc = io.ga(KSL_AND(i), bx, c);
+            const V o = i == 0 ? io.gx(KSL_CHI0, a, bc) : io.gxo(i, a, bc);        // chi.out[i], i > 0, IS the round's output = midRound[r+1][i]
             io.arr(C_, o); io.arr(C_ + 64, a); io.arr(C_ + 128, b); io.arr(C_ + 192, c); io.arr(C_ + 256, bx); io.arr(C_ + 320, bc);
             io.arr(C_ + 384, bx); io.arr(C_ + 448, b);           // NotArray [out | a]
             garr(io, C_ + 512, bc, bx, c); garr(io, C_ + 896, o, a, bc);
@@ -173,11 +234,11 @@ template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64
     // ---- Iota(r) @98944 (:273-283): out@0 in@1600 roundConstants@3200 | RoundConstants @3264 | XorArray @3328
     {
         const uint32_t Ib = 98944;
-        const u64 rc = ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL;
+        const V rc = io.rc(r);
 #pragma unroll
         for (int i = 0; i < 25; i++) io.arr(Ib + 1600 + 64 * i, ch[i]);
         io.arr(Ib + 3200, rc); io.arr(Ib + 3264, rc);
-        const u64 o = ch[0] ^ rc;
+        const V o = io.gxo(0, ch[0], rc);
         garr(io, Ib + 3328, o, ch[0], rc);
         out[0] = o;
 #pragma unroll
@@ -187,6 +248,14 @@ template <class IO> __device__ __forceinline__ void round_walk(IO& io, const u64
     }
 #pragma unroll
     for (int i = 0; i < 25; i++) io.arr(64 * i, out[i]);
+}
+// the alias table of a KeccakfRound block (KECCAKF_ROUND_WIRES codes): false if the walk did not name every wire exactly once
+static inline bool keccak_round_alias_table(uint16_t* tab) {
+    for (uint32_t i = 0; i < KECCAKF_ROUND_WIRES; i++) tab[i] = 0xFFFFu;
+    SymIO io; io.tab = tab; io.ok = true;
+    round_walk(io, 0);
+    for (uint32_t i = 0; i < KECCAKF_ROUND_WIRES; i++) if (tab[i] == 0xFFFFu) io.ok = false;
+    return io.ok;
 }
 
 // Keccakf block offsets (:356-367): out@0 in@1600 midRound[25]@3200 | KeccakfRound(r) @43200 + r*102656
@@ -208,7 +277,7 @@ template <bool CHECK> __global__ void __launch_bounds__(64, 4) k_chain(KArgs A) 
     for (int i = 0; i < 25; i++) st[i] = 0;
     auto put = [&](uint32_t idx, u64 v) { if (CHECK) bad |= G[idx + lane] ^ v; else G[idx + lane] = v; };
     for (uint32_t b = 0; b < sp.n; b++) {
-        const uint32_t Ab = sp.abs_b + b * ABSORB_WIRES;
+        const uint32_t Ab = sp.abs_b + b * ABSORB_BITS;
         u64 blk[17], aux[25];
 #pragma unroll
         for (int i = 0; i < 17; i++) blk[i] = G[sp.src_b + b * 1088 + 64 * i + lane];
@@ -254,7 +323,7 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t b = A.perm_block[pi];
     const u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
-    const uint32_t Ab = sp.abs_b + b * ABSORB_WIRES, Kf = Ab + AB_KECCAKF;
+    const uint32_t Ab = sp.abs_b + b * ABSORB_BITS, Kf = Ab + AB_KECCAKF;
     u64 bad = 0;
 #pragma unroll
     for (int i = 0; i < 25; i++) {
@@ -280,37 +349,75 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
     if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
 }
 
-// One KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain), writes (GenIO) or verifies
-// (CheckIO) the 102 656 wires of the round.  This is the HBM-streaming kernel.
+// One KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain); generation writes the 76 gate-output
+// arrays of the round (38.9 KB per 64 witnesses), evaluation reads them + midRound[r] + midRound[r+1] (126 arrays = 64.5 KB) and checks every
+// XOR / AND gate of the round on stored operands.  (Rounds 1-3 stored all 102 656 wires of the block: 821 KB per item.)
+#define KR_CHECK_ARRAYS (KR_STORED + 50u)
 template <bool CHECK, bool NT> __device__ __forceinline__ void rounds_item(const KArgs& A, uint32_t x, uint32_t y, uint32_t lane) {
     const uint32_t pi = A.first + x / 24, r = x % 24;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
-    const uint32_t Kf = sp.abs_b + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF;
+    const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
     u64* G = A.bits + (uint64_t)y * A.group_stride;
-    u64 in[25], out[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) in[i] = G[Kf + KF_MID + 1600 * r + 64 * i + lane];
     if (CHECK) {
-        CheckIOT<NT> io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane; io.bad = 0;
-        round_walk(io, in, (int)r, out);
+        CheckIOT<NT> io; io.lane = lane; io.bad = 0;
+        io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r; io.out_ = io.in_ + 1600;
+        round_walk(io, (int)r);
         u64 bad = io.bad;
-#pragma unroll
-        for (int i = 0; i < 25; i++) bad |= out[i] ^ G[Kf + KF_MID + 1600 * (r + 1) + 64 * i + lane];   // midRound[r+1] <== round.out
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
         if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
     } else {
-        GenIO io; io.base = G + Kf + KF_ROUNDS + r * KECCAKF_ROUND_WIRES; io.lane = lane;
-        round_walk(io, in, (int)r, out);
+        GenIO io; io.lane = lane;
+        io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r;
+        round_walk(io, (int)r);
     }
 }
 // grid = (24 * permutations, groups): one wavefront per item
 template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
     rounds_item<CHECK, NT>(A, blockIdx.x, blockIdx.y, threadIdx.x);
 }
-// (A persistent form -- a fixed number of resident wavefronts, 1-4 per SIMD, pulling items from a counter so that the streaming kernel keeps
-//  its register slots while latency-bound kernels run beside it -- was measured in round 3: the evaluation alone 4.09 -> 4.73 ms, in the
-//  pipelined step 7.0 ms either way, the step 14.8 -> 15.2 ms; removed.  profiles/round3_experiments.txt)
+
+// the 64-witness word of the wire at offset o of an Absorb block whose storage starts at BIT rank ab (A = this group's slab); *neg: the
+// wire is the complement of that word
+__device__ __forceinline__ u64 absorb_wire_word(const u64* A, uint32_t ab, uint32_t o, const uint16_t* tab, uint32_t* neg) {
+    *neg = 0;
+    if (o < AB_DIRECT) return A[ab + o];
+    const uint32_t q = o - AB_DIRECT, r = q / KECCAKF_ROUND_WIRES, e = tab[q - r * KECCAKF_ROUND_WIRES];
+    const uint32_t slot = e >> 7, k = (e >> 1) & 63u;
+    *neg = e & 1u;
+    if (slot < KS_ST) return A[ab + AB_KECCAKF + KF_MID + 1600 * r + 64 * slot + k];
+    if (slot < KS_OUT) return A[ab + AB_DIRECT + r * KR_BITS + 64 * (slot - KS_ST) + k];
+    if (slot < KS_ZERO) return A[ab + AB_KECCAKF + KF_MID + 1600 * (r + 1) + 64 * (slot - KS_OUT) + k];
+    if (slot == KS_ZERO) return 0;
+    return ((KECCAK_RC_DEV[r] >> k) & 1) ? ~0ULL : 0ULL;
+}
+// .wtns expansion of the wires [o0, o0 + count) of ONE Absorb block for witness `sel` of a group: stored wires directly, alias wires through
+// the table (keccak_round_alias_table)
+__global__ void __launch_bounds__(256) k_emit_absorb(const u64* G, uint8_t* out, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        uint32_t neg;
+        const u64 word = absorb_wire_word(G, ab, o0 + t, tab, &neg);
+        const uint32_t v = (uint32_t)((word >> sel) & 1) ^ neg;
+        uint4* q = (uint4*)(out + (uint64_t)t * 32);
+        q[0] = make_uint4(v, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
+    }
+}
+// the same for the reduced witness: wires [wire0, wire0 + count) = offsets o0.. of the block, kept wires land at their rank
+__global__ void __launch_bounds__(256) k_emit_absorb_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab,
+                                                         const unsigned long long* rbits, const uint32_t* rpre, uint32_t k0, uint32_t kn) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const uint32_t w = wire0 + t;
+        const unsigned long long word_k = rbits[w >> 6];
+        if (!((word_k >> (w & 63)) & 1)) continue;
+        const uint32_t p = rpre[w >> 6] + (uint32_t)__popcll(word_k & ((1ull << (w & 63)) - 1)) - k0;
+        if (p >= kn) continue;
+        uint32_t neg;
+        const u64 word = absorb_wire_word(G, ab, o0 + t, tab, &neg);
+        const uint32_t v = (uint32_t)((word >> sel) & 1) ^ neg;
+        uint4* q = (uint4*)(out + (uint64_t)p * 32);
+        q[0] = make_uint4(v, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
+    }
+}
 
 // .wtns expansion of a contiguous run of BIT wires for witness `sel` of one group: 8 B in, 32 B out per wire.
 __global__ void __launch_bounds__(256) k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel) {

@@ -58,3 +58,9 @@ void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngrou
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);
 // reduced form: wires [wire0, wire0 + count) with BIT ranks from bit_base; kept wires land at out + 32 * (rank - k0) when rank - k0 < kn
 void launch_k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t bit_base, uint32_t count, uint32_t sel, const unsigned long long* rbits, const uint32_t* rpre, uint32_t k0, uint32_t kn, hipStream_t st);
+// an Absorb block (circuits.hpp ABSORB_BITS): wires at offsets [o0, o0 + count) of the block whose storage starts at BIT rank ab; tab = the round
+// blocks' alias table on the device (keccak_alias_table_host fills the host copy: KECCAKF_ROUND_WIRES codes, false = the walk is inconsistent)
+void launch_k_emit_absorb(const u64* G, uint8_t* out, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab, hipStream_t st);
+void launch_k_emit_absorb_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab, const unsigned long long* rbits,
+                              const uint32_t* rpre, uint32_t k0, uint32_t kn, hipStream_t st);
+bool keccak_alias_table_host(uint16_t* tab);

@@ -141,6 +141,7 @@ struct pob_ctx {
     UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
+    uint16_t* d_ktab = nullptr;                        // alias table of a KeccakfRound block (keccak_kernels.hpp): which stored wire / constant each of its 102 656 wires is
     // packed inputs, double-buffered: a batch is uploaded into the buffer the current batch does NOT use (generation AND evaluation read the
     // inputs), pob_generate switches; ev_in_done[b] = the last generation / evaluation that read buffer b
     uint8_t* d_in_fr[2] = {nullptr, nullptr}; int32_t* d_in_sm[2] = {nullptr, nullptr}; int in_cur = 0, in_next = 0; uint32_t n_next = 0;
@@ -159,8 +160,8 @@ struct pob_ctx {
         int64_t queued_idx = -1; bool pre_made = false; // pob_emit_queue: the witness the next pob_emit_begin* will ask for / its window 0 is made
         std::vector<uint32_t> status_host; uint64_t status_gen = 0;      // the batch's generation statuses, fetched once per generation
         const uint32_t* map_ptr = nullptr; uint64_t map_sample = 0;     // reduced: address / sampled fingerprint of the caller's map at its last full validation
-        struct Run { uint32_t w, b, n; };
-        std::vector<Run> runs;                          // the Keccak-owned BIT runs (wire index, BIT rank, count), sorted by wire index
+        struct Run { uint32_t w, b, n, absorb; };
+        std::vector<Run> runs;                          // the Keccak kernels' wires, sorted by wire index: contiguous stored runs (wire index, BIT rank, count) and Absorb blocks (absorb = 1: stored + alias wires, b = the block's first BIT rank)
         // which G units write into which window (found by one probe pass per window size): a window launches only those
         uint64_t probe_win = 0, probe_map = 0; uint32_t* d_order = nullptr; unsigned long long* d_probe = nullptr;
         struct WSeg { uint32_t cls, first, count; };
@@ -341,6 +342,7 @@ static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_i
     info->max_batch = max_batch;
     info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;      // (derived wires take no storage)
     info->n_derived = pl.total.q;
+    info->n_alias = (uint64_t)nperms * ABSORB_ALIAS;
     info->keccak_bit_wires = 0;
     for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
 }
@@ -512,6 +514,12 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         HIPC(hipMemcpy(h->d_perm_block, perm_block.data(), h->nperms * 4, hipMemcpyHostToDevice));
     }
     HIPC(hipMemcpy(h->d_pos, POS_TABLE_MONT, sizeof(POS_TABLE_MONT), hipMemcpyHostToDevice));
+    if (h->nperms) {                                    // the round blocks' alias table (emission expands the unstored wires through it)
+        std::vector<uint16_t> tab(KECCAKF_ROUND_WIRES);
+        if (!keccak_alias_table_host(tab.data())) { h->err = "internal: the KeccakfRound walk does not name every wire of the block exactly once"; return POB_E_STATE; }
+        HIPC(hipMalloc(&h->d_ktab, tab.size() * 2));
+        HIPC(hipMemcpy(h->d_ktab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    }
     HIPC(hipMemset(h->d_status_raw, 0xFF, npad * 4)); HIPC(hipMemset(h->d_chk, 0xFF, npad * 4)); HIPC(hipMemset(h->d_bad, 0xFF, npad * 4));
     hipLaunchKernelGGL(k_init_invlut, dim3((8193 + 63) / 64), dim3(64), 0, h->stream2, h->d_inv);
     HIPC(hipGetLastError());
@@ -523,7 +531,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
+                    h->d_inv, h->d_pow256, h->d_ktab, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -854,12 +862,15 @@ static int emit_make_window(pob_ctx* h, uint32_t idx, uint64_t k, int slot) {
     for (const pob_ctx::Emit::Run& r : E.runs) {
         const uint64_t lo = std::max<uint64_t>(r.w, wire_lo), hi = std::min<uint64_t>((uint64_t)r.w + r.n, wire_hi);
         if (lo >= hi) continue;
-        if (!E.red) launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), idx % 64, st);
-        else {
+        if (!E.red) {
+            if (r.absorb) launch_k_emit_absorb(Gp, E.d_win[slot] + (lo - w0) * 32, r.b, (uint32_t)(lo - r.w), (uint32_t)(hi - lo), idx % 64, h->d_ktab, st);
+            else launch_k_emit_bits(Gp, E.d_win[slot] + (lo - w0) * 32, 0, (uint32_t)(r.b + (lo - r.w)), (uint32_t)(hi - lo), idx % 64, st);
+        } else {
             const auto a = std::lower_bound(E.keep.begin() + w0, E.keep.begin() + w0 + wn, (uint32_t)lo), b = std::lower_bound(a, E.keep.begin() + w0 + wn, (uint32_t)hi);
             if (a == b) continue;                                           // (a round block whose wires are all dropped costs nothing)
             const uint64_t lo2 = *a, hi2 = (uint64_t)*(b - 1) + 1;
-            launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
+            if (r.absorb) launch_k_emit_absorb_red(Gp, E.d_win[slot], (uint32_t)lo2, r.b, (uint32_t)(lo2 - r.w), (uint32_t)(hi2 - lo2), idx % 64, h->d_ktab, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
+            else launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
         }
     }
     HIPC(hipGetLastError());
@@ -931,8 +942,9 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
             HIPC(hipEventCreateWithFlags(&E.ev_free[k], hipEventDisableTiming));
         }
         for (const SpongeDesc& sp : h->plan.sponges) {
-            E.runs.push_back({sp.kin_w, sp.kin_b, sp.n * 1088}); E.runs.push_back({sp.fin_w, sp.fin_b, sp.n * 1088});
-            E.runs.push_back({sp.fs_w, sp.fs_b, (sp.n + 1) * 1600}); E.runs.push_back({sp.abs_w, sp.abs_b, sp.n * ABSORB_WIRES});
+            E.runs.push_back({sp.kin_w, sp.kin_b, sp.n * 1088, 0}); E.runs.push_back({sp.fin_w, sp.fin_b, sp.n * 1088, 0});
+            E.runs.push_back({sp.fs_w, sp.fs_b, (sp.n + 1) * 1600, 0});
+            for (uint32_t b = 0; b < sp.n; b++) E.runs.push_back({sp.abs_w + b * ABSORB_WIRES, sp.abs_b + b * ABSORB_BITS, ABSORB_WIRES, 1});
         }
         std::sort(E.runs.begin(), E.runs.end(), [](const pob_ctx::Emit::Run& a, const pob_ctx::Emit::Run& b) { return a.w < b.w; });
     }

@@ -74,7 +74,7 @@ struct PolBase {
     HD SmRef sms(uint32_t n) { SmRef r = {cur.w, cur.s}; cur.w += n; cur.s += n; return r; }
     HD uint32_t dvs(uint32_t n) { const uint32_t w = cur.w; cur.w += n; cur.q += n; return w; }     // n derived wires: no storage, the first one's wire index
     HD FrRef frs(uint32_t n) { FrRef r = {cur.w, cur.f}; cur.w += n; cur.f += n; return r; }
-    HD void skip_bits(uint32_t n) { cur.w += n; cur.b += n; }
+    HD void skip_alias(uint32_t nw, uint32_t nb) { cur.w += nw; cur.b += nb; }       // nw wires of which nb are stored BIT wires, the rest aliases of them (Absorb blocks, circuits.hpp)
 };
 
 // ------------------------------------------------------------------ host-side layout planner policy

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_planner_wire_count_matches_model(main, w):
     info = pkg.plan_info(main)
     assert info.n_witness == w                              # SURVEY.md app. C / BASELINE.md section 2
-    assert info.n_bit + info.n_sm + info.n_fr + info.n_derived + 1 == w      # every wire has exactly one storage class or is derived (+ the constant wire)
+    assert info.n_bit + info.n_sm + info.n_fr + info.n_derived + info.n_alias + 1 == w      # every wire is stored in exactly one class, derived, or an alias (+ the constant wire)
 
 
 def test_planner_matches_oracle_on_other_instantiations():
