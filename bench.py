@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: ONE global batch of this many witnesses per step, split over the ranks (BASELINE config 4: 8192)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: two calculators work on consecutive batches (pob_set_partner): batch k+1's latency-bound generation stages run beside batch k's evaluation")
+    ap.add_argument("--sched", default=None, help="EXPERIMENT: POB_SCHED for the library (private = own side streams per calculator, no gate)")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
     ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
@@ -113,6 +114,8 @@ def main():
     else:
         B, first0, GB = args.batch, rank * args.batch, world * args.batch
     PIPE = bool(args.pipeline)
+    if args.sched:
+        os.environ["POB_SCHED"] = args.sched
     NB = 1 if args.dbg_no_upload else max(1, args.distinct_batches)
 
     # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
@@ -120,7 +123,8 @@ def main():
     batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + first0,
                                    pow_device=dev_index if args.depth > 12 else None) for b in range(NB)]
     t_synth = (time.time() - t0) / NB
-    NC = 2 if PIPE else 1
+    NC = max(2, args.pipeline) if PIPE else 1
+    LINK = PIPE and NC == 2 and args.sched != "private"
     calcs = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(NC)]
     info = calcs[0].info
     # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch); the Python packer beside it
@@ -139,7 +143,7 @@ def main():
     # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
     streams = [torch.cuda.Stream(device=dev_index, priority=-1) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
     recs = [D.device_records(calcs[c], B) for c in range(NC)]
-    if PIPE:
+    if LINK:
         calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
     gs = torch.cuda.Stream(device=dev_index)              # the record gather of the multi-GPU job: after the batch's evaluation, beside the next batch's work
     gathered_ev = [None] * NC
@@ -152,7 +156,9 @@ def main():
         if args.dbg_no_fetch:
             state["validated"] += B
             return
+        _t = time.perf_counter()
         rec = calcs[c].wait_records()
+        state["t_wait"] = state.get("t_wait", 0.0) + time.perf_counter() - _t
         assert rec.shape[0] == B
         assert not rec["status"].any(), ("a witness failed", np.nonzero(rec["status"])[0][:4], rec["status"][np.nonzero(rec["status"])[0][:4]])
         assert (rec["check_status"] == W.CLEAN).all() and (rec["bad_wire"] == W.CLEAN).all(), "the constraint evaluator flagged a witness (or did not run)"
@@ -163,7 +169,9 @@ def main():
 
     def finish(c):
         """evaluation of calculator c's batch, its records (now with the verdict) to the host and to the other ranks"""
+        _t = time.perf_counter()
         calcs[c].constraint_check(streams[c].cuda_stream)
+        state["t_chk"] = state.get("t_chk", 0.0) + time.perf_counter() - _t
         if not args.dbg_no_fetch:
             calcs[c].fetch_records()
         if world > 1:
@@ -184,7 +192,9 @@ def main():
             uploaded[c] = True
         if gathered_ev[c] is not None:
             streams[c].wait_event(gathered_ev[c])                         # the gather of THIS calculator's previous batch has read its records
+        _t = time.perf_counter()
         calcs[c].generate(streams[c].cuda_stream)
+        state["t_gen"] = state.get("t_gen", 0.0) + time.perf_counter() - _t
 
     def run(nsteps, k0=0):
         """nsteps batches through the service loop, fill and drain included: every batch is uploaded, generated, evaluated, fetched and validated
@@ -193,13 +203,13 @@ def main():
         pend = []                                         # (calculator, distinct batch) enqueued but not yet validated, oldest first
         prev = None
         for k in range(k0, k0 + nsteps):
-            c, b = (k % 2 if PIPE else 0), k % NB
+            c, b = (k % NC if PIPE else 0), k % NB
             if PIPE:
                 if prev is not None:
                     finish(prev[0]); pend.append(prev)
                 start(c, b)
                 prev = (c, b)
-                while len(pend) > 1:
+                while len(pend) > NC - 1:
                     validate(*pend.pop(0))
             else:
                 start(c, b)
@@ -224,11 +234,12 @@ def main():
         probing = True
         for c in calcs:
             c.probe_check_kernel(True)                    # HIP events around the dominant kernel of every evaluation from here on
-    state.update(validated=0, h2d_bytes=0)
+    state.update(validated=0, h2d_bytes=0, t_gen=0.0, t_chk=0.0, t_wait=0.0)
     t0 = time.perf_counter()
     run(args.steps, k0=args.warmup)
     fence()
     dt = time.perf_counter() - t0
+    host_ms = {k: round(state[k] / args.steps * 1e3, 3) for k in ("t_gen", "t_chk", "t_wait")}
     assert state["validated"] == args.steps * B, "not every batch was validated inside the timed region"
     validated_timed = state["validated"]
     h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
@@ -286,7 +297,8 @@ def main():
     # ---- the same service loop without the pipeline (one calculator), 10 batches: reported beside `value`, same run, same box
     single = None
     if PIPE and not args.no_single:
-        calcs[0].set_partner(None)
+        if LINK:
+            calcs[0].set_partner(None)
         PIPE_save, PIPE = PIPE, False
         run(2)
         fence()
@@ -301,7 +313,8 @@ def main():
             dt1 = float(t1max.item())
         single = {"what": "one calculator per GPU, no pipeline (bench.py --pipeline 0), 10 batches of the same service loop after the timed region",
                   "value": round(GB * 10 / dt1, 1), "ms_per_step": round(dt1 / 10 * 1e3, 3)}
-        calcs[0].set_partner(calcs[1])
+        if LINK:
+            calcs[0].set_partner(calcs[1])
 
     groups = (B + 63) // 64
     stream0 = streams[0].cuda_stream
@@ -423,7 +436,7 @@ def main():
                        "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {B} (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
                        "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
-                       "input_synthesis_s_per_batch": round(t_synth, 2),
+                       "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,
                        "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),
                        "json_to_packed": {"what": "input.json texts -> packed rows in pinned memory, pob_pack_json_batch on all host cores (bit-equal to the Python loader on a sample of this batch)",
                                           "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},

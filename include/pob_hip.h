@@ -116,7 +116,8 @@ int pob_set_partner(pob_handle h, pob_handle partner);
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.
  * status[i] = 0 ok, else (template id << 12 | source line) of the first failing assert; outputs[i][32] = public
  * output (commitment) canonical LE.  check_status / bad_wire (may be NULL): result of pob_constraint_check:
- * first failing === site and lowest wire whose stored value contradicts its definition (0xFFFFFFFF = none).      */
+ * first failing === site and lowest wire whose stored value contradicts its definition (0xFFFFFFFF = none;
+ * POB_NOT_EVALUATED = no pob_constraint_check has run on this batch).                                             */
 int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* check_status, uint32_t* bad_wire);
 /* Device-resident results for the RCCL gather: status u32[max_batch_padded], outputs u8[max_batch_padded][32]. */
 int pob_results_device(pob_handle h, void** d_status, void** d_outputs);
@@ -156,6 +157,10 @@ int pob_emit_begin(pob_handle h, uint32_t idx, uint64_t window_wires);
  * `window_wires` KEPT wires; a Keccak round block whose wires are all dropped costs nothing.  pob_emit_next then hands out windows
  * of the reduced payload (first_wire / n_wires count kept wires).  The map is uploaded once per (handle, keep pointer contents).   */
 int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uint64_t n_keep, uint64_t window_wires);
+/* A caller that emits many witnesses through ONE map pins it: the map at this address and length is hashed now and recognised by address from then
+ * on (the unpinned calls above hash the caller's whole map every time to recognise it: 9 ms for the production map's 86 MB).  The caller promises
+ * that keep[0..n_keep) stays allocated and unchanged until it is unpinned (keep = NULL) or the handle is closed.  One pinned map per handle. */
+int pob_reduced_map_pin(pob_handle h, const uint32_t* keep, uint64_t n_keep);
 int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires);
 /* Announce the witness that will be emitted AFTER the current (or the next) one, with the same payload kind and window size: its first
  * window -- the one that holds most gadget wires and takes longest to expand -- is then expanded while the current witness' last windows are

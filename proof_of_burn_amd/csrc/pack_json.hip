@@ -114,25 +114,29 @@ struct Parser {
         while (s < e && *s >= '0' && *s <= '9') s++;
         if (s < e && (*s == '.' || *s == 'e' || *s == 'E')) return fail("a JSON number with a fraction or exponent is not an integer input");
         if (a == s) return fail("unsupported input value");
+        if (s - a > 1 && *a == '0') return fail("a JSON number must not have leading zeros");      // (json.loads refuses 007; the string "007" is fine)
         return digits(a, s, 10, neg, out);
     }
     // a scalar, possibly wrapped in one-element arrays
     bool wrapped_scalar(U256& out) {
         ws();
         int depth = 0;
-        while (s < e && *s == '[') { s++; depth++; ws(); }
+        while (s < e && *s == '[') { s++; depth++; ws(); if (depth > MAX_NEST) return fail("arrays nested too deeply"); }
         if (!scalar(out)) return false;
         for (; depth; depth--) { ws(); if (s >= e || *s != ']') return fail("a scalar input must be a value or a one-element array"); s++; }
         return true;
     }
     // a (nested) array flattened row-major into int32 slots; returns the element count through n
-    bool flat(int32_t* dst, uint32_t cap, uint32_t& n, bool& big) {
+    // (the recursion is bounded: a hostile text of nothing but '[' must not overflow the stack of a loader thread)
+    enum { MAX_NEST = 16 };
+    bool flat(int32_t* dst, uint32_t cap, uint32_t& n, bool& big, int depth = 0) {
         ws();
         if (s < e && *s == '[') {
+            if (depth >= MAX_NEST) return fail("arrays nested too deeply");
             s++; ws();
             if (s < e && *s == ']') { s++; return true; }
             for (;;) {
-                if (!flat(dst, cap, n, big)) return false;
+                if (!flat(dst, cap, n, big, depth + 1)) return false;
                 ws();
                 if (s < e && *s == ',') { s++; continue; }
                 if (s < e && *s == ']') { s++; return true; }
@@ -142,7 +146,8 @@ struct Parser {
         if (s < e && *s >= '0' && *s <= '9') {                  // the bulk of an input: short non-negative decimal numbers (bytes, lengths)
             const char* a = s; uint64_t v = 0;
             while (s < e && *s >= '0' && *s <= '9' && s - a < 10) { v = v * 10 + (uint64_t)(*s - '0'); s++; }
-            if (s < e && (*s == ',' || *s == ']' || *s == ' ' || *s == '\n')) {
+            if (s - a > 1 && *a == '0') { s = a; }                // (leading zeros: the general path refuses them)
+            else if (s < e && (*s == ',' || *s == ']' || *s == ' ' || *s == '\n')) {
                 if (n < cap) { if (v >= (1ull << 31)) { big = true; dst[n] = 0x7FFFFFFF; } else dst[n] = (int32_t)v; }
                 n++;
                 return true;
@@ -197,7 +202,7 @@ bool pack_one(const Shape& sh, const char* json, uint64_t len, uint8_t* fr_row, 
     // slot of every small input in the int32 row (declaration order) and its element count
     uint32_t off[7] = {0, 0, 0, 0, 0, 0, 0}, cnt[7] = {1, 1, 1, 1, 1, 1, 1};
     if (nsmn) { cnt[1] = sh.L * sh.LB; cnt[2] = sh.L; cnt[4] = sh.HBy; uint32_t o = 0; for (int k = 0; k < 7; k++) { off[k] = o; o += cnt[k]; } }
-    uint32_t seen_fr = 0, seen_sm = 0; bool big = false;
+    uint32_t seen_fr = 0, seen_sm = 0, big_sm = 0;          // big_sm: bit k = small input k holds a value that does not fit its int32 slot (of its LAST occurrence: a duplicate key replaces the earlier value, like json.loads)
     std::string unexpected;
     p.ws();
     if (p.s >= p.e || *p.s != '{') { err = "input.json must be an object"; return false; }
@@ -223,6 +228,7 @@ bool pack_one(const Shape& sh, const char* json, uint64_t len, uint8_t* fr_row, 
         } else {
             for (int k = 0; k < nsmn && hit < 0; k++) if (strlen(POB_SM[k]) == kl && !memcmp(POB_SM[k], a, kl)) hit = k;
             if (hit >= 0) {
+                bool big = false;
                 if (cnt[hit] == 1 && hit != 2) {               // scalar small input (layerLens is an array even when maxNumLayers = 1)
                     U256 v;
                     if (!p.wrapped_scalar(v)) { err = std::string(POB_SM[hit]) + ": " + p.err; return false; }
@@ -233,6 +239,7 @@ bool pack_one(const Shape& sh, const char* json, uint64_t len, uint8_t* fr_row, 
                     if (n != cnt[hit]) { err = std::string(POB_SM[hit]) + " has " + std::to_string(n) + " elements, circuit expects " + std::to_string(cnt[hit]); return false; }
                 }
                 seen_sm |= 1u << hit;
+                big_sm = big ? (big_sm | (1u << hit)) : (big_sm & ~(1u << hit));
             } else {
                 if (!unexpected.empty()) unexpected += ", ";
                 unexpected.append(a, kl);
@@ -250,7 +257,7 @@ bool pack_one(const Shape& sh, const char* json, uint64_t len, uint8_t* fr_row, 
     for (int k = 0; k < nfr; k++) if (!((seen_fr >> k) & 1)) { if (!missing.empty()) missing += ", "; missing += frn[k]; }
     for (int k = 0; k < nsmn; k++) if (!((seen_sm >> k) & 1)) { if (!missing.empty()) missing += ", "; missing += POB_SM[k]; }
     if (!missing.empty() || !unexpected.empty()) { err = "missing [" + missing + "] unexpected [" + unexpected + "]"; return false; }
-    *forced = big ? FAIL_INPUT_RANGE : 0;
+    *forced = big_sm ? FAIL_INPUT_RANGE : 0;
     return true;
 }
 void put_err(char* dst, uint32_t cap, const std::string& m) { if (dst && cap) { snprintf(dst, cap, "%s", m.c_str()); } }

@@ -158,8 +158,9 @@ struct pob_ctx {
         uint64_t win_wires = 0, alloc_wires = 0, next_make = 0, next_take = 0, nwin = 0; uint32_t idx = 0; bool active = false;
         uint32_t first_slot = 0;                        // slot of the current witness' window 0 (window k: (first_slot + k) % NSLOT)
         int64_t queued_idx = -1; bool pre_made = false; // pob_emit_queue: the witness the next pob_emit_begin* will ask for / its window 0 is made
+        uint64_t pre_made_gen = 0;                       // ... from the resident vector of THIS generation (h->gen_count when the window was expanded)
         std::vector<uint32_t> status_host; uint64_t status_gen = 0;      // the batch's generation statuses, fetched once per generation
-        const uint32_t* map_ptr = nullptr; uint64_t map_sample = 0;     // reduced: address / sampled fingerprint of the caller's map at its last full validation
+        const uint32_t* pin_ptr = nullptr; uint64_t pin_n = 0, pin_id = 0;     // reduced: a map the caller pinned (pob_reduced_map_pin): contents promised unchanged, not hashed again
         struct Run { uint32_t w, b, n, absorb; };
         std::vector<Run> runs;                          // the Keccak kernels' wires, sorted by wire index: contiguous stored runs (wire index, BIT rank, count) and Absorb blocks (absorb = 1: stored + alias wires, b = the block's first BIT rank)
         // which G units write into which window (found by one probe pass per window size): a window launches only those
@@ -190,6 +191,7 @@ struct pob_ctx {
     // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
     // waits for the end of that evaluation; the evaluation then uses the pool's two evaluation streams
     pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
+    bool priv = false, serial = false; hipStream_t own_side[4] = {nullptr, nullptr, nullptr, nullptr};    // EXPERIMENT (POB_SCHED=private): this handle's own side streams, no gate between handles
     hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false, evaluated = false;
     // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
     hipStream_t s_upload = nullptr;                         // = the pool's upload stream
@@ -454,6 +456,15 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         P->refs++; h->pool = P;
     }
     h->stream2 = h->pool->stream2; h->stream_k = h->pool->stream_k;
+    hipStream_t p_track1 = h->pool->track1, p_track2 = h->pool->track2;
+    { const char* e = getenv("POB_SCHED"); h->priv = e && !strcmp(e, "private"); }
+    if (h->priv) {
+        const char* ns = getenv("POB_SCHED_STREAMS"); int n = ns ? atoi(ns) : 4;
+        if (n == 0) { h->serial = true; n = 1; }                 // EXPERIMENT: everything on the caller's stream
+        for (int k = 0; k < 4; k++) { if (k < n) HIPC(hipStreamCreateWithPriority(&h->own_side[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi)); }
+        h->stream2 = h->own_side[0]; h->stream_k = n > 1 ? h->own_side[1] : h->own_side[0];
+        p_track1 = n > 2 ? h->own_side[2] : h->own_side[0]; p_track2 = n > 3 ? h->own_side[3] : p_track1;
+    }
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_g_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_k_done, hipEventDisableTiming));
@@ -462,12 +473,12 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < Plan::MAX_TRACKS; t++) {        // (streams for every track slot: the evaluation uses tracks 1 and 2's whatever the circuit)
         pob_ctx::Track& T = h->tracks[t];
-        T.s_main = t == 1 ? h->pool->track1 : t == 2 ? h->pool->track2 : t == 3 ? h->pool->track2 : t == 6 ? h->pool->track1 : h->stream2;   // tracks 4 and 5 follow each other on the BN254 stream; 3 follows 2; 6 follows 1
+        T.s_main = t == 1 ? p_track1 : t == 2 ? p_track2 : t == 3 ? p_track2 : t == 6 ? p_track1 : h->stream2;   // tracks 4 and 5 follow each other on the BN254 stream; 3 follows 2; 6 follows 1
         T.s_heavy = T.s_main;
         HIPC(hipEventCreateWithFlags(&T.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_join, hipEventDisableTiming));
         HIPC(hipEventCreateWithFlags(&T.ev_start, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&T.ev_end, hipEventDisableTiming));
     }
-    h->stream3 = h->pool->track1;
+    h->stream3 = p_track1;
     const uint64_t G = h->groups, npad = G * 64;
     HIPC(hipMalloc(&h->d_bits, G * (uint64_t)std::max(pl.total.b, 1u) * 8));
     HIPC(hipMalloc(&h->d_sm, G * (uint64_t)std::max(pl.total.s, 1u) * 256));
@@ -544,6 +555,7 @@ void pob_close(pob_handle h) {
     for (hipEvent_t e : h->ev_kchk) if (e) hipEventDestroy(e);
     if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
+    for (hipStream_t q : h->own_side) if (q) hipStreamDestroy(q);
     if (h->pool) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         StreamPool* P = h->pool;
@@ -640,9 +652,9 @@ int pob_generate(pob_handle h, void* stream_) {
     //  then enqueued AHEAD of the wide track 5, whose stream it normally shares: it moves to track 2's.
     // (a strictly PHASED schedule -- evaluation kernel alone | the G work of both batches | expansion alone -- was measured too: the evaluation
     //  kernel then runs at 0.77 of the HBM peak inside the step, but the G phase takes 5.3 ms by itself and the step 14.87 ms instead of 13.5)
-    const bool gate = h->partner && h->partner->gen_done_rec;
+    const bool gate = !h->priv && h->partner && h->partner->gen_done_rec;
     const bool gate_late = gate && h->plan.ntracks > 1;
-    auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner) ? h->pool->track2 : h->tracks[t].s_main; };
+    auto track_stream = [&](uint32_t t) { return h->serial ? st : (t == 4 && h->partner && !h->priv) ? h->pool->track2 : h->tracks[t].s_main; };
     if (gate && !gate_late) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
@@ -650,10 +662,10 @@ int pob_generate(pob_handle h, void* stream_) {
     // one track: its stages in order; within a stage the BN254 / Poseidon units run on the track's second stream beside the light ones,
     // then the stage's Keccak sponges.  Tracks forked after a stage are enqueued completely (highest first) before the next stage, so every
     // event is recorded before anything waits on it.
-    const bool rounds_async = h->partner != nullptr;          // the main track's round expansion leaves the track (pipeline mode)
+    const bool rounds_async = h->partner != nullptr || h->priv;          // the main track's round expansion leaves the track (pipeline mode)
     std::vector<hipEvent_t> pending;
     std::function<int(uint32_t)> run_track = [&](uint32_t t) -> int {
-        hipStream_t sm = t ? track_stream(t) : st, sh = t ? track_stream(t) : h->stream2;
+        hipStream_t sm = t ? track_stream(t) : st, sh = t ? track_stream(t) : h->serial ? st : h->stream2;
         hipEvent_t ef = t ? h->tracks[t].ev_fork : h->ev_fork, ej = t ? h->tracks[t].ev_join : h->ev_join;
         for (uint32_t sid = t * Plan::TRACK_STRIDE; sid < (t + 1) * Plan::TRACK_STRIDE && sid <= pl.max_stage; sid++) {
             for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) HIPC(hipStreamWaitEvent(sm, h->tracks[u].ev_end, 0));
@@ -681,12 +693,12 @@ int pob_generate(pob_handle h, void* stream_) {
                 if (rounds_async && t == 0) {
                     // nothing in the generation reads a KeccakfRound block's wires (k_chain wrote every state a later stage uses): the
                     // main track's HBM-streaming expansion leaves the track here and is only joined before the results are collected
-                    HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->stream_k, h->ev_rounds_fork, 0));
+                    HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->serial ? st : h->stream_k, h->ev_rounds_fork, 0));
                     // pipeline: the write-saturating expansion does not run beside the partner's evaluation, it follows it -- IN ORDER on the
                     // device's one streaming stream, where the partner's Keccak evaluation was enqueued before (pob_constraint_check): the two
                     // HBM-saturating kernels of the two batches alternate on one hardware queue without an event hand-over between them
                     // (0.3 ms per phase change when the evaluation ran on the caller's stream and the expansion waited for its end through an event)
-                    sk = h->stream_k; pending.push_back(ks.ev_done);
+                    sk = h->serial ? st : h->stream_k; pending.push_back(ks.ev_done);
                 }
                 launch_k_rounds(K, false, ks.perm_count, G, sk);
                 HIPC(hipEventRecord(ks.ev_done, sk));
@@ -710,6 +722,7 @@ int pob_generate(pob_handle h, void* stream_) {
     HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
     HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
     h->generated = true; h->evaluated = false; h->gen_count++;
+    h->em.queued_idx = -1;                              // an announcement (pob_emit_queue) names a witness of the batch it was made for; a window pre-made from that batch is not reused (pre_made_gen)
     return POB_OK;
 }
 
@@ -728,7 +741,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     static const uint32_t side_plan[2][5] = {{F_N2B, F_SC, F_LD, F_RANGE, F_GM}, {F_RL, F_POS, F_MISC, F_SELROW, F_COUNT}};      // (F_GM: gadget-level mains only; F_COUNT: no family)
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
-    hipStream_t side[2] = {h->partner ? h->pool->chk1 : h->stream2, h->partner ? h->pool->chk2 : h->stream3};
+    hipStream_t side[2] = {h->serial ? st : (h->partner && !h->priv) ? h->pool->chk1 : h->stream2, h->serial ? st : (h->partner && !h->priv) ? h->pool->chk2 : h->stream3};
     HIPC(hipEventRecord(h->ev_fork, st));
     for (int k = 0; k < 2; k++) {
         HIPC(hipStreamWaitEvent(side[k], h->ev_fork, 0));
@@ -742,14 +755,14 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // pipeline: on the device's streaming stream, directly behind this batch's round expansion (in order: no event between the two) and
         // ahead of the partner's next expansion; it needs the G side of the generation (its tail runs beside the expansion), not the
         // result collection on the caller's stream.  A lone handle: on the caller's stream.
-        hipStream_t sk = h->partner ? h->stream_k : st;
+        hipStream_t sk = h->serial ? st : (h->partner || h->priv) ? h->stream_k : st;
         if (sk != st) HIPC(hipStreamWaitEvent(sk, h->ev_g_done, 0));
         if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
         launch_k_rounds(K, true, h->nperms, G, sk);
         if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
         // (pipeline: the narrow sponge-chain evaluation -- 84 wavefronts per group, 0.18 ms -- on an evaluation stream beside the families, not in
         //  order between the two chip-filling kernels of the streaming stream, where the machine idled for its duration: -0.02 ms, three interleaved pairs)
-        launch_k_chain(K, true, h->nperms, G, h->partner ? side[1] : sk);
+        launch_k_chain(K, true, h->nperms, G, (h->partner || h->priv) ? side[1] : sk);
         if (sk != st) { HIPC(hipEventRecord(h->ev_k_done, sk)); HIPC(hipStreamWaitEvent(st, h->ev_k_done, 0)); }
     }
     HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
@@ -814,8 +827,8 @@ int pob_results(pob_handle h, uint32_t* status, uint8_t* outputs, uint32_t* chec
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t* r = (const uint32_t*)(rec + (uint64_t)i * POB_RECORD_BYTES);
         if (status) status[i] = r[0];
-        if (check_status) check_status[i] = r[1] == POB_NOT_EVALUATED ? 0xFFFFFFFFu : r[1];
-        if (bad_wire) bad_wire[i] = r[2] == POB_NOT_EVALUATED ? 0xFFFFFFFFu : r[2];
+        if (check_status) check_status[i] = r[1];       // POB_NOT_EVALUATED when no pob_constraint_check ran on this batch (0xFFFFFFFF = clean)
+        if (bad_wire) bad_wire[i] = r[2];
         if (outputs) memcpy(outputs + (uint64_t)i * 32, r + 3, 32);
     }
     return POB_OK;
@@ -891,13 +904,6 @@ static uint64_t fnv64(const void* p, size_t n) {
     return hsh ? hsh : 1;
 }
 
-// fingerprint of 1 024 evenly spaced 16-entry blocks of a map (and its ends): recognises the map a caller passes again and again -- the full
-// hash of a production map (86 MB) costs 9 ms per witness, a third of a reduced emission
-static uint64_t fnv64_sampled(const uint32_t* keep, uint64_t n) {
-    uint64_t hsh = fnv64(keep, std::min<uint64_t>(n, 64) * 4) ^ fnv64(keep + (n > 64 ? n - 64 : 0), std::min<uint64_t>(n, 64) * 4);
-    if (n > (1u << 15)) for (uint64_t b = 0; b < 1024; b++) hsh = (hsh * 1099511628211ull) ^ fnv64(keep + (n / 1024) * b, 64);
-    return hsh ? hsh : 1;
-}
 // the generation statuses of the current batch on the host (one D2H per generation): no witness is emitted for a failed input
 static int emit_statuses(pob_ctx* h) {
     pob_ctx::Emit& E = h->em;
@@ -927,7 +933,7 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
     const uint64_t nwin_ = (E.total + window_wires - 1) / window_wires;
     // the witness announced with pob_emit_queue, same payload and window size: its first window has been expanded (and is being copied)
     // behind the previous witness' last windows already -- continue from there, nothing to wait for
-    if (E.pre_made && E.queued_idx == (int64_t)idx && E.win_wires == window_wires && E.nwin == nwin_ && E.probe_map == E.map_id && E.status_gen == h->gen_count) {
+    if (E.pre_made && E.pre_made_gen == h->gen_count && E.queued_idx == (int64_t)idx && E.win_wires == window_wires && E.nwin == nwin_ && E.probe_map == E.map_id) {
         E.first_slot = (E.first_slot + (uint32_t)E.nwin) % NS;
         E.idx = idx; E.next_make = 1; E.next_take = 0; E.active = true; E.queued_idx = -1; E.pre_made = false;
         return POB_OK;
@@ -1005,10 +1011,10 @@ int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uin
     HIPC(hipSetDevice(h->device));
     pob_ctx::Emit& E = h->em;
     const uint64_t W = h->plan.total.w;
-    // the map the caller passed last time (same address, same length, same sampled fingerprint) is not hashed / validated again
-    const uint64_t sample = fnv64_sampled(keep, n_keep);
-    const bool same = E.map_id && keep == E.map_ptr && E.keep.size() == n_keep && sample == E.map_sample;
-    const uint64_t id = same ? E.map_id : (fnv64(keep, n_keep * 4) ^ (n_keep << 1));
+    // a map the caller PINNED (pob_reduced_map_pin: same address and length, contents promised unchanged) is not hashed again; any other map is
+    // hashed in full every time (86 MB / 9 ms for the production map): an address can be recycled for a different map of the same length
+    const bool pinned = E.pin_id && keep == E.pin_ptr && n_keep == E.pin_n;
+    const uint64_t id = pinned ? E.pin_id : (fnv64(keep, n_keep * 4) ^ (n_keep << 1));
     if (id != E.map_id || E.keep.size() != n_keep) {
         // a new map: validate (wire 0 first, strictly increasing, inside the circuit), build the bitmap and the per-word ranks, upload
         if (keep[0] != 0 || keep[n_keep - 1] >= W) { h->err = "reduced map: keep[0] must be wire 0 and every index must be < nWitness"; return POB_E_ARG; }
@@ -1016,6 +1022,7 @@ int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uin
         std::vector<unsigned long long> bits(nwords, 0); std::vector<uint32_t> pre(nwords, 0);
         for (uint64_t i = 0; i < n_keep; i++) {
             if (i && keep[i] <= keep[i - 1]) { h->err = "reduced map: wire indices must be strictly increasing"; return POB_E_ARG; }
+            if (keep[i] >= W) { h->err = "reduced map: every index must be < nWitness"; return POB_E_ARG; }      // (before bits[] is touched)
             bits[keep[i] >> 6] |= 1ull << (keep[i] & 63);
         }
         uint32_t acc = 0;
@@ -1030,9 +1037,16 @@ int pob_emit_begin_reduced(pob_handle h, uint32_t idx, const uint32_t* keep, uin
         E.keep.assign(keep, keep + n_keep);
         E.queued_idx = -1; E.pre_made = false;
     }
-    E.map_ptr = keep; E.map_sample = sample;
     E.red = true; E.map_id = id; E.total = n_keep;
     return emit_start(h, idx, window_wires);
+}
+
+int pob_reduced_map_pin(pob_handle h, const uint32_t* keep, uint64_t n_keep) {
+    if (!h) return POB_E_ARG;
+    pob_ctx::Emit& E = h->em;
+    if (!keep || n_keep == 0) { E.pin_ptr = nullptr; E.pin_n = 0; E.pin_id = 0; return POB_OK; }     // unpin
+    E.pin_ptr = keep; E.pin_n = n_keep; E.pin_id = fnv64(keep, n_keep * 4) ^ (n_keep << 1);
+    return POB_OK;
 }
 
 int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint64_t* n_wires) {
@@ -1051,7 +1065,7 @@ int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint
     // ... and when this witness has no more windows to make, the first window of the witness announced with pob_emit_queue
     if (E.next_make == E.nwin && E.nwin - E.next_take <= 2 && E.queued_idx >= 0 && !E.pre_made) {
         int rc = emit_make_window(h, (uint32_t)E.queued_idx, 0, (int)((E.first_slot + E.nwin) % NS)); if (rc) return rc;
-        E.pre_made = true;
+        E.pre_made = true; E.pre_made_gen = h->gen_count;
     }
     const uint64_t k = E.next_take++;
     const int slot = (int)((E.first_slot + k) % NS);

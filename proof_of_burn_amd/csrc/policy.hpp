@@ -86,6 +86,7 @@ struct PlanNote { uint32_t what, n; Cur cur; uint32_t a[7]; };
 struct CountP : PolBase {
     static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
     uint32_t nput = 0;    // wires written: the planner's cost estimate of a unit (long units are dispatched first)
+    uint32_t nb = 0, ns = 0, nf = 0;      // ... by storage class (tools/plan_stats.cpp)
     PlanNote notes[PLAN_MAX_NOTES]; uint32_t nnotes = 0;
     bool notes_overflow = false;          // a composite with more split sub-blocks than the table holds: the planner refuses the plan (Plan::take_notes)
     HD void note(uint32_t what, uint32_t n, Cur c, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0, uint32_t a6 = 0) {
@@ -93,12 +94,12 @@ struct CountP : PolBase {
         PlanNote& x = notes[nnotes++]; x.what = what; x.n = n; x.cur = c;
         x.a[0] = a0; x.a[1] = a1; x.a[2] = a2; x.a[3] = a3; x.a[4] = a4; x.a[5] = a5; x.a[6] = a6;
     }
-    HD B put(BitRef, B v) { nput++; return v; }
-    HD S put(SmRef, S v) { nput++; return v; }
-    HD F put(FrRef, const F& v) { nput += 8; return v; }
-    HD B hint(BitRef, B v) { nput++; return v; }
-    HD S hint(SmRef, S v) { nput++; return v; }
-    HD F hint(FrRef, const F& v) { nput += 8; return v; }
+    HD B put(BitRef, B v) { nput++; nb++; return v; }
+    HD S put(SmRef, S v) { nput++; ns++; return v; }
+    HD F put(FrRef, const F& v) { nput += 8; nf++; return v; }
+    HD B hint(BitRef, B v) { nput++; nb++; return v; }
+    HD S hint(SmRef, S v) { nput++; ns++; return v; }
+    HD F hint(FrRef, const F& v) { nput += 8; nf++; return v; }
     HD B get(BitRef) { return 0; }
     HD S get(SmRef) { return 0; }
     HD S get_lane(SmRef, uint32_t) { return 0; }
@@ -119,7 +120,7 @@ struct CountP : PolBase {
     HD uint32_t lane_id() { return 0; }
     // lane-distributed BIT access (see DevPol): n wires
     HD B run_get(uint32_t, uint32_t) { return 0; }
-    HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; }
+    HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; nb += n; }
     HD B run_bcast(B, uint32_t) { return 0; }
     HD B run_set(B run, uint32_t, B) { return run; }
     HD B run_perm(B run, uint32_t) { return run; }

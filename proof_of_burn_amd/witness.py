@@ -156,6 +156,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_results_wait.argtypes = [vp, ctypes.POINTER(vp), u32p]
     lib.pob_emit_begin_reduced.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint64]
     lib.pob_write_wtns_reduced.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_char_p]
+    lib.pob_reduced_map_pin.argtypes = [vp, vp, ctypes.c_uint64]
     lib.pob_emit_measure_ex.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_generate.argtypes = [vp, vp]
     lib.pob_constraint_check.argtypes = [vp, vp]
@@ -186,7 +187,7 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
-                    "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
+                    "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
                     "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
@@ -384,8 +385,9 @@ def pack_json(main, texts: Sequence[bytes | str], threads: int = 0, out: "Pinned
 class Result:
     status: int                 # 0 = ok; else (template id << 12) | source line of the first failing assert
     outputs: list | None        # public output signals (None when failed) -- tests/test.py:40-47,65-68
-    check_status: int | None = None
-    bad_wire: int | None = None
+    check_status: int | None = None      # with_check: 0 = every === holds, else the first failing site; None = not asked for / not evaluated
+    bad_wire: int | None = None          # with_check: lowest wire whose stored value contradicts its definition (None = none / not evaluated)
+    evaluated: bool | None = None        # with_check: False when no constraint_check has run on this batch (check_status / bad_wire are None then)
 
     @property
     def ok(self) -> bool:
@@ -534,8 +536,10 @@ class WitnessCalculator:
                 out = None if st else [int.from_bytes(outs[i].tobytes(), "little")]
             r = Result(st, out)
             if with_check:
-                r.check_status = 0 if chk[i] == 0xFFFFFFFF else int(chk[i])
-                r.bad_wire = None if bad[i] == 0xFFFFFFFF else int(bad[i])
+                r.evaluated = int(chk[i]) != NOT_EVALUATED
+                if r.evaluated:
+                    r.check_status = 0 if chk[i] == CLEAN else int(chk[i])
+                    r.bad_wire = None if bad[i] == CLEAN else int(bad[i])
             res.append(r)
         return res
 
@@ -569,10 +573,18 @@ class WitnessCalculator:
     def write_wtns(self, idx: int, path: str):
         self._ck(self.lib.pob_write_wtns(self.h, idx, os.fsencode(path)))
 
-    @staticmethod
-    def _keep_array(keep) -> np.ndarray:
+    def _keep_array(self, keep) -> np.ndarray:
+        """the map as a contiguous uint32 array, PINNED in the library (pob_reduced_map_pin: recognised by address afterwards instead of being
+        hashed per witness).  The array object the caller passed and its contiguous form stay referenced here while pinned, so the address
+        cannot be recycled for another map; a different object is a different map (hashed, validated, pinned in its turn)."""
         keep = getattr(keep, "keep", keep)                 # circuit_model.o1.ReducedMap or a plain array of surviving O0 wire indices
-        return np.ascontiguousarray(keep, dtype=np.uint32)
+        held = getattr(self, "_pinned_map", None)
+        if held is not None and (held[0] is keep or held[1] is keep):
+            return held[1]
+        k = np.ascontiguousarray(keep, dtype=np.uint32)
+        self._ck(self.lib.pob_reduced_map_pin(self.h, k.ctypes.data, k.size))
+        self._pinned_map = (keep, k)
+        return k
 
     def write_wtns_reduced(self, idx: int, path: str, keep):
         """O1-style reduced .wtns (circuit_model.o1.reduce_map): only the surviving wires are expanded on the GPU and cross PCIe

@@ -496,7 +496,8 @@ def test_reading_a_batch_does_not_stall_the_partner(pkg):
         a.upload_packed_async(pin.fr, pin.sm, pin.forced); a.generate(sa.cuda_stream)
         b.upload_packed_async(pin.fr, pin.sm, pin.forced)
         a.constraint_check(sa.cuda_stream); a.fetch_records()
-        b.generate(sb.cuda_stream)                      # its round expansion follows the end of a's evaluation
+        for _ in range(4):                              # (four generations of the same inputs: several times a's evaluation, whatever the box)
+            b.generate(sb.cuda_stream)
         done_b = torch.cuda.Event(); done_b.record(sb)
         rec = a.wait_records()                          # returns when a's records are on the host ...
         still_running += 0 if done_b.query() else 1     # ... while b is still generating

@@ -158,6 +158,29 @@ def test_native_json_loader_equals_the_python_loader():
             W.pack_inputs(fix, [d])
         with pytest.raises((KeyError, ValueError)):
             W.pack_json(fix, [json.dumps(d)])
+    # texts json.loads itself refuses or resolves: a number with leading zeros is refused (the STRING "007" is 7 for both); a duplicate key
+    # counts with its LAST value only -- an out-of-range first value must not leave the witness marked as failed; hostile nesting is an
+    # input error, not a stack overflow of the loader thread
+    good = json.dumps(base)
+    assert '"numLayers": ' in good
+    nl = base["numLayers"]
+    with pytest.raises(ValueError):
+        json.loads(good.replace(f'"numLayers": {nl}', '"numLayers": 007'))
+    with pytest.raises((KeyError, ValueError)):
+        W.pack_json(fix, [good.replace(f'"numLayers": {nl}', '"numLayers": 007')])
+    with pytest.raises((KeyError, ValueError)):
+        W.pack_json(fix, [good.replace(f'"layerLens": [', '"layerLens": [00, ', 1)])
+    assert np.array_equal(W.pack_json(fix, [good.replace(f'"numLayers": {nl}', f'"numLayers": "00{nl}"')])[1], py[1][:1])
+    dup = good[:-1] + f', "numLayers": {nl}' + "}"
+    dup = dup.replace(f'"numLayers": {nl}', f'"numLayers": {2 ** 40}', 1)                     # first occurrence out of range, last one valid
+    assert json.loads(dup)["numLayers"] == nl
+    nat = W.pack_json(fix, [dup])
+    assert all(np.array_equal(x[:1], y) for x, y in zip(py, nat)) and nat[2][0] == 0
+    dup2 = good[:-1] + f', "numLayers": {2 ** 40}' + "}"                                        # ... and the other way round
+    assert W.pack_json(fix, [dup2])[2][0] == W.FAIL_INPUT_RANGE == W.pack_inputs(fix, [json.loads(dup2)])[2][0]
+    for hostile in ('{"layers": ' + "[" * 200000, '{"numLayers": ' + "[" * 200000):
+        with pytest.raises((KeyError, ValueError)):
+            W.pack_json(fix, [hostile])
     # Spend (no small inputs) and the production shape
     with open(os.path.join(ROOT, "tests", "golden", "test_spend_input.json")) as f:
         sp = json.load(f)
