@@ -192,6 +192,13 @@ int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_
  * to corrupt: corrupting the stored wire they are a function / a copy of changes them with it.)                                    */
 enum { POB_CLASS_BIT = 0, POB_CLASS_SM = 1, POB_CLASS_FR = 2 };
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask);
+/* Test hook: how many IsZero.inv wires the emitter has written since the last reset through each of its paths: out[0] from the table of small
+ * inverses (|operand| <= 4096), out[1] by Fermat exponentiation (larger small operands), out[2] / out[3] field-element operands, non-zero
+ * (Kaliski inversion) / zero.  Call when an emission is complete.                                                                     */
+int pob_debug_emit_counters(pob_handle h, uint64_t out[4], int reset);
+/* Test hook: the device code's two field inversions (the generator's / emitter's Kaliski almost-inverse and the emitter's Fermat fall-back) on n
+ * canonical 32-byte LE inputs < p (0 -> 0), canonical outputs.                                                                          */
+int pob_debug_fr_inv(int device, const uint8_t* in, uint32_t n, uint8_t* out_kaliski, uint8_t* out_fermat);
 /* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the
  * first Poseidon block); "pad.div.out" / "pad.div.rem" of KeccakBytes instance k (the Divide hint of divide.circom:23-24); ProofOfBurn only: "sc.exists" [k] of layer 1's SubstringCheck. */
 int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire);

@@ -75,6 +75,15 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32
     if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
 }
 static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st);
+// test hook (pob_debug_fr_inv): both field inversions of the device code on n canonical inputs
+__global__ void k_fr_inv_test(const uint32_t* in, uint32_t* out_kaliski, uint32_t* out_fermat, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fr c; for (int j = 0; j < 8; j++) c.l[j] = in[t * 8 + j];
+    const Fr x = fr_to_mont(c);
+    const Fr a = fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv(x)), b = fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv_fermat(x));
+    for (int j = 0; j < 8; j++) { out_kaliski[t * 8 + j] = a.l[j]; out_fermat[t * 8 + j] = b.l[j]; }
+}
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
 // emission window pre-fill (0xEE..: not a field element, so a wire nobody owns is caught by the byte compare); rocclr's fill kernel
@@ -141,6 +150,7 @@ struct pob_ctx {
     UnitDesc* d_units = nullptr; uint32_t* d_order = nullptr; CircuitLayout* d_L = nullptr;
     SpongeDesc* d_sponges = nullptr; uint32_t *d_perm_sponge = nullptr, *d_perm_block = nullptr;
     uint32_t *d_pos = nullptr, *d_inv = nullptr, *d_pow256 = nullptr; uint32_t npow256 = 0;
+    uint32_t* d_emit_ctr = nullptr;                    // EmitP's path counters (pob_debug_emit_counters)
     uint16_t* d_ktab = nullptr;                        // alias table of a KeccakfRound block (keccak_kernels.hpp): which stored wire / constant each of its 102 656 wires is
     // packed inputs, double-buffered: a batch is uploaded into the buffer the current batch does NOT use (generation AND evaluation read the
     // inputs), pob_generate switches; ev_in_done[b] = the last generation / evaluation that read buffer b
@@ -276,7 +286,7 @@ static GArgs gargs(pob_ctx* h) {
     A.bits_stride = h->plan.total.b; A.sm_stride = (uint64_t)h->plan.total.s * 64; A.fr_stride = (uint64_t)h->plan.total.f * 512;
     A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr[h->in_cur]; A.in_sm = h->d_in_sm[h->in_cur];
     A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
-    A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad;
+    A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad; A.emit_counters = h->d_emit_ctr;
     return A;
 }
 static KArgs kargs(pob_ctx* h) {
@@ -491,6 +501,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipMalloc(&h->d_perm_block, std::max<size_t>(h->nperms, 1) * 4));
     HIPC(hipMalloc(&h->d_pos, sizeof(POS_TABLE_MONT)));
     HIPC(hipMalloc(&h->d_inv, 8193 * 32));
+    HIPC(hipMalloc(&h->d_emit_ctr, 4 * 4)); HIPC(hipMemset(h->d_emit_ctr, 0, 4 * 4));
     {   // 256^i (Montgomery) and 256^i * R^2 for i < 136*NB (SubstringCheck's M[] / exists[], substring_check.circom:45-49,91)
         h->npow256 = 136u * (uint32_t)std::max(pl.L.pob.NB, 1);
         std::vector<Fr> tab(2 * (size_t)h->npow256);
@@ -542,7 +553,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_ktab, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
+                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -1248,6 +1259,35 @@ int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32
         hipLaunchKernelGGL(k_xor_u32, dim3(1), dim3(1), 0, own_stream(h), h->d_fr + ((uint64_t)group * t.f + index) * 512 + sub * 64 + lane, xor_mask);
     } else return POB_E_ARG;
     HIPC(hipStreamSynchronize(own_stream(h)));
+    return POB_OK;
+}
+
+// the two field inversions of the device code (Kaliski almost-inverse: fr_inv; Fermat ladder: fr_inv_fermat, the emitter's fall-back beyond its table of
+// small inverses) on n canonical 32-byte LE inputs < p; 0 -> 0
+int pob_debug_fr_inv(int device, const uint8_t* in, uint32_t n, uint8_t* out_kaliski, uint8_t* out_fermat) {
+    if (!in || !out_kaliski || !out_fermat || n == 0) return POB_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return POB_E_HIP;
+    uint32_t *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+    const size_t bytes = (size_t)n * 32;
+    int rc = POB_E_HIP;
+    if (hipMalloc(&d_in, bytes) == hipSuccess && hipMalloc(&d_a, bytes) == hipSuccess && hipMalloc(&d_b, bytes) == hipSuccess &&
+        hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(k_fr_inv_test, dim3((n + 63) / 64), dim3(64), 0, 0, d_in, d_a, d_b, n);
+        if (hipMemcpy(out_kaliski, d_a, bytes, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(out_fermat, d_b, bytes, hipMemcpyDeviceToHost) == hipSuccess) rc = POB_OK;
+    }
+    if (d_in) hipFree(d_in); if (d_a) hipFree(d_a); if (d_b) hipFree(d_b);
+    return rc;
+}
+
+// which inverse paths of the emitter have run since the last reset (policy.hpp EmitP::ctr); the emission must be complete (pob_emit_next returned its last window)
+int pob_debug_emit_counters(pob_handle h, uint64_t out[4], int reset) {
+    if (!h || !out) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    uint32_t c[4];
+    HIPC(hipStreamSynchronize(own_stream(h)));
+    HIPC(hipMemcpy(c, h->d_emit_ctr, sizeof c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) out[k] = c[k];
+    if (reset) HIPC(hipMemset(h->d_emit_ctr, 0, sizeof c));
     return POB_OK;
 }
 

@@ -426,7 +426,10 @@ struct EmitP : DevPol {
     // reduced witness (pob_emit_begin_reduced): bit w of rbits = wire w survives, rpre[w / 64] = kept wires below 64 * (w / 64); a
     // surviving wire lands at its RANK among the kept wires and windows count kept wires.  Null: the O0 payload, position = wire index.
     const unsigned long long* rbits; const uint32_t* rpre;
-    __device__ __forceinline__ void w32(uint32_t w, const F& canon) {
+    // test hook (pob_debug_emit_counters): [0] IsZero.inv from the table of small inverses, [1] by Fermat exponentiation (|operand| > 4096),
+    // [2] field-element IsZero.inv of a NON-zero operand (Kaliski inversion), [3] of a zero operand -- counted per emitted wire, probe passes excluded
+    uint32_t* ctr;
+    __device__ __forceinline__ void w32(uint32_t w, const F& canon, int path = -1) {
         if (rbits) {
             const unsigned long long word = rbits[w >> 6];
             if (!((word >> (w & 63)) & 1)) return;
@@ -434,6 +437,7 @@ struct EmitP : DevPol {
         }
         if (probe) { atomicOr(probe + unit, 1ull << (w / wn)); return; }
         if (w - w0 >= wn) return;
+        if (path >= 0) atomicAdd(ctr + path, 1u);
         uint4* q = (uint4*)(out + (size_t)(w - w0) * 32);
         q[0] = make_uint4(canon.l[0], canon.l[1], canon.l[2], canon.l[3]);
         q[1] = make_uint4(canon.l[4], canon.l[5], canon.l[6], canon.l[7]);
@@ -455,7 +459,7 @@ struct EmitP : DevPol {
     __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
     __device__ __forceinline__ void derived_inv(uint32_t w, S x) { emit_inv(w, x); }
     __device__ __forceinline__ void derived_fr(uint32_t w, const F& v) { if (m.lane == sel) w32(w, fr_from_mont(v)); }
-    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) w32(w, fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv(x))); }
+    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) { const bool z = fr_is_zero(x); w32(w, z ? fr_zero() : fr_from_mont(fr_inv(x)), z ? 3 : 2); } }
     // the selected witness' value in every lane (a unit that has many inverses to rebuild spreads them over the lanes: circuits.hpp U_SC_RANGE)
     __device__ __forceinline__ F bcast_sel(const F& v) {
         F r;
@@ -473,7 +477,7 @@ struct EmitP : DevPol {
             } else {
                 c = fr_from_mont(fr_inv_fermat(fr_from_i64(k)));
             }
-            w32(w, c);
+            w32(w, c, (k >= -4096 && k <= 4096) ? 0 : 1);
         }
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}

@@ -175,6 +175,8 @@ def load_library() -> ctypes.CDLL:
     lib.pob_probe_check_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     lib.pob_debug_xor_bits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
     lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.pob_debug_emit_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    lib.pob_debug_fr_inv.argtypes = [ctypes.c_int, vp, ctypes.c_uint32, vp, vp]
     lib.pob_debug_ref.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
     lib.pob_keccak256.restype = None
@@ -189,7 +191,7 @@ def load_library() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -650,6 +652,12 @@ class WitnessCalculator:
     def poke(self, cls: int, index: int, lane: int, xor_mask: int = 1, sub: int = 0, group: int = 0):
         """XOR one stored value of one witness of the resident vector (storage class, rank in the class, lane)"""
         self._ck(self.lib.pob_debug_poke(self.h, cls, group, index, sub, lane, xor_mask))
+
+    def emit_counters(self, reset: bool = True) -> dict:
+        """IsZero.inv wires written by the emitter since the last reset, by path (pob_debug_emit_counters)"""
+        out = (ctypes.c_uint64 * 4)()
+        self._ck(self.lib.pob_debug_emit_counters(self.h, out, 1 if reset else 0))
+        return {"table": int(out[0]), "fermat": int(out[1]), "field_nonzero": int(out[2]), "field_zero": int(out[3])}
 
     def debug_ref(self, name: str, k: int = 0):
         cls, idx, wire = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()

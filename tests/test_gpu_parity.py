@@ -152,9 +152,11 @@ def test_constraint_evaluator_corruption_sweep(pkg, which):
 @pytest.mark.parametrize("which", ["spend", "pob"])
 def test_constraint_evaluator_detects_sm_sb_fr_pokes(pkg, which):
     """the evaluator on every storage class, not only bits: >= 1000 SM, >= 300 FR (and 300 more BIT) uniformly drawn
-    stored values of a 64-witness group are corrupted, 63 lanes per pass (lane 0 = control); each pass must flag exactly the poked
-    lanes.  SM covers the IsZero.inv hints stored as operands and the Divide quotient/remainder, FR the Poseidon state, the
-    SubstringCheck M[] / IsEqual operands and inverses.  Then the named wires, one at a time, with the reported wire checked."""
+    STORED values of a 64-witness group are corrupted, 63 lanes per pass (lane 0 = control); each pass must flag exactly the poked
+    lanes.  SM covers the inputs, hashes, selector / shift outputs and the Divide quotient / remainder hints, FR the Poseidon states and
+    the sub-string numbers (the operand wires of IsZero / IsEqual, M[], the copies and the Keccak round blocks' alias wires are not
+    stored -- policy.hpp DV, keccak_kernels.hpp -- so there is nothing of them to corrupt).  Then the named wires, one at a time, with the
+    reported wire checked."""
     if which == "spend":
         s = _suite("test_spend"); main = "Spend(31)"
         named = [("poseidon", k) for k in (1, 77, 200, 413, 640, 900)] + [("pad.div.out", 0), ("pad.div.rem", 0), ("commitment", 0)]
@@ -454,8 +456,92 @@ def test_gpu_witness_satisfies_the_independent_r1cs(pkg):
         calc.poke(cls, idx, 0, mask)
         assert bad and all(wire in wires for _, wires in bad), (name, wire, bad[:3])
     calc.close()
-    # (the production instantiation's 215.9 M rows x 6.9 GB payload go through the same code: `python -m proof_of_burn_amd.circuit_model
-    #  check "ProofOfBurn(16, 4, 16, ...)" witness.wtns`; not run here: it needs ~25 GB of host memory next to the other tests' buffers)
+    # (the production instantiation's 215.9 M rows: test_production_gpu_witness_satisfies_the_independent_r1cs)
+
+
+PROD = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
+
+
+def test_production_batch_payloads_beyond_group_0(pkg):
+    """ONE 1 024-witness production batch (BASELINE config 3's shape): the O0 payload and the reduced payload of witnesses 64, 511 and 1 023 --
+    groups 1, 7 and 15: emission addresses the resident slab by idx / 64 and the lane by idx % 64 -- equal the oracle's, every record of the
+    batch is clean, and the emitter's inverse paths that ran are counted (the field-element inverses of SubstringCheck's IsEqual(exists)
+    operands run at production parameters; the Fermat path needs a small operand beyond +-4096, which no valid production witness has:
+    tests/test_hostsim_cpu.py drives it through a Selector(6000) main)"""
+    from proof_of_burn_amd import inputs as gen
+    from proof_of_burn_amd.circuit_model import keepmap
+    batch = gen.synthetic_batch(1024, depth=10, seed=0xB0B, distinct_keys=16)
+    calc = pkg.WitnessCalculator(PROD, max_batch=1024)
+    res = calc.calculate(batch.inputs, check=True)
+    assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res) and [r.outputs[0] for r in res] == batch.commitments
+    keep, nw = keepmap.load(PROD)
+    assert nw == calc.nwitness
+    calc.emit_counters()
+    for idx in (64, 511, 1023):
+        ora = O.run(PROD, batch.inputs[idx])
+        assert not ora.failed and ora.outputs() == [batch.commitments[idx]]
+        ref = ora.witness_numpy()
+        gpu = calc.witness_payload(idx)
+        assert np.array_equal(gpu, ref), f"witness {idx}: first differing wire {_first_diff(gpu, ref)}"
+        del gpu
+        red = calc.witness_payload_reduced(idx, keep, window_wires=1 << 24)
+        assert np.array_equal(red.reshape(-1, 32), ref.reshape(-1, 32)[keep]), f"witness {idx}: reduced payload differs from the oracle's kept wires"
+        del red, ref, ora
+    c = calc.emit_counters()
+    assert c["table"] > 0 and c["field_nonzero"] >= 3 * 7000 and c["field_zero"] > 0, c
+    print("emitter inverse paths over 3 O0 + 3 reduced production payloads:", c)
+    calc.close()
+
+
+@pytest.mark.parametrize("depth", [8, 9, 10, 16])
+def test_production_payload_across_depths(pkg, depth):
+    """production instantiation, proofs of depth 8 / 9 / 10 / 16 (the derived and alias wires are data-dependent): the whole O0 payload of a
+    witness of group 1 against the oracle"""
+    from proof_of_burn_amd import inputs as gen
+    n = 66
+    batch = gen.synthetic_batch(n, depth=depth, seed=1000 + depth, distinct_keys=2, pow_device=0 if depth > 12 else None)
+    calc = pkg.WitnessCalculator(PROD, max_batch=n)
+    res = calc.calculate(batch.inputs, check=True)
+    assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res) and [r.outputs[0] for r in res] == batch.commitments
+    idx = n - 1
+    ora = O.run(PROD, batch.inputs[idx])
+    assert not ora.failed and ora.outputs() == [batch.commitments[idx]]
+    gpu, ref = calc.witness_payload(idx), ora.witness_numpy()
+    assert np.array_equal(gpu, ref), f"depth {depth}: first differing wire {_first_diff(gpu, ref)}"
+    calc.close()
+
+
+def test_production_gpu_witness_satisfies_the_independent_r1cs(pkg):
+    """the referee on HEAD: all 215 962 292 rows of the production instantiation (proof_of_burn_amd/circuit_model, which shares no code with
+    the generators) hold on a GPU-emitted witness of group 1 of a synthetic 10-layer batch"""
+    from proof_of_burn_amd import inputs as gen
+    from proof_of_burn_amd.circuit_model import check as CK, circuit
+    n = 70
+    batch = gen.synthetic_batch(n, depth=10, seed=0xC0FFEE, distinct_keys=2)
+    calc = pkg.WitnessCalculator(PROD, max_batch=n)
+    res = calc.calculate(batch.inputs, check=True)
+    assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res)
+    payload = calc.witness_payload(n - 1)
+    calc.close()
+    c = circuit(PROD)
+    assert c.n_wires == 215_907_954 and c.n_constraints == 215_962_292
+    assert CK.check_witness(c, CK.Witness(payload)) == []
+
+
+def test_device_field_inversions(pkg):
+    """the device code's two field inversions (Kaliski almost-inverse: generation and the emitter's field-element IsZero.inv; Fermat ladder: the
+    emitter's fall-back beyond its table of small inverses, unreachable for a valid witness -- tests/test_hostsim_cpu.py) on the GPU against
+    pow(x, p - 2, p)"""
+    import random
+    from proof_of_burn_amd import witness as W
+    rng = random.Random(5)
+    xs = [0, 1, 2, 4097, 65_535, W.P - 4097, W.P - 1, 2 ** 253 % W.P] + [rng.randrange(W.P) for _ in range(2040)]
+    buf = b"".join(x.to_bytes(32, "little") for x in xs)
+    a, b = ctypes.create_string_buffer(len(buf)), ctypes.create_string_buffer(len(buf))
+    assert pkg.load_library().pob_debug_fr_inv(0, buf, len(xs), a, b) == 0
+    for k, x in enumerate(xs):
+        want = pow(x, W.P - 2, W.P)
+        assert int.from_bytes(a.raw[32 * k:32 * k + 32], "little") == want and int.from_bytes(b.raw[32 * k:32 * k + 32], "little") == want, (k, x)
 
 
 def test_pow_search_gpu_matches_host(pkg):

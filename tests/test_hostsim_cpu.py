@@ -77,6 +77,26 @@ def test_spend_suite_wtns_and_evaluator(pkg, tmp_path):
         assert pos == keep.size
     calc.emit_queue(0)                                       # an announcement that is not followed: the prepared window is dropped
     assert np.array_equal(calc.witness_payload(3), ref3) and np.array_equal(calc.witness_payload(3), ref3)
+    # a window pre-made from one batch must not serve the next batch: announce witness 0, drain witness 3 (witness 0's first window of batch A
+    # is expanded behind it), generate batch B = the cases in reverse order, begin witness 0 with the same window size
+    order = [c["input"] for c in s["cases"]]
+    for win in (1_000_000, 5_000_000):
+        calc.calculate(order)
+        calc.emit_queue(0)
+        for _ in calc.witness_windows(3, window_wires=win):
+            pass
+        resB = calc.calculate(order[::-1])
+        assert resB[0].ok
+        got0 = np.concatenate([v.copy() for _, v in calc.witness_windows(0, window_wires=win)])
+        assert np.array_equal(got0, ref3), ("the first window came from the previous batch", win)
+    res = calc.calculate(order, check=True)
+    # a batch that was generated but not evaluated says so (it is not reported as clean)
+    calc.generate()
+    r0 = calc.results(with_check=True)[0]
+    assert r0.evaluated is False and r0.check_status is None and r0.bad_wire is None
+    calc.constraint_check()
+    r0 = calc.results(with_check=True)[0]
+    assert r0.evaluated is True and r0.check_status == 0 and r0.bad_wire is None
     bad_idx = next(i for i, r in enumerate(res) if not r.ok)
     with pytest.raises(RuntimeError):
         calc.emit_queue(bad_idx)                             # no witness for a failed input, announced or not
@@ -331,3 +351,44 @@ def test_gadget_mains_at_production_sizes(pkg):
         total += nok
     assert not bad, bad[:4]
     assert total >= 10
+
+
+def test_emitter_inverse_paths_and_field_inversions(pkg):
+    """the emitter's inverse paths.  IsZero.inv of a SMALL operand comes from the table of inverses of -4096..4096; the Fermat fall-back beyond
+    the table (policy.hpp EmitP::emit_inv) is unreachable for a valid witness of these circuits: every IsEqual / IsZero over small operands
+    compares byte positions, bytes or lengths that an assert bounds (positions < 136 * 16, lengths by AssertLessEqThan / Num2Bits(16) -- a
+    LeafDetector main with layerLen = 60 001 fails AssertLessEqThan, it does not reach the emitter), and gadget mains bound their template
+    parameters by 4 096.  So: (i) the counters over whole emitted payloads say which paths ran (table, field-element inverses; Fermat: 0),
+    (ii) both field inversions of the device code are compared with pow(x, p - 2, p) directly (pob_debug_fr_inv), the values a Fermat
+    fall-back would see (|k| > 4096, p - k) included"""
+    import json
+    from proof_of_burn_amd import witness as W
+    with open(os.path.join(ROOT, "tests", "golden", "suites.json")) as f:
+        suites = json.load(f)
+    ld = next(x for x in suites if x["main"].startswith("LeafDetector"))
+    calc = pkg.WitnessCalculator(ld["main"], max_batch=2)
+    res = calc.calculate([ld["cases"][0]["input"], dict(ld["cases"][0]["input"], layerLen=60_001)], check=True)
+    assert res[0].ok and not res[1].ok
+    calc.emit_counters()
+    assert np.array_equal(calc.witness_payload(0), O.run(ld["main"], ld["cases"][0]["input"]).witness_numpy())
+    c = calc.emit_counters()
+    assert c["table"] > 0 and c["fermat"] == 0, c
+    calc.close()
+    sp = next(x for x in suites if x["main"].startswith("SubstringCheck"))
+    calc = pkg.WitnessCalculator(sp["main"], max_batch=1)
+    ok_case = next(cs for cs in sp["cases"] if cs["expected"] is not None)
+    assert calc.calculate(ok_case["input"], check=True)[0].ok
+    calc.emit_counters()
+    assert np.array_equal(calc.witness_payload(0), O.run(sp["main"], ok_case["input"]).witness_numpy())
+    c = calc.emit_counters()
+    assert c["field_nonzero"] > 0 and c["fermat"] == 0, c               # SubstringCheck's IsEqual(exists) operands: field-element inverses
+    calc.close()
+    import ctypes, random
+    rng = random.Random(11)
+    xs = [0, 1, 2, 4097, 60_001 - 16, W.P - 4097, W.P - 1, W.P - 5000, 2 ** 253 % W.P] + [rng.randrange(W.P) for _ in range(55)]
+    buf = b"".join(x.to_bytes(32, "little") for x in xs)
+    a, b = ctypes.create_string_buffer(len(buf)), ctypes.create_string_buffer(len(buf))
+    assert pkg.load_library().pob_debug_fr_inv(0, buf, len(xs), a, b) == 0
+    for k, x in enumerate(xs):
+        want = pow(x, W.P - 2, W.P)
+        assert int.from_bytes(a.raw[32 * k:32 * k + 32], "little") == want and int.from_bytes(b.raw[32 * k:32 * k + 32], "little") == want, (k, x)
