@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurements")
     ap.add_argument("--no-single", action="store_true", help="skip the single-calculator steps after the timed region")
-    ap.add_argument("--probe-in-timed-region", action="store_true", help="record the HIP events around the dominant kernel inside the timed steps (default: in extra steps after them)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the depth16 / strong_slice legs after the timed region")
+    ap.add_argument("--probe-after", action="store_true", help="record the HIP events around the Keccak round evaluation kernel in 16 extra steps after the timed region instead of inside it")
     ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
     ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
     ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records of the LAST batch (uint8 [N*B, 44]) to this .npy")
@@ -151,6 +152,8 @@ def main():
     state = {"last_gather": None, "validated": 0, "kchk_ms": [], "h2d_bytes": 0}
     uploaded = [False] * NC
 
+    work = {"pinned": pinned, "expect": expect}             # the input batches the loop cycles through (the extra legs swap in their own)
+
     def validate(c, b):
         """every record of the batch calculator c has just finished: host-visible, checked before the clock stops"""
         if args.dbg_no_fetch:
@@ -162,7 +165,7 @@ def main():
         assert rec.shape[0] == B
         assert not rec["status"].any(), ("a witness failed", np.nonzero(rec["status"])[0][:4], rec["status"][np.nonzero(rec["status"])[0][:4]])
         assert (rec["check_status"] == W.CLEAN).all() and (rec["bad_wire"] == W.CLEAN).all(), "the constraint evaluator flagged a witness (or did not run)"
-        assert np.array_equal(rec["commitment"], expect[b]), "commitment mismatch"
+        assert np.array_equal(rec["commitment"], work["expect"][b]), "commitment mismatch"
         state["validated"] += B
         if probing:
             state["kchk_ms"].append(calcs[c].probe_check_kernel(True, read=True))
@@ -185,7 +188,7 @@ def main():
                 state["last_gather"] = out
 
     def start(c, b):
-        pin = pinned[b]
+        pin = work["pinned"][b]
         if not (args.dbg_no_upload and uploaded[c]):
             calcs[c].upload_packed_async(pin.fr, pin.sm, pin.forced)      # H2D from pinned memory on the device's upload stream
             state["h2d_bytes"] += pin.fr.nbytes + pin.sm.nbytes
@@ -203,7 +206,7 @@ def main():
         pend = []                                         # (calculator, distinct batch) enqueued but not yet validated, oldest first
         prev = None
         for k in range(k0, k0 + nsteps):
-            c, b = (k % NC if PIPE else 0), k % NB
+            c, b = (k % NC if PIPE else 0), k % len(work["pinned"])
             if PIPE:
                 if prev is not None:
                     finish(prev[0]); pend.append(prev)
@@ -230,7 +233,7 @@ def main():
     if args.warmup:
         run(args.warmup)
     fence()
-    if args.probe_in_timed_region:
+    if not args.probe_after and not args.dbg_no_fetch:
         probing = True
         for c in calcs:
             c.probe_check_kernel(True)                    # HIP events around the dominant kernel of every evaluation from here on
@@ -244,7 +247,7 @@ def main():
     validated_timed = state["validated"]
     h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
     probe_steps = 0
-    if not args.probe_in_timed_region and not args.dbg_no_fetch:
+    if args.probe_after and not args.dbg_no_fetch:
         # the dominant kernel as it runs IN the service loop: the same loop for a few more batches with HIP events around each of its launches
         # (outside the timed region: timing events make the runtime time-stamp every dispatch of the queue)
         probing = True
@@ -316,6 +319,35 @@ def main():
         if LINK:
             calcs[0].set_partner(calcs[1])
 
+    # ---- extra legs, same calculators, same service loop, after the timed region (rank 0 of a 1-GPU run):
+    #   depth16       BASELINE config 5's shape on one GPU: batches of 16-layer proofs (byteSecurityRelax = 1, 3-zero-byte proof of work)
+    #   strong_slice  BASELINE config 4 as one GPU sees it: this GPU's slice of ONE global batch of 8192 split over 8 GPUs (witnesses 0..1023 of it)
+    def leg(batches_, steps_):
+        pins = [PinnedInputs(calcs[0], B) for _ in batches_]
+        for pin_, bt_ in zip(pins, batches_):
+            calcs[0].pack_json([json.dumps(inp).encode() for inp in bt_.inputs], out=pin_)
+        work.update(pinned=pins, expect=[np.array([list(c.to_bytes(32, "little")) for c in bt_.commitments], dtype=np.uint8) for bt_ in batches_])
+        run(4)
+        fence()
+        state.update(validated=0)
+        t1 = time.perf_counter()
+        run(steps_, k0=4)
+        fence()
+        dtl = time.perf_counter() - t1
+        assert state["validated"] == steps_ * B
+        work.update(pinned=pinned, expect=expect)
+        for pin_ in pins:
+            pin_.free()
+        return {"ms_per_step": round(dtl / steps_ * 1e3, 3), "value": round(B * steps_ / dtl, 1), "unit": "witnesses/s", "steps": steps_, "batch": B, "validated_witnesses": steps_ * B}
+    depth16 = strong_slice = None
+    if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch:
+        probing = False
+        deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=dev_index) for b in range(2)]
+        depth16 = dict(leg(deep, 20), what=f"BASELINE config 5's shape on one GPU: batch={B} of 16-layer (max-depth) MPT proofs per step, same service loop, 2 distinct batches cycled")
+        sl = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * 8 * B) for b in range(2)]
+        strong_slice = dict(leg(sl, 20), what=f"BASELINE config 4 as one GPU sees it: rank 0's slice (witnesses [0, {B})) of ONE global batch of {8 * B} split over 8 GPUs, per step; "
+                                               f"the other ranks' slices and the all-gather of the 44-byte records need the node")
+
     groups = (B + 63) // 64
     stream0 = streams[0].cuda_stream
     # ---- roofline of the dominant kernel: Keccak round constraint evaluation, HBM-read bound.
@@ -339,7 +371,7 @@ def main():
     resident = int(info.group_bytes) * groups
     traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
-        pmc_file = next(p for p in ("round3_pmc_k_rounds.json", "round2_pmc_k_rounds.json", "round1_pmc_k_rounds.json") if os.path.exists(os.path.join(ROOT, "profiles", p)))
+        pmc_file = next(p for p in ("round4_pmc_k_rounds.json",) if os.path.exists(os.path.join(ROOT, "profiles", p)))      # (rounds 1-3 measured the full-layout kernel: not this one)
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups / pmc["groups"])
@@ -351,7 +383,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
                 "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
-                "measured": (("in the timed loop" if args.probe_in_timed_region else f"in {probe_steps} more batches of the same pipelined service loop right after the timed region")
+                "measured": ((f"in {probe_steps} more batches of the same pipelined service loop right after the timed region" if args.probe_after else "in the timed region, every step")
                              + ": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel)") if in_step else "alone",
                 "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
                 "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
@@ -432,6 +464,11 @@ def main():
                                    f"region: H2D of the packed inputs from pinned memory, generate, per-gate constraint evaluation, records {{status, verdict, commitment}} D2H, "
                                    f"every record validated on the host" + (", one all-gather of the records" if world > 1 else ""),
                        "wires_per_witness": int(info.n_witness), "resident_bytes_per_witness": int(info.group_bytes // 64),
+                       "wire_classes": {"stored_bit": int(info.n_bit), "stored_sm": int(info.n_sm), "stored_fr": int(info.n_fr), "derived": int(info.n_derived),
+                                        "alias": int(info.n_alias), "constant_one": 1,
+                                        "what": "stored: resident in HBM (8 B per BIT wire, 256 B per SM wire, 2 KiB per FR wire, per 64 witnesses); derived: functions of stored wires, "
+                                                "rebuilt by the emitter; alias: Keccak round-block wires that ARE another stored wire (copy / rotated / negated / constant), expanded by the emitter"},
+                       "full_layout_round3": {"resident_bytes_per_witness": 27225718, "ms_per_step": 11.257, "witnesses_per_s": 90963, "what": "BENCH_r03.json: every wire of the Keccak round blocks stored"},
                        "canonical_bytes_per_witness": int(info.n_witness) * 32,
                        "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {B} (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
                        "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
@@ -441,6 +478,7 @@ def main():
                        "json_to_packed": {"what": "input.json texts -> packed rows in pinned memory, pob_pack_json_batch on all host cores (bit-equal to the Python loader on a sample of this batch)",
                                           "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
             "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "kernel_pipeline_only": bare, "single_witness_latency": latency,
+            "depth16": depth16, "strong_slice": strong_slice,
         }
         print(json.dumps(line))
     for c in calcs:

@@ -23,11 +23,22 @@ def init(backend: str | None = None):
     rank, local_rank, world = env_rank()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            # every launcher this job supports (torch.distributed.run, the driver's command line, tests through free_port()) sets MASTER_PORT: the ranks
+            # of one job must agree on it, so it cannot be picked here, per process
+            raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: launch through torch.distributed.run, or set MASTER_PORT (distributed.free_port()) for every rank")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or os.environ.get("POB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def free_port() -> int:
+    """a TCP port the kernel says is free right now (for a launcher that starts the ranks of ONE job itself: pick once, hand it to every rank)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def shard_bounds(total: int, rank: int, world: int):

@@ -3,6 +3,8 @@ executed on the HIP calculator instead of `circom -c` + the emitted binary.  Eve
 (tests/test.py:146-201) runs: the two circuits with a `component main` (ProofOfBurn(...), Spend(...)) and the 54
 gadget-level mains the harness wraps around one template of circuits/utils (csrc/gadget_mains.hpp).
 """
+import sys
+
 from .witness import WitnessCalculator
 
 
@@ -20,6 +22,11 @@ def run(main, test_cases):
                 good.append(i)
             except (KeyError, ValueError, TypeError):
                 pass
+            except NotImplementedError as e:
+                # a byte / length / selector signal given a value outside int32: the reference reduces it mod p and runs (tests/test.py:65-73: None
+                # or outputs).  The gadget path keeps such signals as int32 and cannot represent it: reported as None -- LOUDLY, and if the
+                # reference's list expects outputs for this case the comparison below raises
+                print(f"warning: {main} case {i}: {e}; reported as None", file=sys.stderr)
         if good:
             res = calc.calculate([test_cases[i][0] for i in good])
             for i, r in zip(good, res):

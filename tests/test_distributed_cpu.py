@@ -1,7 +1,6 @@
 """N>1 plumbing on CPU: world_size-2 gloo run of the slice-per-rank sharding and the single result all-gather
 (proof_of_burn_amd/distributed.py).  The GPU path uses the same functions with backend "nccl" (= RCCL)."""
 import os
-import socket
 import subprocess
 import sys
 import textwrap
@@ -135,14 +134,61 @@ PIPE_WORKER = textwrap.dedent("""
 """)
 
 
-def _run_two_ranks(script):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+# BASELINE config 4's split with a remainder: EIGHT ranks, ONE global batch of 8 191 Spend(31) witnesses (slices of 1 024 and 1 023), every rank a REAL
+# calculator on the CPU shim (generate + evaluate its slice), records gathered with one all-gather.  Every rank checks the gathered job: its own slice
+# is where shard_bounds says, the first and last witness of EVERY rank's slice equal a fresh two-witness calculation, the failing witnesses are exactly
+# the ones built to fail, every valid witness evaluated clean.
+WORLD8_WORKER = textwrap.dedent("""
+    import ctypes, json, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from proof_of_burn_amd import distributed as D, witness as W
+    W.LIB_PATH, W._lib = %r, None
+    rank, local_rank, world = D.init("gloo")
+    assert world == 8
+    s = next(x for x in json.load(open(os.path.join(%r, "tests", "golden", "suites.json"))) if x["name"] == "test_spend")
+    base = s["cases"][0]["input"]
+    TOTAL = 8191
+    def witness(g):
+        d = dict(base); d["extraCommitment"] = 7 * g + 1; d["withdrawnBalance"] = str(1 + g %% 1000)
+        if g %% 1021 == 5: d["withdrawnBalance"] = str(int(base["balance"]) + 1 + g)        # fails spend.circom:41
+        return d
+    def records(calc, n):
+        buf = (ctypes.c_uint8 * (D.RECORD_BYTES * n)).from_address(calc.records_device_ptr())
+        return torch.from_numpy(np.ctypeslib.as_array(buf).reshape(n, D.RECORD_BYTES).copy())
+    lo, hi = D.shard_bounds(TOTAL, rank, world)
+    assert hi - lo == (1024 if rank < 7 else 1023)
+    calc = W.WitnessCalculator("Spend(31)", max_batch=hi - lo)
+    calc.calculate([witness(g) for g in range(lo, hi)], check=True)
+    mine = records(calc, hi - lo)
+    calc.close()
+    got = D.gather_records(mine, total=TOTAL)
+    assert got.shape == (TOTAL, D.RECORD_BYTES) and torch.equal(got[lo:hi], mine)
+    st, _ = D.unpack_records(got)
+    cs, bw = D.unpack_verdicts(got)
+    fails = [g %% 1021 == 5 for g in range(TOTAL)]
+    assert (st != 0).tolist() == fails and sum(fails) == 9
+    ok = torch.tensor([not f for f in fails])
+    assert bool(((cs == D.CLEAN) & (bw == D.CLEAN))[ok].all())
+    edge = W.WitnessCalculator("Spend(31)", max_batch=2)
+    for r in range(world):
+        a, b = D.shard_bounds(TOTAL, r, world)
+        edge.calculate([witness(a), witness(b - 1)], check=True)
+        e = records(edge, 2)
+        assert torch.equal(got[a], e[0]) and torch.equal(got[b - 1], e[1]), r
+    edge.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def _run_two_ranks(script, world=2, timeout=170):
+    port = D.free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=170)[0] for p in procs]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
@@ -171,3 +217,21 @@ def test_two_ranks_pipeline_two_calculators_each(tmp_path):
     script = tmp_path / "pipe_worker.py"
     script.write_text(PIPE_WORKER % (ROOT, lib, ROOT))
     _run_two_ranks(script)
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_uneven_global_batch(tmp_path):
+    from tests.hostsim import build as hb
+    lib = hb.build()
+    script = tmp_path / "world8_worker.py"
+    script.write_text(WORLD8_WORKER % (ROOT, lib, ROOT))
+    _run_two_ranks(script, world=8, timeout=560)
+
+
+def test_init_refuses_a_job_without_a_port(monkeypatch):
+    """the ranks of one job must agree on the rendezvous port: it comes from the launcher (torch.distributed.run / MASTER_PORT), never from a default"""
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        D.init("gloo")
+    a, b = D.free_port(), D.free_port()
+    assert 1024 < a < 65536 and 1024 < b < 65536

@@ -365,16 +365,14 @@ def test_max_depth_and_ragged_batches(pkg):
 
 
 def _run_bench(args, env_extra=None, nproc=1, timeout=900):
-    import socket
     import subprocess
     import sys
+    from proof_of_burn_amd import distributed as D
     env = dict(os.environ, **(env_extra or {}))
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        port = D.free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -604,11 +602,13 @@ def test_rccl_world_of_one_gathers_the_device_records(pkg, tmp_path):
     all_gather_into_tensor on a side stream: RCCL loads, accepts the view and returns the records"""
     import subprocess
     import sys
+    from proof_of_burn_amd import distributed as Dd
+    D_free_port = Dd.free_port()
     script = tmp_path / "rccl1.py"
     script.write_text(f"""
 import json, os, sys
 sys.path.insert(0, {ROOT!r})
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", GPU_MAX_HW_QUEUES="16")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str({D_free_port}), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", GPU_MAX_HW_QUEUES="16")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch, torch.distributed as dist
 from proof_of_burn_amd import WitnessCalculator, distributed as D, witness as W
