@@ -167,6 +167,19 @@ int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint
  * still being copied, and the pob_emit_begin* / pob_write_wtns* call for it continues from there (three window slots per handle).  Without
  * it every witness pays its first expansion un-overlapped (6 of 134 ms for the production circuit).  POB_E_STATE: next_idx failed an assert. */
 int pob_emit_queue(pob_handle h, uint32_t next_idx);
+/* Emit-time self-check of what is written (the reference checks every `===` on the values it writes: inline asserts of the emitted calculator, e.g.
+ * circomlib comparators.circom IsZero, utils/substring_check.circom:45-49).  The constraint evaluator reads STORED wires; the derived wires (n_derived)
+ * exist only in the emitter's output, so their own relations are evaluated THERE, on the canonical values as written into each emission window by a
+ * kernel that re-reads the window before it is copied to the host:
+ *     every IsZero [out | in | inv]:                 in * inv === 1 - out,   in * out === 0
+ *     every IsEqual [out | in[2]] over an IsZero:    IsZero.in === in[1] - in[0],   out === IsZero.out
+ *     SubstringCheck's M[]:                          M[i+1] === M[i] + mainInput[i] * 256^i
+ * enable = 1: every following O0 emission (pob_emit_begin / pob_emit_witness / pob_write_wtns; not the reduced form) is checked; the first one also
+ * runs a recording pass that finds the sites.  pob_emit_selfcheck_result, called when the emission is complete: relations checked, relations skipped
+ * because their wires straddle two windows, and the lowest wire whose relation does not hold (0xFFFFFFFF = none).  A witness emitted from a
+ * corrupted resident vector (pob_debug_poke of an operand) violates the relations of the derived wires that consume the operand.             */
+int pob_emit_selfcheck(pob_handle h, int enable);
+int pob_emit_selfcheck_result(pob_handle h, uint64_t* checked, uint64_t* skipped, uint32_t* first_bad_wire);
 /* Measurement: `count` witnesses from `first_idx` on, back to back through the window pipeline into pinned host memory.          */
 int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes);
 /* The same with an optional reduced map (keep != NULL: pob_emit_begin_reduced).  The first witness a handle emits at a window size
@@ -201,7 +214,7 @@ int pob_debug_emit_counters(pob_handle h, uint64_t out[4], int reset);
 int pob_debug_fr_inv(int device, const uint8_t* in, uint32_t n, uint8_t* out_kaliski, uint8_t* out_fermat);
 /* Test hook: storage class, rank within the class and wire index of a few named wires: "commitment"; "poseidon" (k-th wire of the
  * first Poseidon block); "pad.div.out" / "pad.div.rem" of KeccakBytes instance k (the Divide hint of divide.circom:23-24); ProofOfBurn only: "sc.exists" [k] of layer 1's SubstringCheck. */
-int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire);
+int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t* index, uint64_t* wire);      /* also "kb.inLen": inLen of KeccakBytes instance k */
 
 /* Host helper used by the input producers (next row f1): Keccak-256 of a byte string.                           */
 void pob_keccak256(const uint8_t* msg, uint64_t len, uint8_t out[32]);

@@ -204,7 +204,7 @@ template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
 template <class P> HD void iseq_derived(P& p, Cur c, S a, S b) {
     p.derived(c.w + 1, a); p.derived(c.w + 2, b);
     const S x = (S)((uint32_t)b - (uint32_t)a);
-    p.derived(c.w + 4, x); p.derived_inv(c.w + 5, x);
+    p.derived(c.w + 4, x); p.derived_inv(c.w + 5, x, true);
 }
 template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t lo, uint32_t hi) {
     const uint32_t m = 136 * r.mb, cnt = hi - lo, ln = p.lane_id();     // cnt <= 16 bytes
@@ -856,6 +856,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             Fr b1 = {{(uint32_t)p.get(src + k), 0, 0, 0, 0, 0, 0, 0}};
             acc = fr_add(fr_mul(b1, p.k256r(k)), acc);
             p.derived_fr(sc.M_w + k + 1, acc);
+            p.site_m(sc.M_w + k + 1, sc.mi_w + k, k);
         }
     } break;
     UCASE(U_SC_RANGE) {           // positions [a1, a2) of the existence loop (:83-95): IsEqual(isLastIndex), IsEqual(exists) per position
@@ -899,7 +900,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         }
         if constexpr (P::is_emit) {      // the cnt inverses of the emitted witness: one per lane, ONE inversion time per unit (a lane at a time they were 10 ms per unit)
             const F inv = fr_is_zero(ddL) ? fr_zero() : fr_inv(ddL);
-            if (ln < cnt) p.w32(cur_add(cur_add(sc.c_loop, FP_ISEQ_S, lo + ln), FP_ISEQ_F, lo + ln).w + 11, fr_from_mont(inv));
+            if (ln < cnt) p.w32(cur_add(cur_add(sc.c_loop, FP_ISEQ_S, lo + ln), FP_ISEQ_F, lo + ln).w + 11, fr_from_mont(inv), (fr_is_zero(ddL) ? 3 : 2) | 4);      // (counted: pob_debug_emit_counters)
         }
         p.run_put(cnt, sc.isl.w + lo + ln, sc.isl.i + lo + ln, runIsl);
         p.run_put(cnt, sc.alw.w + lo + 1 + ln, sc.alw.i + lo + 1 + ln, runAlw);

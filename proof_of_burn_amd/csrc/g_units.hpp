@@ -27,7 +27,7 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
     p.decl_order = A.L->decl_order;
     if constexpr (P::is_gen) p.status = 0;
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false; }
-    if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.ctr = A.emit_counters; p.unit = A.order[A.first + blockIdx.x]; }
+    if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.ctr = A.emit_counters; p.sites = A.emit_sites; p.sites_cap = A.emit_sites_cap; p.unit = A.order[A.first + blockIdx.x]; }
     for (int pass = 0;; pass++) {
         const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
         if constexpr ((MASK & ~FAM_LIGHT) == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)

@@ -91,9 +91,9 @@ template <class P> HD S gBits2Num8(P& p, BitRef src) {
 // ============================================================================ circomlib: comparators.circom
 // IsZero  [out | in | inv];  inv <-- in!=0 ? 1/in : 0;  out <== -in*inv+1;  in*out === 0
 // Small operands: `in` and `inv` are DERIVED wires (policy.hpp) -- the emitter rebuilds them from the caller's operand; out = [in == 0].
-template <class P> HD B gIsZeroS(P& p, S in) {
+template <class P> HD B gIsZeroS(P& p, S in, bool iseq = false) {        // iseq: the child of an IsEqual (the emitter's self-check also evaluates in === in[1] - in[0], out === IsZero.out)
     BitRef o = p.bits(1); const uint32_t w = p.dvs(2);
-    p.derived(w, in); p.derived_inv(w + 1, in);
+    p.derived(w, in); p.derived_inv(w + 1, in, iseq);
     return p.put(o, p.ballot(in == 0));
 }
 template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) {
@@ -114,7 +114,7 @@ template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) 
 template <class P> HD B gIsEqualS(P& p, S a, S b) {
     BitRef o = p.bits(1); const uint32_t w = p.dvs(2);
     p.derived(w, a); p.derived(w + 1, b);
-    return p.put(o, gIsZeroS(p, (S)((uint32_t)b - (uint32_t)a)));
+    return p.put(o, gIsZeroS(p, (S)((uint32_t)b - (uint32_t)a), true));
 }
 // IsEqual over field elements with DERIVED operand wires (policy.hpp): [out | in[2]] || IsZero [out | in | inv]; out = [a == b], the four
 // field-element wires are rebuilt by the emitter (the inverse with one exponentiation per emitted wire -- emission is for sampled witnesses)
@@ -588,7 +588,7 @@ HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 1, 0, 6 * N + 2}; return 
 template <class P> HD void iseq_derived_w(P& p, uint32_t w, S a, S b) {
     p.derived(w + 1, a); p.derived(w + 2, b);
     const S x = (S)((uint32_t)b - (uint32_t)a);
-    p.derived(w + 4, x); p.derived_inv(w + 5, x);
+    p.derived(w + 4, x); p.derived_inv(w + 5, x, true);
 }
 // entries [lo, hi) of the Selector block sb over src[i * stride]: the bits as lane-distributed runs (32 entries: isEq[], and the children's two
 // outputs each as one run of 64), the derived wires for the emitter.  out = the selected value (src[select]).

@@ -20,6 +20,7 @@ struct GArgs {
     uint32_t emit_w0, emit_wn;                         // emission window: wires [emit_w0, emit_w0 + emit_wn) land at emit_out + 32 * (w - emit_w0)
     unsigned long long* emit_probe;                    // probe pass: nothing is written, bit (w / emit_wn) of emit_probe[unit] is set instead
     const unsigned long long* emit_rbits; const uint32_t* emit_rpre;   // reduced witness: kept-wire bitmap + per-word rank (policy.hpp EmitP); null = O0 payload
+    uint32_t* emit_sites; uint32_t emit_sites_cap;     // self-check site-recording pass (policy.hpp EmitP::sites)
     uint32_t* emit_counters;                           // which of the emitter's inverse paths ran (policy.hpp EmitP::ctr, pob_debug_emit_counters)
 };
 struct KArgs {

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <time.h>
 #include <algorithm>
+#include <array>
 #include <functional>
 #include <string>
 #include <mutex>
@@ -83,6 +84,36 @@ __global__ void k_fr_inv_test(const uint32_t* in, uint32_t* out_kaliski, uint32_
     const Fr x = fr_to_mont(c);
     const Fr a = fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv(x)), b = fr_is_zero(x) ? fr_zero() : fr_from_mont(fr_inv_fermat(x));
     for (int j = 0; j < 8; j++) { out_kaliski[t * 8 + j] = a.l[j]; out_fermat[t * 8 + j] = b.l[j]; }
+}
+// ---- emit-time self-check (pob_emit_selfcheck): the relations of the DERIVED wires, evaluated on the canonical values as written into the emission window
+// (reference: circomlib comparators.circom IsZero `out <== -in*inv + 1; in*out === 0`, IsEqual `in[1] - in[0] ==> isz.in; isz.out ==> out`;
+//  substring_check.circom:45-49 `M[i+1] <== M[i] + mainInput[i] * 256^i`).  One thread per site; sites whose wires are not all inside the window are counted as
+// skipped by the host (IsZero / IsEqual) or here (M).  res[0] = lowest violated wire, res[1] = M sites skipped.
+__device__ __forceinline__ Fr sc_load(const uint8_t* win, uint32_t w0, uint32_t w) {
+    const uint32_t* q = (const uint32_t*)(win + (size_t)(w - w0) * 32);
+    Fr c; for (int j = 0; j < 8; j++) c.l[j] = q[j];
+    return fr_to_mont(c);
+}
+__global__ void __launch_bounds__(64) k_selfcheck_z(const uint8_t* win, uint32_t w0, const uint32_t* sites, uint32_t n, uint32_t* res) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t s = sites[t], w = s & 0x7FFFFFFFu;                  // IsZero [out | in | inv] at w
+    const Fr out = sc_load(win, w0, w), in = sc_load(win, w0, w + 1), inv = sc_load(win, w0, w + 2);
+    bool ok = fr_eq(fr_mul(in, inv), fr_sub(fr_one_mont(), out)) && fr_is_zero(fr_mul(in, out));
+    if (s >> 31) {                                                       // IsEqual [out | in[2]] at w - 3
+        const Fr eo = sc_load(win, w0, w - 3), a = sc_load(win, w0, w - 2), b = sc_load(win, w0, w - 1);
+        ok = ok && fr_eq(in, fr_sub(b, a)) && fr_eq(eo, out);
+    }
+    if (!ok) atomicMin(res, w);
+}
+__global__ void __launch_bounds__(64) k_selfcheck_m(const uint8_t* win, uint32_t w0, uint32_t wn, const uint32_t* sites, uint32_t n, const uint32_t* pow256, uint32_t* res) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t wn1 = sites[3 * t], wb = sites[3 * t + 1], k = sites[3 * t + 2];
+    if (wn1 - 1 - w0 >= wn || wn1 - w0 >= wn || wb - w0 >= wn) { atomicAdd(res + 1, 1u); return; }
+    Fr pw; for (int j = 0; j < 8; j++) pw.l[j] = pow256[(size_t)k * 8 + j];                      // 256^k, Montgomery
+    const Fr next = sc_load(win, w0, wn1), prev = sc_load(win, w0, wn1 - 1), by = sc_load(win, w0, wb);
+    if (!fr_eq(next, fr_add(prev, fr_mul(by, pw)))) atomicMin(res, wn1);
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
@@ -179,6 +210,9 @@ struct pob_ctx {
         std::vector<std::vector<WSeg>> wsegs;
         // reduced witness (pob_emit_begin_reduced): the kept O0 wire indices (host copy for the run intersections), their bitmap and the
         // per-word rank on the device; map_id = 0: O0 payload.  total = wires of the payload being emitted (W or the kept count)
+        // self-check (pob_emit_selfcheck): site tables (sorted by wire), built once per handle by a recording pass of the emitter; d_sc_res: {lowest violated wire, M sites skipped}
+        bool sc_on = false, sc_built = false; std::vector<uint32_t> sc_z, sc_m_next; uint32_t *d_sc_z = nullptr, *d_sc_m = nullptr, *d_sc_res = nullptr;
+        uint64_t sc_checked = 0, sc_skipped = 0;
         bool red = false; uint64_t map_id = 0, total = 0; std::vector<uint32_t> keep; unsigned long long* d_rbits = nullptr; uint32_t* d_rpre = nullptr;
     } em;
     // schedule
@@ -553,7 +587,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre};
+                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_res};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -897,6 +931,20 @@ static int emit_make_window(pob_ctx* h, uint32_t idx, uint64_t k, int slot) {
             else launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
         }
     }
+    if (E.sc_on && !E.red) {        // the derived wires' relations on the values just written into this window
+        const auto za = std::lower_bound(E.sc_z.begin(), E.sc_z.end(), (uint32_t)(w0 + 3), [](uint32_t s, uint32_t v) { return (s & 0x7FFFFFFFu) < v; });
+        const auto zb = std::lower_bound(za, E.sc_z.end(), (uint32_t)std::max<uint64_t>(w0 + wn, 2) - 2, [](uint32_t s, uint32_t v) { return (s & 0x7FFFFFFFu) < v; });
+        const uint32_t nz = (uint32_t)(zb - za);
+        const uint32_t* zs = E.d_sc_z + (za - E.sc_z.begin()); uint8_t* wbuf = E.d_win[slot]; uint32_t* res = E.d_sc_res;
+        if (nz) hipLaunchKernelGGL(k_selfcheck_z, dim3((nz + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, zs, nz, res);
+        E.sc_checked += nz;
+        // M sites whose M[k+1] lies in this window (the kernel skips and counts the ones whose other wires do not)
+        const auto ma = std::lower_bound(E.sc_m_next.begin(), E.sc_m_next.end(), (uint32_t)w0), mb = std::lower_bound(ma, E.sc_m_next.end(), (uint32_t)(w0 + wn));
+        const uint32_t nm = (uint32_t)(mb - ma);
+        const uint32_t* msites = E.d_sc_m + 3 * (ma - E.sc_m_next.begin()); const uint32_t* pw = h->d_pow256;
+        if (nm) hipLaunchKernelGGL(k_selfcheck_m, dim3((nm + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, (uint32_t)wn, msites, nm, pw, res);
+        E.sc_checked += nm;
+    }
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(E.ev_made[slot], st));
     HIPC(hipStreamWaitEvent(E.s_copy, E.ev_made[slot], 0));
@@ -1002,6 +1050,40 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         if (!order.empty()) HIPC(hipMemcpy(E.d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
         E.probe_win = window_wires; E.probe_map = E.map_id;
     } else if (nwin_ > 64) { E.probe_win = 0; E.probe_map = E.map_id; }       // (too many windows for the probe's 64-bit masks: every unit runs for every window)
+    if (E.sc_on && !E.red && !E.sc_built) {
+        // site-recording pass: every emitting unit once with EmitP::sites set (nothing is written); the sites are layout constants of the handle
+        const uint32_t cap = std::max(h->plan.total.q, 1u);
+        uint32_t* d_rec = nullptr;
+        const size_t words = 2 + (size_t)cap + 3 * (size_t)cap;
+        HIPC(hipMalloc(&d_rec, words * 4));
+        HIPC(hipMemsetAsync(d_rec, 0, 8, own_stream(h)));
+        GArgs A = gargs(h);
+        A.emit_sel = idx % 64; A.emit_group = idx / 64; A.emit_w0 = 0; A.emit_wn = (uint32_t)E.total; A.emit_out = nullptr; A.emit_sites = d_rec; A.emit_sites_cap = cap;
+        for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, own_stream(h)); }
+        HIPC(hipGetLastError());
+        std::vector<uint32_t> rec(words);
+        HIPC(hipMemcpyAsync(rec.data(), d_rec, words * 4, hipMemcpyDeviceToHost, own_stream(h)));
+        HIPC(hipStreamSynchronize(own_stream(h)));
+        HIPC(hipFree(d_rec));
+        if (rec[0] > cap || rec[1] > cap) { h->err = "internal: more self-check sites than derived wires"; return POB_E_STATE; }
+        E.sc_z.assign(rec.begin() + 2, rec.begin() + 2 + rec[0]);
+        std::sort(E.sc_z.begin(), E.sc_z.end(), [](uint32_t a, uint32_t b) { return (a & 0x7FFFFFFFu) < (b & 0x7FFFFFFFu); });
+        std::vector<std::array<uint32_t, 3>> ms(rec[1]);
+        for (uint32_t i = 0; i < rec[1]; i++) for (int j = 0; j < 3; j++) ms[i][j] = rec[2 + (size_t)cap + 3 * (size_t)i + j];
+        std::sort(ms.begin(), ms.end());
+        E.sc_m_next.resize(ms.size());
+        for (size_t i = 0; i < ms.size(); i++) E.sc_m_next[i] = ms[i][0];
+        HIPC(hipMalloc(&E.d_sc_z, std::max<size_t>(E.sc_z.size(), 1) * 4)); HIPC(hipMalloc(&E.d_sc_m, std::max<size_t>(ms.size(), 1) * 12)); HIPC(hipMalloc(&E.d_sc_res, 8));
+        if (!E.sc_z.empty()) HIPC(hipMemcpy(E.d_sc_z, E.sc_z.data(), E.sc_z.size() * 4, hipMemcpyHostToDevice));
+        if (!ms.empty()) HIPC(hipMemcpy(E.d_sc_m, ms.data(), ms.size() * 12, hipMemcpyHostToDevice));
+        E.sc_built = true;
+    }
+    if (E.sc_on && !E.red) {
+        const uint32_t init[2] = {0xFFFFFFFFu, 0};
+        HIPC(hipMemcpyAsync(E.d_sc_res, init, 8, hipMemcpyHostToDevice, own_stream(h)));
+        HIPC(hipStreamSynchronize(own_stream(h)));
+        E.sc_checked = 0; E.sc_skipped = 0;
+    }
     for (int k = 0; k < NS; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
     E.win_wires = window_wires; E.nwin = nwin_; E.idx = idx; E.next_make = 0; E.next_take = 0; E.first_slot = 0; E.active = true;
     for (; E.next_make < std::min<uint64_t>(1, E.nwin); E.next_make++) { int rc = emit_make_window(h, idx, E.next_make, (int)((E.first_slot + E.next_make) % NS)); if (rc) return rc; }
@@ -1082,6 +1164,28 @@ int pob_emit_next(pob_handle h, const uint8_t** data, uint64_t* first_wire, uint
     const int slot = (int)((E.first_slot + k) % NS);
     HIPC(hipEventSynchronize(E.ev_copied[slot]));
     *data = E.h_pin[slot]; *first_wire = k * E.win_wires; *n_wires = std::min(E.win_wires, E.total - k * E.win_wires);
+    return POB_OK;
+}
+
+int pob_emit_selfcheck(pob_handle h, int enable) {
+    if (!h) return POB_E_ARG;
+    h->em.sc_on = enable != 0;
+    h->em.queued_idx = -1; h->em.pre_made = false;       // (a window pre-made without the check is not part of a checked emission)
+    return POB_OK;
+}
+
+int pob_emit_selfcheck_result(pob_handle h, uint64_t* checked, uint64_t* skipped, uint32_t* first_bad_wire) {
+    if (!h) return POB_E_ARG;
+    pob_ctx::Emit& E = h->em;
+    if (!E.sc_on || !E.sc_built) { h->err = "no self-checked emission yet (pob_emit_selfcheck, then an O0 emission)"; return POB_E_STATE; }
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipStreamSynchronize(own_stream(h)));
+    uint32_t res[2];
+    HIPC(hipMemcpy(res, E.d_sc_res, 8, hipMemcpyDeviceToHost));
+    const uint64_t all = E.sc_z.size() + E.sc_m_next.size();
+    if (checked) *checked = E.sc_checked - res[1];
+    if (skipped) *skipped = all - (E.sc_checked - res[1]);
+    if (first_bad_wire) *first_bad_wire = res[0];
     return POB_OK;
 }
 
@@ -1305,6 +1409,7 @@ int pob_debug_ref(pob_handle h, const char* name, uint32_t k, int* cls, uint64_t
         return POB_E_ARG;
     }
     if (n == "commitment") { const FrRef r = h->circuit == POB_CIRCUIT_PROOF_OF_BURN ? L.pm.commitment : L.sm.commitment; return set(POB_CLASS_FR, r.i, r.w); }
+    if (n == "kb.inLen") { if (k >= L.nkb) return POB_E_ARG; return set(POB_CLASS_SM, L.kbs[k].inLen.i, L.kbs[k].inLen.w); }
     if (n == "pad.div.out" || n == "pad.div.rem") {       // of KeccakBytes instance k
         if (k >= L.nkb) return POB_E_ARG;
         const KBRefs& r = L.kbs[k];

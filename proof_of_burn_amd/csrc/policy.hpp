@@ -104,9 +104,10 @@ struct CountP : PolBase {
     HD S get(SmRef) { return 0; }
     HD S get_lane(SmRef, uint32_t) { return 0; }
     HD void derived(uint32_t, S) {}               // a DERIVED wire (see the header): value v / the inverse of x; only the emitter does anything
-    HD void derived_inv(uint32_t, S) {}
+    HD void derived_inv(uint32_t, S, bool = false) {}       // (true: the IsZero is the child of an IsEqual [out | in[2]] -- the emitter's self-check, EmitP::w32)
     HD void derived_fr(uint32_t, const F&) {}     // ... with a field-element value (Montgomery) / the field inverse of x (0 for 0)
     HD void derived_fr_inv(uint32_t, const F&) {}
+    HD void site_m(uint32_t, uint32_t, uint32_t) {}         // self-check site of SubstringCheck's M[] recurrence (EmitP)
     HD F get(FrRef) { return fr_zero(); }
     HD void raw_put(FrRef, const F&) {}
     HD B ballot(bool) { return 0; }
@@ -240,7 +241,7 @@ template <class P, int N> HD __attribute__((always_inline)) void fr_commit(P& p,
 // n DERIVED wires w0 + t*dw, t < n, that all carry the value v (inv: the field inverse of v, 0 for 0): nothing but the emitter touches them
 template <class P> HD __attribute__((always_inline)) void derived_rows_same(P& p, uint32_t w0, uint32_t dw, uint32_t n, S v, bool inv = false) {
     if constexpr (P::is_emit) {
-        for (uint32_t t = 0; t < n; t++) { if (inv) p.derived_inv(w0 + t * dw, v); else p.derived(w0 + t * dw, v); }
+        for (uint32_t t = 0; t < n; t++) { if (inv) p.derived_inv(w0 + t * dw, v, true); else p.derived(w0 + t * dw, v); }      // (inv: the IsZero.inv wires of IsEqual children)
     } else { (void)p; (void)w0; (void)dw; (void)n; (void)v; (void)inv; }
 }
 #ifdef __HIPCC__
@@ -280,7 +281,8 @@ struct DevPol : PolBase {
     __device__ __forceinline__ B ld(BitRef r) { return m.bits[r.i]; }
     __device__ __forceinline__ S ld(SmRef r) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs_sm, (int)m.lane4, (int)(POB_UNI(r.i) << 8), 0); }
     __device__ __forceinline__ void derived(uint32_t, S) {}
-    __device__ __forceinline__ void derived_inv(uint32_t, S) {}
+    __device__ __forceinline__ void derived_inv(uint32_t, S, bool = false) {}
+    __device__ __forceinline__ void site_m(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void derived_fr(uint32_t, const F&) {}
     __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&) {}
     __device__ __forceinline__ F ld(FrRef r) {
@@ -429,7 +431,17 @@ struct EmitP : DevPol {
     // test hook (pob_debug_emit_counters): [0] IsZero.inv from the table of small inverses, [1] by Fermat exponentiation (|operand| > 4096),
     // [2] field-element IsZero.inv of a NON-zero operand (Kaliski inversion), [3] of a zero operand -- counted per emitted wire, probe passes excluded
     uint32_t* ctr;
+    // SELF-CHECK (pob_emit_selfcheck): the relations of the derived wires are evaluated on the values WRITTEN INTO THE WINDOW by a kernel that
+    // re-reads them (pob_host.hip k_selfcheck_*).  Where those relations live is found once per handle by a site-recording pass: `sites` non-null
+    // = nothing is written, every IsZero.inv wire (the calls of w32 that carry a path) appends its gadget's first wire -- IsZero [out | in | inv],
+    // bit 31: child of an IsEqual [out | in[2]] -- to sites[2 ..], every step of SubstringCheck's M[] recurrence a triple behind them.
+    // path: 0..3 = the inverse path counted, | 4 = IsEqual parent.
+    uint32_t* sites; uint32_t sites_cap;
+    __device__ __forceinline__ void site_m(uint32_t w_next, uint32_t w_byte, uint32_t k) {      // M[k+1] (wire w_next) === M[k] (w_next - 1) + mainInput[k] (w_byte) * 256^k
+        if (sites && m.lane == sel) { const uint32_t i = atomicAdd(sites + 1, 1u); if (i < sites_cap) { uint32_t* q = sites + 2 + sites_cap + 3 * (size_t)i; q[0] = w_next; q[1] = w_byte; q[2] = k; } }
+    }
     __device__ __forceinline__ void w32(uint32_t w, const F& canon, int path = -1) {
+        if (sites) { if (path >= 0) { const uint32_t i = atomicAdd(sites, 1u); if (i < sites_cap) sites[2 + i] = (w - 2) | ((path & 4) ? 0x80000000u : 0u); } return; }
         if (rbits) {
             const unsigned long long word = rbits[w >> 6];
             if (!((word >> (w & 63)) & 1)) return;
@@ -437,7 +449,7 @@ struct EmitP : DevPol {
         }
         if (probe) { atomicOr(probe + unit, 1ull << (w / wn)); return; }
         if (w - w0 >= wn) return;
-        if (path >= 0) atomicAdd(ctr + path, 1u);
+        if (path >= 0) atomicAdd(ctr + (path & 3), 1u);
         uint4* q = (uint4*)(out + (size_t)(w - w0) * 32);
         q[0] = make_uint4(canon.l[0], canon.l[1], canon.l[2], canon.l[3]);
         q[1] = make_uint4(canon.l[4], canon.l[5], canon.l[6], canon.l[7]);
@@ -457,9 +469,9 @@ struct EmitP : DevPol {
     __device__ __forceinline__ S hint(SmRef r, S v) { return put(r, v); }
     __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
     __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
-    __device__ __forceinline__ void derived_inv(uint32_t w, S x) { emit_inv(w, x); }
+    __device__ __forceinline__ void derived_inv(uint32_t w, S x, bool iseq = false) { emit_inv(w, x, iseq); }
     __device__ __forceinline__ void derived_fr(uint32_t w, const F& v) { if (m.lane == sel) w32(w, fr_from_mont(v)); }
-    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) { const bool z = fr_is_zero(x); w32(w, z ? fr_zero() : fr_from_mont(fr_inv(x)), z ? 3 : 2); } }
+    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) { const bool z = fr_is_zero(x); w32(w, z ? fr_zero() : fr_from_mont(fr_inv(x)), (z ? 3 : 2) | 4); } }       // (always an IsEqual's child: gadgets.hpp iseqf_derived)
     // the selected witness' value in every lane (a unit that has many inverses to rebuild spreads them over the lanes: circuits.hpp U_SC_RANGE)
     __device__ __forceinline__ F bcast_sel(const F& v) {
         F r;
@@ -467,7 +479,7 @@ struct EmitP : DevPol {
         for (int k = 0; k < 8; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], (int)sel);
         return r;
     }
-    __device__ __forceinline__ void emit_inv(uint32_t w, S k) {
+    __device__ __forceinline__ void emit_inv(uint32_t w, S k, bool iseq = false) {
         if (m.lane == sel) {
             F c;
             if (k >= -4096 && k <= 4096) {
@@ -477,7 +489,7 @@ struct EmitP : DevPol {
             } else {
                 c = fr_from_mont(fr_inv_fermat(fr_from_i64(k)));
             }
-            w32(w, c, (k >= -4096 && k <= 4096) ? 0 : 1);
+            w32(w, c, ((k >= -4096 && k <= 4096) ? 0 : 1) | (iseq ? 4 : 0));
         }
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}

@@ -176,6 +176,8 @@ def load_library() -> ctypes.CDLL:
     lib.pob_debug_xor_bits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
     lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.pob_debug_emit_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    lib.pob_emit_selfcheck.argtypes = [vp, ctypes.c_int]
+    lib.pob_emit_selfcheck_result.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     lib.pob_debug_fr_inv.argtypes = [ctypes.c_int, vp, ctypes.c_uint32, vp, vp]
     lib.pob_debug_ref.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.pob_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
@@ -191,7 +193,7 @@ def load_library() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_result", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -609,6 +611,16 @@ class WitnessCalculator:
                 return
             buf = (ctypes.c_uint8 * (32 * wn.value)).from_address(p.value)
             yield w0.value, np.frombuffer(buf, dtype=np.uint8)
+
+    def emit_selfcheck(self, enable: bool = True):
+        """every following O0 emission evaluates the derived wires' own relations on the values written into its windows (pob_emit_selfcheck)"""
+        self._ck(self.lib.pob_emit_selfcheck(self.h, 1 if enable else 0))
+
+    def emit_selfcheck_result(self) -> dict:
+        """of the last complete self-checked emission: relations checked / skipped (wires in two windows) and the lowest violated wire (None = none)"""
+        c, s, w = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32()
+        self._ck(self.lib.pob_emit_selfcheck_result(self.h, ctypes.byref(c), ctypes.byref(s), ctypes.byref(w)))
+        return {"checked": int(c.value), "skipped": int(s.value), "first_bad_wire": None if w.value == 0xFFFFFFFF else int(w.value)}
 
     def emit_queue(self, next_idx: int):
         """announce the witness emitted after the current / next one (pob_emit_queue): its first window is expanded behind the current one's last"""

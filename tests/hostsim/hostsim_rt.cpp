@@ -5,6 +5,18 @@
 #include <execinfo.h>
 #include <dlfcn.h>
 
+// AddressSanitizer build (tests/hostsim/build.py san=True): the fiber switches are announced to the runtime, which otherwise takes a fiber's
+// stack for a wild pointer into the launcher's
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HS_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+#ifndef HS_ASAN
+#define HS_ASAN 0
+#endif
+
 hs_idx blockIdx, blockDim, gridDim;
 hs_tid threadIdx;
 uint32_t g_lds[1 << 16];                  // `extern __shared__ uint32_t g_lds[]` of g_units.hpp
@@ -12,7 +24,8 @@ uint32_t g_lds[1 << 16];                  // `extern __shared__ uint32_t g_lds[]
 namespace {
 const int MAXT = 256;
 const size_t STACK = 4u << 20;
-struct Fiber { void* sp; char* stack; bool alive; };
+struct Fiber { void* sp; char* stack; bool alive; void* fake; };
+const void* main_bottom; size_t main_size; void* main_fake;      // (ASan: the launcher's stack, learnt at the first switch away from it)
 Fiber fib[MAXT];
 void* main_sp;
 int nthreads, cur, alive;
@@ -49,11 +62,28 @@ void yield_next() {            // round-robin to the next living fiber, or back 
     const int me = cur;
     for (int k = 1; k <= nthreads; k++) {
         const int t = (me + k) % nthreads;
-        if (fib[t].alive) { if (t == me) return; cur = t; hs_switch(&fib[me].sp, fib[t].sp); return; }
+        if (fib[t].alive) {
+            if (t == me) return;
+            cur = t;
+#if HS_ASAN
+            __sanitizer_start_switch_fiber(fib[me].alive ? &fib[me].fake : nullptr, fib[t].stack, STACK);
+#endif
+            hs_switch(&fib[me].sp, fib[t].sp);
+#if HS_ASAN
+            __sanitizer_finish_switch_fiber(fib[me].fake, nullptr, nullptr);
+#endif
+            return;
+        }
     }
+#if HS_ASAN
+    __sanitizer_start_switch_fiber(nullptr, main_bottom, main_size);      // the last fiber of the block ends: back to the launcher
+#endif
     hs_switch(&fib[me].sp, main_sp);
 }
 extern "C" void hs_entry() {
+#if HS_ASAN
+    { const void* b; size_t n; __sanitizer_finish_switch_fiber(nullptr, &b, &n); if (!main_bottom) { main_bottom = b; main_size = n; } }
+#endif
     (*body)();
     fib[cur].alive = false; alive--;
     yield_next();
@@ -123,6 +153,12 @@ void hs_launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
         tag[0] = tag[1] = ~0ull;
         for (int t = 0; t < nthreads; t++) make_fiber(t);
         cur = 0;
+#if HS_ASAN
+        __sanitizer_start_switch_fiber(&main_fake, fib[0].stack, STACK);
+#endif
         hs_switch(&main_sp, fib[0].sp);
+#if HS_ASAN
+        __sanitizer_finish_switch_fiber(main_fake, nullptr, nullptr);
+#endif
     }
 }

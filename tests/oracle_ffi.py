@@ -102,8 +102,14 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("pob_oracle.c", "fr.h", "poseidon_consts.h")]
+    if os.environ.get("ORACLE_SAN") == "1":      # AddressSanitizer + UBSan build of the oracle (tools/run_sanitizers.py: clang's runtime is preloaded)
+        so = os.path.join(ORACLE_DIR, "liboracle_san.so")
+        if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang", "-O1", "-g", "-fPIC", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                                   "-fno-omit-frame-pointer", "-shared-libasan", "-shared", "-o", so, os.path.join(ORACLE_DIR, "pob_oracle.c")])
+        return so
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so

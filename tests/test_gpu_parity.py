@@ -486,7 +486,7 @@ def test_production_batch_payloads_beyond_group_0(pkg):
         assert np.array_equal(red.reshape(-1, 32), ref.reshape(-1, 32)[keep]), f"witness {idx}: reduced payload differs from the oracle's kept wires"
         del red, ref, ora
     c = calc.emit_counters()
-    assert c["table"] > 0 and c["field_nonzero"] >= 3 * 7000 and c["field_zero"] > 0, c
+    assert c["table"] > 0 and c["field_nonzero"] >= 3 * 7000 and c["field_zero"] > 0 and c["fermat"] == 0, c
     print("emitter inverse paths over 3 O0 + 3 reduced production payloads:", c)
     calc.close()
 
@@ -524,6 +524,33 @@ def test_production_gpu_witness_satisfies_the_independent_r1cs(pkg):
     c = circuit(PROD)
     assert c.n_wires == 215_907_954 and c.n_constraints == 215_962_292
     assert CK.check_witness(c, CK.Witness(payload)) == []
+
+
+def test_emit_selfcheck_on_written_values(pkg):
+    """pob_emit_selfcheck on the production instantiation: the derived wires' own relations (IsZero, IsEqual, SubstringCheck's M[] recurrence)
+    evaluated on the values WRITTEN into the emission windows -- clean for a valid witness of group 1 (payload == the oracle's), and a witness
+    emitted from a resident vector whose KeccakBytes.inLen operand was poked violates the relations of the derived IsEqual([i, inLen]) wires
+    that consume it: the check names such a wire.  (tests/test_hostsim_cpu.py runs the same on the fixture instantiation.)"""
+    from proof_of_burn_amd import inputs as gen
+    n = 66
+    batch = gen.synthetic_batch(n, depth=10, seed=0x5E1F, distinct_keys=2)
+    calc = pkg.WitnessCalculator(PROD, max_batch=n)
+    assert all(r.ok and r.check_status == 0 for r in calc.calculate(batch.inputs, check=True))
+    ref = O.run(PROD, batch.inputs[n - 1]).witness_numpy()
+    calc.emit_selfcheck(True)
+    assert np.array_equal(calc.witness_payload(n - 1), ref)
+    r = calc.emit_selfcheck_result()
+    assert r["first_bad_wire"] is None and r["checked"] > 300_000 and r["skipped"] < 100, r
+    print("self-check of one production witness:", r)
+    for kb in (0, 3):
+        cls, idx, wire = calc.debug_ref("kb.inLen", kb)
+        calc.poke(cls, idx, 1, 1, group=1)                 # lane 1 of group 1 = witness 65 = n - 1
+        got = calc.witness_payload(n - 1)
+        r = calc.emit_selfcheck_result()
+        calc.poke(cls, idx, 1, 1, group=1)
+        assert not np.array_equal(got, ref) and r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 200_000, (kb, wire, r)
+    assert np.array_equal(calc.witness_payload(n - 1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
+    calc.close()
 
 
 def test_device_field_inversions(pkg):

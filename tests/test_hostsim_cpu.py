@@ -398,3 +398,30 @@ def test_emitter_inverse_paths_and_field_inversions(pkg):
     for k, x in enumerate(xs):
         want = pow(x, W.P - 2, W.P)
         assert int.from_bytes(a.raw[32 * k:32 * k + 32], "little") == want and int.from_bytes(b.raw[32 * k:32 * k + 32], "little") == want, (k, x)
+
+
+def test_emit_selfcheck_on_written_values(pkg):
+    """pob_emit_selfcheck: the derived wires' own relations (IsZero: in * inv === 1 - out, in * out === 0; IsEqual: IsZero.in === in[1] - in[0],
+    out === IsZero.out; SubstringCheck: M[i+1] === M[i] + mainInput[i] * 256^i) evaluated on the values WRITTEN into the emission windows.  Clean for
+    valid witnesses (one window and many); a witness emitted from a resident vector with a poked OPERAND (KeccakBytes.inLen, a SubstringCheck input byte)
+    violates the relations of the derived wires that consume it, and the check names such a wire"""
+    s = _suite("test_proof_of_burn")
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=2)
+    inp = s["cases"][0]["input"]
+    assert all(r.ok for r in calc.calculate([inp, inp], check=True))
+    ref = O.run(POB_FIX, inp).witness_numpy()
+    calc.emit_selfcheck(True)
+    got = np.concatenate([v.copy() for _, v in calc.witness_windows(1, window_wires=1_000_000)])          # 65 windows
+    assert np.array_equal(got, ref)
+    r = calc.emit_selfcheck_result()
+    assert r["first_bad_wire"] is None and r["checked"] > 50_000 and r["skipped"] < 200, r
+    # KeccakBytes.inLen of the first KeccakBytes: the IsEqual([i, inLen]) operands are derived from it, the stored isEq[] bits are not
+    cls, idx, wire = calc.debug_ref("kb.inLen", 0)
+    calc.poke(cls, idx, 1, 1)
+    got = calc.witness_payload(1)
+    r = calc.emit_selfcheck_result()
+    assert not np.array_equal(got, ref) and r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 40_000, (wire, r)
+    calc.poke(cls, idx, 1, 1)
+    assert np.array_equal(calc.witness_payload(1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
+    calc.emit_selfcheck(False)
+    calc.close()

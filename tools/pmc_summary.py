@@ -3,7 +3,9 @@
 (separate passes, as MI355X_MICROARCH.md prescribes) and write profiles/<name>.json, which bench.py reads for `traffic`.
 
 gfx950 correction (MI355X_MICROARCH.md "HBM"): FETCH_SIZE counts 64 B per 128-B request of a coalesced stream, i.e. exactly
-half the bytes -> doubled here; WRITE_SIZE is used as reported (it matches the algorithmic write bytes to 0.2 %)."""
+half the bytes -> doubled here (calibrated on this kernel family in round 3: the full-layout kernel streamed 27 GB that cannot sit in the 256 MB L3
+and read 0.51 x raw); WRITE_SIZE is used as reported (it matched the algorithmic write bytes to 0.2 %).  Round 4: the compact round blocks (76 stored
+arrays of 64 wires per block instead of 1 604)."""
 import json
 import sqlite3
 import sys
@@ -32,9 +34,9 @@ def main(fetch_db, write_db, out):
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --batch %d" % (groups * 64),
         "groups": groups,
         "k_rounds_check": {"fetch_size_kb_raw": chk["avg_kb"], "hbm_read_bytes_per_launch": chk["avg_kb"] * 1024 * 2,
-                           "algorithmic_bytes_per_launch": perms_rounds * groups * (102656 + 3200) * 8},
+                           "algorithmic_bytes_per_launch": perms_rounds * groups * (76 + 50) * 64 * 8},      # the 76 stored arrays of a round block + midRound[r] + midRound[r+1]
         "k_rounds_gen": {"write_size_kb_raw": gen["avg_kb"], "hbm_write_bytes_per_launch": gen["avg_kb"] * 1024,
-                         "algorithmic_bytes_per_launch": (gen["grid_x_threads"] // 64) * groups * 102656 * 8},
+                         "algorithmic_bytes_per_launch": (gen["grid_x_threads"] // 64) * groups * 76 * 64 * 8},                  # the 76 stored arrays
     }
     for k in ("k_rounds_check", "k_rounds_gen"):
         d = res[k]
