@@ -70,7 +70,10 @@ HD constexpr uint32_t fam_of(uint32_t k) {
          : (k == U_POB_INPUT_FR || k == U_POB_RANGE || k == U_POB_N2B || k == U_PC_POST || k == U_RL_ACC || k == U_POW_PRE || k == U_SP_INPUT || k == CK_N2BE) ? F_N2B
          : F_MISC;
 }
-#define UCASE(K) case K: if constexpr (((MASK) >> fam_of(K)) & 1u)
+// the kernel a unit's GENERATION is compiled into may differ from its evaluation / emission family: PublicCommitment's head is a long BIT/SM unit whose
+// generation needs more than the light kernel's 64 VGPRs (it spilled 12) -- it is generated by the <= 128-VGPR kernel, evaluated and emitted where it was
+HD constexpr uint32_t gen_fam_of(uint32_t k) { return k == U_PC_PRE ? (uint32_t)F_N2B : fam_of(k); }
+#define UCASE(K) case K: if constexpr (((MASK) >> (P::is_gen ? gen_fam_of(K) : fam_of(K))) & 1u)
 
 struct PobParams { int L, NB, HB, minNib, amountBytes, powZero; Fr maxIntended, maxActual; };   // Montgomery
 struct SpendParams { int maxAmountBytes; };
@@ -346,6 +349,7 @@ template <class P> GD void kb_post(P& p, const KBRefs& r) {
 // compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
 // this lane-per-witness code); F_SC / F_POS / F_N2B do BN254 arithmetic.
 HD bool unit_is_heavy(uint32_t k) { return fam_of(k) >= F_SC; }
+HD bool unit_gen_is_heavy(uint32_t k) { return gen_fam_of(k) >= F_SC; }
 
 template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
 
@@ -803,7 +807,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             sc.out = p.bits(1); sc.mi_w = p.dvs(mm); sc.ml = p.sms(1); sc.si = p.sms(sl);
             sc.num = p.frs(1); sc.M_w = p.dvs(mm + 1); sc.ex = p.bits(kk); sc.isl = p.bits(kk); sc.alw = p.bits(kk + 1); sc.sums = p.sms(kk + 1); sc.dne = p.bits(1);
             const S mainLen = p.get(sc.ml);                  // mainInput[] / mainLen are written by U_SC_MI (inputs only: pre-work track)
-            for (int k = 0; k < sl; k++) p.put(sc.si + k, p.get(M.reducedLayerKeccaks + (31 * i + k)));
+            copy_n(p, sc.si, M.reducedLayerKeccaks + (uint32_t)(31 * i), sl);      // (batched: the evaluator's compares are resolved per 8 wires -- as single puts LLVM sank all 31 compares and spilled 311 VGPRs)
             sc.c_abs_sub = p.cur;
             gAssertByteString(p, sl, sc.si);
             sc.abs_main_in = SmRef{p.dvs(mm), 0};

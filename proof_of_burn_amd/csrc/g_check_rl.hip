@@ -1,2 +1,2 @@
 #include "g_units.hpp"
-POB_DEFINE_G_LAUNCH(launch_g_check_rl, CheckP, FAM_BIT(F_RL), 6)
+POB_DEFINE_G_LAUNCH(launch_g_check_rl, CheckP, FAM_BIT(F_RL), 5)

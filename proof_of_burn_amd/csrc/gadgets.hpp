@@ -777,11 +777,21 @@ template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef
 template <class P> GD F gLittleEndianBytes2NumF(P& p, int N, SmRef src) {
     FrRef o = p.frs(1); SmRef in = p.sms(N);
     Fr c = fr_zero();
+    // in[] <== src[] in batches of 8 (two-phase: the evaluator's loads of a batch are issued together and its compares resolved at the batch's end --
+    // as 31 single puts LLVM sank every compare to the end of the unit and the SubstringCheck head spilled 311 VGPRs)
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint32_t w = 0;
-        for (int k = 0; k < 4; k++) { int idx = 4 * j + k; if (idx < N) w |= ((uint32_t)p.put(in + idx, p.get(src + idx)) & 0xffu) << (8 * k); }
-        c.l[j] = w;
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        if (j0 < N) {
+            SmRef rr[8]; S vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int idx = j0 + q < N ? j0 + q : N - 1; rr[q] = in + (uint32_t)idx; }
+            const SmLoaded<8> h = sm_load(p, rr);
+#pragma unroll
+            for (int q = 0; q < 8; q++) vv[q] = p.get(src + (uint32_t)(j0 + q < N ? j0 + q : N - 1));
+            sm_commit(p, rr, h, vv);
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (j0 + q < N) c.l[(j0 + q) >> 2] |= ((uint32_t)(P::is_check ? h.s[q] : vv[q]) & 0xffu) << (8 * ((j0 + q) & 3));
+        }
     }
     gAssertByteString(p, N, in);          // (values >= 256 fail here, so masking above never hides an error)
     return p.put(o, fr_to_mont(c));

@@ -268,7 +268,7 @@ static inline bool keccak_round_alias_table(uint16_t* tab) {
 // Sponge chain (Final/Absorb, keccak.circom:304-349): everything of Keccak(n)/Final(n)/Absorb x n EXCEPT the 24 round
 // blocks and the output selector: Keccak.in, Final.in, Final.s[0..n], Absorb own wires + 17 XorArrays, Keccakf in/out/midRound.
 // (<= 128 VGPRs: the small sponges of a side track must fit the slot a k_rounds wave frees, see g_gen_heavy_small.hip)
-template <bool CHECK> __global__ void __launch_bounds__(64, 4) k_chain(KArgs A) {
+template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) {
     const uint32_t lane = threadIdx.x;
     const SpongeDesc sp = A.sponges[A.first + blockIdx.x];
     u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;

@@ -276,7 +276,7 @@ static hipStream_t own_stream(pob_ctx* h);      // the handle's own stream (call
 // 3 = SubstringCheck BN254, 4 = Poseidon blocks with the state spread over lanes (poseidon_wide.hpp)
 // 5 = gadget-level mains (gadget_mains.hpp)
 #define N_GEN_CLASSES 6
-static uint32_t unit_class(uint32_t kind) { return fam_of(kind) == F_GM ? 5 : kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : unit_is_heavy(kind) ? 1 : 0; }
+static uint32_t unit_class(uint32_t kind, bool gen = false) { return fam_of(kind) == F_GM ? 5 : kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : (gen ? unit_gen_is_heavy(kind) : unit_is_heavy(kind)) ? 1 : 0; }
 static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
     if (cls == 5) launch_g_gen_gm(A, nunits, ngroups, st);
     else if (cls == 4) launch_pos_wide(A, nunits, ngroups, st);
@@ -437,7 +437,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             pob_ctx::Seg sg{s, lds, (uint32_t)h->order.size(), 0};
             for (uint32_t u = 0; u < pl.units.size(); u++) {
                 if (!(pl.units[u].flags & UNIT_GEN)) continue;
-                if (pl.units[u].stage == s && unit_class(pl.units[u].kind) == lds) h->order.push_back(u);
+                if (pl.units[u].stage == s && unit_class(pl.units[u].kind, true) == lds) h->order.push_back(u);
             }
             sg.count = (uint32_t)h->order.size() - sg.first;
             std::stable_sort(h->order.begin() + sg.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
@@ -1312,7 +1312,7 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
         std::vector<uint32_t> sel;
         for (uint32_t u = 0; u < h->plan.units.size(); u++) if (h->plan.units[u].kind == kind && (h->plan.units[u].flags & need)) sel.push_back(u);
         if (sel.empty()) { *avg_ms = 0; hipEventDestroy(e0); hipEventDestroy(e1); return POB_OK; }
-        nsel = (uint32_t)sel.size(); sel_cls = unit_class(kind); sel_fam = fam_of(kind);
+        nsel = (uint32_t)sel.size(); sel_cls = unit_class(kind, which >= 200); sel_fam = fam_of(kind);
         HIPC(hipMalloc(&d_sel, nsel * 4)); HIPC(hipMemcpy(d_sel, sel.data(), nsel * 4, hipMemcpyHostToDevice));
         A.order = d_sel; A.first = 0;
     }

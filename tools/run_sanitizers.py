@@ -12,6 +12,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 QUICK = "spend_suite or run_shim or inverse_paths"
+# (the loaded library is checked too: a run that silently used the uninstrumented build would prove nothing)
 FULL = ("spend_suite or fixture_suite or pokes_in_every_class_spend or service_loop or reference_suites_on_the_shim or run_shim or gadget_mains_evaluator or "
         "gadget_mains_seeded or production_sizes or inverse_paths or pipelined")
 
@@ -25,6 +26,9 @@ def main(mode="quick"):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hostsim_cpu.py", "-x", "-q", "-p", "no:cacheprovider", "-k", QUICK if mode == "quick" else FULL],
                        cwd=ROOT, env=env, capture_output=True, text=True)
     out = r.stdout + r.stderr
+    for lib in ("tests/hostsim/libpob_hostsim_san.so", "oracle/liboracle_san.so"):
+        if not os.path.exists(os.path.join(ROOT, lib)):
+            print(f"{lib} was not built: the run did not use the sanitizer builds"); return 1
     findings = [ln for ln in out.splitlines() if "ERROR: AddressSanitizer" in ln or "runtime error:" in ln or "SUMMARY: " in ln]
     print(f"sanitizers ({mode}): -fsanitize=address,undefined on tests/hostsim/libpob_hostsim_san.so + oracle/liboracle_san.so, runtime {os.path.basename(rt)}")
     print(f"pytest rc {r.returncode} in {time.time() - t0:.0f} s; findings: {len(findings)}")
