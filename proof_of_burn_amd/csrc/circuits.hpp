@@ -81,7 +81,8 @@ struct SpendParams { int maxAmountBytes; };
 // footprints {wires, BIT, SM, FR} of fixed-size components
 #define FP_ISEQ_S (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv] over small operands: two BIT outputs, four DERIVED operand wires (policy.hpp)
 #define FP_ISEQ_F (Cur{6, 2, 0, 0, 4})       // ... over field elements with derived operand wires (gIsEqualFd)
-#define FP_N2B8 (Cur{9, 8, 0, 0, 1})         // Num2Bits(8) [out[8] | in] of KeccakBytes' byte loop: `in` derived
+#define FP_N2B8 (Cur{9, 0, 0, 0, 9})         // Num2Bits(8) [out[8] | in] of KeccakBytes' byte loop: derived (the byte's bits are stored once, as Keccak's inBlocks)
+#define FP_ISEQ_D (Cur{6, 0, 0, 0, 6})       // IsEqual + IsZero whose two outputs are copies of a stored bit of the parent (Pad's isEq[] / isLast[]): all six wires derived
 
 // references to main's own wires (proof_of_burn.circom:41-72 in/out, :113-200 intermediates)
 struct PobMain {
@@ -101,7 +102,7 @@ struct SpendMain {   // spend.circom:33-38, :43-49
 };
 // KeccakBytes own wires, Pad's own wires, and the Keccak/Final/SelectorArray2D wires its G units touch
 struct KBRefs {
-    SmRef out, in, inLen, numBlocks; BitRef inBitsArray, inBits, inBlocks, outBits, outBytes;
+    SmRef out, in, inLen, numBlocks; BitRef inBitsArray, inBits, inBlocks, outBits, outBytes;       // (round 4: of these only inBlocks is stored; a DERIVED BIT array has .i = NO_RANK)
     uint32_t padded_w, pad_o_w, pad_in_w;          // padded[m], Pad.out[m], Pad.in[m]: derived wires (functions of the byte, inLen, numBlocks)
     SmRef pad_nb, pad_il, pad_dv, pad_rm; BitRef pad_flt, pad_isEq, pad_isLast;
     Cur c_loop;                       // first IsEqual of Pad's isEq loop; then m isLast IsEquals, m Num2Bits(8), Flatten(m,8)
@@ -182,11 +183,16 @@ HD PosOff pos_off(int t) {
 // || AssertLessThan(16)(inLen, m), Pad(mb,136) :412-446 [out[m], numBlocks | in[m], inLen | div, rem, filter[m+1], isEq[m], isLast[m]]
 //    || Divide(16)(inLen,136), AssertLessEqThan(16)(numBlocks, mb), IsEqual([i,inLen]) x m, IsEqual([i,numBlocks*136-1]) x m
 // || Num2Bits(8) x m, Flatten(m,8), Keccak(mb), Reshape(32,8), Bits2Num(8) x 32
+#define NO_RANK 0xFFFFFFFFu
+template <class P> HD BitRef dbits(P& p, uint32_t n) { BitRef r = {p.dvs(n), NO_RANK}; return r; }      // n DERIVED BIT wires: wire indices only
 template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
     const uint32_t m = 136 * mb;
     r.mb = mb;
     r.out = p.sms(32); r.in = p.sms(m); r.inLen = p.sms(1); r.padded_w = p.dvs(m); r.numBlocks = p.sms(1);
-    r.inBitsArray = p.bits(8 * m); r.inBits = p.bits(8 * m); r.inBlocks = p.bits(8 * m); r.outBits = p.bits(256); r.outBytes = p.bits(256);
+    // the padded bytes' bits exist six times in the circuit (Num2Bits(8).out, inBitsArray, Flatten in / out, inBits, inBlocks): stored ONCE, as inBlocks (the sponge's
+    // source); the hash bits ten times (Selector.out, SelectorArray2D.out, Final.out, Keccak.finalState / out, outBits, Reshape in / out, outBytes, Bits2Num.in): stored
+    // once, as Selector.out.  The copies are derived wires (policy.hpp run_derived).
+    r.inBitsArray = dbits(p, 8 * m); r.inBits = dbits(p, 8 * m); r.inBlocks = p.bits(8 * m); r.outBits = dbits(p, 256); r.outBytes = dbits(p, 256);
     inLen = p.put(r.inLen, inLen);
     gAssertLessThanS(p, 16, inLen, (S)m);
     r.pad_o_w = p.dvs(m); r.pad_nb = p.sms(1); r.pad_in_w = p.dvs(m); r.pad_il = p.sms(1); r.pad_dv = p.sms(1); r.pad_rm = p.sms(1);
@@ -201,7 +207,7 @@ template <class P> GD void kb_head(P& p, int mb, S inLen, KBRefs& r) {
     p.put(r.numBlocks, nb);
     p.put(r.pad_flt, ~(B)0);
     r.c_loop = p.cur;
-    p.cur = cur_add(cur_add(cur_add(p.cur, FP_ISEQ_S, 2 * m), FP_N2B8, m), Cur{16u * m, 16u * m, 0, 0}, 1);   // -> Keccak(mb)
+    p.cur = cur_add(cur_add(cur_add(p.cur, FP_ISEQ_D, 2 * m), FP_N2B8, m), Cur{16u * m, 0, 0, 0, 16u * m}, 1);   // -> Keccak(mb)   (Flatten(m, 8) [out | in]: derived)
 }
 // the four derived operand wires of an IsEqual([a, b]) child at cursor c (its two BIT wires are written by the caller as part of a run)
 template <class P> HD void iseq_derived(P& p, Cur c, S a, S b) {
@@ -213,14 +219,14 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
     const uint32_t m = 136 * r.mb, cnt = hi - lo, ln = p.lane_id();     // cnt <= 16 bytes
     const S inLen = p.get(r.inLen), nb = p.get(r.numBlocks);
     const S last = (S)((uint32_t)nb * 136u - 1u);
-    const Cur cE = r.c_loop, cL = cur_add(cE, FP_ISEQ_S, m), cN = cur_add(cL, FP_ISEQ_S, m), cF = cur_add(cN, FP_N2B8, m);
-    const BitRef flat_o = {cF.w, cF.b}, flat_i = {cF.w + 8 * m, cF.b + 8 * m};
+    const Cur cE = r.c_loop, cL = cur_add(cE, FP_ISEQ_D, m), cN = cur_add(cL, FP_ISEQ_D, m), cF = cur_add(cN, FP_N2B8, m);
+    const uint32_t flat_o_w = cF.w, flat_i_w = cF.w + 8 * m;
     // filter[i] = prod_{j<i}(1 - isEq[j]) = [inLen >= i] (unsigned: an out-of-range inLen never hits); the evaluator re-reads it
     B f = P::is_gen ? p.ballot((uint32_t)inLen >= lo) : p.get(r.pad_flt + lo);
     B runE = 0, runL = 0, runF = 0, runPairE = 0, runPairL = 0, bits0 = 0, bits1 = 0;
     for (uint32_t t = 0; t < cnt; t++) {
         const uint32_t i = lo + t;
-        const Cur ce = cur_add(cE, FP_ISEQ_S, i), cl = cur_add(cL, FP_ISEQ_S, i);
+        const Cur ce = cur_add(cE, FP_ISEQ_D, i), cl = cur_add(cL, FP_ISEQ_D, i);
         const S v = p.put(r.in + i, p.get(src + i));
         const S xe = (S)((uint32_t)inLen - i), xl = (S)((uint32_t)last - i);
         iseq_derived(p, ce, (S)i, inLen); iseq_derived(p, cl, (S)i, last);      // IsEqual([i, inLen]), IsEqual([i, numBlocks*136 - 1]): operand wires derived
@@ -241,31 +247,31 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
     p.run_put(cnt, r.pad_isEq.w + lo + ln, r.pad_isEq.i + lo + ln, runE);
     p.run_put(cnt, r.pad_flt.w + lo + 1 + ln, r.pad_flt.i + lo + 1 + ln, runF);
     p.run_put(cnt, r.pad_isLast.w + lo + ln, r.pad_isLast.i + lo + ln, runL);
-    {   // the IsEqual children's [IsEqual.out, IsZero.out] pairs
+    {   // the IsEqual children's [IsEqual.out, IsZero.out] pairs: copies of isEq[i] / isLast[i]
         const uint32_t i = lo + (ln >> 1), wh = ln & 1;
-        p.run_put(2 * cnt, cE.w + 6 * i + 3 * wh, cE.b + 2 * i + wh, runPairE);
-        p.run_put(2 * cnt, cL.w + 6 * i + 3 * wh, cL.b + 2 * i + wh, runPairL);
+        p.run_derived(2 * cnt, cE.w + 6 * i + 3 * wh, runPairE);
+        p.run_derived(2 * cnt, cL.w + 6 * i + 3 * wh, runPairL);
     }
-    for (uint32_t h2 = 0; h2 < 2 && 8 * h2 < cnt; h2++) {      // Num2Bits(8).out, inBitsArray, Flatten in/out, inBits, Keccak's inBlocks
+    for (uint32_t h2 = 0; h2 < 2 && 8 * h2 < cnt; h2++) {      // Keccak's inBlocks (stored) and its five copies: Num2Bits(8).out, inBitsArray, Flatten in/out, inBits
         const uint32_t n = (cnt - 8 * h2 < 8 ? cnt - 8 * h2 : 8) * 8;
         const B x = h2 ? bits1 : bits0;
         const uint32_t j = 8 * (lo + 8 * h2) + ln, i = lo + 8 * h2 + (ln >> 3);
-        p.run_put(n, cN.w + 9 * i + (ln & 7), cN.b + j, x);
-        p.run_put(n, r.inBitsArray.w + j, r.inBitsArray.i + j, x);
-        p.run_put(n, flat_i.w + j, flat_i.i + j, x);
-        p.run_put(n, flat_o.w + j, flat_o.i + j, x);
-        p.run_put(n, r.inBits.w + j, r.inBits.i + j, x);
         p.run_put(n, r.inBlocks.w + j, r.inBlocks.i + j, x);
+        p.run_derived(n, cN.w + 9 * i + (ln & 7), x);
+        p.run_derived(n, r.inBitsArray.w + j, x);
+        p.run_derived(n, flat_i_w + j, x);
+        p.run_derived(n, flat_o_w + j, x);
+        p.run_derived(n, r.inBits.w + j, x);
     }
 }
 // Keccak(n) :374-385 / Final(n) :330-349 own wires + the n Absorb blocks (K kernels) + SelectorArray2D own wires.
 template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
     const uint32_t n = r.mb;
-    r.k_out = p.bits(256); r.k_in = p.bits(n * 1088); r.k_blocks = p.sms(1); r.k_finalState = p.bits(1600);
-    r.f_out = p.bits(1600); r.f_in = p.bits(n * 1088); r.f_blocks = p.sms(1); r.f_s = p.bits((n + 1) * 1600);
+    r.k_out = dbits(p, 256); r.k_in = p.bits(n * 1088); r.k_blocks = p.sms(1); r.k_finalState = dbits(p, 1600);
+    r.f_out = dbits(p, 1600); r.f_in = p.bits(n * 1088); r.f_blocks = p.sms(1); r.f_s = p.bits((n + 1) * 1600);
     r.abs_w = p.cur.w; r.abs_b = p.cur.b;
     p.skip_alias(n * ABSORB_WIRES, n * ABSORB_BITS);
-    r.sel_out = p.bits(1600); r.sel_arrays = p.bits((n + 1) * 1600); r.sel_select = p.sms(1); r.sel_T = p.bits(1600 * (n + 1));
+    r.sel_out = dbits(p, 1600); r.sel_arrays = dbits(p, (n + 1) * 1600); r.sel_select = p.sms(1); r.sel_T = dbits(p, 1600 * (n + 1));      // (copies of Selector.out / of Final.s: derived)
 }
 // selectors [j0, j1) of row `row` of SelectorArray2D(n+1, 25, 64) (selector.circom:91-111) + the copies of its outputs;
 // the hash output (first 256 selector outputs) also flows through outBits, Reshape, outBytes, Bits2Num, out[] and the parent's copy.
@@ -276,40 +282,45 @@ template <class P> GD void kb_declare_keccak(P& p, KBRefs& r) {
 // IsEqual (comparators.circom): [out | in[2]] || IsZero [out | in | inv]
 template <class P, int N1> GD void kb_selrow_n(P& p, const KBRefs& r, uint32_t row, uint32_t j0, uint32_t j1) {
     const uint32_t n1 = N1 ? (uint32_t)N1 : r.mb + 1, n = j1 - j0, ln = p.lane_id();
-    const uint32_t fw = 9 * n1 + 3, fb = 5 * n1 + 2, fq = 4 * n1 + 1;       // footprint of one selector: wires, BIT, derived (no SM)
+    const uint32_t fw = 9 * n1 + 3, fb = 1, fq = 9 * n1 + 2;                // footprint of one selector: wires, stored BIT (Selector.out), derived (no SM)
     const Cur c0 = p.cur;
     const uint32_t idx = row * 64 + j0 + ln;
     const S blocks = p.get(r.numBlocks);
     p.require(p.ballot((uint32_t)blocks < n1), FAILCODE(T_SELECTOR, 43));
     const uint32_t bw = c0.w + ln * fw, bb = c0.b + ln * fb;                // this lane's selector block
+    // Of a selector's 9 n1 + 3 wires ONE is stored: its output (round 4).  vals[] / SelectorArray2D.arrays / arraysT are copies of Final.s, isEq[] and the
+    // IsEqual children's outputs functions of numBlocks, sum[] the running OR of isEq & vals: derived wires, rebuilt by the emitter from the same expressions
+    // (rounds 1-3 stored all 5 n1 + 2 bits: 1.36 M of the G side's 2.59 M stored BIT wires and a fifth of its wave cycles in generation and evaluation).
     B acc = 0;
-    p.run_put(n, bw + 2 * n1 + 2, bb + 2 * n1 + 1, 0);                      // sum[0]
+    p.run_derived(n, bw + 2 * n1 + 2, 0);                                   // sum[0]
 #pragma unroll
     for (uint32_t k = 0; k < n1; k++) {
         const B v = p.run_get(n, r.f_s.i + k * 1600 + idx);
         const B e = p.ballot((uint32_t)blocks == k);
-        p.run_put(n, r.sel_arrays.w + k * 1600 + idx, r.sel_arrays.i + k * 1600 + idx, v);
-        p.run_put(n, r.sel_T.w + idx * n1 + k, r.sel_T.i + idx * n1 + k, v);
-        p.run_put(n, bw + 1 + k, bb + 1 + k, v);                            // vals[k]
-        p.run_put(n, bw + n1 + 2 + k, bb + n1 + 1 + k, e);                  // isEq[k]
         acc |= e & v;
-        p.run_put(n, bw + 2 * n1 + 3 + k, bb + 2 * n1 + 2 + k, acc);        // sum[k+1]
-        const uint32_t cw = bw + 3 * n1 + 3 + 6 * k, cb = bb + 3 * n1 + 2 + 2 * k;
-        p.run_put(n, cw, cb, e);                                            // IsEqual.out
-        p.run_put(n, cw + 3, cb + 1, e);                                    // IsZero.out
+        if constexpr (P::is_emit) {
+            p.run_derived(n, r.sel_arrays.w + k * 1600 + idx, v);
+            p.run_derived(n, r.sel_T.w + idx * n1 + k, v);
+            p.run_derived(n, bw + 1 + k, v);                                // vals[k]
+            p.run_derived(n, bw + n1 + 2 + k, e);                           // isEq[k]
+            p.run_derived(n, bw + 2 * n1 + 3 + k, acc);                     // sum[k+1]
+            const uint32_t cw = bw + 3 * n1 + 3 + 6 * k;
+            p.run_derived(n, cw, e);                                        // IsEqual.out
+            p.run_derived(n, cw + 3, e);                                    // IsZero.out
+        }
     }
-    p.run_put(n, bw, bb, acc);                                              // Selector.out
-    p.run_put(n, r.sel_out.w + idx, r.sel_out.i + idx, acc);
-    p.run_put(n, r.f_out.w + idx, r.f_out.i + idx, acc);
-    p.run_put(n, r.k_finalState.w + idx, r.k_finalState.i + idx, acc);
-    if (row < 4) {           // the 256 hash bits: Keccak.out, KeccakBytes.outBits, Reshape in/out, outBytes, Bits2Num(8).in
-        const uint32_t pw = r.c_post.w, pb = r.c_post.b;
-        p.run_put(n, r.k_out.w + idx, r.k_out.i + idx, acc);
-        p.run_put(n, r.outBits.w + idx, r.outBits.i + idx, acc);
-        p.run_put(n, pw + 256 + idx, pb + 256 + idx, acc);
-        p.run_put(n, pw + idx, pb + idx, acc);
-        p.run_put(n, r.outBytes.w + idx, r.outBytes.i + idx, acc);
-        p.run_put(n, pw + 512 + 9 * (idx >> 3) + 1 + (idx & 7), pb + 512 + idx, acc);
+    p.run_put(n, bw, bb, acc);                                              // Selector.out: the stored copy (the evaluator checks it against OR_k isEq_k & Final.s_k)
+    p.run_derived(n, r.sel_out.w + idx, acc);
+    p.run_derived(n, r.f_out.w + idx, acc);
+    p.run_derived(n, r.k_finalState.w + idx, acc);
+    if (row < 4) {           // the 256 hash bits: Keccak.out, KeccakBytes.outBits, Reshape in/out, outBytes, Bits2Num(8).in -- derived copies
+        const uint32_t pw = r.c_post.w;
+        p.run_derived(n, r.k_out.w + idx, acc);
+        p.run_derived(n, r.outBits.w + idx, acc);
+        p.run_derived(n, pw + 256 + idx, acc);
+        p.run_derived(n, pw + idx, acc);
+        p.run_derived(n, r.outBytes.w + idx, acc);
+        p.run_derived(n, pw + 512 + 9 * (idx >> 3) + 1 + (idx & 7), acc);
         for (uint32_t jj = 0; jj < n; jj += 8) {                            // Bits2Num(8) outputs, per witness
             S by = 0;
 #pragma unroll
@@ -339,7 +350,7 @@ template <class P> GD void kb_selrow(P& p, const KBRefs& r, uint32_t row, uint32
 template <class P> GD void kb_post(P& p, const KBRefs& r) {
     S nb = p.get(r.numBlocks);
     p.put(r.k_blocks, nb); p.put(r.f_blocks, nb); p.put(r.sel_select, nb);
-    p.cur = cur_add(r.c_post, Cur{512 + 32 * 9, 512 + 32 * 8, 32, 0}, 1);
+    p.cur = cur_add(r.c_post, Cur{512 + 32 * 9, 0, 32, 0, 512 + 32 * 8}, 1);       // (Reshape(32,8) [out | in] and the Bits2Num(8) inputs: derived copies of the hash bits)
 }
 
 #include "gadget_mains.hpp"

@@ -457,13 +457,14 @@ template <class P> GD void gAssertBitsF(P& p, int nb, const F& in) {
     gNum2BitsF(p, nb, x, &v);
     bv_put(p, bits, nb, v);
 }
-#define FP_ABITS8 (Cur{18, 16, 0, 0, 2})     // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]: 16 stored bits, the two `in` copies derived
+#define FP_ABITS8 (Cur{18, 0, 0, 0, 18})     // AssertBits(8) [in | bits[8]] + Num2Bits(8) [out[8] | in]: every wire is a function of the byte -> DERIVED (round 4: the 16 bits too; rounds 1-3 stored them)
 // ---------------------------------------------------------------------------- AssertByteString(N) in ranges (assert.circom:26-31)
-// own in[N] (first wire own_w) is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8.  The three copies of the byte -- own
-// in[i], AssertBits.in, Num2Bits.in -- are DERIVED wires (policy.hpp): only the 16 bits per byte are stored
+// own in[N] (first wire own_w) is declared by the caller; child i (AssertBits(8)) lives at c0 + i*FP_ABITS8.  Everything is a function of the source
+// byte and DERIVED (policy.hpp): the three copies of the byte -- own in[i], AssertBits.in, Num2Bits.in -- and, since round 4, the two copies of its 8
+// bits: generation and evaluation only hold the assert (byte < 256), the emitter writes the 19 wires per byte
 template <class P> GD void abs_range(P& p, Cur c0, uint32_t own_w, SmRef src, uint32_t lo, uint32_t hi) {
-    // per byte i: own in[i]; AssertBits(8) [in | bits[8]] || Num2Bits(8) [out[8] | in] at c0 + i*FP_ABITS8.  The 16 BIT wires of a
-    // byte are consecutive in BIT rank (bits[8] then out[8]), so 4 bytes make one lane-distributed run of 64 wires.
+    // per byte i: own in[i]; AssertBits(8) [in | bits[8]] || Num2Bits(8) [out[8] | in] at c0 + i*FP_ABITS8.  The 16 bit wires of a
+    // byte are consecutive wires (bits[8] then out[8]), so 4 bytes make one lane-distributed run of 64 wires for the emitter.
     const uint32_t ln = p.lane_id();
     for (uint32_t i0 = lo; i0 < hi; i0 += 8) {
         const uint32_t cnt = hi - i0 < 8 ? hi - i0 : 8;
@@ -474,15 +475,19 @@ template <class P> GD void abs_range(P& p, Cur c0, uint32_t own_w, SmRef src, ui
             const S v = p.get(src + i);
             p.derived(own_w + i, v); p.derived(c.w, v); p.derived(c.w + 17, v);
             p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
+            if constexpr (P::is_emit) {
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
+                for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
+            }
         }
-        for (uint32_t h2 = 0; h2 < 2 && 4 * h2 < cnt; h2++) {       // bytes i0 + 4*h2 .. +3: 16 wires each
-            const uint32_t nb = cnt - 4 * h2 < 4 ? cnt - 4 * h2 : 4;
-            const uint32_t t = 4 * h2 + (ln >> 4), q = ln & 15, i = i0 + t;
-            const B x = p.run_perm(compact, 8 * t + (q & 7));
-            p.run_put(16 * nb, c0.w + 18 * i + 1 + q, c0.b + 16 * i + q, x);
-        }
+        if constexpr (P::is_emit) {
+            for (uint32_t h2 = 0; h2 < 2 && 4 * h2 < cnt; h2++) {       // bytes i0 + 4*h2 .. +3: 16 wires each (bits[8] then out[8])
+                const uint32_t nb = cnt - 4 * h2 < 4 ? cnt - 4 * h2 : 4;
+                const uint32_t t = 4 * h2 + (ln >> 4), q = ln & 15, i = i0 + t;
+                const B x = p.run_perm(compact, 8 * t + (q & 7));
+                p.run_derived(16 * nb, c0.w + 18 * i + 1 + q, x);
+            }
+        } else { (void)compact; (void)ln; }
     }
 }
 
@@ -579,10 +584,10 @@ HD SelBlk sel_blk(Cur c, uint32_t N) {
     SelBlk s;
     s.o = SmRef{c.w, c.s}; s.vals_w = c.w + 1; s.sel_w = c.w + 1 + N;
     s.isEq = BitRef{c.w + 2 + N, c.b}; s.sum_w = c.w + 2 + 2 * N;
-    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 1, c.f, c.q + 2 * N + 2};
+    s.kids = Cur{c.w + 3 * N + 3, c.b + N, c.s + 1, c.f, c.q + 2 * N + 2};      // (the children store nothing: their two outputs are copies of isEq[i])
     return s;
 }
-HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, 3 * N, 1, 0, 6 * N + 2}; return r; }
+HD Cur sel_fp(uint32_t N) { Cur r = {9 * N + 3, N, 1, 0, 8 * N + 2}; return r; }      // stored: out (SM) and isEq[N]; vals / select / sum / the IsEqual children: derived
 #define FP_ISEQ_S_ (Cur{6, 2, 0, 0, 4})       // IsEqual [out | in[2]] + IsZero [out | in | inv]: two BIT outputs, four derived operand wires
 // four derived operand wires of an IsEqual([a, b]) child whose first wire is w
 template <class P> HD void iseq_derived_w(P& p, uint32_t w, S a, S b) {
@@ -603,7 +608,7 @@ template <class P> GD void sel_range(P& p, const SelBlk& sb, SmRef src, uint32_t
             runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
         }
         p.run_put(n, sb.isEq.w + i0 + ln, sb.isEq.i + i0 + ln, runE);
-        p.run_put(2 * n, sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), sb.kids.b + 2 * i0 + ln, runK);
+        p.run_derived(2 * n, sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), runK);      // IsEqual.out / IsZero.out of child i: copies of isEq[i]
         if constexpr (P::is_emit) {
             for (uint32_t t = 0; t < n; t++) {
                 const uint32_t i = i0 + t;

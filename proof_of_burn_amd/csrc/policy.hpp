@@ -122,6 +122,8 @@ struct CountP : PolBase {
     // lane-distributed BIT access (see DevPol): n wires
     HD B run_get(uint32_t, uint32_t) { return 0; }
     HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; nb += n; }
+    HD void run_derived(uint32_t, uint32_t, B) {}      // n DERIVED BIT wires as a lane-distributed run (lane k: wire index, that wire's 64-witness mask): the emitter only
+    HD void derived_bit(uint32_t, B) {}
     HD B run_bcast(B, uint32_t) { return 0; }
     HD B run_set(B run, uint32_t, B) { return run; }
     HD B run_perm(B run, uint32_t) { return run; }
@@ -285,6 +287,8 @@ struct DevPol : PolBase {
     __device__ __forceinline__ void site_m(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void derived_fr(uint32_t, const F&) {}
     __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&) {}
+    __device__ __forceinline__ void run_derived(uint32_t, uint32_t, B) {}
+    __device__ __forceinline__ void derived_bit(uint32_t, B) {}
     __device__ __forceinline__ F ld(FrRef r) {
         F v; const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
@@ -494,6 +498,9 @@ struct EmitP : DevPol {
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B, uint32_t) {}
+    // derived BIT wires: lane k < n writes wire w (its own) from the mask x it holds / one wave-uniform wire
+    __device__ __forceinline__ void run_derived(uint32_t n, uint32_t w, B x) { if (m.lane < n) { Fr c = {{(uint32_t)((x >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); } }
+    __device__ __forceinline__ void derived_bit(uint32_t w, B v) { if (m.lane == 0) { Fr c = {{(uint32_t)((v >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); } }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B) {
         if (m.lane < n) { B s = run_ld_off(i << 3); Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); }
     }
