@@ -79,9 +79,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU per step (weak scaling)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: ONE global batch of this many witnesses per step, split over the ranks (BASELINE config 4: 8192)")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="1: two calculators work on consecutive batches (pob_set_partner): batch k+1's latency-bound generation stages run beside batch k's evaluation")
-    ap.add_argument("--sched", default=None, help="EXPERIMENT: POB_SCHED for the library (private = own side streams per calculator, no gate)")
+    ap.add_argument("--schedule", choices=["inorder", "tracks"], default="inorder",
+                    help="inorder: every calculator enqueues its whole batch in dependency order on ONE stream (pob_set_inorder) and --pipeline of them are in flight; "
+                         "tracks: round 2-3's schedule, two linked calculators (pob_set_partner) whose tracks run on the device's side streams")
+    ap.add_argument("--pipeline", type=int, default=-1, help="calculators in flight, each on consecutive batches (default: 4 in-order ones / 2 linked track ones; 0 = one calculator, no pipeline)")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
     ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
@@ -114,9 +115,10 @@ def main():
         B, first0, GB = hi - lo, lo, args.total_batch                   # this rank's slice of every global batch
     else:
         B, first0, GB = args.batch, rank * args.batch, world * args.batch
+    INORDER = args.schedule == "inorder"
+    if args.pipeline < 0:
+        args.pipeline = 4 if INORDER else 2
     PIPE = bool(args.pipeline)
-    if args.sched:
-        os.environ["POB_SCHED"] = args.sched
     NB = 1 if args.dbg_no_upload else max(1, args.distinct_batches)
 
     # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
@@ -124,9 +126,12 @@ def main():
     batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + first0,
                                    pow_device=dev_index if args.depth > 12 else None) for b in range(NB)]
     t_synth = (time.time() - t0) / NB
-    NC = max(2, args.pipeline) if PIPE else 1
-    LINK = PIPE and NC == 2 and args.sched != "private"
+    NC = (max(2, args.pipeline) if INORDER else 2) if PIPE else 1
+    LINK = PIPE and not INORDER
     calcs = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(NC)]
+    if INORDER:
+        for c in calcs:
+            c.set_inorder(True)
     info = calcs[0].info
     # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch); the Python packer beside it
     texts = [[json.dumps(inp).encode() for inp in bt.inputs] for bt in batches]
@@ -152,7 +157,7 @@ def main():
     state = {"last_gather": None, "validated": 0, "kchk_ms": [], "h2d_bytes": 0}
     uploaded = [False] * NC
 
-    work = {"pinned": pinned, "expect": expect}             # the input batches the loop cycles through (the extra legs swap in their own)
+    work = {"pinned": pinned, "expect": expect, "NC": NC}    # the input batches the loop cycles through and the calculators in flight (the extra legs swap in their own)
 
     def validate(c, b):
         """every record of the batch calculator c has just finished: host-visible, checked before the clock stops"""
@@ -205,14 +210,15 @@ def main():
         batch k-2 after it has enqueued batch k, so the device never waits for the host."""
         pend = []                                         # (calculator, distinct batch) enqueued but not yet validated, oldest first
         prev = None
+        nc = work["NC"]
         for k in range(k0, k0 + nsteps):
-            c, b = (k % NC if PIPE else 0), k % len(work["pinned"])
-            if PIPE:
+            c, b = k % nc, k % len(work["pinned"])
+            if nc > 1:
                 if prev is not None:
                     finish(prev[0]); pend.append(prev)
                 start(c, b)
                 prev = (c, b)
-                while len(pend) > NC - 1:
+                while len(pend) > nc - 1:
                     validate(*pend.pop(0))
             else:
                 start(c, b)
@@ -298,26 +304,35 @@ def main():
                 "value": round(GB * 20 / dtb, 1), "ms_per_step": round(dtb / 20 * 1e3, 3)}
 
     # ---- the same service loop without the pipeline (one calculator), 10 batches: reported beside `value`, same run, same box
-    single = None
+    single = tracks_pipeline = None
     if PIPE and not args.no_single:
+        def timed(nsteps):
+            run(2)
+            fence()
+            t1 = time.perf_counter()
+            run(nsteps)
+            fence()
+            d = time.perf_counter() - t1
+            if world > 1:
+                tm = torch.tensor([d], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d = float(tm.item())
+            return {"value": round(GB * nsteps / d, 1), "ms_per_step": round(d / nsteps * 1e3, 3)}
+        # the same service loop on ONE calculator with the track schedule (the lowest latency for a lone batch), and on round 3's pipeline (two linked track calculators)
         if LINK:
             calcs[0].set_partner(None)
-        PIPE_save, PIPE = PIPE, False
-        run(2)
-        fence()
-        t1 = time.perf_counter()
-        run(10)
-        fence()
-        dt1 = time.perf_counter() - t1
-        PIPE = PIPE_save
-        if world > 1:
-            t1max = torch.tensor([dt1], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-            dist.all_reduce(t1max, op=dist.ReduceOp.MAX)
-            dt1 = float(t1max.item())
-        single = {"what": "one calculator per GPU, no pipeline (bench.py --pipeline 0), 10 batches of the same service loop after the timed region",
-                  "value": round(GB * 10 / dt1, 1), "ms_per_step": round(dt1 / 10 * 1e3, 3)}
-        if LINK:
-            calcs[0].set_partner(calcs[1])
+        for c in calcs[:2]:
+            c.set_inorder(False)
+        work["NC"] = 1
+        single = dict(timed(10), what="one calculator per GPU, track schedule, no pipeline (bench.py --schedule tracks --pipeline 0): 10 batches of the same service loop after the timed region")
+        calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
+        work["NC"] = 2
+        tracks_pipeline = dict(timed(20), what="round 3's schedule on this build (bench.py --schedule tracks): two linked track calculators (pob_set_partner), 20 batches after the timed region")
+        if not LINK:
+            calcs[0].set_partner(None)
+            for c in calcs[:2]:
+                c.set_inorder(True)
+        work["NC"] = NC
 
     # ---- extra legs, same calculators, same service loop, after the timed region (rank 0 of a 1-GPU run):
     #   depth16       BASELINE config 5's shape on one GPU: batches of 16-layer proofs (byteSecurityRelax = 1, 3-zero-byte proof of work)
@@ -339,7 +354,36 @@ def main():
         for pin_ in pins:
             pin_.free()
         return {"ms_per_step": round(dtl / steps_ * 1e3, 3), "value": round(B * steps_ / dtl, 1), "unit": "witnesses/s", "steps": steps_, "batch": B, "validated_witnesses": steps_ * B}
-    depth16 = strong_slice = None
+    depth16 = strong_slice = deeper = None
+    if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch and INORDER and PIPE:
+        # the same loop with EIGHT calculators in flight, 96 steps: what a longer-running service reaches (fill and drain weigh (N - 1) / K of a K-step run, and the
+        # round evaluation kernel shares the machine with more launches: its in-step time is reported beside the throughput)
+        extra = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(8 - NC)] if NC < 8 else []
+        for c in extra:
+            c.set_inorder(True); c.probe_check_kernel(True)
+        for c in calcs:
+            c.probe_check_kernel(True)
+        n_before = len(calcs)
+        calcs.extend(extra); streams.extend(torch.cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
+        gathered_ev.extend([None] * len(extra)); uploaded.extend([False] * len(extra))
+        work["NC"] = len(calcs)
+        probing = True
+        run(len(calcs)); fence()
+        state.update(validated=0, kchk_ms=[])
+        t1 = time.perf_counter()
+        run(96, k0=len(calcs)); fence()
+        dtd = time.perf_counter() - t1
+        probing = False
+        k8 = float(np.mean(state["kchk_ms"]))
+        deeper = {"what": f"{len(calcs)} in-order calculators in flight, 96 steps of the same service loop after the timed region", "calculators_in_flight": len(calcs), "steps": 96,
+                  "ms_per_step": round(dtd / 96 * 1e3, 3), "value": round(B * 96 / dtd, 1), "unit": "witnesses/s", "validated_witnesses": state["validated"],
+                  "round_evaluation_ms_in_step": round(k8, 4)}
+        for c in calcs:
+            c.probe_check_kernel(False)
+        for c in extra:
+            c.close()
+        del calcs[n_before:], streams[n_before:], recs[n_before:], gathered_ev[n_before:], uploaded[n_before:]
+        work["NC"] = NC
     if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch:
         probing = False
         deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=dev_index) for b in range(2)]
@@ -470,15 +514,17 @@ def main():
                                                 "rebuilt by the emitter; alias: Keccak round-block wires that ARE another stored wire (copy / rotated / negated / constant), expanded by the emitter"},
                        "full_layout_round3": {"resident_bytes_per_witness": 27225718, "ms_per_step": 11.257, "witnesses_per_s": 90963, "what": "BENCH_r03.json: every wire of the Keccak round blocks stored"},
                        "canonical_bytes_per_witness": int(info.n_witness) * 32,
-                       "parallelism": f"one slice per GPU x{world}, " + (f"two calculators pipelined over consecutive batches of {B} (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
+                       "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
+                                                                                     + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
+                       "schedule": args.schedule, "calculators_in_flight": NC,
                        "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,
                        "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),
                        "json_to_packed": {"what": "input.json texts -> packed rows in pinned memory, pob_pack_json_batch on all host cores (bit-equal to the Python loader on a sample of this batch)",
                                           "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
-            "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "kernel_pipeline_only": bare, "single_witness_latency": latency,
-            "depth16": depth16, "strong_slice": strong_slice,
+            "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "tracks_pipeline": tracks_pipeline, "kernel_pipeline_only": bare, "single_witness_latency": latency,
+            "depth16": depth16, "strong_slice": strong_slice, "deeper_pipeline": deeper,
         }
         print(json.dumps(line))
     for c in calcs:

@@ -113,6 +113,15 @@ int pob_sync(pob_handle h);
  * symmetric (one call links both handles and drops their previous links); partner = NULL unlinks; pob_close unlinks. */
 int pob_set_partner(pob_handle h, pob_handle partner);
 
+/* Schedule of a calculator (no counterpart in the reference, whose calculator runs one witness per process, Makefile:4-5).
+ * Default -- TRACKS: pob_generate / pob_constraint_check spread the circuit's independent parts over side streams of the device (lowest latency for ONE batch:
+ * what a lone calculator wants; pob_set_partner pipelines two of them).
+ * on = 1 -- IN ORDER: every launch of the calculator goes to the caller's stream, in dependency order, with no side stream and no event (a cross-stream hand-over
+ * costs 0.1-0.3 ms on this runtime, a dependent kernel boundary on one stream 1.5 us): the units of every track that are ready at the same depth of the stage graph
+ * leave in ONE launch per kernel class.  A batch takes longer by itself; a job that keeps several calculators in flight, each on a stream of its own (bench.py: 8),
+ * fills the machine with them instead: 1.8-2.2 ms per 1 024 production witnesses against 2.8 ms for the two-calculator track pipeline.                      */
+int pob_set_inorder(pob_handle h, int on);
+
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.
  * status[i] = 0 ok, else (template id << 12 | source line) of the first failing assert; outputs[i][32] = public
  * output (commitment) canonical LE.  check_status / bad_wire (may be NULL): result of pob_constraint_check:
@@ -174,6 +183,7 @@ int pob_emit_queue(pob_handle h, uint32_t next_idx);
  *     every IsZero [out | in | inv]:                 in * inv === 1 - out,   in * out === 0
  *     every IsEqual [out | in[2]] over an IsZero:    IsZero.in === in[1] - in[0],   out === IsZero.out
  *     SubstringCheck's M[]:                          M[i+1] === M[i] + mainInput[i] * 256^i
+ *     a derived copy of a STORED wire:               Pad.isEq[i] / isLast[i] / Selector.isEq[i] (stored) === the IsEqual child's out, its IsZero's out (derived)
  * enable = 1: every following O0 emission (pob_emit_begin / pob_emit_witness / pob_write_wtns; not the reduced form) is checked; the first one also
  * runs a recording pass that finds the sites.  pob_emit_selfcheck_result, called when the emission is complete: relations checked, relations skipped
  * because their wires straddle two windows, and the lowest wire whose relation does not hold (0xFFFFFFFF = none).  A witness emitted from a

@@ -251,6 +251,7 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
         const uint32_t i = lo + (ln >> 1), wh = ln & 1;
         p.run_derived(2 * cnt, cE.w + 6 * i + 3 * wh, runPairE);
         p.run_derived(2 * cnt, cL.w + 6 * i + 3 * wh, runPairL);
+        if constexpr (P::is_emit) { if (ln < 2 * cnt) { p.site_c(cE.w + 6 * i + 3 * wh, r.pad_isEq.w + i); p.site_c(cL.w + 6 * i + 3 * wh, r.pad_isLast.w + i); } }      // (self-check: isEq[i] <== IsEqual.out)
     }
     for (uint32_t h2 = 0; h2 < 2 && 8 * h2 < cnt; h2++) {      // Keccak's inBlocks (stored) and its five copies: Num2Bits(8).out, inBitsArray, Flatten in/out, inBits
         const uint32_t n = (cnt - 8 * h2 < 8 ? cnt - 8 * h2 : 8) * 8;

@@ -609,6 +609,7 @@ template <class P> GD void sel_range(P& p, const SelBlk& sb, SmRef src, uint32_t
         }
         p.run_put(n, sb.isEq.w + i0 + ln, sb.isEq.i + i0 + ln, runE);
         p.run_derived(2 * n, sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), runK);      // IsEqual.out / IsZero.out of child i: copies of isEq[i]
+        if constexpr (P::is_emit) { if (ln < 2 * n) p.site_c(sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), sb.isEq.w + i0 + (ln >> 1)); }
         if constexpr (P::is_emit) {
             for (uint32_t t = 0; t < n; t++) {
                 const uint32_t i = i0 + t;

@@ -106,6 +106,16 @@ __global__ void __launch_bounds__(64) k_selfcheck_z(const uint8_t* win, uint32_t
     }
     if (!ok) atomicMin(res, w);
 }
+// copy constraints a === b between a derived wire and the stored wire it must equal (pairs {higher wire, lower wire}; both inside the window)
+__global__ void __launch_bounds__(64) k_selfcheck_c(const uint8_t* win, uint32_t w0, const uint32_t* sites, uint32_t n, uint32_t* res) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t a = sites[2 * t], b = sites[2 * t + 1];
+    if (b < w0) { atomicAdd(res + 1, 1u); return; }                     // (the lower wire lies in the window before: skipped and counted)
+    const uint4* p = (const uint4*)(win + (size_t)(a - w0) * 32); const uint4* q = (const uint4*)(win + (size_t)(b - w0) * 32);
+    const uint4 x0 = p[0], x1 = p[1], y0 = q[0], y1 = q[1];
+    if (x0.x != y0.x || x0.y != y0.y || x0.z != y0.z || x0.w != y0.w || x1.x != y1.x || x1.y != y1.y || x1.z != y1.z || x1.w != y1.w) atomicMin(res, a);
+}
 __global__ void __launch_bounds__(64) k_selfcheck_m(const uint8_t* win, uint32_t w0, uint32_t wn, const uint32_t* sites, uint32_t n, const uint32_t* pow256, uint32_t* res) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -211,7 +221,7 @@ struct pob_ctx {
         // reduced witness (pob_emit_begin_reduced): the kept O0 wire indices (host copy for the run intersections), their bitmap and the
         // per-word rank on the device; map_id = 0: O0 payload.  total = wires of the payload being emitted (W or the kept count)
         // self-check (pob_emit_selfcheck): site tables (sorted by wire), built once per handle by a recording pass of the emitter; d_sc_res: {lowest violated wire, M sites skipped}
-        bool sc_on = false, sc_built = false; std::vector<uint32_t> sc_z, sc_m_next; uint32_t *d_sc_z = nullptr, *d_sc_m = nullptr, *d_sc_res = nullptr;
+        bool sc_on = false, sc_built = false; std::vector<uint32_t> sc_z, sc_m_next, sc_c_hi; uint32_t *d_sc_z = nullptr, *d_sc_m = nullptr, *d_sc_c = nullptr, *d_sc_res = nullptr;
         uint64_t sc_checked = 0, sc_skipped = 0;
         bool red = false; uint64_t map_id = 0, total = 0; std::vector<uint32_t> keep; unsigned long long* d_rbits = nullptr; uint32_t* d_rpre = nullptr;
     } em;
@@ -231,11 +241,20 @@ struct pob_ctx {
     struct Track { hipStream_t s_main = nullptr, s_heavy = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr, ev_end = nullptr; };
     Track tracks[Plan::MAX_TRACKS];
     uint32_t nperms = 0;
+    // IN-ORDER schedule (pob_set_inorder): the whole generation / evaluation of the calculator on the CALLER's stream, no side stream and no event; a job gets
+    // its concurrency from keeping several such calculators in flight, each on a stream of its own.  The stage graph is flattened into LEVELS (longest
+    // dependency path): every unit of a level, of whatever track, goes out in one launch per kernel class, then the level's sponges; the round expansion of
+    // every sponge is ONE launch at the end (nothing of the generation reads it).
+    bool inorder = false;
+    struct LSeg { uint32_t level, cls, first, count; };
+    std::vector<LSeg> lsegs;                            // generation launches in level order (cls: generation class; first / count into `order`)
+    struct LK { uint32_t level, sp_first, sp_count; };
+    std::vector<LK> lksegs;                             // sponge-chain launches per level
+    uint32_t nlevels = 0;
     bool generated = false; uint64_t gen_count = 0;
     // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
     // waits for the end of that evaluation; the evaluation then uses the pool's two evaluation streams
     pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
-    bool priv = false, serial = false; hipStream_t own_side[4] = {nullptr, nullptr, nullptr, nullptr};    // EXPERIMENT (POB_SCHED=private): this handle's own side streams, no gate between handles
     hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false, evaluated = false;
     // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
     hipStream_t s_upload = nullptr;                         // = the pool's upload stream
@@ -470,6 +489,46 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         if (sg.count) h->chk_segs.push_back(sg);
     }
 
+    {   // ---- levels of the in-order schedule.  G units of global stage sid = node (sid, G); its sponges = node (sid, K) one level later.
+        //      A stage depends on the stage before it in its track, on the stage its track forked after, and on the last stage of every track joined before it.
+        const uint32_t NS = (pl.max_stage / Plan::TRACK_STRIDE + 1) * Plan::TRACK_STRIDE;
+        std::vector<int> lvl_end(NS, 0), lvl_g(NS, 0);
+        std::vector<char> has_g(NS, 0), has_k(NS, 0);
+        for (const pob_ctx::Seg& sg : h->segs) has_g[sg.stage] = 1;
+        for (const pob_ctx::KSeg& ks : h->ksegs) has_k[ks.stage] = 1;
+        std::vector<int> track_end(Plan::MAX_TRACKS, 0);
+        // tracks in an order in which every fork parent and every joined track is complete when needed: a track is joined only by a lower-numbered track and
+        // forked from a lower-numbered one, so resolve iteratively until nothing changes (the graph is tiny)
+        for (int pass = 0; pass < (int)Plan::MAX_TRACKS + 2; pass++) {
+            for (uint32_t t = 0; t < std::max(pl.ntracks, 1u); t++) {
+                int cur = t ? lvl_end[pl.track_fork[t]] : 0;
+                for (uint32_t s2 = 0; s2 < Plan::TRACK_STRIDE; s2++) {
+                    const uint32_t sid = t * Plan::TRACK_STRIDE + s2;
+                    if (sid >= NS) break;
+                    for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) cur = std::max(cur, track_end[u]);
+                    if (has_g[sid]) { cur += 1; lvl_g[sid] = cur; }
+                    if (has_k[sid]) cur += 1;
+                    lvl_end[sid] = cur;
+                }
+                track_end[t] = cur;
+            }
+        }
+        int nlev = 0;
+        for (uint32_t sid = 0; sid < NS; sid++) nlev = std::max(nlev, lvl_end[sid]);
+        h->nlevels = (uint32_t)nlev;
+        for (int lv = 1; lv <= nlev; lv++) {
+            for (uint32_t cls = N_GEN_CLASSES; cls-- > 0;) {     // (the narrow BN254 / Poseidon launches of a level first: they are its long poles)
+                pob_ctx::LSeg ls{(uint32_t)lv, cls, (uint32_t)h->order.size(), 0};
+                for (const pob_ctx::Seg& sg : h->segs) if (sg.lds == cls && has_g[sg.stage] && lvl_g[sg.stage] == lv)
+                    for (uint32_t j = 0; j < sg.count; j++) h->order.push_back(h->order[sg.first + j]);
+                ls.count = (uint32_t)h->order.size() - ls.first;
+                std::stable_sort(h->order.begin() + ls.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
+                if (ls.count) h->lsegs.push_back(ls);
+            }
+            for (const pob_ctx::KSeg& ks : h->ksegs) if (lvl_end[ks.stage] == lv) h->lksegs.push_back({(uint32_t)lv, ks.sp_first, ks.sp_count});
+        }
+    }
+
     HIPC(hipSetDevice(device));
     // the side-track streams get dispatch priority: their few workgroups take the next free slots instead of queueing behind the
     // 30k workgroups of a Keccak expansion running on the caller's stream
@@ -501,14 +560,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     }
     h->stream2 = h->pool->stream2; h->stream_k = h->pool->stream_k;
     hipStream_t p_track1 = h->pool->track1, p_track2 = h->pool->track2;
-    { const char* e = getenv("POB_SCHED"); h->priv = e && !strcmp(e, "private"); }
-    if (h->priv) {
-        const char* ns = getenv("POB_SCHED_STREAMS"); int n = ns ? atoi(ns) : 4;
-        if (n == 0) { h->serial = true; n = 1; }                 // EXPERIMENT: everything on the caller's stream
-        for (int k = 0; k < 4; k++) { if (k < n) HIPC(hipStreamCreateWithPriority(&h->own_side[k], hipStreamNonBlocking, k == 1 ? prio_lo : prio_hi)); }
-        h->stream2 = h->own_side[0]; h->stream_k = n > 1 ? h->own_side[1] : h->own_side[0];
-        p_track1 = n > 2 ? h->own_side[2] : h->own_side[0]; p_track2 = n > 3 ? h->own_side[3] : p_track1;
-    }
     HIPC(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_g_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_k_done, hipEventDisableTiming));
@@ -587,7 +638,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_res};
+                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_c, h->em.d_sc_res};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -600,7 +651,6 @@ void pob_close(pob_handle h) {
     for (hipEvent_t e : h->ev_kchk) if (e) hipEventDestroy(e);
     if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
-    for (hipStream_t q : h->own_side) if (q) hipStreamDestroy(q);
     if (h->pool) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         StreamPool* P = h->pool;
@@ -689,6 +739,25 @@ int pob_generate(pob_handle h, void* stream_) {
     const uint32_t G = (h->n + 63) / 64;
     if (h->upload_pending) { HIPC(hipStreamWaitEvent(st, h->ev_upload, 0)); h->upload_pending = false; }
     h->rec_slot ^= 1;                                   // this batch's records go to the other pinned buffer: the previous batch's stay readable
+    if (h->inorder) {
+        GArgs A = gargs(h);
+        KArgs K = kargs(h);
+        launch_inputs(h, false, G, st);
+        size_t ki = 0;
+        for (uint32_t lv = 1; lv <= h->nlevels; lv++) {
+            for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) { A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st); }
+            for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
+        }
+        if (h->nperms) { K.first = 0; launch_k_rounds(K, false, h->nperms, G, st); }
+        HIPC(hipGetLastError());
+        HIPC(hipEventRecord(h->ev_g_done, st));
+        { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
+        HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
+        HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
+        h->generated = true; h->evaluated = false; h->gen_count++;
+        h->em.queued_idx = -1;
+        return POB_OK;
+    }
     // pipeline: this generation's latency-bound work starts with the partner's evaluation (= once the partner's generation is complete)
     // (starting ALL of them even earlier, beside the partner's expansion, was measured: no gain -- the chip-filling launches take from the
     //  expansion what they gain).  The first stage and the NARROW tracks forked after it (the burn-address / RLP / account chains: a few
@@ -697,9 +766,9 @@ int pob_generate(pob_handle h, void* stream_) {
     //  then enqueued AHEAD of the wide track 5, whose stream it normally shares: it moves to track 2's.
     // (a strictly PHASED schedule -- evaluation kernel alone | the G work of both batches | expansion alone -- was measured too: the evaluation
     //  kernel then runs at 0.77 of the HBM peak inside the step, but the G phase takes 5.3 ms by itself and the step 14.87 ms instead of 13.5)
-    const bool gate = !h->priv && h->partner && h->partner->gen_done_rec;
+    const bool gate = h->partner && h->partner->gen_done_rec;
     const bool gate_late = gate && h->plan.ntracks > 1;
-    auto track_stream = [&](uint32_t t) { return h->serial ? st : (t == 4 && h->partner && !h->priv) ? h->pool->track2 : h->tracks[t].s_main; };
+    auto track_stream = [&](uint32_t t) { return (t == 4 && h->partner) ? h->pool->track2 : h->tracks[t].s_main; };
     if (gate && !gate_late) HIPC(hipStreamWaitEvent(st, h->partner->ev_gen_done, 0));
     GArgs A = gargs(h);
     KArgs K = kargs(h);
@@ -707,10 +776,10 @@ int pob_generate(pob_handle h, void* stream_) {
     // one track: its stages in order; within a stage the BN254 / Poseidon units run on the track's second stream beside the light ones,
     // then the stage's Keccak sponges.  Tracks forked after a stage are enqueued completely (highest first) before the next stage, so every
     // event is recorded before anything waits on it.
-    const bool rounds_async = h->partner != nullptr || h->priv;          // the main track's round expansion leaves the track (pipeline mode)
+    const bool rounds_async = h->partner != nullptr;          // the main track's round expansion leaves the track (pipeline mode)
     std::vector<hipEvent_t> pending;
     std::function<int(uint32_t)> run_track = [&](uint32_t t) -> int {
-        hipStream_t sm = t ? track_stream(t) : st, sh = t ? track_stream(t) : h->serial ? st : h->stream2;
+        hipStream_t sm = t ? track_stream(t) : st, sh = t ? track_stream(t) : h->stream2;
         hipEvent_t ef = t ? h->tracks[t].ev_fork : h->ev_fork, ej = t ? h->tracks[t].ev_join : h->ev_join;
         for (uint32_t sid = t * Plan::TRACK_STRIDE; sid < (t + 1) * Plan::TRACK_STRIDE && sid <= pl.max_stage; sid++) {
             for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) HIPC(hipStreamWaitEvent(sm, h->tracks[u].ev_end, 0));
@@ -738,12 +807,12 @@ int pob_generate(pob_handle h, void* stream_) {
                 if (rounds_async && t == 0) {
                     // nothing in the generation reads a KeccakfRound block's wires (k_chain wrote every state a later stage uses): the
                     // main track's HBM-streaming expansion leaves the track here and is only joined before the results are collected
-                    HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->serial ? st : h->stream_k, h->ev_rounds_fork, 0));
+                    HIPC(hipEventRecord(h->ev_rounds_fork, sk)); HIPC(hipStreamWaitEvent(h->stream_k, h->ev_rounds_fork, 0));
                     // pipeline: the write-saturating expansion does not run beside the partner's evaluation, it follows it -- IN ORDER on the
                     // device's one streaming stream, where the partner's Keccak evaluation was enqueued before (pob_constraint_check): the two
                     // HBM-saturating kernels of the two batches alternate on one hardware queue without an event hand-over between them
                     // (0.3 ms per phase change when the evaluation ran on the caller's stream and the expansion waited for its end through an event)
-                    sk = h->serial ? st : h->stream_k; pending.push_back(ks.ev_done);
+                    sk = h->stream_k; pending.push_back(ks.ev_done);
                 }
                 launch_k_rounds(K, false, ks.perm_count, G, sk);
                 HIPC(hipEventRecord(ks.ev_done, sk));
@@ -783,10 +852,29 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     // plan (30 configurations, profiles/round2_scheduling_experiments.txt): the Keccak evaluation after the families costs 8.1 ms per
     // pass, beside them 5.8; starting it before the END of the generation (per sponge segment, beside the generation's tail) gains
     // nothing -- the tail is latency-bound on the same memory system and stretches by what the evaluation saves.
+    if (h->inorder) {
+        // one stream: the Keccak round evaluation (the batch's one bandwidth-bound kernel) first, then the sponge chains, the inputs and the eight families
+        // (the round evaluation on a high-priority stream of the device, forked and joined per batch, was measured: 4 / 6 / 8 / 12 calculators in flight
+        //  2.39 / 2.04 / 1.91 / 2.14 ms per step against 2.19 / 2.09 / 1.87 / 2.07 here, the kernel 0.49-0.74 against 0.42-0.80 ms: nothing; removed)
+        if (!h->plan.sponges.empty()) {
+            KArgs K = kargs(h); K.first = 0;
+            if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
+            launch_k_rounds(K, true, h->nperms, G, st);
+            if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
+            launch_k_chain(K, true, h->nperms, G, st);
+        }
+        launch_inputs(h, true, G, st);
+        for (const pob_ctx::Seg& sg : h->chk_segs) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
+        HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true;
+        HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));
+        HIPC(hipGetLastError());
+        return POB_OK;
+    }
     static const uint32_t side_plan[2][5] = {{F_N2B, F_SC, F_LD, F_RANGE, F_GM}, {F_RL, F_POS, F_MISC, F_SELROW, F_COUNT}};      // (F_GM: gadget-level mains only; F_COUNT: no family)
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
-    hipStream_t side[2] = {h->serial ? st : (h->partner && !h->priv) ? h->pool->chk1 : h->stream2, h->serial ? st : (h->partner && !h->priv) ? h->pool->chk2 : h->stream3};
+    hipStream_t side[2] = {h->partner ? h->pool->chk1 : h->stream2, h->partner ? h->pool->chk2 : h->stream3};
     HIPC(hipEventRecord(h->ev_fork, st));
     for (int k = 0; k < 2; k++) {
         HIPC(hipStreamWaitEvent(side[k], h->ev_fork, 0));
@@ -800,14 +888,14 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // pipeline: on the device's streaming stream, directly behind this batch's round expansion (in order: no event between the two) and
         // ahead of the partner's next expansion; it needs the G side of the generation (its tail runs beside the expansion), not the
         // result collection on the caller's stream.  A lone handle: on the caller's stream.
-        hipStream_t sk = h->serial ? st : (h->partner || h->priv) ? h->stream_k : st;
+        hipStream_t sk = h->partner ? h->stream_k : st;
         if (sk != st) HIPC(hipStreamWaitEvent(sk, h->ev_g_done, 0));
         if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
         launch_k_rounds(K, true, h->nperms, G, sk);
         if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
         // (pipeline: the narrow sponge-chain evaluation -- 84 wavefronts per group, 0.18 ms -- on an evaluation stream beside the families, not in
         //  order between the two chip-filling kernels of the streaming stream, where the machine idled for its duration: -0.02 ms, three interleaved pairs)
-        launch_k_chain(K, true, h->nperms, G, (h->partner || h->priv) ? side[1] : sk);
+        launch_k_chain(K, true, h->nperms, G, h->partner ? side[1] : sk);
         if (sk != st) { HIPC(hipEventRecord(h->ev_k_done, sk)); HIPC(hipStreamWaitEvent(st, h->ev_k_done, 0)); }
     }
     HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
@@ -821,6 +909,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
 
 int pob_set_partner(pob_handle h, pob_handle partner) {
     if (!h || h == partner || (partner && partner->device != h->device)) return POB_E_ARG;
+    if (partner && (h->inorder || partner->inorder)) { h->err = "the two-calculator pipeline links calculators with the track schedule, not in-order ones"; return POB_E_STATE; }
     if (partner && hw_queues_env() < POB_PIPELINE_HW_QUEUES) {
         // ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two linked handles keep ~10 streams busy and a job with
         // more live streams than queues runs 30-150x slower (unrelated kernels serialise behind each other): refuse instead of crawling
@@ -832,6 +921,13 @@ int pob_set_partner(pob_handle h, pob_handle partner) {
     for (pob_handle q : {h, partner}) if (q && q->partner) { q->partner->partner = nullptr; q->partner = nullptr; }
     h->partner = partner; h->gen_done_rec = h->check_done_rec = false;
     if (partner) { partner->partner = h; partner->gen_done_rec = partner->check_done_rec = false; }
+    return POB_OK;
+}
+
+int pob_set_inorder(pob_handle h, int on) {
+    if (!h) return POB_E_ARG;
+    if (on && h->partner) { h->err = "an in-order calculator has no partner: unlink first (pob_set_partner(h, NULL))"; return POB_E_STATE; }
+    h->inorder = on != 0;
     return POB_OK;
 }
 
@@ -944,6 +1040,12 @@ static int emit_make_window(pob_ctx* h, uint32_t idx, uint64_t k, int slot) {
         const uint32_t* msites = E.d_sc_m + 3 * (ma - E.sc_m_next.begin()); const uint32_t* pw = h->d_pow256;
         if (nm) hipLaunchKernelGGL(k_selfcheck_m, dim3((nm + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, (uint32_t)wn, msites, nm, pw, res);
         E.sc_checked += nm;
+        // copy sites whose HIGHER wire lies in this window
+        const auto ca = std::lower_bound(E.sc_c_hi.begin(), E.sc_c_hi.end(), (uint32_t)w0), cb = std::lower_bound(ca, E.sc_c_hi.end(), (uint32_t)(w0 + wn));
+        const uint32_t ncs = (uint32_t)(cb - ca);
+        const uint32_t* csites = E.d_sc_c + 2 * (ca - E.sc_c_hi.begin());
+        if (ncs) hipLaunchKernelGGL(k_selfcheck_c, dim3((ncs + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, csites, ncs, res);
+        E.sc_checked += ncs;
     }
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(E.ev_made[slot], st));
@@ -1054,9 +1156,9 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         // site-recording pass: every emitting unit once with EmitP::sites set (nothing is written); the sites are layout constants of the handle
         const uint32_t cap = std::max(h->plan.total.q, 1u);
         uint32_t* d_rec = nullptr;
-        const size_t words = 2 + (size_t)cap + 3 * (size_t)cap;
+        const size_t words = 4 + (size_t)cap + 3 * (size_t)cap + 2 * (size_t)cap;
         HIPC(hipMalloc(&d_rec, words * 4));
-        HIPC(hipMemsetAsync(d_rec, 0, 8, own_stream(h)));
+        HIPC(hipMemsetAsync(d_rec, 0, 16, own_stream(h)));
         GArgs A = gargs(h);
         A.emit_sel = idx % 64; A.emit_group = idx / 64; A.emit_w0 = 0; A.emit_wn = (uint32_t)E.total; A.emit_out = nullptr; A.emit_sites = d_rec; A.emit_sites_cap = cap;
         for (const pob_ctx::Seg& sg : h->emit_segs) { A.first = sg.first; launch_g_emit(A, sg.lds, sg.count, own_stream(h)); }
@@ -1065,14 +1167,21 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         HIPC(hipMemcpyAsync(rec.data(), d_rec, words * 4, hipMemcpyDeviceToHost, own_stream(h)));
         HIPC(hipStreamSynchronize(own_stream(h)));
         HIPC(hipFree(d_rec));
-        if (rec[0] > cap || rec[1] > cap) { h->err = "internal: more self-check sites than derived wires"; return POB_E_STATE; }
-        E.sc_z.assign(rec.begin() + 2, rec.begin() + 2 + rec[0]);
+        if (rec[0] > cap || rec[1] > cap || rec[2] > cap) { h->err = "internal: more self-check sites than derived wires"; return POB_E_STATE; }
+        E.sc_z.assign(rec.begin() + 4, rec.begin() + 4 + rec[0]);
         std::sort(E.sc_z.begin(), E.sc_z.end(), [](uint32_t a, uint32_t b) { return (a & 0x7FFFFFFFu) < (b & 0x7FFFFFFFu); });
         std::vector<std::array<uint32_t, 3>> ms(rec[1]);
-        for (uint32_t i = 0; i < rec[1]; i++) for (int j = 0; j < 3; j++) ms[i][j] = rec[2 + (size_t)cap + 3 * (size_t)i + j];
+        for (uint32_t i = 0; i < rec[1]; i++) for (int j = 0; j < 3; j++) ms[i][j] = rec[4 + (size_t)cap + 3 * (size_t)i + j];
         std::sort(ms.begin(), ms.end());
         E.sc_m_next.resize(ms.size());
         for (size_t i = 0; i < ms.size(); i++) E.sc_m_next[i] = ms[i][0];
+        std::vector<std::array<uint32_t, 2>> cs(rec[2]);
+        for (uint32_t i = 0; i < rec[2]; i++) for (int j = 0; j < 2; j++) cs[i][j] = rec[4 + 4 * (size_t)cap + 2 * (size_t)i + j];
+        std::sort(cs.begin(), cs.end());
+        E.sc_c_hi.resize(cs.size());
+        for (size_t i = 0; i < cs.size(); i++) E.sc_c_hi[i] = cs[i][0];
+        HIPC(hipMalloc(&E.d_sc_c, std::max<size_t>(cs.size(), 1) * 8));
+        if (!cs.empty()) HIPC(hipMemcpy(E.d_sc_c, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
         HIPC(hipMalloc(&E.d_sc_z, std::max<size_t>(E.sc_z.size(), 1) * 4)); HIPC(hipMalloc(&E.d_sc_m, std::max<size_t>(ms.size(), 1) * 12)); HIPC(hipMalloc(&E.d_sc_res, 8));
         if (!E.sc_z.empty()) HIPC(hipMemcpy(E.d_sc_z, E.sc_z.data(), E.sc_z.size() * 4, hipMemcpyHostToDevice));
         if (!ms.empty()) HIPC(hipMemcpy(E.d_sc_m, ms.data(), ms.size() * 12, hipMemcpyHostToDevice));
@@ -1182,7 +1291,7 @@ int pob_emit_selfcheck_result(pob_handle h, uint64_t* checked, uint64_t* skipped
     HIPC(hipStreamSynchronize(own_stream(h)));
     uint32_t res[2];
     HIPC(hipMemcpy(res, E.d_sc_res, 8, hipMemcpyDeviceToHost));
-    const uint64_t all = E.sc_z.size() + E.sc_m_next.size();
+    const uint64_t all = E.sc_z.size() + E.sc_m_next.size() + E.sc_c_hi.size();
     if (checked) *checked = E.sc_checked - res[1];
     if (skipped) *skipped = all - (E.sc_checked - res[1]);
     if (first_bad_wire) *first_bad_wire = res[0];

@@ -108,6 +108,7 @@ struct CountP : PolBase {
     HD void derived_fr(uint32_t, const F&) {}     // ... with a field-element value (Montgomery) / the field inverse of x (0 for 0)
     HD void derived_fr_inv(uint32_t, const F&) {}
     HD void site_m(uint32_t, uint32_t, uint32_t) {}         // self-check site of SubstringCheck's M[] recurrence (EmitP)
+    HD void site_c(uint32_t, uint32_t) {}                   // self-check site of a copy constraint a === b between a derived wire and the stored wire it must equal
     HD F get(FrRef) { return fr_zero(); }
     HD void raw_put(FrRef, const F&) {}
     HD B ballot(bool) { return 0; }
@@ -285,6 +286,7 @@ struct DevPol : PolBase {
     __device__ __forceinline__ void derived(uint32_t, S) {}
     __device__ __forceinline__ void derived_inv(uint32_t, S, bool = false) {}
     __device__ __forceinline__ void site_m(uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void site_c(uint32_t, uint32_t) {}
     __device__ __forceinline__ void derived_fr(uint32_t, const F&) {}
     __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&) {}
     __device__ __forceinline__ void run_derived(uint32_t, uint32_t, B) {}
@@ -438,14 +440,18 @@ struct EmitP : DevPol {
     // SELF-CHECK (pob_emit_selfcheck): the relations of the derived wires are evaluated on the values WRITTEN INTO THE WINDOW by a kernel that
     // re-reads them (pob_host.hip k_selfcheck_*).  Where those relations live is found once per handle by a site-recording pass: `sites` non-null
     // = nothing is written, every IsZero.inv wire (the calls of w32 that carry a path) appends its gadget's first wire -- IsZero [out | in | inv],
-    // bit 31: child of an IsEqual [out | in[2]] -- to sites[2 ..], every step of SubstringCheck's M[] recurrence a triple behind them.
+    // bit 31: child of an IsEqual [out | in[2]] -- to sites[4 ..], every step of SubstringCheck's M[] recurrence a triple behind them, every copy constraint
+    // between a derived wire and a STORED one (an IsEqual child's outputs === the parent's stored isEq[] bit) a pair behind those.  sites[0..2] = the three counts.
     // path: 0..3 = the inverse path counted, | 4 = IsEqual parent.
     uint32_t* sites; uint32_t sites_cap;
     __device__ __forceinline__ void site_m(uint32_t w_next, uint32_t w_byte, uint32_t k) {      // M[k+1] (wire w_next) === M[k] (w_next - 1) + mainInput[k] (w_byte) * 256^k
-        if (sites && m.lane == sel) { const uint32_t i = atomicAdd(sites + 1, 1u); if (i < sites_cap) { uint32_t* q = sites + 2 + sites_cap + 3 * (size_t)i; q[0] = w_next; q[1] = w_byte; q[2] = k; } }
+        if (sites && m.lane == sel) { const uint32_t i = atomicAdd(sites + 1, 1u); if (i < sites_cap) { uint32_t* q = sites + 4 + sites_cap + 3 * (size_t)i; q[0] = w_next; q[1] = w_byte; q[2] = k; } }
+    }
+    __device__ __forceinline__ void site_c(uint32_t w, uint32_t src) {              // wire w === wire src  (one lane calls)
+        if (sites) { const uint32_t i = atomicAdd(sites + 2, 1u); if (i < sites_cap) { uint32_t* q = sites + 4 + 4 * (size_t)sites_cap + 2 * (size_t)i; q[0] = w > src ? w : src; q[1] = w > src ? src : w; } }
     }
     __device__ __forceinline__ void w32(uint32_t w, const F& canon, int path = -1) {
-        if (sites) { if (path >= 0) { const uint32_t i = atomicAdd(sites, 1u); if (i < sites_cap) sites[2 + i] = (w - 2) | ((path & 4) ? 0x80000000u : 0u); } return; }
+        if (sites) { if (path >= 0) { const uint32_t i = atomicAdd(sites, 1u); if (i < sites_cap) sites[4 + i] = (w - 2) | ((path & 4) ? 0x80000000u : 0u); } return; }
         if (rbits) {
             const unsigned long long word = rbits[w >> 6];
             if (!((word >> (w & 63)) & 1)) return;

@@ -177,6 +177,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.pob_debug_emit_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.pob_emit_selfcheck.argtypes = [vp, ctypes.c_int]
+    lib.pob_set_inorder.argtypes = [vp, ctypes.c_int]
     lib.pob_emit_selfcheck_result.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     lib.pob_debug_fr_inv.argtypes = [ctypes.c_int, vp, ctypes.c_uint32, vp, vp]
     lib.pob_debug_ref.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
@@ -193,7 +194,7 @@ def load_library() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_result", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -611,6 +612,10 @@ class WitnessCalculator:
                 return
             buf = (ctypes.c_uint8 * (32 * wn.value)).from_address(p.value)
             yield w0.value, np.frombuffer(buf, dtype=np.uint8)
+
+    def set_inorder(self, on: bool = True):
+        """every launch of this calculator on the caller's stream, in dependency order, no side streams (pob_set_inorder): for jobs that keep several calculators in flight"""
+        self._ck(self.lib.pob_set_inorder(self.h, 1 if on else 0))
 
     def emit_selfcheck(self, enable: bool = True):
         """every following O0 emission evaluates the derived wires' own relations on the values written into its windows (pob_emit_selfcheck)"""

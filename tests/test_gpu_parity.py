@@ -1,6 +1,7 @@
 """GPU parity tests (run on the MI355X: `pytest -m gpu`).  Everything goes through the C ABI (libpob_hip.so);
 the CPU oracle is only the checker.  Bit-exact bar: public outputs, failure sets and the FULL canonical witness
 payload (every one of the W 32-byte wires) must equal the oracle's."""
+import ctypes
 import json
 import os
 
@@ -540,7 +541,7 @@ def test_emit_selfcheck_on_written_values(pkg):
     calc.emit_selfcheck(True)
     assert np.array_equal(calc.witness_payload(n - 1), ref)
     r = calc.emit_selfcheck_result()
-    assert r["first_bad_wire"] is None and r["checked"] > 300_000 and r["skipped"] < 100, r
+    assert r["first_bad_wire"] is None and r["checked"] > 200_000 and r["skipped"] < 100, r
     print("self-check of one production witness:", r)
     for kb in (0, 3):
         cls, idx, wire = calc.debug_ref("kb.inLen", kb)
@@ -551,6 +552,41 @@ def test_emit_selfcheck_on_written_values(pkg):
         assert not np.array_equal(got, ref) and r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 200_000, (kb, wire, r)
     assert np.array_equal(calc.witness_payload(n - 1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
     calc.close()
+
+
+def test_inorder_schedule_equals_the_track_schedule(pkg):
+    """pob_set_inorder on the GPU, production instantiation: 130 witnesses (three groups) generated and evaluated in dependency order on ONE stream, twice
+    over; every record equals the track schedule's, the whole payload of a witness of group 2 equals the oracle's, and four in-order calculators driven
+    round-robin on four streams (the bench's service loop in small) agree with it batch by batch"""
+    import torch
+    from proof_of_burn_amd import inputs as gen
+    n = 130
+    batches = [gen.synthetic_batch(n, depth=10, seed=0x10 + k, distinct_keys=2) for k in range(3)]
+    ref = pkg.WitnessCalculator(PROD, max_batch=n)
+    want = []
+    for bt in batches:
+        res = ref.calculate(bt.inputs, check=True)
+        assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res) and [r.outputs[0] for r in res] == bt.commitments
+        want.append([(r.status, r.outputs, r.check_status, r.bad_wire) for r in res])
+    ref.close()
+    calcs = [pkg.WitnessCalculator(PROD, max_batch=n) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in calcs]
+    for c in calcs:
+        c.set_inorder(True)
+    for rnd in range(2):
+        for k, c in enumerate(calcs):
+            c.upload(batches[(k + rnd) % 3].inputs)
+            c.generate(streams[k].cuda_stream)
+            c.constraint_check(streams[k].cuda_stream)
+        for k, c in enumerate(calcs):
+            got = [(r.status, r.outputs, r.check_status, r.bad_wire) for r in c.results(with_check=True)]
+            assert got == want[(k + rnd) % 3], (rnd, k)
+    ora = O.run(PROD, batches[0].inputs[n - 1])
+    idx0 = next(k for k in range(4) if (k + 1) % 3 == 0)         # the calculator that holds batch 0 after round 1
+    gpu = calcs[idx0].witness_payload(n - 1)
+    assert np.array_equal(gpu, ora.witness_numpy()), f"first differing wire {_first_diff(gpu, ora.witness_numpy())}"
+    for c in calcs:
+        c.close()
 
 
 def test_device_field_inversions(pkg):

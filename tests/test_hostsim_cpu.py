@@ -425,3 +425,32 @@ def test_emit_selfcheck_on_written_values(pkg):
     assert np.array_equal(calc.witness_payload(1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
     calc.emit_selfcheck(False)
     calc.close()
+
+
+def test_inorder_schedule_equals_the_track_schedule(pkg):
+    """pob_set_inorder: the calculator's whole generation and evaluation in dependency order on ONE stream (the units of every track that are ready at the same depth
+    of the stage graph in one launch per kernel class).  The shim executes launches one after the other in enqueue order -- which is exactly what an in-order stream
+    does -- so a level that ran ahead of something it reads would show here: reference outputs, evaluator clean, payload == the oracle's, for Spend(31), the fixture
+    instantiation (all tracks) and a Keccak gadget main"""
+    for main, suite in (("Spend(31)", "test_spend"), (POB_FIX, "test_proof_of_burn")):
+        s = _suite(suite)
+        calc = pkg.WitnessCalculator(main, max_batch=8)
+        calc.set_inorder(True)
+        for rnd in range(2):                                # (twice: the second batch reuses every buffer)
+            res = calc.calculate([c["input"] for c in s["cases"]], check=True)
+            assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
+            assert all(r.check_status == 0 and r.bad_wire is None for r in res if r.ok)
+        i = next(k for k, r in enumerate(res) if r.ok)
+        assert np.array_equal(calc.witness_payload(i), O.run(main, s["cases"][i]["input"]).witness_numpy())
+        calc.set_inorder(False)
+        res2 = calc.calculate([c["input"] for c in s["cases"]], check=True)
+        assert [(r.status, r.outputs, r.check_status, r.bad_wire) for r in res2] == [(r.status, r.outputs, r.check_status, r.bad_wire) for r in res]
+        calc.close()
+    from tests import gadget_cases as GC
+    by_name = {s["main"]: s for s in GC.gadget_suites()}
+    s = by_name["PublicCommitment(2)"] if "PublicCommitment(2)" in by_name else next(v for k, v in by_name.items() if k.startswith("PublicCommitment"))
+    calc = pkg.WitnessCalculator(s["main"], max_batch=len(s["cases"]))
+    calc.set_inorder(True)
+    res = calc.calculate([c["input"] for c in s["cases"]], check=True)
+    assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
+    calc.close()
