@@ -527,6 +527,16 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             }
             for (const pob_ctx::KSeg& ks : h->ksegs) if (lvl_end[ks.stage] == lv) h->lksegs.push_back({(uint32_t)lv, ks.sp_first, ks.sp_count});
         }
+        if (getenv("POB_DEBUG_LEVELS")) {       // (diagnostic: the in-order launch list with the unit kinds of every launch)
+            for (const pob_ctx::LSeg& ls : h->lsegs) {
+                fprintf(stderr, "level %2u class %u: %5u units:", ls.level, ls.cls, ls.count);
+                std::vector<uint32_t> kinds(U_KIND_COUNT, 0);
+                for (uint32_t j = 0; j < ls.count; j++) kinds[pl.units[h->order[ls.first + j]].kind]++;
+                for (uint32_t k = 0; k < U_KIND_COUNT; k++) if (kinds[k]) fprintf(stderr, " %u x kind %u", kinds[k], k);
+                fprintf(stderr, "\n");
+            }
+            for (const pob_ctx::LK& lk : h->lksegs) fprintf(stderr, "level %2u sponges: %u (first %u)\n", lk.level, lk.sp_count, lk.sp_first);
+        }
     }
 
     HIPC(hipSetDevice(device));
