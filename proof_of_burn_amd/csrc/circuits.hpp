@@ -40,7 +40,7 @@ enum UnitKind : uint32_t {
     // evaluator-only units (UNIT_CHECK): sub-blocks of composite units run as wavefronts of their own, from STORED wires
     U_SC_MI,             // SubstringCheck(a0).mainInput / mainLen copies (inputs only: runs on the pre-work track)
     CK_POS_SEG,          // a0 = T, a1 = segment (>= 1) of the Poseidon block at cur (gadgets.hpp gPoseidonSegStored)
-    CK_SR_COLS,          // columns [a2, a3) of temps[][] of the ShiftRight(a0, a1) block at cur (gadgets.hpp gShiftRightCols)
+    CK_SR_COLS,          // (rounds 2-3: columns of ShiftRight's stored temps[][]; they are derived wires now -- the kind is never planned, the number stays)
     CK_SL_ROWS,          // rows [a1, a2) of the ShiftLeft(a0) block at cur, IsEqual children from cursor (a3, a4, a5) on (gShiftLeftRows)
     CK_N2BE,             // Num2BigEndianBytes(a0) at cur; a1,a2 = source FR wire; a3,a4,a5 = caller's copy of out[] (w, i, present);
                          // also a GENERATION unit (same stage as its composite): a6,a7 = a wire of an earlier stage with the source's value
@@ -561,7 +561,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         S q, r;
         gDivide(p, 7, nibLen, (S)2, q, r);
         p.put(R.t_dv, q); p.put(R.t_rm, r);
-        R.s_o = p.sms(n2); R.s_in = p.sms(n2); R.s_cn = p.sms(1); R.s_isEq = p.bits(n2 * n2); R.s_temp = p.sms(n2 * n2);
+        R.s_o = p.sms(n2); R.s_in = p.sms(n2); R.s_cn = p.sms(1); R.s_isEq = p.bits(n2 * n2); R.s_temp = SmRef{p.dvs(n2 * n2), NO_RANK};      // (temp[][]: derived)
         copy_n(p, R.s_in, M.addressHashNibbles, (int)(n2));
         S count = p.put(R.s_cn, n2 - nibLen);
         gAssertLessEqThanS(p, 16, count, (S)n2);
@@ -579,7 +579,9 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             p.cur = cur_add(R.c_sl_iseq, FP_ISEQ_S, i * n);
             for (uint32_t j = 0; j < n; j++) {
                 B e = p.put(R.s_isEq + (i * n + j), gIsEqualS(p, (S)i, (S)((S)j - count)));
-                acc += p.put(R.s_temp + (i * n + j), p.bit(e) ? p.get(M.addressHashNibbles + j) : 0);
+                const S tv = p.bit(e) ? p.get(M.addressHashNibbles + j) : 0;
+                p.derived(R.s_temp.w + i * n + j, tv);
+                acc += tv;
             }
             p.put(R.s_o + i, acc);
         }
@@ -932,9 +934,6 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         else if (d.a[0] == 4) gPoseidonSegStored<P, 4>(p, pos_off(4), d.cur, d.a[1]);
         else gPoseidonSegStored<P, 5>(p, pos_off(5), d.cur, d.a[1]);
     } break;
-    UCASE(CK_SR_COLS) {
-        if constexpr (P::is_check || P::is_count) gShiftRightCols(p, (int)d.a[0], (int)d.a[1], d.cur, d.a[2], d.a[3]);
-    } break;
     UCASE(CK_SL_ROWS) {
         if constexpr (P::is_check || P::is_count) gShiftLeftRows(p, (int)d.a[0], d.cur, Cur{d.a[3], d.a[4], d.a[5], d.cur.f, d.cur.q}, d.a[1], d.a[2]);
     } break;
@@ -1008,7 +1007,6 @@ struct Plan {
                 if (stage % TRACK_STRIDE == 0) throw std::runtime_error("layout planner: a Poseidon composite needs a stage before it");
                 record(U_POS_WIDE, stage - 1, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4], nt.a[5]);
             } else if (nt.what == NOTE_N2BE) record(CK_N2BE, stage, nt.cur, nt.n, nt.a[0], nt.a[1], nt.a[2], nt.a[3], nt.a[4], nt.a[5], nt.a[6]);
-            else if (nt.what == NOTE_SHIFTRIGHT) { for (uint32_t j = 0; j < nt.n; j += 8) record(CK_SR_COLS, stage, nt.cur, nt.n, nt.a[0], j, std::min(j + 8, nt.n)); }
             else if (nt.what == NOTE_SHIFTLEFT) { for (uint32_t i = 0; i < nt.n; i += 2) record(CK_SL_ROWS, stage, nt.cur, nt.n, i, std::min(i + 2, nt.n), nt.a[0], nt.a[1], nt.a[2]); }
         }
         q.nnotes = 0;

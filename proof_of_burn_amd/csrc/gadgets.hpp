@@ -653,7 +653,7 @@ template <class P> GD SmRef gSelectorArray1D(P& p, int n, int q, SmRef src, S se
 // block) as CK_SL_ROWS units of their own and the composite only steps over them
 template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count, bool split = false) {
     const Cur blk = p.cur;
-    SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(n * n); SmRef temp = p.sms(n * n);
+    SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(n * n); const uint32_t temp_w = p.dvs(n * n);      // temp[i][j] = isEq[i][j] * in[j]: DERIVED (round 4)
     count = p.put(cn, count);
     copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)n);
@@ -665,7 +665,9 @@ template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count, bool spl
         S acc = 0;
         for (int j = 0; j < n; j++) {
             B e = p.put(isEq + (i * n + j), gIsEqualS(p, (S)i, (S)(j - count)));
-            acc += p.put(temp + (i * n + j), p.bit(e) ? p.get(in + j) : 0);
+            const S tv = p.bit(e) ? p.get(in + j) : 0;
+            p.derived(temp_w + (uint32_t)(i * n + j), tv);
+            acc += tv;
         }
         p.put(o + i, acc);
     }
@@ -674,14 +676,16 @@ template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count, bool spl
 // rows [i0, i1) of the ShiftLeft(n) block at `blk` (IsEqual children from `ciseq` on), from the stored count / in[]
 template <class P> GD void gShiftLeftRows(P& p, int n, Cur blk, Cur ciseq, uint32_t i0, uint32_t i1) {
     const SmRef o = {blk.w, blk.s}, in = o + (uint32_t)n, cn = in + (uint32_t)n;
-    const BitRef isEq = {cn.w + 1, blk.b}; const SmRef temp = {isEq.w + (uint32_t)(n * n), cn.i + 1};
+    const BitRef isEq = {cn.w + 1, blk.b}; const uint32_t temp_w = isEq.w + (uint32_t)(n * n);
     const S count = p.get(cn);
     for (uint32_t i = i0; i < i1; i++) {
         S acc = 0;
         p.cur = cur_add(ciseq, FP_ISEQ_S_, i * (uint32_t)n);
         for (uint32_t j = 0; j < (uint32_t)n; j++) {
             B e = p.put(isEq + (i * n + j), gIsEqualS(p, (S)i, (S)((S)j - count)));
-            acc += p.put(temp + (i * n + j), p.bit(e) ? p.get(in + j) : 0);
+            const S tv = p.bit(e) ? p.get(in + j) : 0;
+            p.derived(temp_w + i * (uint32_t)n + j, tv);
+            acc += tv;
         }
         p.put(o + i, acc);
     }
@@ -690,14 +694,14 @@ template <class P> GD void gShiftLeftRows(P& p, int n, Cur blk, Cur ciseq, uint3
 // `split`: the caller is a composite unit of the device plan -- the evaluator runs the (ms+1) x n temps[][] (almost all of the block) as
 // CK_SR_COLS units of their own
 template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count, bool split = false) {
-    if constexpr (P::is_count) { if (split) p.note(NOTE_SHIFTRIGHT, (uint32_t)n, p.cur, (uint32_t)ms); }
-    SmRef o = p.sms(n + ms), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(ms + 1); SmRef temps = p.sms((ms + 1) * n);
+    (void)split;       // (rounds 2-3: the evaluator ran the stored temps[][] as CK_SR_COLS units of their own; round 4: temps[i][j] = isEq[i] * in[j] are DERIVED wires, nothing to evaluate)
+    SmRef o = p.sms(n + ms), in = p.sms(n), cn = p.sms(1); BitRef isEq = p.bits(ms + 1); const uint32_t temps_w = p.dvs((ms + 1) * n);
     count = p.put(cn, count);
     copy_n(p, in, src, (int)(n));
     gAssertLessEqThanS(p, 16, count, (S)ms);
     for (int i = 0; i <= ms; i++) p.put(isEq + i, gIsEqualS(p, (S)i, count));      // isEq[i] = [i == count]
-    // temps[i][j] = isEq[i] * in[j]: each in[j] is read once (not once per i), the column is written without reading anything back
-    if (!(P::is_check && split)) {
+    // temps[i][j] = isEq[i] * in[j]: the emitter rebuilds the (ms + 1) x n products from the stored count and bytes
+    if constexpr (P::is_emit) {
         for (int j0 = 0; j0 < n; j0 += 8) {
             S v[8];
 #pragma unroll
@@ -705,7 +709,7 @@ template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count,
             for (int i = 0; i <= ms; i++) {
                 const bool hit = (uint32_t)i == (uint32_t)count;
 #pragma unroll
-                for (int q = 0; q < 8; q++) if (j0 + q < n) p.put(temps + (uint32_t)(i * n + j0 + q), hit ? v[q] : 0);
+                for (int q = 0; q < 8; q++) if (j0 + q < n) p.derived(temps_w + (uint32_t)(i * n + j0 + q), hit ? v[q] : 0);
             }
         }
     }
@@ -724,23 +728,6 @@ template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count,
         for (int q = 0; q < 8; q++) if (t0 + q < n + ms) p.put(o + (uint32_t)(t0 + q), v[q]);
     }
     return o;
-}
-// columns [j0, j1) of temps[][] of the ShiftRight(n, ms) block at `blk`: temps[i][j] == isEq[i] * in[j] on the STORED isEq[] / in[]
-template <class P> GD void gShiftRightCols(P& p, int n, int ms, Cur blk, uint32_t j0, uint32_t j1) {
-    const SmRef o = {blk.w, blk.s}, in = o + (uint32_t)(n + ms), cn = in + (uint32_t)n;
-    const BitRef isEq = {cn.w + 1, blk.b}; const SmRef temps = {isEq.w + (uint32_t)(ms + 1), cn.i + 1};
-    uint64_t hits = 0;                                   // bit i: isEq[i] of this lane's witness (ms + 1 <= 64)
-    for (int i = 0; i <= ms; i++) hits |= (uint64_t)p.bit(p.get(isEq + (uint32_t)i)) << i;
-    for (uint32_t c0 = j0; c0 < j1; c0 += 8) {
-        S v[8];
-#pragma unroll
-        for (uint32_t q = 0; q < 8; q++) v[q] = p.get(in + (c0 + q < j1 ? c0 + q : j1 - 1));
-        for (int i = 0; i <= ms; i++) {
-            const bool hit = (hits >> i) & 1;
-#pragma unroll
-            for (uint32_t q = 0; q < 8; q++) if (c0 + q < j1) p.put(temps + ((uint32_t)i * (uint32_t)n + c0 + q), hit ? v[q] : 0);
-        }
-    }
 }
 // Mask(n) :18-30  [out[n] | in[n], count | filter[n]] || Filter(n)
 template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {

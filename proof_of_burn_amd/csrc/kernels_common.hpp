@@ -40,6 +40,8 @@ void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipSt
 void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_pos_wide(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_n2b(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_g_gen_all(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);       // light | BN254 | SubstringCheck units in one kernel (in-order calculators)
+void launch_g_check_narrow(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);  // MISC | RL | POS | N2B evaluation families in one kernel (in-order calculators)
 void launch_g_check_misc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_range(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_selrow(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);

@@ -247,6 +247,7 @@ struct pob_ctx {
     // every sponge is ONE launch at the end (nothing of the generation reads it).
     bool inorder = false;
     struct LSeg { uint32_t level, cls, first, count; };
+    Seg chk_narrow{0, 0, 0, 0};                          // in-order evaluation: the units of the four narrow families, one launch
     std::vector<LSeg> lsegs;                            // generation launches in level order (cls: generation class; first / count into `order`)
     struct LK { uint32_t level, sp_first, sp_count; };
     std::vector<LK> lksegs;                             // sponge-chain launches per level
@@ -295,12 +296,14 @@ static hipStream_t own_stream(pob_ctx* h);      // the handle's own stream (call
 // 3 = SubstringCheck BN254, 4 = Poseidon blocks with the state spread over lanes (poseidon_wide.hpp)
 // 5 = gadget-level mains (gadget_mains.hpp)
 #define N_GEN_CLASSES 6
+#define CLS_ALL 6          // in-order calculators: classes 0, 1 and 3 of a level in one launch (g_gen_all.hip)
 static uint32_t unit_class(uint32_t kind, bool gen = false) { return fam_of(kind) == F_GM ? 5 : kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : (gen ? unit_gen_is_heavy(kind) : unit_is_heavy(kind)) ? 1 : 0; }
 static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
     if (cls == 5) launch_g_gen_gm(A, nunits, ngroups, st);
     else if (cls == 4) launch_pos_wide(A, nunits, ngroups, st);
     else if (cls == 3) launch_g_gen_sc(A, nunits, ngroups, st);
     else if (cls == 1) launch_g_gen_n2b(A, nunits, ngroups, st);
+    else if (cls == CLS_ALL) launch_g_gen_all(A, nunits, ngroups, st);
     else launch_g_gen_light(A, nunits, ngroups, st);
 }
 static void launch_g_check(const GArgs& A, uint32_t fam, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
@@ -517,9 +520,11 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         for (uint32_t sid = 0; sid < NS; sid++) nlev = std::max(nlev, lvl_end[sid]);
         h->nlevels = (uint32_t)nlev;
         for (int lv = 1; lv <= nlev; lv++) {
-            for (uint32_t cls = N_GEN_CLASSES; cls-- > 0;) {     // (the narrow BN254 / Poseidon launches of a level first: they are its long poles)
+            // (one launch per class -- BN254 | SubstringCheck | light -- instead of the merged one: 2.24 ms per step against 2.04 with 4 calculators in flight, 1.83 against 1.72
+            //  with 8, two interleaved pairs on one box: profiles/round4_experiments.txt 10)
+            for (uint32_t cls : {4u, 5u, (uint32_t)CLS_ALL}) {     // the lane-spread Poseidon blocks (a level's longest pole) first, gadget mains, then EVERYTHING else in one launch
                 pob_ctx::LSeg ls{(uint32_t)lv, cls, (uint32_t)h->order.size(), 0};
-                for (const pob_ctx::Seg& sg : h->segs) if (sg.lds == cls && has_g[sg.stage] && lvl_g[sg.stage] == lv)
+                for (const pob_ctx::Seg& sg : h->segs) if ((cls == CLS_ALL ? (sg.lds == 0 || sg.lds == 1 || sg.lds == 3) : sg.lds == cls) && has_g[sg.stage] && lvl_g[sg.stage] == lv)
                     for (uint32_t j = 0; j < sg.count; j++) h->order.push_back(h->order[sg.first + j]);
                 ls.count = (uint32_t)h->order.size() - ls.first;
                 std::stable_sort(h->order.begin() + ls.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
@@ -537,6 +542,16 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             }
             for (const pob_ctx::LK& lk : h->lksegs) fprintf(stderr, "level %2u sponges: %u (first %u)\n", lk.level, lk.sp_count, lk.sp_first);
         }
+    }
+
+    {   // in-order evaluation: the four narrow families as ONE launch (g_check_narrow.hip), the wide ones (RANGE, SELROW, LD, SC) and the gadget mains as they are
+        h->chk_narrow = pob_ctx::Seg{0, 0, (uint32_t)h->order.size(), 0};
+        for (uint32_t u = 0; u < pl.units.size(); u++) {
+            const uint32_t f = fam_of(pl.units[u].kind);
+            if ((pl.units[u].flags & UNIT_CHECK) && (f == F_MISC || f == F_RL || f == F_POS || f == F_N2B)) h->order.push_back(u);
+        }
+        h->chk_narrow.count = (uint32_t)h->order.size() - h->chk_narrow.first;
+        std::stable_sort(h->order.begin() + h->chk_narrow.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
     }
 
     HIPC(hipSetDevice(device));
@@ -874,7 +889,8 @@ int pob_constraint_check(pob_handle h, void* stream_) {
             launch_k_chain(K, true, h->nperms, G, st);
         }
         launch_inputs(h, true, G, st);
-        for (const pob_ctx::Seg& sg : h->chk_segs) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
+        for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));
