@@ -531,15 +531,35 @@ template <class P> GD void gAssertGreaterEqThanF(P& p, int nb, const F& a, const
 }
 
 // ============================================================================ circuits/utils/array.circom
+template <class P> HD void iseq_derived_w(P& p, uint32_t w, S a, S b);
 // Filter(N) :26-39  [out[N] | in | isEq[N]] || IsEqual([i, in]) x N;  out[i] = out[i-1]*(1-isEq[i])
-template <class P> GD BitRef gFilter(P& p, int N, S in) {
+// isEq[k] = [in == k], out[k] = prod_{j <= k}(1 - isEq[j]) = [in > k] (unsigned: a value outside 0..N-1 never hits): both are written / verified as lane-distributed
+// runs against those functions of the STORED `in` -- no wire is read back (as a loop of single puts, each of the caller's reads of out[k] waited for the stores before
+// it: 2-5 us per wire under load, the pole of the RLP assembly units).  The IsEqual children are derived wires (their outputs are copies of isEq[k]).
+// oruns (N <= 256): the out[] bits as runs of 64 (lane t of oruns[r] = wire 64 r + t), for a caller that copies them (Mask)
+template <class P> GD BitRef gFilter(P& p, int N, S in, B* oruns = nullptr) {
     BitRef o = p.bits(N); SmRef i = p.sms(1); BitRef isEq = p.bits(N);
     in = p.put(i, in);
-    B prev = ~(B)0;
-    for (int k = 0; k < N; k++) {
-        B e = p.put(isEq + k, gIsEqualS(p, (S)k, in));
-        prev = p.put(o + k, prev & ~e);
+    const uint32_t kids_w = p.dvs(6u * (uint32_t)N), ln = p.lane_id();
+    B keep[4] = {0, 0, 0, 0};
+    for (uint32_t k0 = 0; k0 < (uint32_t)N; k0 += 32) {
+        const uint32_t n = (uint32_t)N - k0 < 32 ? (uint32_t)N - k0 : 32;
+        B runE = 0, runO = 0, runK = 0;
+        for (uint32_t t = 0; t < n; t++) {
+            const B e = p.ballot((uint32_t)in == k0 + t), ob = p.ballot((uint32_t)in > k0 + t);
+            runE = p.run_set(runE, t, e); runO = p.run_set(runO, t, ob);
+            runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
+            if (oruns) keep[(k0 >> 6) & 3] = p.run_set(keep[(k0 >> 6) & 3], (k0 & 63) + t, ob);
+        }
+        p.run_put(n, isEq.w + k0 + ln, isEq.i + k0 + ln, runE);
+        p.run_put(n, o.w + k0 + ln, o.i + k0 + ln, runO);
+        p.run_derived(2 * n, kids_w + 6 * (k0 + (ln >> 1)) + 3 * (ln & 1), runK);      // IsEqual.out / IsZero.out of child k: copies of isEq[k]
+        if constexpr (P::is_emit) {
+            if (ln < 2 * n) p.site_c(kids_w + 6 * (k0 + (ln >> 1)) + 3 * (ln & 1), isEq.w + k0 + (ln >> 1));
+            for (uint32_t t = 0; t < n; t++) iseq_derived_w(p, kids_w + 6 * (k0 + t), (S)(k0 + t), in);
+        }
     }
+    if (oruns) { for (int r = 0; r < 4; r++) oruns[r] = keep[r]; }
     return o;
 }
 // Fit(M,N) :47-57  [out[N] | in[M]]
@@ -733,11 +753,33 @@ template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count,
 template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef flt = p.bits(n);
     count = p.put(cn, count);
-    BitRef f = gFilter(p, n, count);
-    for (int i = 0; i < n; i++) {
-        B fb = p.put(flt + i, p.get(f + i));
-        S v = p.put(in + i, p.get(src + i));
-        p.put(o + i, p.bit(fb) ? v : 0);
+    B fr[4];
+    gFilter(p, n, count, fr);                                    // n <= 256
+    const uint32_t ln = p.lane_id();
+    B fl[4] = {0, 0, 0, 0};                                      // the evaluator's STORED filter[] (the relation out = filter * in is evaluated on stored operands)
+    for (uint32_t k0 = 0; k0 < (uint32_t)n; k0 += 64) {
+        const uint32_t m = (uint32_t)n - k0 < 64 ? (uint32_t)n - k0 : 64;
+        if constexpr (P::is_check) fl[k0 >> 6] = p.run_get(m, flt.i + k0 + ln);
+        p.run_put(m, flt.w + k0 + ln, flt.i + k0 + ln, fr[k0 >> 6]);      // filter[] <== Filter.out (from the values, not read back)
+    }
+    // in[] <== src[], out[i] <== filter[i] * in[i]: batches of 8 (loads of a batch in flight together, no wire read back)
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        SmRef ri[8], ro[8]; S vv[8], ov[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint32_t i = (uint32_t)(i0 + q < n ? i0 + q : n - 1); ri[q] = in + i; ro[q] = o + i; }
+        const SmLoaded<8> hi = sm_load(p, ri);
+        const SmLoaded<8> ho = sm_load(p, ro);
+#pragma unroll
+        for (int q = 0; q < 8; q++) vv[q] = p.get(src + (uint32_t)(i0 + q < n ? i0 + q : n - 1));
+        sm_commit(p, ri, hi, vv);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = (uint32_t)(i0 + q < n ? i0 + q : n - 1);
+            const S v = P::is_check ? hi.s[q] : vv[q];
+            const bool fb = P::is_check ? p.bit(p.run_bcast(fl[i >> 6], i & 63)) : (uint32_t)count > i;
+            ov[q] = fb ? v : 0;
+        }
+        sm_commit(p, ro, ho, ov);
     }
     return o;
 }
@@ -757,9 +799,24 @@ template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef
     x = gMask(p, Lb, ib, bLen);
     copy_n(p, mB, x, (int)(Lb));
     x = gShiftRight(p, Lb, La, mB, aLen, split);
-    for (int i = 0; i < La + Lb; i++) {
-        S s = p.put(sB + i, p.get(x + i));
-        p.put(o + i, i < La ? p.get(mA + i) + s : s);
+    // shiftedB[] <== ShiftRight.out[], out[i] <== maskedA[i] + shiftedB[i]: batches of 8 (as single puts every read of the wires written just before waited for the
+    // store in front of it: 2 (La + Lb) store -> load round trips, the longest stretch of the RLP leaf / account assembly)
+    for (int i0 = 0; i0 < La + Lb; i0 += 8) {
+        SmRef rs[8], ro[8]; S xv[8], av[8], ov[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint32_t i = (uint32_t)(i0 + q < La + Lb ? i0 + q : La + Lb - 1); rs[q] = sB + i; ro[q] = o + i; }
+        const SmLoaded<8> hs = sm_load(p, rs);
+        const SmLoaded<8> ho = sm_load(p, ro);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = (uint32_t)(i0 + q < La + Lb ? i0 + q : La + Lb - 1);
+            xv[q] = p.get(x + i);
+            av[q] = i < (uint32_t)La ? p.get(mA + i) : 0;
+        }
+        sm_commit(p, rs, hs, xv);
+#pragma unroll
+        for (int q = 0; q < 8; q++) ov[q] = av[q] + (P::is_check ? hs.s[q] : xv[q]);
+        sm_commit(p, ro, ho, ov);
     }
     outLen = p.put(ol, aLen + bLen);
     return o;
