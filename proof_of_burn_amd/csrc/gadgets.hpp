@@ -225,7 +225,9 @@ template <class P> GD S gMux1SF(P& p, S c0, const F& c1, B s) {
 // ============================================================================ circomlib: compconstant / aliascheck / Num2Bits_strict
 // CompConstant(ct = p-1)  [out | in[254] | parts[127], sout] || Num2Bits(135)
 template <class P> GD B gCompConstantPm1(P& p, const BV& v, const F& c) {      // v / c: the 254 input bits / their canonical value
-    BitRef o = p.bits(1); BitRef in = p.bits(254); FrRef parts = p.frs(127); FrRef sout = p.frs(1);
+    // parts[127] are DERIVED wires (round 4): each is a function of two stored input bits and constants; generation and evaluation only carry their running sum (as 127
+    // stored field elements they were the unit's cost: 1 016 limb-row stores in generation, 127 pinned eight-limb compares -- one memory round trip each -- in evaluation)
+    BitRef o = p.bits(1); BitRef in = p.bits(254); const uint32_t parts_w = p.dvs(127); FrRef sout = p.frs(1);
     const uint32_t PM1[8] = {0xf0000000u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     bv_put(p, in, 254, v);
     // a, b, e as canonical 256-bit integers kept in Montgomery form
@@ -245,7 +247,8 @@ template <class P> GD B gCompConstantPm1(P& p, const BV& v, const F& c) {      /
                 } else if (cmsb && !clsb) {                                                              // b*sm*sl - a*sm + a
                     pv = a; if (sm && sl) pv = fr_add(pv, b); if (sm) pv = fr_sub(pv, a);
                 } else pv = (sm && sl) ? fr_zero() : a;                                                  // -a*sm*sl + a
-                sum = fr_add(sum, p.put(parts + i, pv));
+                p.derived_fr(parts_w + (uint32_t)i, pv);
+                sum = fr_add(sum, pv);
                 b = fr_sub(b, e); a = fr_add(a, e); e = fr_add(e, e);
             }
         }
@@ -762,7 +765,15 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
         if constexpr (P::is_check) fl[k0 >> 6] = p.run_get(m, flt.i + k0 + ln);
         p.run_put(m, flt.w + k0 + ln, flt.i + k0 + ln, fr[k0 >> 6]);      // filter[] <== Filter.out (from the values, not read back)
     }
-    // in[] <== src[], out[i] <== filter[i] * in[i]: batches of 8 (loads of a batch in flight together, no wire read back)
+    // in[] <== src[], out[i] <== filter[i] * in[i].  Generation / emission: batches of 8 (loads of a batch in flight together, no wire read back).  The evaluator has no
+    // stores in front of its loads and the compiler pipelines the plain loop; pinned batches measured 0.25 -> 0.29 ms on the RLP leaf tail
+    if constexpr (P::is_check) {
+        for (int i = 0; i < n; i++) {
+            const S v = p.put(in + (uint32_t)i, p.get(src + (uint32_t)i));
+            p.put(o + (uint32_t)i, p.bit(p.run_bcast(fl[i >> 6], (uint32_t)i & 63)) ? v : 0);
+        }
+        return o;
+    }
     for (int i0 = 0; i0 < n; i0 += 8) {
         SmRef ri[8], ro[8]; S vv[8], ov[8];
 #pragma unroll
@@ -801,6 +812,14 @@ template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef
     x = gShiftRight(p, Lb, La, mB, aLen, split);
     // shiftedB[] <== ShiftRight.out[], out[i] <== maskedA[i] + shiftedB[i]: batches of 8 (as single puts every read of the wires written just before waited for the
     // store in front of it: 2 (La + Lb) store -> load round trips, the longest stretch of the RLP leaf / account assembly)
+    if constexpr (P::is_check) {        // (the evaluator: no stores in front of its loads, the plain loop pipelines)
+        for (int i = 0; i < La + Lb; i++) {
+            const S sv = p.put(sB + (uint32_t)i, p.get(x + (uint32_t)i));
+            p.put(o + (uint32_t)i, i < La ? p.get(mA + (uint32_t)i) + sv : sv);
+        }
+        outLen = p.put(ol, aLen + bLen);
+        return o;
+    }
     for (int i0 = 0; i0 < La + Lb; i0 += 8) {
         SmRef rs[8], ro[8]; S xv[8], av[8], ov[8];
 #pragma unroll
