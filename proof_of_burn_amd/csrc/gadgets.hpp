@@ -545,14 +545,17 @@ template <class P> GD BitRef gFilter(P& p, int N, S in, B* oruns = nullptr) {
     in = p.put(i, in);
     const uint32_t kids_w = p.dvs(6u * (uint32_t)N), ln = p.lane_id();
     B keep[4] = {0, 0, 0, 0};
-    for (uint32_t k0 = 0; k0 < (uint32_t)N; k0 += 32) {
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {                           // chunks of 32 wires; c is a compile-time constant (keep[] stays in registers)
+        const uint32_t k0 = 32 * c;
+        if (k0 >= (uint32_t)N) continue;
         const uint32_t n = (uint32_t)N - k0 < 32 ? (uint32_t)N - k0 : 32;
         B runE = 0, runO = 0, runK = 0;
         for (uint32_t t = 0; t < n; t++) {
             const B e = p.ballot((uint32_t)in == k0 + t), ob = p.ballot((uint32_t)in > k0 + t);
             runE = p.run_set(runE, t, e); runO = p.run_set(runO, t, ob);
             runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
-            if (oruns) keep[(k0 >> 6) & 3] = p.run_set(keep[(k0 >> 6) & 3], (k0 & 63) + t, ob);
+            keep[c >> 1] = p.run_set(keep[c >> 1], 32 * (c & 1) + t, ob);
         }
         p.run_put(n, isEq.w + k0 + ln, isEq.i + k0 + ln, runE);
         p.run_put(n, o.w + k0 + ln, o.i + k0 + ln, runO);
@@ -562,7 +565,10 @@ template <class P> GD BitRef gFilter(P& p, int N, S in, B* oruns = nullptr) {
             for (uint32_t t = 0; t < n; t++) iseq_derived_w(p, kids_w + 6 * (k0 + t), (S)(k0 + t), in);
         }
     }
-    if (oruns) { for (int r = 0; r < 4; r++) oruns[r] = keep[r]; }
+    if (oruns) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) oruns[r] = keep[r];
+    }
     return o;
 }
 // Fit(M,N) :47-57  [out[N] | in[M]]
@@ -759,18 +765,18 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     B fr[4];
     gFilter(p, n, count, fr);                                    // n <= 256
     const uint32_t ln = p.lane_id();
-    B fl[4] = {0, 0, 0, 0};                                      // the evaluator's STORED filter[] (the relation out = filter * in is evaluated on stored operands)
-    for (uint32_t k0 = 0; k0 < (uint32_t)n; k0 += 64) {
-        const uint32_t m = (uint32_t)n - k0 < 64 ? (uint32_t)n - k0 : 64;
-        if constexpr (P::is_check) fl[k0 >> 6] = p.run_get(m, flt.i + k0 + ln);
-        p.run_put(m, flt.w + k0 + ln, flt.i + k0 + ln, fr[k0 >> 6]);      // filter[] <== Filter.out (from the values, not read back)
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) {
+        const uint32_t k0 = 64 * r;
+        if (k0 < (uint32_t)n) p.run_put((uint32_t)n - k0 < 64 ? (uint32_t)n - k0 : 64, flt.w + k0 + ln, flt.i + k0 + ln, fr[r]);      // filter[] <== Filter.out (from the values, not read back)
     }
     // in[] <== src[], out[i] <== filter[i] * in[i].  Generation / emission: batches of 8 (loads of a batch in flight together, no wire read back).  The evaluator has no
     // stores in front of its loads and the compiler pipelines the plain loop; pinned batches measured 0.25 -> 0.29 ms on the RLP leaf tail
-    if constexpr (P::is_check) {
+    if constexpr (P::is_check) {        // (out = filter * in on the STORED filter[] and in[])
         for (int i = 0; i < n; i++) {
+            const B fb = p.get(flt + (uint32_t)i);
             const S v = p.put(in + (uint32_t)i, p.get(src + (uint32_t)i));
-            p.put(o + (uint32_t)i, p.bit(p.run_bcast(fl[i >> 6], (uint32_t)i & 63)) ? v : 0);
+            p.put(o + (uint32_t)i, p.bit(fb) ? v : 0);
         }
         return o;
     }
@@ -786,9 +792,7 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t i = (uint32_t)(i0 + q < n ? i0 + q : n - 1);
-            const S v = P::is_check ? hi.s[q] : vv[q];
-            const bool fb = P::is_check ? p.bit(p.run_bcast(fl[i >> 6], i & 63)) : (uint32_t)count > i;
-            ov[q] = fb ? v : 0;
+            ov[q] = (uint32_t)count > i ? vv[q] : 0;
         }
         sm_commit(p, ro, ho, ov);
     }
