@@ -653,10 +653,11 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         p.put(M.leafLen, p.put(R.ol, cl));
     } break;
     UCASE(U_POW_POST) {           // :73-79
-        B fr[4];
-        gFilter(p, 32, p.get(L.pw.mzb), fr);
+        B fr[4] = {0, 0, 0, 0};
+        const BitRef f = gFilter(p, 32, p.get(L.pw.mzb), fr);
         for (int i = 0; i < 32; i++) {
-            B z = p.put(L.pw.sbz + i, p.run_bcast(fr[0], (uint32_t)i));      // shouldBeZero[i] <== Filter.out[i] (from the values: not read back)
+            // shouldBeZero[i] <== Filter.out[i]: generation / emission from the values (not read back), the evaluator from the stored wire
+            B z = p.put(L.pw.sbz + i, P::is_check ? p.get(f + (uint32_t)i) : p.run_bcast(fr[0], (uint32_t)i));
             p.require(p.ballot(p.get(L.pw.keccak + i) == 0) | ~z, FAILCODE(T_POW, 79));
         }
     } break;

@@ -544,19 +544,27 @@ template <class P> GD BitRef gFilter(P& p, int N, S in, B* oruns = nullptr) {
     BitRef o = p.bits(N); SmRef i = p.sms(1); BitRef isEq = p.bits(N);
     in = p.put(i, in);
     const uint32_t kids_w = p.dvs(6u * (uint32_t)N), ln = p.lane_id();
-    B keep[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (uint32_t c = 0; c < 8; c++) {                           // chunks of 32 wires; c is a compile-time constant (keep[] stays in registers)
-        const uint32_t k0 = 32 * c;
-        if (k0 >= (uint32_t)N) continue;
-        const uint32_t n = (uint32_t)N - k0 < 32 ? (uint32_t)N - k0 : 32;
-        B runE = 0, runO = 0, runK = 0;
+    if constexpr (P::is_check) {        // the evaluator: no stores in front of its loads, the plain loop of single wires pipelines (as runs the RLP leaf tail took 0.35 ms, so 0.25)
+        (void)kids_w; (void)ln;
+        B prev = ~(B)0;
+        for (int k = 0; k < N; k++) {
+            const B e = p.put(isEq + (uint32_t)k, p.ballot((uint32_t)in == (uint32_t)k));
+            prev = p.put(o + (uint32_t)k, prev & ~e);
+        }
+        return o;
+    }
+    B keep0 = 0, keep1 = 0, keep2 = 0, keep3 = 0;               // (four scalars selected by a uniform compare chain: ONE loop body -- unrolled eight times the unit outgrew the
+                                                                 //  instruction cache -- and no dynamically indexed register array)
+    for (uint32_t k0 = 0; k0 < (uint32_t)N; k0 += 32) {
+        const uint32_t n = (uint32_t)N - k0 < 32 ? (uint32_t)N - k0 : 32, r = k0 >> 6, l0 = k0 & 63;
+        B runE = 0, runO = 0, runK = 0, kp = 0;
         for (uint32_t t = 0; t < n; t++) {
             const B e = p.ballot((uint32_t)in == k0 + t), ob = p.ballot((uint32_t)in > k0 + t);
             runE = p.run_set(runE, t, e); runO = p.run_set(runO, t, ob);
             runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
-            keep[c >> 1] = p.run_set(keep[c >> 1], 32 * (c & 1) + t, ob);
+            kp = p.run_set(kp, l0 + t, ob);
         }
+        if (r == 0) keep0 |= kp; else if (r == 1) keep1 |= kp; else if (r == 2) keep2 |= kp; else keep3 |= kp;
         p.run_put(n, isEq.w + k0 + ln, isEq.i + k0 + ln, runE);
         p.run_put(n, o.w + k0 + ln, o.i + k0 + ln, runO);
         p.run_derived(2 * n, kids_w + 6 * (k0 + (ln >> 1)) + 3 * (ln & 1), runK);      // IsEqual.out / IsZero.out of child k: copies of isEq[k]
@@ -565,10 +573,7 @@ template <class P> GD BitRef gFilter(P& p, int N, S in, B* oruns = nullptr) {
             for (uint32_t t = 0; t < n; t++) iseq_derived_w(p, kids_w + 6 * (k0 + t), (S)(k0 + t), in);
         }
     }
-    if (oruns) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) oruns[r] = keep[r];
-    }
+    if (oruns) { oruns[0] = keep0; oruns[1] = keep1; oruns[2] = keep2; oruns[3] = keep3; }
     return o;
 }
 // Fit(M,N) :47-57  [out[N] | in[M]]
@@ -762,9 +767,18 @@ template <class P> GD SmRef gShiftRight(P& p, int n, int ms, SmRef src, S count,
 template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     SmRef o = p.sms(n), in = p.sms(n), cn = p.sms(1); BitRef flt = p.bits(n);
     count = p.put(cn, count);
-    B fr[4];
-    gFilter(p, n, count, fr);                                    // n <= 256
+    B fr[4] = {0, 0, 0, 0};
+    const BitRef f = gFilter(p, n, count, fr);                   // n <= 256
     const uint32_t ln = p.lane_id();
+    if constexpr (P::is_check) {        // (filter[] <== Filter.out, in[] <== src[], out = filter * in: all on STORED wires, plain loop)
+        (void)ln;
+        for (int i = 0; i < n; i++) {
+            const B fb = p.put(flt + (uint32_t)i, p.get(f + (uint32_t)i));
+            const S v = p.put(in + (uint32_t)i, p.get(src + (uint32_t)i));
+            p.put(o + (uint32_t)i, p.bit(fb) ? v : 0);
+        }
+        return o;
+    }
 #pragma unroll
     for (uint32_t r = 0; r < 4; r++) {
         const uint32_t k0 = 64 * r;
@@ -772,14 +786,6 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     }
     // in[] <== src[], out[i] <== filter[i] * in[i].  Generation / emission: batches of 8 (loads of a batch in flight together, no wire read back).  The evaluator has no
     // stores in front of its loads and the compiler pipelines the plain loop; pinned batches measured 0.25 -> 0.29 ms on the RLP leaf tail
-    if constexpr (P::is_check) {        // (out = filter * in on the STORED filter[] and in[])
-        for (int i = 0; i < n; i++) {
-            const B fb = p.get(flt + (uint32_t)i);
-            const S v = p.put(in + (uint32_t)i, p.get(src + (uint32_t)i));
-            p.put(o + (uint32_t)i, p.bit(fb) ? v : 0);
-        }
-        return o;
-    }
     for (int i0 = 0; i0 < n; i0 += 8) {
         SmRef ri[8], ro[8]; S vv[8], ov[8];
 #pragma unroll
