@@ -6,7 +6,9 @@ A "step" = one batch through the hot path as a SERVICE LOOP would run it: the ba
 constraint evaluation reads that resident vector back, the per-witness result records {status, evaluator verdict, commitment} are packed
 AFTER the evaluation, copied to pinned host memory and VALIDATED on the host (every record of every batch: status 0, evaluator clean,
 commitment equal to the host-side formula) -- all of it inside the timed region.  Consecutive batches carry DIFFERENT inputs
-(--distinct-batches of them, cycled).  Workload at N=1: BASELINE.json configs[2] -- batch = 1024 proof_of_burn witnesses of the
+(--distinct-batches of them, cycled).  The loop keeps --pipeline (4) IN-ORDER calculators in flight, each on a stream of its own, on consecutive
+batches (pob_set_inorder: a calculator's whole batch in dependency order on one stream); --schedule tracks is round 3's
+two-calculator pipeline.  Workload at N=1: BASELINE.json configs[2] -- batch = 1024 proof_of_burn witnesses of the
 production instantiation ProofOfBurn(16,4,16,50,31,2,1e19,1e20) on synthetic 10-layer MPT proofs; for N > 1 every rank gets its own 1024
 (weak scaling; --total-batch B splits ONE global batch over the ranks instead: BASELINE config 4 as written), one slice per GPU, no
 data-path collective except ONE all-gather of the 44-byte result records per batch.

@@ -441,6 +441,16 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
             assert all(r.check_status == 0 and r.bad_wire is None for r in res if r.ok)
         i = next(k for k, r in enumerate(res) if r.ok)
         assert np.array_equal(calc.witness_payload(i), O.run(main, s["cases"][i]["input"]).witness_numpy())
+        # the merged evaluation kernels see a corrupted vector like the per-family ones: one stored value of each class of witness i poked, flagged, restored
+        sizes = calc.class_sizes()
+        for cls in (EC.BIT, EC.SM, EC.FR):
+            idx = sizes[cls] // 3
+            calc.poke(cls, idx, i, 1 if cls == EC.BIT else 4)
+            calc.constraint_check()
+            flagged = [r.bad_wire is not None or r.check_status != 0 for r in calc.results(with_check=True)]
+            calc.poke(cls, idx, i, 1 if cls == EC.BIT else 4)
+            assert flagged[i] and not [k for k, f in enumerate(flagged) if f and res[k].ok and k != i], (main, cls, idx, flagged)
+        calc.constraint_check()
         calc.set_inorder(False)
         res2 = calc.calculate([c["input"] for c in s["cases"]], check=True)
         assert [(r.status, r.outputs, r.check_status, r.bad_wire) for r in res2] == [(r.status, r.outputs, r.check_status, r.bad_wire) for r in res]
