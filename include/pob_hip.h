@@ -33,8 +33,10 @@ typedef struct {
                                     no other unit reads them (policy.hpp DV): the operand wires in[0], in[1], IsZero.in, IsZero.inv of every IsZero /
                                     IsEqual (over small operands and, in SubstringCheck, over field elements), copies (Selector.vals[],
                                     SelectorArray1D.arrays / arraysT, Pad's and AssertByteString's byte copies, SubstringCheck.mainInput[]) and running
-                                    sums (Selector.sum[], SubstringCheck.M[]).  Generation and evaluation skip them; the emitter rebuilds them from
-                                    the same expressions                                                                                              */
+                                    sums (Selector.sum[], SubstringCheck.M[]); round 4: BIT-valued copies of stored bits (the padded bytes' bits, the
+                                    hash bits, the Keccak output selectors' vals[] / isEq[] / sum[] and their children, AssertByteString's bits) and the
+                                    products of ShiftRight / ShiftLeft / CompConstant.  Generation and evaluation skip them; the emitter rebuilds them from
+                                    the same expressions; pob_emit_selfcheck evaluates their relations on the values it writes                         */
     uint64_t n_alias;            /* wires of the Keccak round blocks that are not stored because they ARE another wire: copies of a stored gate
                                     output / of the round's input or output state, possibly at a rotated bit position (ShL / ShR / RhoPi) or negated
                                     (NotArray), or constants (shifted-out positions, round constants).  76 of the 1 604 arrays of a KeccakfRound

@@ -22,6 +22,15 @@
 //          * running sums that are functions of stored wires: Selector.sum[], SubstringCheck.M[];
 //        1.29 M of the 1.36 M non-BIT wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors'
 //        as an int8 class of their own, IsZero.inv as its operand code, M[] and the IsEqual(exists) operands as field elements).
+//        Round 4 added BIT-valued derived wires, written by the emitter as lane-distributed runs (run_derived) or single bits (derived_bit):
+//          * copies of a stored bit: five of the six copies of every padded byte's bits (only Keccak's inBlocks is stored), nine of the ten copies of the
+//            hash bits (only Selector.out), vals[] / arrays / arraysT of the Keccak output selectors (copies of Final.s), the IsEqual children's outputs
+//            under every stored isEq[] / isLast[] bit;
+//          * functions of a stored value: the Keccak output selectors' isEq[] / sum[] (of numBlocks and Final.s), AssertByteString's 16 bits per byte;
+//        and the products temps[][] / temp[][] of ShiftRight / ShiftLeft (isEq[i] * in[j]) and parts[] of CompConstant: 3.54 M derived wires in all.
+//   AL   wires (ALIAS, round 4): the wires of a KeccakfRound block other than its 76 stored gate-output arrays -- copies of a stored array / of the round's
+//        input or output state, possibly rotated or negated, or constants.  skip_alias() advances the wire index only; keccak_kernels.hpp names each of
+//        them once (the walker that generates and evaluates, run on a symbolic value type) and the emitter expands through that table.  197 M wires.
 //
 // Storage index of a wire = its rank among the wires of its class in wire order, so any contiguous
 // run of same-class wires (e.g. a whole Keccak-f block, 2 506 944 BIT wires) is contiguous in HBM.
