@@ -415,13 +415,27 @@ def test_emit_selfcheck_on_written_values(pkg):
     assert np.array_equal(got, ref)
     r = calc.emit_selfcheck_result()
     assert r["first_bad_wire"] is None and r["checked"] > 50_000 and r["skipped"] < 200, r
-    # KeccakBytes.inLen of the first KeccakBytes: the IsEqual([i, inLen]) operands are derived from it, the stored isEq[] bits are not
+    calc.emit_selfcheck(False)
+    calc.close()
+    # a poked operand, on Spend(31) (its PublicCommitment hashes through a KeccakBytes): KeccakBytes.inLen -- the IsEqual([i, inLen]) children are derived from it, the
+    # stored isEq[] bits they must equal are not
+    sp = _suite("test_spend")
+    calc = pkg.WitnessCalculator("Spend(31)", max_batch=2)
+    inp = sp["cases"][0]["input"]
+    assert all(r.ok for r in calc.calculate([inp, inp], check=True))
+    ref = O.run("Spend(31)", inp).witness_numpy()
+    calc.emit_selfcheck(True)
+    assert np.array_equal(calc.witness_payload(1), ref)
+    r = calc.emit_selfcheck_result()
+    assert r["first_bad_wire"] is None and r["checked"] > 1000, r
     cls, idx, wire = calc.debug_ref("kb.inLen", 0)
     calc.poke(cls, idx, 1, 1)
     got = calc.witness_payload(1)
     r = calc.emit_selfcheck_result()
     assert not np.array_equal(got, ref) and r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 40_000, (wire, r)
-    calc.poke(cls, idx, 1, 1)                               # (restored; the GPU version emits the restored vector once more and finds it clean)
+    assert np.array_equal(calc.witness_payload(0), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None      # the neighbouring witness is untouched
+    calc.poke(cls, idx, 1, 1)
+    assert np.array_equal(calc.witness_payload(1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
     calc.emit_selfcheck(False)
     calc.close()
 
