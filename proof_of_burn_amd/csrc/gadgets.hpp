@@ -230,9 +230,10 @@ template <class P> GD B gCompConstantPm1(P& p, const BV& v, const F& c) {      /
     BitRef o = p.bits(1); BitRef in = p.bits(254); const uint32_t parts_w = p.dvs(127); FrRef sout = p.frs(1);
     const uint32_t PM1[8] = {0xf0000000u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     bv_put(p, in, 254, v);
-    // a, b, e as canonical 256-bit integers kept in Montgomery form
-    Fr bc = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0}};
-    F b = fr_to_mont(bc), a = fr_one_mont(), e = fr_one_mont(), sum = fr_zero();
+    // a = 1 + (2^i - 1), b = 2^128 - 2^i, e = 2^i as plain 160-bit integers (every part is 0, a or b: the four polynomials of compconstant.circom:33-44 evaluated at the
+    // two signal bits; the sum stays below 2^136).  Rounds 1-3 carried them as Montgomery field elements through ~4 field additions per part: 508 called additions per
+    // CompConstant were most of the 0.2 ms of a Num2BigEndianBytes unit -- the longest unit of two generation levels of the production circuit.
+    uint32_t av[5] = {1, 0, 0, 0, 0}, bv[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0}, ev[5] = {1, 0, 0, 0, 0}, sv[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         for (int t = 0; t < 16; t++) {
@@ -240,19 +241,34 @@ template <class P> GD B gCompConstantPm1(P& p, const BV& v, const F& c) {      /
             if (i < 127) {
                 const uint32_t clsb = (PM1[j] >> (2 * t)) & 1, cmsb = (PM1[j] >> (2 * t + 1)) & 1;
                 const bool sl = (c.l[j] >> (2 * t)) & 1, sm = (c.l[j] >> (2 * t + 1)) & 1;
-                F pv;
-                if (!cmsb && !clsb) pv = (sm || sl) ? b : fr_zero();                                    // -b*sm*sl + b*sm + b*sl
-                else if (!cmsb && clsb) {                                                                // a*sm*sl - a*sl + b*sm - a*sm + a
-                    pv = a; if (sm && sl) pv = fr_add(pv, a); if (sl) pv = fr_sub(pv, a); if (sm) { pv = fr_add(pv, b); pv = fr_sub(pv, a); }
-                } else if (cmsb && !clsb) {                                                              // b*sm*sl - a*sm + a
-                    pv = a; if (sm && sl) pv = fr_add(pv, b); if (sm) pv = fr_sub(pv, a);
-                } else pv = (sm && sl) ? fr_zero() : a;                                                  // -a*sm*sl + a
-                p.derived_fr(parts_w + (uint32_t)i, pv);
-                sum = fr_add(sum, pv);
-                b = fr_sub(b, e); a = fr_add(a, e); e = fr_add(e, e);
+                // which of {0, a, b} the part is
+                bool ta, tb;
+                if (!cmsb && !clsb) { ta = false; tb = sm || sl; }                                         // -b*sm*sl + b*sm + b*sl
+                else if (!cmsb && clsb) { ta = !sm && !sl; tb = sm; }                                      // a*sm*sl - a*sl + b*sm - a*sm + a
+                else if (cmsb && !clsb) { ta = !sm; tb = sm && sl; }                                       // b*sm*sl - a*sm + a
+                else { ta = !(sm && sl); tb = false; }                                                     // -a*sm*sl + a
+                uint32_t pv[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) pv[q] = ta ? av[q] : tb ? bv[q] : 0u;
+                if constexpr (P::is_emit) {
+                    Fr pc = {{pv[0], pv[1], pv[2], pv[3], pv[4], 0, 0, 0}};
+                    p.derived_fr(parts_w + (uint32_t)i, fr_to_mont(pc));
+                }
+                uint32_t cy = 0, bw = 0, cy2 = 0;
+#pragma unroll
+                for (int q = 0; q < 5; q++) {                                                              // sum += part;  b -= e;  a += e
+                    const uint64_t x = (uint64_t)sv[q] + pv[q] + cy; sv[q] = (uint32_t)x; cy = (uint32_t)(x >> 32);
+                    const uint64_t y = (uint64_t)bv[q] - ev[q] - bw; bv[q] = (uint32_t)y; bw = (uint32_t)(y >> 63);
+                    const uint64_t z = (uint64_t)av[q] + ev[q] + cy2; av[q] = (uint32_t)z; cy2 = (uint32_t)(z >> 32);
+                }
+#pragma unroll
+                for (int q = 4; q > 0; q--) ev[q] = (ev[q] << 1) | (ev[q - 1] >> 31);                      // e *= 2
+                ev[0] <<= 1;
             }
         }
     }
+    Fr sumc = {{sv[0], sv[1], sv[2], sv[3], sv[4], 0, 0, 0}};
+    const F sum = fr_to_mont(sumc);
     F so = p.put(sout, sum), sc;
     gNum2BitsF(p, 135, so, nullptr, &sc);
     return p.put(o, p.ballot(canon_bit(sc, 127)));
