@@ -77,7 +77,7 @@ def cpu_baseline(batch, info, single_samples: int, budget_s: float = 25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=180, help="timed batches (180 x 11.6 ms = a 2 s timed region)")
+    ap.add_argument("--steps", type=int, default=180, help="timed batches (180 x ~1.9 ms = a 0.35 s timed region)")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU per step (weak scaling)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: ONE global batch of this many witnesses per step, split over the ranks (BASELINE config 4: 8192)")

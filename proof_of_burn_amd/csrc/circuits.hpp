@@ -685,17 +685,18 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         p.put(M.burnKey, p.input_fr(0)); p.put(M.actualBalance, p.input_fr(1)); p.put(M.intendedBalance, p.input_fr(2));
         p.put(M.revealAmount, p.input_fr(3)); p.put(M.burnExtraCommitment, p.input_fr(4)); p.put(M.proofExtraCommitment, p.input_fr(5));
     } break;
-    UCASE(U_POB_RANGE) {   // proof_of_burn.circom:84-97
+    UCASE(U_POB_RANGE) {   // proof_of_burn.circom:84-97 in five parallel parts (a[0]): each comparison's bit decompositions are one wavefront's work
         const int AB8 = prm.amountBytes * 8;
-        F intended = p.get(M.intendedBalance), actual = p.get(M.actualBalance), reveal = p.get(M.revealAmount);
-        gAssertLessEqThanF(p, AB8, intended, prm.maxIntended);
-        gAssertLessEqThanF(p, AB8, actual, prm.maxActual);
-        gAssertLessEqThanF(p, AB8, intended, actual);
-        S relax = p.get(M.byteSecurityRelax);
-        gAssertLessEqThanS(p, 16, (S)((uint32_t)relax * 2u), (S)prm.minNib);
-        gAssertGreaterEqThanS(p, 16, p.get(M.numLeafAddressNibbles), (S)((uint32_t)prm.minNib - (uint32_t)relax * 2u));
-        gAssertBitsF(p, AB8, reveal);
-        gAssertLessEqThanF(p, AB8, reveal, intended);
+        F intended = p.get(M.intendedBalance);
+        if (d.a[0] == 0) gAssertLessEqThanF(p, AB8, intended, prm.maxIntended);
+        else if (d.a[0] == 1) gAssertLessEqThanF(p, AB8, p.get(M.actualBalance), prm.maxActual);
+        else if (d.a[0] == 2) gAssertLessEqThanF(p, AB8, intended, p.get(M.actualBalance));
+        else if (d.a[0] == 3) {
+            S relax = p.get(M.byteSecurityRelax);
+            gAssertLessEqThanS(p, 16, (S)((uint32_t)relax * 2u), (S)prm.minNib);
+            gAssertGreaterEqThanS(p, 16, p.get(M.numLeafAddressNibbles), (S)((uint32_t)prm.minNib - (uint32_t)relax * 2u));
+            gAssertBitsF(p, AB8, p.get(M.revealAmount));
+        } else gAssertLessEqThanF(p, AB8, p.get(M.revealAmount), intended);
     } break;
     UCASE(U_POB_POSEIDONS) {      // :113 (a[0] = 0) remainingCoin = Poseidon3, :116 (a[0] = 1) nullifier = Poseidon2 -- two parallel units
         // (evaluation / emission only: generation runs the two blocks as U_POS_WIDE units, which also write remainingCoin / nullifier)
@@ -760,7 +761,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         { CountP q; q.cur = p.cur; q.decl_order = p.decl_order; gCountBytes(q, N, A.by); A.c_sl = q.cur; gShiftLeft(q, N, A.by, 0); A.c_lt = q.cur; }
         p.cur = A.c_lt;
         B single = p.put(A.isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
-        p.put(A.isz, gIsZeroF(p, x));
+        p.put(A.isz, gIsZeroFd(p, x));
         const S length = P::is_gen ? (S)N - lead : p.get(A.len);
         p.put(A.frb, gMux1SF(p, 0x80 + length, x, single));
         A.c_concat = p.cur;
@@ -1160,7 +1161,7 @@ struct Plan {
         //             | 5 consumers (SubstringCheck, PublicCommitment) | 6 ... | 10 final ===          (side tracks: see above)
         unit(U_POB_INPUT_FR, 0);
         for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
-        unit(U_POB_RANGE, TB + 1);
+        for (int k = 0; k < 5; k++) unit(U_POB_RANGE, TB + 1, k);
         for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, TP + 1, i); abs_units(TP + 1, LB, M.layers + i * LB); }
         unit(U_POB_HDR_ASSERT, TP + 1); abs_units(TP + 1, HBy, M.blockHeader);
         // The three Poseidon blocks (:113, :116, burn_address.circom:55) run in TB + 1 as U_POS_WIDE units (state spread over lanes);

@@ -96,19 +96,12 @@ template <class P> HD B gIsZeroS(P& p, S in, bool iseq = false) {        // iseq
     p.derived(w, in); p.derived_inv(w + 1, in, iseq);
     return p.put(o, p.ballot(in == 0));
 }
-template <class P> GD B gIsZeroF(P& p, const F& in, bool inv_is_stored = false) {
-    BitRef o = p.bits(1); FrRef i = p.frs(1); FrRef v = p.frs(1);
-    F x = p.put(i, in);
-    F iv;
-    if (P::is_gen && !inv_is_stored) iv = p.hint(v, fr_inv_inl(x));
-    else if (P::is_gen) iv = p.get(v);                    // pre-computed by a batched inversion
-    else iv = p.hint(v, x);
-    F t = fr_mul(x, iv);                                  // in*inv (Montgomery)
-    bool t0 = fr_is_zero(t), t1 = fr_eq(t, fr_one_mont());
-    p.require(p.ballot(t0 || t1), FAILCODE(T_ISZERO, 30));
-    B out = p.put(o, p.ballot(t0));
-    p.require(p.ballot(fr_is_zero(x)) | ~out, FAILCODE(T_ISZERO, 31));
-    return out;
+// IsZero over a field element with DERIVED in/inv wires: out = [in == 0] needs no inverse; the emitter rebuilds in and inv and its self-check
+// evaluates in*inv === 1 - out, in*out === 0 on the written values
+template <class P> GD B gIsZeroFd(P& p, const F& in) {
+    BitRef o = p.bits(1); const uint32_t w = p.dvs(2);
+    if constexpr (P::is_emit) { p.derived_fr(w, in); p.derived_fr_inv(w + 1, in, false); }
+    return p.put(o, p.ballot(fr_is_zero(in)));
 }
 // IsEqual  [out | in[2]] || IsZero(in[1]-in[0])      (small operands: in[] are derived wires)
 template <class P> HD B gIsEqualS(P& p, S a, S b) {
@@ -711,6 +704,24 @@ template <class P> GD SmRef gShiftLeft(P& p, int n, SmRef src, S count, bool spl
     if constexpr (P::is_check) {
         if (split) { p.cur = cur_add(p.cur, FP_ISEQ_S_, (uint32_t)(n * n)); return o; }
     }
+    if constexpr (P::is_gen) {
+        // generation: the n^2 IsEqual outputs are stores only (no in[j] load behind them: 961 memory round trips for n = 31), out[i] = in[i + count] is a per-witness gather
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) p.put(isEq + (i * n + j), gIsEqualS(p, (S)i, (S)(j - count)));
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            S v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = i0 + q < n ? i0 + q : n - 1;
+                const uint32_t idx = (uint32_t)(i + count);
+                v[q] = p.get_lane(src, idx < (uint32_t)n ? idx : 0u);
+                if (idx >= (uint32_t)n) v[q] = 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (i0 + q < n) p.put(o + (uint32_t)(i0 + q), v[q]);
+        }
+        return o;
+    }
     for (int i = 0; i < n; i++) {
         S acc = 0;
         for (int j = 0; j < n; j++) {
@@ -1079,9 +1090,25 @@ template <class P> GD B gSubstringCheck(P& p, int mm, int sl, SmRef mainSrc, S m
 // CountBytes(N) :16-49  [len | bytes[N] | isZero[N], stillZero[N]] || IsZero x N
 template <class P> GD S gCountBytes(P& p, int N, SmRef src) {
     SmRef o = p.sms(1), by = p.sms(N); BitRef iz = p.bits(N), sz = p.bits(N);
-    for (int i = 0; i < N; i++) p.put(iz + i, gIsZeroS(p, p.put(by + i, p.get(src + i))));
+    // one pass, the bytes in batches of 8, isZero[] / stillZero[] from the values (as two loops of single wires every byte was a load behind a store and every
+    // isZero[i] was read back right after it had been written: 2 N memory round trips)
     B still = ~(B)0; S lead = 0;
-    for (int i = 0; i < N; i++) { still = p.put(sz + i, still & p.get(iz + i)); lead += (S)p.bit(still); }
+    for (int i0 = 0; i0 < N; i0 += 8) {
+        SmRef rr[8]; S vv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) rr[q] = by + (uint32_t)(i0 + q < N ? i0 + q : N - 1);
+        const SmLoaded<8> h = sm_load(p, rr);
+#pragma unroll
+        for (int q = 0; q < 8; q++) vv[q] = p.get(src + (uint32_t)(i0 + q < N ? i0 + q : N - 1));
+        sm_commit(p, rr, h, vv);
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (i0 + q < N) {
+            const uint32_t i = (uint32_t)(i0 + q);
+            const B z = p.put(iz + i, gIsZeroS(p, P::is_check ? h.s[q] : vv[q]));
+            still = p.put(sz + i, still & z);
+            lead += (S)p.bit(still);
+        }
+    }
     return p.put(o, N - lead);
 }
 // RlpInteger(N) :67-110  [out[N+1], outLen | in | bytes[N], length, bigEndian[N], isSingleByte, isZero, firstRlpByte]
@@ -1096,7 +1123,7 @@ template <class P> GD SmRef gRlpInteger(P& p, int N, const F& in, S& outLen) {
     r = gShiftLeft(p, N, by, N - length);
     copy_n(p, be, r, (int)(N));
     B single = p.put(isb, gLessThanF(p, 8 * N, x, fr_from_i64(128)));
-    B zero = p.put(isz, gIsZeroF(p, x));
+    B zero = p.put(isz, gIsZeroFd(p, x));
     S first = p.put(frb, gMux1SF(p, 0x80 + length, x, single));
     bool sb = p.bit(single), zb = p.bit(zero);
     p.put(o, first + (zb ? 0x80 : 0));

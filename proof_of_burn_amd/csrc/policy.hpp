@@ -115,7 +115,7 @@ struct CountP : PolBase {
     HD void derived(uint32_t, S) {}               // a DERIVED wire (see the header): value v / the inverse of x; only the emitter does anything
     HD void derived_inv(uint32_t, S, bool = false) {}       // (true: the IsZero is the child of an IsEqual [out | in[2]] -- the emitter's self-check, EmitP::w32)
     HD void derived_fr(uint32_t, const F&) {}     // ... with a field-element value (Montgomery) / the field inverse of x (0 for 0)
-    HD void derived_fr_inv(uint32_t, const F&) {}
+    HD void derived_fr_inv(uint32_t, const F&, bool = true) {}
     HD void site_m(uint32_t, uint32_t, uint32_t) {}         // self-check site of SubstringCheck's M[] recurrence (EmitP)
     HD void site_c(uint32_t, uint32_t) {}                   // self-check site of a copy constraint a === b between a derived wire and the stored wire it must equal
     HD F get(FrRef) { return fr_zero(); }
@@ -297,7 +297,7 @@ struct DevPol : PolBase {
     __device__ __forceinline__ void site_m(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void site_c(uint32_t, uint32_t) {}
     __device__ __forceinline__ void derived_fr(uint32_t, const F&) {}
-    __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&) {}
+    __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&, bool = true) {}
     __device__ __forceinline__ void run_derived(uint32_t, uint32_t, B) {}
     __device__ __forceinline__ void derived_bit(uint32_t, B) {}
     __device__ __forceinline__ F ld(FrRef r) {
@@ -490,7 +490,7 @@ struct EmitP : DevPol {
     __device__ __forceinline__ void derived(uint32_t w, S v) { if (m.lane == sel) w32(w, small(v)); }          // (shadow DevPol's no-ops)
     __device__ __forceinline__ void derived_inv(uint32_t w, S x, bool iseq = false) { emit_inv(w, x, iseq); }
     __device__ __forceinline__ void derived_fr(uint32_t w, const F& v) { if (m.lane == sel) w32(w, fr_from_mont(v)); }
-    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x) { if (m.lane == sel) { const bool z = fr_is_zero(x); w32(w, z ? fr_zero() : fr_from_mont(fr_inv(x)), (z ? 3 : 2) | 4); } }       // (always an IsEqual's child: gadgets.hpp iseqf_derived)
+    __device__ __forceinline__ void derived_fr_inv(uint32_t w, const F& x, bool iseq = true) { if (m.lane == sel) { const bool z = fr_is_zero(x); w32(w, z ? fr_zero() : fr_from_mont(fr_inv(x)), (z ? 3 : 2) | (iseq ? 4 : 0)); } }       // (iseq: an IsEqual's child, gadgets.hpp iseqf_derived; false: a bare IsZero, gIsZeroFd)
     // the selected witness' value in every lane (a unit that has many inverses to rebuild spreads them over the lanes: circuits.hpp U_SC_RANGE)
     __device__ __forceinline__ F bcast_sel(const F& v) {
         F r;
