@@ -97,7 +97,9 @@ int pob_host_alloc(void** p, uint64_t bytes);
 void pob_host_free(void* p);
 
 /* Replaces the run of the calculator (all `<==` / `<--` / `===`; reference Makefile:4-5): enqueues every stage on
- * `stream` (a hipStream_t, NULL = the handle's own stream) for the n uploaded inputs.  Asynchronous.              */
+ * `stream` (a hipStream_t, NULL = the handle's own stream) for the n uploaded inputs.  Asynchronous.  pob_generate and
+ * pob_constraint_check of one handle may be given different streams: each is ordered behind the other's last call by the handle's own events
+ * (the same stream needs none).                                                                                    */
 int pob_generate(pob_handle h, void* stream);
 /* Per-gate constraint evaluator over the resident witness vector (north star; the reference checks inline,
  * e.g. assert.circom:46,62,78, divide.circom:32): re-reads every STORED wire and checks it against its defining expression evaluated on

@@ -257,6 +257,7 @@ struct pob_ctx {
     // waits for the end of that evaluation; the evaluation then uses the pool's two evaluation streams
     pob_ctx* partner = nullptr; struct StreamPool* pool = nullptr;
     hipEvent_t ev_gen_done = nullptr, ev_check_done = nullptr; bool gen_done_rec = false, check_done_rec = false, evaluated = false;
+    hipStream_t gen_stream = nullptr, chk_stream = nullptr; bool gen_ordered = false, chk_ordered = false;      // where the last generation / evaluation was enqueued (a call on ANOTHER stream is ordered behind it by its event)
     // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
     hipStream_t s_upload = nullptr;                         // = the pool's upload stream
     hipEvent_t ev_upload = nullptr, ev_rec[2] = {nullptr, nullptr};   // ev_rec[s]: the records of buffer s are written
@@ -763,6 +764,8 @@ int pob_generate(pob_handle h, void* stream_) {
     if (h->have_next) { h->in_cur = h->in_next; h->n = h->n_next; h->have_next = false; }      // the uploaded batch becomes the current one (else: the same inputs again)
     const uint32_t G = (h->n + 63) / 64;
     if (h->upload_pending) { HIPC(hipStreamWaitEvent(st, h->ev_upload, 0)); h->upload_pending = false; }
+    if (h->chk_ordered && h->chk_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_check_done, 0));      // the previous batch's evaluation still reads the vector this generation overwrites
+    h->chk_ordered = false;
     h->rec_slot ^= 1;                                   // this batch's records go to the other pinned buffer: the previous batch's stay readable
     if (h->inorder) {
         GArgs A = gargs(h);
@@ -777,7 +780,7 @@ int pob_generate(pob_handle h, void* stream_) {
         HIPC(hipGetLastError());
         HIPC(hipEventRecord(h->ev_g_done, st));
         { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
-        HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
+        HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true; h->gen_stream = st; h->gen_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
         h->generated = true; h->evaluated = false; h->gen_count++;
         h->em.queued_idx = -1;
@@ -858,7 +861,7 @@ int pob_generate(pob_handle h, void* stream_) {
     HIPC(hipEventRecord(h->ev_g_done, st));              // every stage of the G side is enqueued behind this point of st (the joined tracks included)
     for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
     { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
-    HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true;
+    HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true; h->gen_stream = st; h->gen_ordered = true;
     HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
     h->generated = true; h->evaluated = false; h->gen_count++;
     h->em.queued_idx = -1;                              // an announcement (pob_emit_queue) names a witness of the batch it was made for; a window pre-made from that batch is not reused (pre_made_gen)
@@ -870,6 +873,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipSetDevice(h->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : own_stream(h);
     const uint32_t G = (h->n + 63) / 64;
+    if (h->gen_ordered && h->gen_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_gen_done, 0));      // evaluation on another stream than the generation's: behind its end
     GArgs A = gargs(h);
     // The evaluation has no dependencies between launches: one kernel per family (+ the two Keccak kernels), spread over the
     // caller's stream and two side streams: the HBM-streaming Keccak round + chain evaluation alone on the caller's stream from the start,
@@ -892,7 +896,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
         for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
-        HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true;
+        HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));
         HIPC(hipGetLastError());
         return POB_OK;
@@ -927,7 +931,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipEventRecord(h->ev_join, side[0])); HIPC(hipEventRecord(h->ev_join3, side[1]));
     HIPC(hipStreamWaitEvent(st, h->ev_join, 0)); HIPC(hipStreamWaitEvent(st, h->ev_join3, 0));
     { int rc = enqueue_collect(h, st, true); if (rc) return rc; }          // the batch's records, now with the evaluator's verdict
-    HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true;
+    HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
     HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));                 // (the evaluation reads the packed inputs too: the input units' relations)
     HIPC(hipGetLastError());
     return POB_OK;

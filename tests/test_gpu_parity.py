@@ -589,6 +589,34 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
         c.close()
 
 
+def test_generation_and_evaluation_on_different_streams(pkg):
+    """pob_generate and pob_constraint_check called with DIFFERENT streams (both schedules): the evaluation is ordered behind the generation's end and the next
+    generation behind the evaluation's end by the handle's own events -- the records of three consecutive batches equal the one-stream run's"""
+    import torch
+    from proof_of_burn_amd import inputs as gen
+    n = 130
+    batches = [gen.synthetic_batch(n, depth=10, seed=0x40 + k, distinct_keys=2) for k in range(3)]
+    bad = dict(batches[1].inputs[70]); bad["numLayers"] = 9                    # one failing witness in the middle batch: the verdicts are not all alike
+    batches[1].inputs[70] = bad
+    ref = pkg.WitnessCalculator(PROD, max_batch=n)
+    want = [[(r.status, r.outputs, r.check_status, r.bad_wire) for r in ref.calculate(bt.inputs, check=True)] for bt in batches]
+    ref.close()
+    assert want[1][70][0] != 0 and all(w[0] == 0 and w[2] == 0 for w in want[0])
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for inorder in (False, True):
+        c = pkg.WitnessCalculator(PROD, max_batch=n)
+        c.set_inorder(inorder)
+        for rnd in range(2):
+            for k, bt in enumerate(batches):
+                c.upload(bt.inputs)
+                c.generate(sa.cuda_stream)
+                c.constraint_check(sb.cuda_stream)
+                if (k + rnd) % 2:                                              # every other batch is read; the others are overwritten while still being evaluated
+                    got = [(r.status, r.outputs, r.check_status, r.bad_wire) for r in c.results(with_check=True)]
+                    assert got == want[k], (inorder, rnd, k)
+        c.close()
+
+
 def test_device_field_inversions(pkg):
     """the device code's two field inversions (Kaliski almost-inverse: generation and the emitter's field-element IsZero.inv; Fermat ladder: the
     emitter's fall-back beyond its table of small inverses, unreachable for a valid witness -- tests/test_hostsim_cpu.py) on the GPU against
