@@ -392,8 +392,8 @@ def test_two_calculators_pipelined_over_consecutive_batches(pkg):
 def test_two_ranks_on_one_gpu_equal_a_single_rank_run(pkg, tmp_path):
     """BASELINE config 4's shape on the hardware at hand: bench.py --gpus 2 as two ranks (own process, own handle, own slice of the
     global batch) sharing GPU 0, result records through ONE all-gather (gloo here, RCCL on a node); the gathered 1024 records must
-    equal a single-rank run of the same 1024 seeds (the two ranks in bench.py's default two-calculator pipeline, the single rank
-    without it).  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
+    equal a single-rank run of the same 1024 seeds (the two ranks with bench.py's default four in-order calculators in flight each, the
+    single rank with one calculator).  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
     a, b = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
     quick = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single"]
     two = _run_bench(["--gpus", "2", "--batch", "512", "--dump-results", a] + quick, {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
