@@ -194,8 +194,8 @@ HD void fr256_submod(uint32_t* a, const uint32_t* b) {   // a <- a - b mod p
 // 2^(768-k) from a table: (x = a*R)  x^-1 * 2^k * 2^(768-k) * 2^-256 = a^-1 * R.
 #include "fr_pow2_table.h"
 static __device__ const uint32_t FR_POW2_TAB[FR_POW2_TAB_LEN * 8] = FR_POW2_TAB_INIT;
-// fr_inv_inl: inlined into its (few) generation call sites -- as a called function it needs more VGPRs than the caller-saved set
-// and saves callee-saved ones on the stack, which is the only scratch those kernels would have; fr_inv: the called form.
+// fr_inv_inl: the inlined form -- as a called function it needs more VGPRs than the caller-saved set and saves callee-saved ones on the
+// stack; fr_inv: the called form.  (Round 4: only the emitter inverts -- every IsZero.inv wire is derived -- and the inversion test kernel.)
 HD Fr fr_inv_inl(Fr a) {
     const uint32_t P[8] = FR_P_LIMBS;
     uint32_t u[8], v[8], r[8], s[8];

@@ -22,7 +22,7 @@
 //          * running sums that are functions of stored wires: Selector.sum[], SubstringCheck.M[];
 //        1.29 M of the 1.36 M non-BIT wires of the production circuit.  Rounds 1-2 stored them (int32 rows, the Keccak selectors'
 //        as an int8 class of their own, IsZero.inv as its operand code, M[] and the IsEqual(exists) operands as field elements).
-//        Round 4 added BIT-valued derived wires, written by the emitter as lane-distributed runs (run_derived) or single bits (derived_bit):
+//        Round 4 added BIT-valued derived wires, written by the emitter as lane-distributed runs (run_derived):
 //          * copies of a stored bit: five of the six copies of every padded byte's bits (only Keccak's inBlocks is stored), nine of the ten copies of the
 //            hash bits (only Selector.out), vals[] / arrays / arraysT of the Keccak output selectors (copies of Final.s), the IsEqual children's outputs
 //            under every stored isEq[] / isLast[] bit;
@@ -133,7 +133,6 @@ struct CountP : PolBase {
     HD B run_get(uint32_t, uint32_t) { return 0; }
     HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; nb += n; }
     HD void run_derived(uint32_t, uint32_t, B) {}      // n DERIVED BIT wires as a lane-distributed run (lane k: wire index, that wire's 64-witness mask): the emitter only
-    HD void derived_bit(uint32_t, B) {}
     HD B run_bcast(B, uint32_t) { return 0; }
     HD B run_set(B run, uint32_t, B) { return run; }
     HD B run_perm(B run, uint32_t) { return run; }
@@ -299,7 +298,6 @@ struct DevPol : PolBase {
     __device__ __forceinline__ void derived_fr(uint32_t, const F&) {}
     __device__ __forceinline__ void derived_fr_inv(uint32_t, const F&, bool = true) {}
     __device__ __forceinline__ void run_derived(uint32_t, uint32_t, B) {}
-    __device__ __forceinline__ void derived_bit(uint32_t, B) {}
     __device__ __forceinline__ F ld(FrRef r) {
         F v; const uint32_t so = POB_UNI(r.i) << 11;
 #pragma unroll
@@ -513,9 +511,8 @@ struct EmitP : DevPol {
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B, uint32_t) {}
-    // derived BIT wires: lane k < n writes wire w (its own) from the mask x it holds / one wave-uniform wire
+    // derived BIT wires: lane k < n writes wire w (its own) from the mask x it holds
     __device__ __forceinline__ void run_derived(uint32_t n, uint32_t w, B x) { if (m.lane < n) { Fr c = {{(uint32_t)((x >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); } }
-    __device__ __forceinline__ void derived_bit(uint32_t w, B v) { if (m.lane == 0) { Fr c = {{(uint32_t)((v >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); } }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B) {
         if (m.lane < n) { B s = run_ld_off(i << 3); Fr c = {{(uint32_t)((s >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); }
     }
