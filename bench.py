@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--probe-after", action="store_true", help="record the HIP events around the Keccak round evaluation kernel in 16 extra steps after the timed region instead of inside it")
     ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
     ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
+    ap.add_argument("--x-kchk-sweep", default="", help="EXPERIMENT (round 5): comma-separated k_rounds_check variants, each run alone and in the loop with 4 and 8 in flight")
     ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records of the LAST batch (uint8 [N*B, 44]) to this .npy")
     args = ap.parse_args()
 
@@ -386,6 +387,35 @@ def main():
             c.close()
         del calcs[n_before:], streams[n_before:], recs[n_before:], gathered_ev[n_before:], uploaded[n_before:]
         work["NC"] = NC
+    if args.x_kchk_sweep:
+        import ctypes
+        lib = ctypes.CDLL(W.LIB_PATH)
+        extra = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(8 - NC)]
+        for c in extra:
+            c.set_inorder(True)
+        calcs.extend(extra); streams.extend(torch.cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
+        gathered_ev.extend([None] * len(extra)); uploaded.extend([False] * len(extra))
+        for c in calcs:
+            c.probe_check_kernel(True)
+        sweep = []
+        for rnd in range(2):
+            for v in [int(x) for x in args.x_kchk_sweep.split(",")]:
+                lib.pob_x_set_kchk(v)
+                row = {"variant": v, "round": rnd, "alone_ms": round(calcs[0].time_kernel(1, iters=8, stream=streams[0].cuda_stream), 4)}
+                for nc in (4, 8):
+                    work["NC"] = nc
+                    probing = True
+                    run(nc); fence()
+                    state.update(validated=0, kchk_ms=[])
+                    t1 = time.perf_counter()
+                    run(64, k0=nc); fence()
+                    d = time.perf_counter() - t1
+                    probing = False
+                    row[f"step_ms_{nc}"] = round(d / 64 * 1e3, 4); row[f"kchk_ms_{nc}"] = round(float(np.mean(state["kchk_ms"])), 4)
+                sweep.append(row)
+                print("SWEEP", json.dumps(row), file=sys.stderr, flush=True)
+        print(json.dumps({"sweep": sweep}))
+        return
     if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch:
         probing = False
         deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=dev_index) for b in range(2)]
@@ -401,8 +431,12 @@ def main():
     #                                + the round input/output states it is checked against.
     t_chk = calcs[0].time_kernel(1, iters=5, stream=stream0)
     t_gen = calcs[0].time_kernel(0, iters=5, stream=stream0)
-    round_bytes = (76 + 2 * 25) * 64 * 8                  # the 76 stored gate-output arrays of a round block + midRound[r] + midRound[r+1] (keccak_kernels.hpp)
-    launch_bytes = info.n_perms * 24 * round_bytes * groups
+    # a wavefront of k_rounds_check covers k = info.kchk_rounds consecutive rounds of a permutation: midRound[r0] once, then per round the 76 stored gate-output
+    # arrays + the stored midRound[r+1] (which stays in registers as the next round's input): 101 k + 25 arrays of 512 B, every resident array of the chunk
+    # counted ONCE (round 4's one-round items fetched -- and counted -- every state twice: 126 arrays per round)
+    kr = int(info.kchk_rounds)
+    launch_bytes = info.n_perms * (24 // kr) * (101 * kr + 25) * 64 * 8 * groups
+    launch_bytes_r4 = info.n_perms * 24 * 126 * 64 * 8 * groups
     alone = launch_bytes / (t_chk * 1e-3) / 1e9
     in_step = launch_bytes / (kchk_in_step * 1e-3) / 1e9 if kchk_in_step else None
     # whole evaluation pass and whole step against the resident vector (write once, read once)
@@ -435,7 +469,9 @@ def main():
                 "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
                 "traffic": traffic,
                 "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
-                "bytes_per_launch": launch_bytes,
+                "bytes_per_launch": launch_bytes, "rounds_per_wavefront": kr,
+                "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
+                                    f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
                 "gen_kernel": {"kernel": "k_rounds<GEN>, alone", "achieved": round(info.n_perms * 24 * (76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)},
                 "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,

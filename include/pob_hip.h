@@ -41,6 +41,10 @@ typedef struct {
                                     output / of the round's input or output state, possibly at a rotated bit position (ShL / ShR / RhoPi) or negated
                                     (NotArray), or constants (shifted-out positions, round constants).  76 of the 1 604 arrays of a KeccakfRound
                                     block are stored (keccak_kernels.hpp); the emitter expands the others through one table                          */
+    uint32_t kchk_rounds;        /* consecutive rounds of a permutation that ONE wavefront of the round evaluation covers (k_rounds_check): it fetches
+                                    midRound[r0] once and then 101 arrays per round, the verified midRound[r+1] staying in registers as the next round's
+                                    input -- (101 k + 25) / k arrays of 512 B per (64 witnesses, round)                                               */
+    uint32_t reserved_;
 } pob_info_t;
 
 /* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference

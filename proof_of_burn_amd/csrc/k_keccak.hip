@@ -5,12 +5,21 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
     if (check) hipLaunchKernelGGL(k_chain_check, dim3(nsponges, ngroups), dim3(64), 0, st, K);
     else hipLaunchKernelGGL(k_chain<false>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
 }
+// EXPERIMENT SWITCH (round 5, to be removed): POB_X_KCHK = <rounds per wavefront> * 1000 + <waves per SIMD> * 100 + <loads in flight per wavefront>, e.g. 4412
+#define KCHK_VARIANTS(X) X(4,4,0) X(4,4,8) X(4,4,12) X(4,4,16) X(4,4,20) X(4,5,8) X(4,5,12) X(4,3,0) X(4,3,16) X(4,3,24) X(6,4,12) X(6,4,16) X(3,4,12) X(3,4,16) X(8,4,16) X(2,4,16) X(1,2,0)
+static int g_kchk = -1;
+static int kchk_variant() { if (g_kchk < 0) { const char* e = getenv("POB_X_KCHK"); g_kchk = e ? atoi(e) : 4412; } return g_kchk; }
+extern "C" void pob_x_set_kchk(int v) { g_kchk = v; }
+int pob_kchk_rounds() { return kchk_variant() / 1000; }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
-    // (non-temporal loads in the evaluation: 4.35 -> 4.09 ms per launch at batch 1024, 0.785 -> 0.836 of the HBM peak)
-    // (compiled for 3 / 4 waves per SIMD -- 168 VGPRs + 64 B scratch / 128 + 152 B -- it is slower alone (4.4-4.7 / 4.6-5.2 ms vs 4.09) and in the step
-    //  (13.3-13.7 / 13.7-14.0 ms vs 13.15-13.2): profiles/round3_experiments.txt)
-    if (check) hipLaunchKernelGGL((k_rounds<true, true>), dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
-    else hipLaunchKernelGGL(k_rounds<false>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
+    if (check) {
+        switch (kchk_variant()) {
+#define X(kr, w, f) case kr * 1000 + w * 100 + f: hipLaunchKernelGGL((k_rounds_check<true, kr, w, f>), dim3(nperms * (24 / kr), ngroups), dim3(64), 0, st, K); break;
+        KCHK_VARIANTS(X)
+#undef X
+        default: abort();
+        }
+    } else hipLaunchKernelGGL(k_rounds_gen, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
 }
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
     uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;

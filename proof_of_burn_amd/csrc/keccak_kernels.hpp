@@ -61,6 +61,7 @@ struct DevIOBase {
     __device__ __forceinline__ V rc(int r) const { return ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL; }
     __device__ __forceinline__ void arr(uint32_t, V) const {}
     __device__ __forceinline__ void gate(uint32_t, V, V, V) const {}
+    __device__ __forceinline__ void out(int, V) const {}
 };
 // generation: the 76 gate outputs are stored; the round's output state is midRound[r+1], which k_chain wrote
 struct GenIO : DevIOBase {
@@ -71,14 +72,65 @@ struct GenIO : DevIOBase {
     __device__ __forceinline__ V gxo(int, V a, V b) const { return a ^ b; }
 };
 // constraint evaluation: every gate's STORED output against the gate function of its STORED operands; the stored value is what the next
-// gate sees.  NT: non-temporal loads (the evaluation streams the vector through the L2s once and never re-reads a line)
-template <bool NT> struct CheckIOT : DevIOBase {
-    const u64* st; const u64* in_; const u64* out_; u64 bad;
+// gate sees.  The round's input state is held in registers (s[]): a wavefront evaluates several consecutive rounds of one permutation, and the
+// stored midRound[r+1] it has just verified as round r's output IS round r+1's input (keccak.circom:356-367) -- every resident array is
+// fetched once.  NT: non-temporal loads (the evaluation streams the vector through the L2s once and never re-reads a line)
+// The 101 loads of a round come in the walk's fixed order (kchk_seq); the compiler, held to 128 VGPRs, issues ONE load per wait whatever it is told, so the
+// loads in flight are written into the source: a ring of DP prefetched arrays -- the gate that consumes load q issues load q + DP, and a scheduling barrier
+// after every gate keeps each load where it is written.
+//   q = 0..24: stored slot q (Xor5 partials, D) | 25..49: theta out, i outer / j inner | 50 + 2i: AND(i), 51 + 2i: chi out i (i = 0: the stored stepChi 0 out) | 100: iota out 0
+HD constexpr int kchk_seq(int q) {        // >= 0: word offset in the round's stored arrays; < 0: -(word offset in midRound[r+1]) - 1
+    if (q < 25) return 64 * q;
+    if (q < 50) return 64 * (25 + (q - 25) / 5 + 5 * ((q - 25) % 5));
+    if (q == 100) return -1;
+    if ((q & 1) == 0) return 64 * (50 + (q - 50) / 2);
+    return q == 51 ? 64 * 75 : -(64 * ((q - 51) / 2)) - 1;
+}
+// ... and its inverse: the position of an array in the sequence (a constant wherever the walk is unrolled: the ring is indexed by constants)
+HD constexpr int kchk_pos(int want) {
+    if (want < 0) { const int i = (-want - 1) / 64; return i == 0 ? 100 : 51 + 2 * i; }
+    const int sl = want / 64;
+    if (sl < 25) return sl;
+    if (sl < 50) return 25 + (sl - 25) % 5 * 5 + (sl - 25) / 5;
+    return sl == 75 ? 51 : 50 + 2 * (sl - 50);
+}
+#define KCHK_LOADS 101
+template <bool NT, int DP = 0> struct CheckIOT : DevIOBase {
+    const u64* st; const u64* out_; u64 bad; V s[25];
+    V ring[DP ? DP : 1];
     __device__ __forceinline__ u64 ldw(const u64* p) const { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
-    __device__ __forceinline__ V in(int i) const { return ldw(in_ + 64 * i + lane); }
-    __device__ __forceinline__ V gx(uint32_t s, V a, V b) { const V v = ldw(st + 64 * s + lane); bad |= v ^ a ^ b; return v; }
-    __device__ __forceinline__ V ga(uint32_t s, V a, V b) { const V v = ldw(st + 64 * s + lane); bad |= v ^ (a & b); return v; }
-    __device__ __forceinline__ V gxo(int i, V a, V b) { const V v = ldw(out_ + 64 * i + lane); bad |= v ^ a ^ b; return v; }
+    __device__ __forceinline__ V ldq(int k) const { const int o = kchk_seq(k); return o >= 0 ? ldw(st + o + lane) : ldw(out_ + (-o - 1) + lane); }
+    __device__ __forceinline__ void begin_round() {
+        lane4 = lane * 4u; POB_OPAQUE(lane4);
+        if constexpr (DP > 0) {
+#pragma unroll
+            for (int k = 0; k < DP; k++) ring[k] = ldq(k);
+        }
+    }
+    // the array at `want` (kchk_seq's coding): it was requested DP gates ago; its slot of the ring takes the array DP positions further on
+    __device__ __forceinline__ V next(int want) {
+        V v;
+        if constexpr (DP > 0) {
+            const int q = kchk_pos(want);
+            v = ring[q % DP];
+            if (q + DP < KCHK_LOADS) ring[q % DP] = ldq(q + DP);
+            __builtin_amdgcn_sched_barrier(0);
+        } else v = want >= 0 ? ldw(st + want + lane) : ldw(out_ + (-want - 1) + lane);
+        return v;
+    }
+    // rotation addresses from an opaque copy of the lane's byte address (refreshed once per round): otherwise the 25 loop-invariant ds_bpermute
+    // addresses of a round are hoisted out of the round loop and held -- or spilled -- across it
+    uint32_t lane4;
+    __device__ __forceinline__ V rotl(V v, int r) const {
+        const int a = (int)((lane4 + 4u * (64u - (uint32_t)r)) & 252u);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(v >> 32));
+        return ((u64)hi << 32) | lo;
+    }
+    __device__ __forceinline__ V in(int i) const { return s[i]; }
+    __device__ __forceinline__ V gx(uint32_t sl, V a, V b) { const V v = next(64 * (int)sl); bad |= v ^ a ^ b; return v; }
+    __device__ __forceinline__ V ga(uint32_t sl, V a, V b) { const V v = next(64 * (int)sl); bad |= v ^ (a & b); return v; }
+    __device__ __forceinline__ V gxo(int i, V a, V b) { const V v = next(-(64 * i) - 1); bad |= v ^ a ^ b; return v; }
+    __device__ __forceinline__ void out(int i, V v) { s[i] = v; }
 };
 // host side: V = the 64 codes of an array; the walk fills the alias table of the block (one per library, shared by every round: the only
 // round-dependent wires are the round constants, coded KS_RC)
@@ -109,6 +161,7 @@ struct SymIO {
     V rc(int) { V v; for (uint32_t k = 0; k < 64; k++) v.e[k] = enc(KS_RC, k); return v; }
     void arr(uint32_t off, const V& v) { for (uint32_t k = 0; k < 64; k++) set(off + k, v.e[k]); }
     void gate(uint32_t off, const V& o, const V& a, const V& b) { for (uint32_t k = 0; k < 64; k++) { set(off + 3 * k, o.e[k]); set(off + 3 * k + 1, a.e[k]); set(off + 3 * k + 2, b.e[k]); } }
+    void out(int, const V&) {}
     void set(uint32_t w, uint16_t e) { if (w >= KECCAKF_ROUND_WIRES || tab[w] != 0xFFFFu) ok = false; else tab[w] = e; }     // every wire exactly once
 };
 
@@ -247,7 +300,7 @@ template <class IO> HD void round_walk(IO& io, int r) {
         for (int i = 0; i < 25; i++) io.arr(Ib + 64 * i, out[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 25; i++) io.arr(64 * i, out[i]);
+    for (int i = 0; i < 25; i++) { io.arr(64 * i, out[i]); io.out(i, out[i]); }
 }
 // the alias table of a KeccakfRound block (KECCAKF_ROUND_WIRES codes): false if the walk did not name every wire exactly once
 static inline bool keccak_round_alias_table(uint16_t* tab) {
@@ -349,32 +402,55 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
     if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
 }
 
-// One KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain); generation writes the 76 gate-output
-// arrays of the round (38.9 KB per 64 witnesses), evaluation reads them + midRound[r] + midRound[r+1] (126 arrays = 64.5 KB) and checks every
-// XOR / AND gate of the round on stored operands.  (Rounds 1-3 stored all 102 656 wires of the block: 821 KB per item.)
-#define KR_CHECK_ARRAYS (KR_STORED + 50u)
-template <bool CHECK, bool NT> __device__ __forceinline__ void rounds_item(const KArgs& A, uint32_t x, uint32_t y, uint32_t lane) {
+// Generation: one KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain), writes the 76 gate-output
+// arrays of the round (38.9 KB per 64 witnesses).  (Rounds 1-3 stored all 102 656 wires of the block: 821 KB per item.)
+__global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
+    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
     const uint32_t pi = A.first + x / 24, r = x % 24;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
     u64* G = A.bits + (uint64_t)y * A.group_stride;
-    if (CHECK) {
-        CheckIOT<NT> io; io.lane = lane; io.bad = 0;
-        io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r; io.out_ = io.in_ + 1600;
-        round_walk(io, (int)r);
-        u64 bad = io.bad;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
-        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
-    } else {
-        GenIO io; io.lane = lane;
-        io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r;
-        round_walk(io, (int)r);
-    }
+    GenIO io; io.lane = lane;
+    io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r;
+    round_walk(io, (int)r);
 }
-// grid = (24 * permutations, groups): one wavefront per item
-template <bool CHECK, bool NT = false> __global__ void __launch_bounds__(64) k_rounds(KArgs A) {
-    rounds_item<CHECK, NT>(A, blockIdx.x, blockIdx.y, threadIdx.x);
+
+// Constraint evaluation: one wavefront per (permutation, KR consecutive rounds, group).  It loads midRound[r0] once, then per round the 76 stored
+// gate outputs and the stored midRound[r+1] (101 arrays = 51 712 B per 64 witnesses), checks every XOR / AND gate of the round on stored operands and
+// keeps the verified midRound[r+1] in registers as the next round's input: (101 KR + 25) / KR arrays per round, each resident array of the chunk
+// fetched once (round 4's one-round items fetched every state twice: 126 arrays per round).
+#define KR_CHECK_ARRAYS(kr) (101u * (kr) + 25u)
+#ifdef POB_HOSTSIM
+#define POB_WAVES_PER_SIMD(n)
+#else
+#define POB_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) {
+    static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
+    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
+    const uint32_t pi = A.first + x / (24 / KR), r0 = x % (24 / KR) * KR;
+    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
+    const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
+    const u64* G = A.bits + (uint64_t)y * A.group_stride;
+    CheckIOT<NT, DP> io; io.lane = lane; io.bad = 0;
+    const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0;
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.s[i] = io.ldw(mid + 64 * i + lane);
+    io.st = G + Ab + AB_DIRECT + r0 * KR_BITS;
+#pragma unroll 1
+    for (uint32_t r = r0; r < r0 + KR; r++) {
+        mid += 1600; io.out_ = mid;
+        io.begin_round();
+        round_walk(io, (int)r);
+        io.st += KR_BITS;
+        if (__any(io.bad != 0)) {       // (corrupted vectors only) which witnesses, and the round block the mismatch belongs to
+            u64 bad = io.bad;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
+            if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
+            io.bad = 0;
+        }
+    }
 }
 
 // the 64-witness word of the wire at offset o of an Absorb block whose storage starts at BIT rank ab (A = this group's slab); *neg: the

@@ -59,6 +59,7 @@ void launch_g_check_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStr
 void launch_g_emit_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
+int pob_kchk_rounds();        // rounds per wavefront of the round evaluation (k_keccak.hip)
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);
 // reduced form: wires [wire0, wire0 + count) with BIT ranks from bit_base; kept wires land at out + 32 * (rank - k0) when rank - k0 < kn
 void launch_k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t bit_base, uint32_t count, uint32_t sel, const unsigned long long* rbits, const uint32_t* rpre, uint32_t k0, uint32_t kn, hipStream_t st);

@@ -412,6 +412,7 @@ static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_i
     info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;      // (derived wires take no storage)
     info->n_derived = pl.total.q;
     info->n_alias = (uint64_t)nperms * ABSORB_ALIAS;
+    info->kchk_rounds = (uint32_t)pob_kchk_rounds(); info->reserved_ = 0;
     info->keccak_bit_wires = 0;
     for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
 }

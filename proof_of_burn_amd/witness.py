@@ -115,7 +115,8 @@ class PobInfo(ctypes.Structure):
                 ("n_fr_inputs", ctypes.c_uint32), ("n_sm_inputs", ctypes.c_uint32), ("n_outputs", ctypes.c_uint32),
                 ("n_units", ctypes.c_uint32), ("n_sponges", ctypes.c_uint32), ("n_perms", ctypes.c_uint32),
                 ("n_stages", ctypes.c_uint32), ("max_batch", ctypes.c_uint32),
-                ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64), ("n_derived", ctypes.c_uint64), ("n_alias", ctypes.c_uint64)]
+                ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64), ("n_derived", ctypes.c_uint64), ("n_alias", ctypes.c_uint64),
+                ("kchk_rounds", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
 
 
 # one result record (include/pob_hip.h POB_RECORD_BYTES = 44)
