@@ -399,9 +399,11 @@ def main():
             c.probe_check_kernel(True)
         sweep = []
         for rnd in range(2):
-            for v in [int(x) for x in args.x_kchk_sweep.split(",")]:
-                lib.pob_x_set_kchk(v)
-                row = {"variant": v, "round": rnd, "alone_ms": round(calcs[0].time_kernel(1, iters=8, stream=streams[0].cuda_stream), 4)}
+            for ent in args.x_kchk_sweep.split(","):
+                v, gw, cw = (int(x) for x in (ent.split("/") + ["0", "0"])[:3])
+                lib.pob_x_set_kchk(v); lib.pob_x_set_kwaves(0, gw); lib.pob_x_set_kwaves(1, cw)
+                row = {"variant": ent, "round": rnd, "alone_ms": round(calcs[0].time_kernel(1, iters=8, stream=streams[0].cuda_stream), 4),
+                       "gen_alone_ms": round(calcs[0].time_kernel(0, iters=8, stream=streams[0].cuda_stream), 4)}
                 for nc in (4, 8):
                     work["NC"] = nc
                     probing = True

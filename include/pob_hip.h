@@ -20,7 +20,7 @@ extern "C" {
 typedef struct pob_ctx* pob_handle;
 
 enum { POB_CIRCUIT_PROOF_OF_BURN = 0, POB_CIRCUIT_SPEND = 1, POB_CIRCUIT_GADGET = 2 };
-enum { POB_OK = 0, POB_E_ARG = -1, POB_E_HIP = -2, POB_E_NOMEM = -3, POB_E_STATE = -4, POB_E_IO = -5 };
+enum { POB_OK = 0, POB_E_ARG = -1, POB_E_HIP = -2, POB_E_NOMEM = -3, POB_E_STATE = -4, POB_E_IO = -5, POB_E_RANGE = -6 };
 
 typedef struct {
     uint64_t n_witness;          /* W: O0 wires incl. the constant-1 wire (= nWitness of the .wtns)            */
@@ -96,6 +96,25 @@ int pob_pack_json(int circuit, const uint64_t* params, int nparams, const char* 
                   uint32_t* forced, char* err, uint32_t errcap);
 int pob_pack_json_batch(int circuit, const uint64_t* params, int nparams, const char* const* json, const uint64_t* len, uint32_t n, int threads,
                         uint8_t* fr, int32_t* sm, uint32_t* forced, char* err, uint32_t errcap);
+/* The same inputs with the byte-class values as BYTES on the wire (round 5: every one of ProofOfBurn's small inputs is a byte, a nibble count or a length --
+ * proof_of_burn.circom:43-72 -- and 10 900 of them per witness as int32 made the upload 44.8 MB per 1 024 witnesses, 0.79 ms of PCIe per 1.9 ms step):
+ *   sm8[n][n_sm_inputs]        the small inputs that are in 0..255, as they are; 0 where the value is not
+ *   exc[n][POB_EXC_CAP]        per witness the (few) small inputs outside 0..255 -- layerLens[] and blockHeaderLen above 255, and whatever a caller feeds
+ *                              out of range on purpose (the reference does: tests/testcases/rlp/integer.py:51-53) -- as {index in the row, int32 value};
+ *                              unused slots: k = POB_EXC_NONE
+ * 11.4 KB per production witness instead of 43.8.  The device widens the rows into the int32 form every kernel reads (one pass on the upload
+ * stream, behind the copy): the two forms are interchangeable batch by batch, results identical.  A witness with more than POB_EXC_CAP values
+ * outside 0..255 does not fit: pob_narrow_inputs / pob_pack_json_batch8 return POB_E_RANGE and the batch goes through the int32 entry points. */
+#define POB_EXC_CAP 32
+#define POB_EXC_NONE 0xFFFFFFFFu
+typedef struct { uint32_t k; int32_t v; } pob_sm_exc_t;
+int pob_upload_inputs8(pob_handle h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n);
+int pob_upload_inputs8_async(pob_handle h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n, void* stream);
+/* int32 rows (pob_pack_json*, the Python packer) -> the byte form; no GPU is touched */
+int pob_narrow_inputs(const int32_t* sm, uint32_t n, uint32_t n_sm_inputs, uint8_t* sm8, pob_sm_exc_t* exc);
+/* the loader straight into the byte form (same acceptance, same forced codes as pob_pack_json_batch) */
+int pob_pack_json_batch8(int circuit, const uint64_t* params, int nparams, const char* const* json, const uint64_t* len, uint32_t n, int threads,
+                         uint8_t* fr, uint8_t* sm8, pob_sm_exc_t* exc, uint32_t* forced, char* err, uint32_t errcap);
 /* Pinned host memory for the above (hipHostMalloc), so that a ctypes / cgo caller need not link the HIP runtime itself. */
 int pob_host_alloc(void** p, uint64_t bytes);
 void pob_host_free(void* p);

@@ -10,16 +10,20 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
 static int g_kchk = -1;
 static int kchk_variant() { if (g_kchk < 0) { const char* e = getenv("POB_X_KCHK"); g_kchk = e ? atoi(e) : 4412; } return g_kchk; }
 extern "C" void pob_x_set_kchk(int v) { g_kchk = v; }
+static int g_kwaves[2] = {0, 0};        // EXPERIMENT: wavefronts per group of the round expansion / evaluation launch (0 = one per item)
+extern "C" void pob_x_set_kwaves(int which, int v) { g_kwaves[which & 1] = v; }
 int pob_kchk_rounds() { return kchk_variant() / 1000; }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
+    KArgs A = K;
     if (check) {
         switch (kchk_variant()) {
-#define X(kr, w, f) case kr * 1000 + w * 100 + f: hipLaunchKernelGGL((k_rounds_check<true, kr, w, f>), dim3(nperms * (24 / kr), ngroups), dim3(64), 0, st, K); break;
+#define X(kr, w, f) case kr * 1000 + w * 100 + f: { A.count = nperms * (24 / kr); const uint32_t gx = g_kwaves[1] > 0 && (uint32_t)g_kwaves[1] < A.count ? g_kwaves[1] : A.count; \
+        hipLaunchKernelGGL((k_rounds_check<true, kr, w, f>), dim3(gx, ngroups), dim3(64), 0, st, A); } break;
         KCHK_VARIANTS(X)
 #undef X
         default: abort();
         }
-    } else hipLaunchKernelGGL(k_rounds_gen, dim3(nperms * 24, ngroups), dim3(64), 0, st, K);
+    } else { A.count = nperms * 24; const uint32_t gx = g_kwaves[0] > 0 && (uint32_t)g_kwaves[0] < A.count ? g_kwaves[0] : A.count; hipLaunchKernelGGL(k_rounds_gen, dim3(gx, ngroups), dim3(64), 0, st, A); }
 }
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
     uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;

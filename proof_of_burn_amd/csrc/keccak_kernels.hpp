@@ -52,8 +52,15 @@ __device__ __forceinline__ u64 lane_rotl(u64 v, int r, uint32_t lane) {
 // Device side of the walker: V = the 64-witness mask of bit position `lane`.  arr / gate (the alias wires) are nothing here.
 struct DevIOBase {
     typedef u64 V;
-    uint32_t lane;
-    __device__ __forceinline__ V rotl(V v, int r) const { return lane_rotl(v, r, lane); }
+    uint32_t lane, lane4;
+    // rotation addresses from an opaque copy of the lane's byte address (refresh(): once per round): otherwise the 25 loop-invariant ds_bpermute addresses
+    // of a round are hoisted out of the kernel's item / round loop and held -- or spilled -- across it
+    __device__ __forceinline__ void refresh() { lane4 = lane * 4u; POB_OPAQUE(lane4); }
+    __device__ __forceinline__ V rotl(V v, int r) const {
+        const int a = (int)((lane4 + 4u * (64u - (uint32_t)r)) & 252u);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(v >> 32));
+        return ((u64)hi << 32) | lo;
+    }
     __device__ __forceinline__ V keep_ge(V v, int s) const { return (int)lane >= s ? v : 0; }
     __device__ __forceinline__ V keep_lt(V v, int s) const { return (int)lane < s ? v : 0; }
     __device__ __forceinline__ V or_disjoint(V, V, V whole) const { return whole; }       // (a | b with disjoint supports = the unmasked rotation)
@@ -101,7 +108,7 @@ template <bool NT, int DP = 0> struct CheckIOT : DevIOBase {
     __device__ __forceinline__ u64 ldw(const u64* p) const { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
     __device__ __forceinline__ V ldq(int k) const { const int o = kchk_seq(k); return o >= 0 ? ldw(st + o + lane) : ldw(out_ + (-o - 1) + lane); }
     __device__ __forceinline__ void begin_round() {
-        lane4 = lane * 4u; POB_OPAQUE(lane4);
+        refresh();
         if constexpr (DP > 0) {
 #pragma unroll
             for (int k = 0; k < DP; k++) ring[k] = ldq(k);
@@ -117,14 +124,6 @@ template <bool NT, int DP = 0> struct CheckIOT : DevIOBase {
             __builtin_amdgcn_sched_barrier(0);
         } else v = want >= 0 ? ldw(st + want + lane) : ldw(out_ + (-want - 1) + lane);
         return v;
-    }
-    // rotation addresses from an opaque copy of the lane's byte address (refreshed once per round): otherwise the 25 loop-invariant ds_bpermute
-    // addresses of a round are hoisted out of the round loop and held -- or spilled -- across it
-    uint32_t lane4;
-    __device__ __forceinline__ V rotl(V v, int r) const {
-        const int a = (int)((lane4 + 4u * (64u - (uint32_t)r)) & 252u);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(v >> 32));
-        return ((u64)hi << 32) | lo;
     }
     __device__ __forceinline__ V in(int i) const { return s[i]; }
     __device__ __forceinline__ V gx(uint32_t sl, V a, V b) { const V v = next(64 * (int)sl); bad |= v ^ a ^ b; return v; }
@@ -404,15 +403,19 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
 
 // Generation: one KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain), writes the 76 gate-output
 // arrays of the round (38.9 KB per 64 witnesses).  (Rounds 1-3 stored all 102 656 wires of the block: 821 KB per item.)
+// grid = (waves, groups): a wavefront takes the items x = blockIdx.x, blockIdx.x + gridDim.x, ... < A.count (= 24 x permutations)
 __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
-    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
-    const uint32_t pi = A.first + x / 24, r = x % 24;
-    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
-    const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
+    const uint32_t lane = threadIdx.x, y = blockIdx.y;
     u64* G = A.bits + (uint64_t)y * A.group_stride;
-    GenIO io; io.lane = lane;
-    io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r;
-    round_walk(io, (int)r);
+#pragma unroll 1
+    for (uint32_t x = blockIdx.x; x < A.count; x += gridDim.x) {
+        const uint32_t pi = A.first + x / 24, r = x % 24;
+        const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
+        const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
+        GenIO io; io.lane = lane; io.refresh();
+        io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r;
+        round_walk(io, (int)r);
+    }
 }
 
 // Constraint evaluation: one wavefront per (permutation, KR consecutive rounds, group).  It loads midRound[r0] once, then per round the 76 stored
@@ -427,11 +430,13 @@ __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
 #endif
 template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) {
     static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
-    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
+    const uint32_t lane = threadIdx.x, y = blockIdx.y;
+    const u64* G = A.bits + (uint64_t)y * A.group_stride;
+#pragma unroll 1
+    for (uint32_t x = blockIdx.x; x < A.count; x += gridDim.x) {       // A.count = (24 / KR) x permutations chunks
     const uint32_t pi = A.first + x / (24 / KR), r0 = x % (24 / KR) * KR;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
-    const u64* G = A.bits + (uint64_t)y * A.group_stride;
     CheckIOT<NT, DP> io; io.lane = lane; io.bad = 0;
     const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0;
 #pragma unroll
@@ -450,6 +455,7 @@ template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(
             if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
             io.bad = 0;
         }
+    }
     }
 }
 

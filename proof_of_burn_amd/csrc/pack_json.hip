@@ -11,12 +11,21 @@
 //   * the byte-sized inputs are range-constrained in-circuit (AssertByteString, AssertBits(16) ...): a value that does not fit the int32
 //     row (>= 2^31 after reduction, e.g. a negative number) marks the witness as failed up front (FAIL_INPUT_RANGE) and is stored as
 //     0x7FFFFFFF (tests/testcases/rlp/integer.py:51-53, assertion.py:87 feed out-of-range values that must fail, not wrap).
-// Host code only (no kernel in this translation unit); pob_pack_json_batch spreads the texts over host threads and writes straight
-// into the caller's (pinned) arrays.
+// Host code only (no kernel in this translation unit); pob_pack_json_batch* spread the texts over the threads of a PERSISTENT pool (round 5: a
+// batch of 1 024 texts is 0.5 ms of parsing on the cores of a GPU box -- starting and joining threads per call cost more than that) and write straight
+// into the caller's (pinned) arrays.  Default width: the CPUs this process may run on (its affinity mask: a rank pinned to its GPU's NUMA node
+// gets that node's cores) divided by LOCAL_WORLD_SIZE when a launcher set it, so that the ranks of a node do not each start a full-width loader.
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <pthread.h>
+#include <sched.h>
+#include <new>
+#include <stdlib.h>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -260,7 +269,116 @@ bool pack_one(const Shape& sh, const char* json, uint64_t len, uint8_t* fr_row, 
     *forced = big_sm ? FAIL_INPUT_RANGE : 0;
     return true;
 }
+
+// ---- the loader's thread pool: workers sleep on a condition variable between batches; a job is "call fn(worker) on `want` workers"; the caller works too
+class LoaderPool {
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(uint32_t)>* job = nullptr; uint64_t gen = 0; uint32_t want = 0, taken = 0, done = 0; bool stop = false;
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(uint32_t)>* f = nullptr; uint32_t slot = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || (gen != seen && taken < want); });
+                if (stop) return;
+                seen = gen;
+                f = job; slot = ++taken;                     // (slot 0 is the caller)
+            }
+            (*f)(slot);
+            { std::lock_guard<std::mutex> lk(mu); if (++done == want) cv_done.notify_one(); }
+        }
+    }
+public:
+    std::mutex call_mu;                                      // one batch at a time through the pool (callers on other threads queue up)
+    ~LoaderPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_work.notify_all(); for (std::thread& t : th) t.join(); }
+    // fn(0) on the calling thread and fn(1 .. helpers) on pool threads; returns when all are done
+    void run(uint32_t helpers, const std::function<void(uint32_t)>& fn) {
+        if (helpers) {
+            std::lock_guard<std::mutex> lk(mu);
+            while (th.size() < helpers) th.emplace_back([this] { loop(); });
+            job = &fn; want = helpers; taken = done = 0; gen++;
+        }
+        if (helpers) cv_work.notify_all();
+        fn(0);
+        if (helpers) { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return done == want; }); want = 0; job = nullptr; }
+    }
+};
+// (leaked on purpose: no join of sleeping threads at exit; a forked child has none of the parent's threads and starts a pool of its own)
+LoaderPool* g_loader_pool = nullptr;
+std::mutex g_loader_pool_mu;
+LoaderPool& loader_pool() {
+    std::lock_guard<std::mutex> lk(g_loader_pool_mu);
+    if (!g_loader_pool) {
+        static bool hooked = false;
+        if (!hooked) { pthread_atfork(nullptr, nullptr, [] { g_loader_pool = nullptr; new (&g_loader_pool_mu) std::mutex(); }); hooked = true; }
+        g_loader_pool = new LoaderPool();
+    }
+    return *g_loader_pool;
+}
+
+uint32_t default_threads() {
+    uint32_t n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (uint32_t)CPU_COUNT(&set);
+    if (!n) n = std::thread::hardware_concurrency();
+    if (!n) n = 1;
+    if (const char* e = getenv("POB_LOADER_THREADS")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int v = atoi(e); if (v > 1) n = n / (uint32_t)v ? n / (uint32_t)v : 1; }
+    return n;
+}
+
+// one int32 row -> bytes + exception slots; false: more than POB_EXC_CAP values outside 0..255
+bool narrow_row(const int32_t* row, uint32_t nsm, uint8_t* b, pob_sm_exc_t* ex) {
+    uint32_t ne = 0;
+    for (uint32_t k = 0; k < nsm; k++) {
+        const int32_t v = row[k];
+        if ((uint32_t)v < 256u) b[k] = (uint8_t)v;
+        else { b[k] = 0; if (ne < POB_EXC_CAP) { ex[ne].k = k; ex[ne].v = v; } ne++; }
+    }
+    for (uint32_t e = ne; e < POB_EXC_CAP; e++) { ex[e].k = POB_EXC_NONE; ex[e].v = 0; }
+    return ne <= POB_EXC_CAP;
+}
+
+// n texts over the pool; sm8 / exc: the byte form (each worker parses into a row of its own and narrows it), else sm: the int32 form
+int pack_batch(const Shape& sh, const char* const* json, const uint64_t* len, uint32_t n, int threads, uint8_t* fr, int32_t* sm, uint8_t* sm8, pob_sm_exc_t* exc,
+               uint32_t* forced, char* err, uint32_t errcap);
 void put_err(char* dst, uint32_t cap, const std::string& m) { if (dst && cap) { snprintf(dst, cap, "%s", m.c_str()); } }
+int pack_batch(const Shape& sh, const char* const* json, const uint64_t* len, uint32_t n, int threads, uint8_t* fr, int32_t* sm, uint8_t* sm8, pob_sm_exc_t* exc,
+               uint32_t* forced, char* err, uint32_t errcap) {
+    uint32_t nt = threads > 0 ? (uint32_t)threads : default_threads();
+    if (nt > (n + 3) / 4) nt = (n + 3) / 4;                        // at least four texts (~0.5 ms of parsing) per thread: waking a sleeping worker costs tens of microseconds
+    if (nt == 0) nt = 1;
+    std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu), overflow(0);
+    std::vector<std::string> errs(nt);
+    const uint32_t smw = sh.nsm ? sh.nsm : 1;                      // (witness.py keeps one dummy column for circuits without small inputs)
+    const bool narrow = sm8 != nullptr;
+    std::function<void(uint32_t)> work = [&](uint32_t t) {
+        std::vector<int32_t> row(narrow ? smw : 0);                // byte form: the int32 row of the text being parsed (43 KB: stays in the core's cache)
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n) return;
+            std::string em;
+            int32_t* dst = narrow ? row.data() : (sm ? sm + (uint64_t)i * smw : nullptr);
+            if (!pack_one(sh, json[i], len[i], fr + (uint64_t)i * sh.nfr * 32, sh.nsm ? dst : nullptr, forced + i, em)) {
+                uint32_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+                if (errs[t].empty()) errs[t] = "input " + std::to_string(i) + ": " + em;
+            } else if (narrow && sh.nsm) {
+                if (!narrow_row(row.data(), sh.nsm, sm8 + (uint64_t)i * sh.nsm, exc + (uint64_t)i * POB_EXC_CAP)) overflow.store(1);
+            }
+        }
+    };
+    {
+        LoaderPool& P = loader_pool();
+        std::lock_guard<std::mutex> lk(P.call_mu);
+        P.run(nt - 1, work);
+    }
+    if (bad.load() != 0xFFFFFFFFu) { for (const std::string& m : errs) if (!m.empty()) { put_err(err, errcap, m); break; } return POB_E_ARG; }
+    if (overflow.load()) { put_err(err, errcap, "a witness has more than POB_EXC_CAP small inputs outside 0..255: use the int32 form for this batch"); return POB_E_RANGE; }
+    return POB_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -280,29 +398,23 @@ int pob_pack_json_batch(int circuit, const uint64_t* params, int nparams, const 
     Shape sh; std::string e;
     if (!make_shape(circuit, params, nparams, sh, e)) { put_err(err, errcap, e); return POB_E_ARG; }
     if (sh.nsm && !sm) return POB_E_ARG;
-    uint32_t nt = threads > 0 ? (uint32_t)threads : std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    if (threads <= 0 && nt > (n + 31) / 32) nt = (n + 31) / 32;   // default: at least 32 texts (~4 ms of parsing) per thread -- starting a thread costs about as much as parsing one text
-    if (nt > n) nt = n;
-    std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu);
-    std::vector<std::string> errs(nt);
-    const uint32_t smw = sh.nsm ? sh.nsm : 1;                   // (witness.py keeps one dummy column for circuits without small inputs)
-    auto work = [&](uint32_t t) {
-        for (;;) {
-            const uint32_t i = next.fetch_add(1);
-            if (i >= n) return;
-            std::string em;
-            if (!pack_one(sh, json[i], len[i], fr + (uint64_t)i * sh.nfr * 32, sm ? sm + (uint64_t)i * smw : nullptr, forced + i, em)) {
-                uint32_t cur = bad.load();
-                while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
-                if (errs[t].empty()) errs[t] = "input " + std::to_string(i) + ": " + em;
-            }
-        }
-    };
-    if (nt == 1) work(0);
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; t++) th.emplace_back(work, t); for (std::thread& x : th) x.join(); }
-    if (bad.load() != 0xFFFFFFFFu) { for (const std::string& m : errs) if (!m.empty()) { put_err(err, errcap, m); break; } return POB_E_ARG; }
-    return POB_OK;
+    return pack_batch(sh, json, len, n, threads, fr, sm, nullptr, nullptr, forced, err, errcap);
+}
+
+int pob_pack_json_batch8(int circuit, const uint64_t* params, int nparams, const char* const* json, const uint64_t* len, uint32_t n, int threads,
+                         uint8_t* fr, uint8_t* sm8, pob_sm_exc_t* exc, uint32_t* forced, char* err, uint32_t errcap) {
+    if (!params || !json || !len || !fr || !forced || n == 0) return POB_E_ARG;
+    Shape sh; std::string e;
+    if (!make_shape(circuit, params, nparams, sh, e)) { put_err(err, errcap, e); return POB_E_ARG; }
+    if (sh.nsm && (!sm8 || !exc)) return POB_E_ARG;
+    return pack_batch(sh, json, len, n, threads, fr, nullptr, sm8, exc, forced, err, errcap);
+}
+
+int pob_narrow_inputs(const int32_t* sm, uint32_t n, uint32_t nsm, uint8_t* sm8, pob_sm_exc_t* exc) {
+    if (!sm || !sm8 || !exc || n == 0 || nsm == 0) return POB_E_ARG;
+    bool ok = true;
+    for (uint32_t i = 0; i < n; i++) ok &= narrow_row(sm + (uint64_t)i * nsm, nsm, sm8 + (uint64_t)i * nsm, exc + (uint64_t)i * POB_EXC_CAP);
+    return ok ? POB_OK : POB_E_RANGE;
 }
 
 }  // extern "C"

@@ -76,6 +76,22 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32
     if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
 }
 static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st);
+// pob_upload_inputs8*: the byte rows widened into the int32 rows every kernel reads (four values per thread when the row length allows aligned words), then the
+// exception slots on top (values outside 0..255: lengths, deliberately out-of-range test inputs)
+__global__ void __launch_bounds__(256) k_widen_sm8(const uint8_t* sm8, int32_t* sm, uint64_t total, uint32_t vec) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        if (t * 4 >= total) return;
+        const uint32_t w = ((const uint32_t*)sm8)[t];
+        ((uint4*)sm)[t] = make_uint4(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24);
+    } else if (t < total) sm[t] = (int32_t)sm8[t];
+}
+__global__ void __launch_bounds__(256) k_apply_exc(const pob_sm_exc_t* exc, int32_t* sm, uint32_t n, uint32_t nsm) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * POB_EXC_CAP) return;
+    const pob_sm_exc_t e = exc[t];
+    if (e.k < nsm) sm[(uint64_t)(t / POB_EXC_CAP) * nsm + e.k] = e.v;
+}
 // test hook (pob_debug_fr_inv): both field inversions of the device code on n canonical inputs
 __global__ void k_fr_inv_test(const uint32_t* in, uint32_t* out_kaliski, uint32_t* out_fermat, uint32_t n) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,6 +213,7 @@ struct pob_ctx {
     // inputs), pob_generate switches; ev_in_done[b] = the last generation / evaluation that read buffer b
     uint8_t* d_in_fr[2] = {nullptr, nullptr}; int32_t* d_in_sm[2] = {nullptr, nullptr}; int in_cur = 0, in_next = 0; uint32_t n_next = 0;
     hipEvent_t ev_in_done[2] = {nullptr, nullptr}; bool in_done_rec[2] = {false, false};
+    uint8_t* d_in_sm8[2] = {nullptr, nullptr}; pob_sm_exc_t* d_in_exc[2] = {nullptr, nullptr};      // staging of the byte form (pob_upload_inputs8*), allocated on first use
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
@@ -665,7 +682,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_c, h->em.d_sc_res};
+                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_in_sm8[0], h->d_in_sm8[1], h->d_in_exc[0], h->d_in_exc[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_c, h->em.d_sc_res};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -738,6 +755,43 @@ int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_
     HIPC(hipEventRecord(h->ev_upload, su));
     h->in_next = t; h->n_next = n; h->upload_pending = true; h->have_next = true;
     return POB_OK;
+}
+
+static int upload8(pob_ctx* h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n, hipStream_t su, bool async) {
+    const int t = h->in_cur ^ 1;
+    const uint64_t nsm = h->plan.nsm_in;
+    if (nsm && !h->d_in_sm8[t]) {
+        const uint64_t npad = ((uint64_t)h->max_batch + 63) / 64 * 64;
+        HIPC(hipMalloc(&h->d_in_sm8[t], npad * nsm + 16));
+        HIPC(hipMalloc(&h->d_in_exc[t], npad * POB_EXC_CAP * sizeof(pob_sm_exc_t)));
+    }
+    if (async) { if (h->upload_pending) HIPC(hipStreamWaitEvent(su, h->ev_upload, 0)); if (h->in_done_rec[t]) HIPC(hipStreamWaitEvent(su, h->ev_in_done[t], 0)); }
+    else { if (h->upload_pending) HIPC(hipEventSynchronize(h->ev_upload)); if (h->in_done_rec[t]) HIPC(hipEventSynchronize(h->ev_in_done[t])); }
+    if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
+    if (nsm) {
+        HIPC(hipMemcpyAsync(h->d_in_sm8[t], sm8, (uint64_t)n * nsm, hipMemcpyHostToDevice, su));
+        HIPC(hipMemcpyAsync(h->d_in_exc[t], exc, (uint64_t)n * POB_EXC_CAP * sizeof(pob_sm_exc_t), hipMemcpyHostToDevice, su));
+        const uint64_t total = (uint64_t)n * nsm; const uint32_t vec = total % 4 == 0;
+        const uint64_t threads = vec ? total / 4 : total;
+        hipLaunchKernelGGL(k_widen_sm8, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, su, h->d_in_sm8[t], h->d_in_sm[t], total, vec);
+        hipLaunchKernelGGL(k_apply_exc, dim3((n * POB_EXC_CAP + 255) / 256), dim3(256), 0, su, h->d_in_exc[t], h->d_in_sm[t], n, (uint32_t)nsm);
+        HIPC(hipGetLastError());
+    }
+    if (async) { HIPC(hipEventRecord(h->ev_upload, su)); } else HIPC(hipStreamSynchronize(su));
+    h->in_next = t; h->n_next = n; h->upload_pending = async; h->have_next = true;
+    return POB_OK;
+}
+int pob_upload_inputs8(pob_handle h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n) {
+    if (!h || n == 0 || n > h->max_batch || (h->plan.nfr_in && !fr_inputs) || (h->plan.nsm_in && (!sm8 || !exc))) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    if (!h->ev_upload) { h->s_upload = h->pool->s_in; HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
+    return upload8(h, fr_inputs, sm8, exc, n, h->s_upload, false);
+}
+int pob_upload_inputs8_async(pob_handle h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n, void* stream_) {
+    if (!h || n == 0 || n > h->max_batch || (h->plan.nfr_in && !fr_inputs) || (h->plan.nsm_in && (!sm8 || !exc))) return POB_E_ARG;
+    HIPC(hipSetDevice(h->device));
+    if (!h->ev_upload) { h->s_upload = h->pool->s_in; HIPC(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)); }
+    return upload8(h, fr_inputs, sm8, exc, n, stream_ ? (hipStream_t)stream_ : h->s_upload, true);
 }
 
 int pob_host_alloc(void** p, uint64_t bytes) {
