@@ -474,7 +474,7 @@ def main():
                 "bytes_per_launch": launch_bytes, "rounds_per_wavefront": kr,
                 "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
                                     f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
-                "gen_kernel": {"kernel": "k_rounds<GEN>, alone", "achieved": round(info.n_perms * 24 * (76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
+                "gen_kernel": {"kernel": "k_rounds_gen, alone (4 rounds per wavefront: 4 x 76 arrays written, midRound[r0] read)", "achieved": round(info.n_perms * 6 * (4 * 76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)},
                 "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,
                                "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),

@@ -5,25 +5,21 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
     if (check) hipLaunchKernelGGL(k_chain_check, dim3(nsponges, ngroups), dim3(64), 0, st, K);
     else hipLaunchKernelGGL(k_chain<false>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
 }
-// EXPERIMENT SWITCH (round 5, to be removed): POB_X_KCHK = <rounds per wavefront> * 1000 + <waves per SIMD> * 100 + <loads in flight per wavefront>, e.g. 4412
-#define KCHK_VARIANTS(X) X(4,4,0) X(4,4,8) X(4,4,12) X(4,4,16) X(4,4,20) X(4,5,8) X(4,5,12) X(4,3,0) X(4,3,16) X(4,3,24) X(6,4,12) X(6,4,16) X(3,4,12) X(3,4,16) X(8,4,16) X(2,4,16) X(1,2,0)
-static int g_kchk = -1;
-static int kchk_variant() { if (g_kchk < 0) { const char* e = getenv("POB_X_KCHK"); g_kchk = e ? atoi(e) : 4412; } return g_kchk; }
-extern "C" void pob_x_set_kchk(int v) { g_kchk = v; }
-static int g_kwaves[2] = {0, 0};        // EXPERIMENT: wavefronts per group of the round expansion / evaluation launch (0 = one per item)
-extern "C" void pob_x_set_kwaves(int which, int v) { g_kwaves[which & 1] = v; }
-int pob_kchk_rounds() { return kchk_variant() / 1000; }
+// EXPERIMENT SWITCH (round 5, to be removed): generation rounds per wavefront
+static int g_kgen = 8;
+extern "C" void pob_x_set_kchk(int) {}
+extern "C" void pob_x_set_kwaves(int which, int v) { if (which == 0 && v > 0) g_kgen = v; }
+int pob_kchk_rounds() { return POB_KCHK_ROUNDS; }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
-    KArgs A = K;
-    if (check) {
-        switch (kchk_variant()) {
-#define X(kr, w, f) case kr * 1000 + w * 100 + f: { A.count = nperms * (24 / kr); const uint32_t gx = g_kwaves[1] > 0 && (uint32_t)g_kwaves[1] < A.count ? g_kwaves[1] : A.count; \
-        hipLaunchKernelGGL((k_rounds_check<true, kr, w, f>), dim3(gx, ngroups), dim3(64), 0, st, A); } break;
-        KCHK_VARIANTS(X)
-#undef X
-        default: abort();
-        }
-    } else { A.count = nperms * 24; const uint32_t gx = g_kwaves[0] > 0 && (uint32_t)g_kwaves[0] < A.count ? g_kwaves[0] : A.count; hipLaunchKernelGGL(k_rounds_gen, dim3(gx, ngroups), dim3(64), 0, st, A); }
+    // evaluation: POB_KCHK_ROUNDS rounds per wavefront, 4 wavefronts per SIMD (124 VGPRs), 12 arrays requested ahead (round 5 sweep: 3 / 4 / 6 / 8 rounds and 8-24
+    // arrays ahead are within 3 % of each other alone and in the step; 5 wavefronts per SIMD spill; profiles/round5_experiments.txt)
+    if (check) hipLaunchKernelGGL((k_rounds_check<true, POB_KCHK_ROUNDS, 4, 12>), dim3(nperms * (24 / POB_KCHK_ROUNDS), ngroups), dim3(64), 0, st, K);
+    else switch (g_kgen) {
+        case 1: hipLaunchKernelGGL(k_rounds_gen<1>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K); break;
+        case 2: hipLaunchKernelGGL(k_rounds_gen<2>, dim3(nperms * 12, ngroups), dim3(64), 0, st, K); break;
+        case 8: hipLaunchKernelGGL(k_rounds_gen<8>, dim3(nperms * 3, ngroups), dim3(64), 0, st, K); break;
+        default: hipLaunchKernelGGL(k_rounds_gen<4>, dim3(nperms * 6, ngroups), dim3(64), 0, st, K); break;
+    }
 }
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
     uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;

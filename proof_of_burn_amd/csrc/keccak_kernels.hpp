@@ -14,6 +14,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels_common.hpp"
+#ifdef POB_HOSTSIM
+#define POB_WAVES_PER_SIMD(n)
+#else
+#define POB_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 
 __device__ __constant__ u64 KECCAK_RC_DEV[24] = {
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
@@ -70,18 +75,16 @@ struct DevIOBase {
     __device__ __forceinline__ void gate(uint32_t, V, V, V) const {}
     __device__ __forceinline__ void out(int, V) const {}
 };
-// generation: the 76 gate outputs are stored; the round's output state is midRound[r+1], which k_chain wrote
+// generation: the 76 gate outputs are stored; the round's output state is midRound[r+1], which k_chain wrote -- and which the wavefront has just
+// computed: it stays in registers (s[]) as the next round's input, so a wavefront that expands several consecutive rounds reads midRound[r0] only
 struct GenIO : DevIOBase {
-    u64* st; const u64* in_;             // the round's stored arrays / midRound[r]
-    __device__ __forceinline__ V in(int i) const { return in_[64 * i + lane]; }
-    __device__ __forceinline__ V gx(uint32_t s, V a, V b) const { const V v = a ^ b; st[64 * s + lane] = v; return v; }
-    __device__ __forceinline__ V ga(uint32_t s, V a, V b) const { const V v = a & b; st[64 * s + lane] = v; return v; }
+    u64* st; V s[25];
+    __device__ __forceinline__ V in(int i) const { return s[i]; }
+    __device__ __forceinline__ V gx(uint32_t sl, V a, V b) const { const V v = a ^ b; st[64 * sl + lane] = v; return v; }
+    __device__ __forceinline__ V ga(uint32_t sl, V a, V b) const { const V v = a & b; st[64 * sl + lane] = v; return v; }
     __device__ __forceinline__ V gxo(int, V a, V b) const { return a ^ b; }
+    __device__ __forceinline__ void out(int i, V v) { s[i] = v; }
 };
-// constraint evaluation: every gate's STORED output against the gate function of its STORED operands; the stored value is what the next
-// gate sees.  The round's input state is held in registers (s[]): a wavefront evaluates several consecutive rounds of one permutation, and the
-// stored midRound[r+1] it has just verified as round r's output IS round r+1's input (keccak.circom:356-367) -- every resident array is
-// fetched once.  NT: non-temporal loads (the evaluation streams the vector through the L2s once and never re-reads a line)
 // The 101 loads of a round come in the walk's fixed order (kchk_seq); the compiler, held to 128 VGPRs, issues ONE load per wait whatever it is told, so the
 // loads in flight are written into the source: a ring of DP prefetched arrays -- the gate that consumes load q issues load q + DP, and a scheduling barrier
 // after every gate keeps each load where it is written.
@@ -369,7 +372,7 @@ template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) 
 
 // Constraint evaluation of the same wires, LOCAL per permutation (every relation of Absorb/Final/Keccakf's own wires is
 // between stored wires, so no permutation needs to be recomputed): grid.x = (sponge, block), grid.y = group.
-__global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
+__global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(4) k_chain_check(KArgs A) {
     const uint32_t lane = threadIdx.x;
     const uint32_t pi = A.first + blockIdx.x;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
@@ -377,7 +380,8 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
     const u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
     const uint32_t Ab = sp.abs_b + b * ABSORB_BITS, Kf = Ab + AB_KECCAKF;
     u64 bad = 0;
-#pragma unroll
+    // (one state word's ~17 loads per iteration: unrolled, all 400 loads are hoisted -- 256 VGPRs, or 556 B of scratch at 128)
+#pragma unroll 1
     for (int i = 0; i < 25; i++) {
         const u64 st = G[sp.fs_b + b * 1600 + 64 * i + lane];                    // Final.s[b]
         if (b == 0) bad |= st;                                                     // s[0] <== 0  (:337-341)
@@ -401,20 +405,25 @@ __global__ void __launch_bounds__(64) k_chain_check(KArgs A) {
     if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
 }
 
-// Generation: one KeccakfRound block per work item (permutation, round, group).  Reads midRound[r] (written by k_chain), writes the 76 gate-output
-// arrays of the round (38.9 KB per 64 witnesses).  (Rounds 1-3 stored all 102 656 wires of the block: 821 KB per item.)
-// grid = (waves, groups): a wavefront takes the items x = blockIdx.x, blockIdx.x + gridDim.x, ... < A.count (= 24 x permutations)
-__global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
-    const uint32_t lane = threadIdx.x, y = blockIdx.y;
+// Generation: one wavefront per (permutation, KR consecutive rounds, group).  Reads midRound[r0] (written by k_chain), writes the 76 gate-output arrays of
+// each of its rounds (38.9 KB per 64 witnesses and round; rounds 1-3 stored all 102 656 wires of the block: 821 KB).  grid = ((24 / KR) x permutations, groups)
+template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
+    static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
+    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
+    const uint32_t pi = A.first + x / (24 / KR), r0 = x % (24 / KR) * KR;
+    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
+    const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
     u64* G = A.bits + (uint64_t)y * A.group_stride;
+    GenIO io; io.lane = lane;
+    const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0;
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.s[i] = mid[64 * i + lane];
+    io.st = G + Ab + AB_DIRECT + r0 * KR_BITS;
 #pragma unroll 1
-    for (uint32_t x = blockIdx.x; x < A.count; x += gridDim.x) {
-        const uint32_t pi = A.first + x / 24, r = x % 24;
-        const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
-        const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
-        GenIO io; io.lane = lane; io.refresh();
-        io.st = G + Ab + AB_DIRECT + r * KR_BITS; io.in_ = G + Ab + AB_KECCAKF + KF_MID + 1600 * r;
+    for (uint32_t r = r0; r < r0 + KR; r++) {
+        io.refresh();
         round_walk(io, (int)r);
+        io.st += KR_BITS;
     }
 }
 
@@ -423,20 +432,14 @@ __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
 // keeps the verified midRound[r+1] in registers as the next round's input: (101 KR + 25) / KR arrays per round, each resident array of the chunk
 // fetched once (round 4's one-round items fetched every state twice: 126 arrays per round).
 #define KR_CHECK_ARRAYS(kr) (101u * (kr) + 25u)
-#ifdef POB_HOSTSIM
-#define POB_WAVES_PER_SIMD(n)
-#else
-#define POB_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#endif
+#define POB_KCHK_ROUNDS 4
 template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) {
     static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
-    const uint32_t lane = threadIdx.x, y = blockIdx.y;
-    const u64* G = A.bits + (uint64_t)y * A.group_stride;
-#pragma unroll 1
-    for (uint32_t x = blockIdx.x; x < A.count; x += gridDim.x) {       // A.count = (24 / KR) x permutations chunks
+    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
     const uint32_t pi = A.first + x / (24 / KR), r0 = x % (24 / KR) * KR;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
+    const u64* G = A.bits + (uint64_t)y * A.group_stride;
     CheckIOT<NT, DP> io; io.lane = lane; io.bad = 0;
     const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0;
 #pragma unroll
@@ -455,7 +458,6 @@ template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(
             if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
             io.bad = 0;
         }
-    }
     }
 }
 

@@ -8,7 +8,7 @@ import sys
 
 def short(n):
     if 'k_rounds' in n:
-        return 'K_CHK' if 'Lb1' in n.split('k_rounds')[1][:8] else 'K_GEN'
+        return 'K_CHK' if 'k_rounds_check' in n else 'K_GEN'
     if 'g_units' in n:
         return ('gCHK' if 'CheckP' in n else 'gEMIT' if 'EmitP' in n else 'gGEN') + '[' + n.split('Lj')[1].split('E')[0] + ']'
     for key, lab in (('poseidon', 'posWide'), ('k_chain_check', 'chainC'), ('k_chain', 'chainG'), ('k_inputs', 'inputs'), ('k_collect', 'collect')):
