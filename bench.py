@@ -103,7 +103,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from proof_of_burn_amd import WitnessCalculator, PinnedInputs, inputs as gen
+    from proof_of_burn_amd import WitnessCalculator, PinnedInputs, TextBatch, inputs as gen
     from proof_of_burn_amd import witness as W
     from proof_of_burn_amd import distributed as D
 
@@ -137,17 +137,18 @@ def main():
             c.set_inorder(True)
     info = calcs[0].info
     # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch); the Python packer beside it
-    texts = [[json.dumps(inp).encode() for inp in bt.inputs] for bt in batches]
+    texts = [TextBatch([json.dumps(inp).encode() for inp in bt.inputs]) for bt in batches]
     pinned = [PinnedInputs(calcs[0], B) for _ in range(NB)]
-    calcs[0].pack_json(texts[0], out=pinned[0])            # (first call: thread start-up, first touch of the texts)
+    calcs[0].pack_json(texts[0], out=pinned[0])            # (first call: the loader pool's threads start, first touch of the texts)
     t0 = time.time()
-    for b in range(NB):
-        calcs[0].pack_json(texts[b], out=pinned[b])
-    t_pack_native = (time.time() - t0) / NB
+    for rep in range(3):
+        for b in range(NB):
+            calcs[0].pack_json(texts[b], out=pinned[b])
+    t_pack_native = (time.time() - t0) / (3 * NB)
     t0 = time.time()
     ref = calcs[0].pack(batches[0].inputs[:min(B, 128)])
     t_pack_py = (time.time() - t0) / min(B, 128) * B
-    assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].sm, pinned[0].forced))), "native loader differs from the Python loader"
+    assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].widened(), pinned[0].forced))), "native loader differs from the Python loader"
     expect = [np.array([list(c.to_bytes(32, "little")) for c in bt.commitments], dtype=np.uint8) for bt in batches]
     # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
     streams = [torch.cuda.Stream(device=dev_index, priority=-1) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
@@ -198,8 +199,7 @@ def main():
     def start(c, b):
         pin = work["pinned"][b]
         if not (args.dbg_no_upload and uploaded[c]):
-            calcs[c].upload_packed_async(pin.fr, pin.sm, pin.forced)      # H2D from pinned memory on the device's upload stream
-            state["h2d_bytes"] += pin.fr.nbytes + pin.sm.nbytes
+            state["h2d_bytes"] += calcs[c].upload_pinned_async(pin)       # H2D from pinned memory on the device's upload stream (byte form: 11.4 KB per witness)
             uploaded[c] = True
         if gathered_ev[c] is not None:
             streams[c].wait_event(gathered_ev[c])                         # the gather of THIS calculator's previous batch has read its records
@@ -282,6 +282,66 @@ def main():
     elif rank == 0 and args.dump_results:
         np.save(args.dump_results, recs[(args.warmup + args.steps + probe_steps - 1) % NC].cpu().numpy())
     kchk_in_step = float(np.mean(state["kchk_ms"])) if state["kchk_ms"] else None
+
+    # ---- the path from input.json TEXT, in the clock (reference Makefile:4-5: the calculator's unit of work starts at the JSON file): the same service loop, but every
+    # batch is parsed from its texts by the native loader (pob_pack_json_batch8 on the persistent loader pool) INSIDE the timed region -- a host thread packs batch k + 2
+    # into a ring of pinned buffers while the device works on batches k, k - 1, ... ; the loop waits for the packer only if it has fallen behind
+    e2e = None
+    if PIPE and INORDER and not args.no_single and not args.dbg_no_fetch:
+        from concurrent.futures import ThreadPoolExecutor
+        ring = [PinnedInputs(calcs[0], B) for _ in range(NC + 3)]
+        ex = ThreadPoolExecutor(1)
+        t_pack_busy = [0.0]
+
+        def pack(k):
+            _t = time.perf_counter()
+            calcs[0].pack_json(texts[k % NB], out=ring[k % len(ring)])
+            t_pack_busy[0] += time.perf_counter() - _t
+            return ring[k % len(ring)]
+
+        def run_e2e(nsteps, k0):
+            fut = {k: ex.submit(pack, k) for k in range(k0, min(k0 + 2, k0 + nsteps))}
+            pend, prev, t_stall = [], None, 0.0
+            for k in range(k0, k0 + nsteps):
+                c = k % NC
+                if prev is not None:
+                    finish(prev[0]); pend.append(prev)
+                _t = time.perf_counter()
+                pin = fut.pop(k).result()
+                t_stall += time.perf_counter() - _t
+                if k + 2 < k0 + nsteps:
+                    fut[k + 2] = ex.submit(pack, k + 2)       # its ring slot held batch k - NC - 1: validated below before this call returns to it
+                state["h2d_bytes"] += calcs[c].upload_pinned_async(pin)
+                if gathered_ev[c] is not None:
+                    streams[c].wait_event(gathered_ev[c])
+                calcs[c].generate(streams[c].cuda_stream)
+                prev = (c, k % NB)
+                while len(pend) > NC - 1:
+                    validate(*pend.pop(0))
+            finish(prev[0]); pend.append(prev)
+            while pend:
+                validate(*pend.pop(0))
+            return t_stall
+        run_e2e(NC + 2, 0); fence()
+        state.update(validated=0); t_pack_busy[0] = 0.0
+        n_e2e = max(args.steps, 40)
+        t1 = time.perf_counter()
+        stall = run_e2e(n_e2e, NC + 2); fence()
+        dte = time.perf_counter() - t1
+        assert state["validated"] == n_e2e * B
+        if world > 1:
+            te = torch.tensor([dte], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            dte = float(te.item())
+        ex.shutdown()
+        for pin_ in ring:
+            pin_.free()
+        loader_ms = t_pack_busy[0] / n_e2e * 1e3
+        e2e = {"what": "the same service loop with the loader inside the timed region: input.json TEXT -> pob_pack_json_batch8 (persistent host thread pool, byte form straight into pinned "
+                       "memory) -> H2D -> generate -> evaluate -> records validated; a host thread parses batch k + 2 while the device works on batch k",
+               "steps": n_e2e, "ms_per_step": round(dte / n_e2e * 1e3, 3), "value": round(GB * n_e2e / dte, 1), "unit": "witnesses/s", "validated_witnesses": n_e2e * B,
+               "loader_ms_per_batch": round(loader_ms, 3), "loader_witnesses_per_s": round(B / max(loader_ms, 1e-9) * 1e3, 1), "host_waited_for_loader_ms_per_step": round(stall / n_e2e * 1e3, 3),
+               "bound": "loader" if loader_ms > dte / n_e2e * 1e3 * 0.95 else "device (the loader keeps ahead)"}
 
     # ---- the bare kernel pipeline (what round 2's bench timed): the same two calculators and batches, but the inputs stay resident (no
     # per-batch H2D), no records are read per batch and nothing is validated inside the loop -- the results are checked once afterwards.
@@ -517,7 +577,7 @@ def main():
         def once():
             ta = time.perf_counter()
             one.pack_json([text], threads=1, out=pin1)
-            one.upload_packed_async(pin1.fr, pin1.sm, pin1.forced)
+            one.upload_pinned_async(pin1)
             one.generate(); one.constraint_check(); one.fetch_records()
             rec = one.wait_records()
             tb = time.perf_counter()
@@ -561,10 +621,10 @@ def main():
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,
                        "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),
-                       "json_to_packed": {"what": "input.json texts -> packed rows in pinned memory, pob_pack_json_batch on all host cores (bit-equal to the Python loader on a sample of this batch)",
+                       "json_to_packed": {"what": "input.json texts -> packed rows (byte form) in pinned memory, pob_pack_json_batch8 on the persistent loader pool (bit-equal to the Python loader on a sample of this batch)",
                                           "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
             "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "tracks_pipeline": tracks_pipeline, "kernel_pipeline_only": bare, "single_witness_latency": latency,
-            "depth16": depth16, "strong_slice": strong_slice, "deeper_pipeline": deeper,
+            "depth16": depth16, "strong_slice": strong_slice, "deeper_pipeline": deeper, "e2e_from_json": e2e,
         }
         print(json.dumps(line))
     for c in calcs:

@@ -5,4 +5,4 @@ include/pob_hip.h) and `witness.py`, the host-side mirror of the reference calcu
 (input.json dict -> outputs / failure / .wtns).  See DESIGN.md.
 """
 from .witness import (P, Result, WitnessCalculator, calculate_witness, keccak256, load_library, parse_main, plan_info,  # noqa: F401
-                      wtns_header, EXPORTED_SYMBOLS, LIB_PATH, PinnedInputs, RECORD_DTYPE)
+                      wtns_header, EXPORTED_SYMBOLS, LIB_PATH, PinnedInputs, TextBatch, RECORD_DTYPE)

@@ -14,6 +14,7 @@ HEADERS = ["fr_dev.hpp", "policy.hpp", "gadgets.hpp", "circuits.hpp", "kernels_c
            "poseidon_consts.h", os.path.join("..", "..", "include", "pob_hip.h")]
 # (host pass at -O1: the only host code of any size is the layout planner, which runs once per pob_open)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-Xarch_host", "-O1", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+HOST_O3 = {"pack_json.hip"}          # host-only translation units whose speed matters (the input.json loader): host pass at -O3 too
 LIB = os.path.join(CSRC, "libpob_hip.so")
 
 
@@ -40,7 +41,8 @@ def _compile(src: str, verbose: bool) -> str:
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
     if _newer(obj, _deps(src, obj)):
         t0 = time.time()
-        cmd = ["hipcc", *FLAGS, "-MD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
+        flags = [f for f in FLAGS if f not in ("-Xarch_host", "-O1")] + ["-O3"] if src in HOST_O3 else FLAGS
+        cmd = ["hipcc", *flags, "-MD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -122,6 +122,9 @@ class PobInfo(ctypes.Structure):
 # one result record (include/pob_hip.h POB_RECORD_BYTES = 44)
 RECORD_DTYPE = np.dtype([("status", "<u4"), ("check_status", "<u4"), ("bad_wire", "<u4"), ("commitment", "u1", (32,))])
 NOT_EVALUATED, CLEAN = 0xFFFFFFFE, 0xFFFFFFFF
+# the byte form of the small inputs (include/pob_hip.h pob_upload_inputs8): per witness POB_EXC_CAP exception slots {index, int32 value}, unused = POB_EXC_NONE
+EXC_CAP, EXC_NONE, E_RANGE = 32, 0xFFFFFFFF, -6
+EXC_DTYPE = np.dtype([("k", "<u4"), ("v", "<i4")])
 
 _lib = None
 
@@ -147,6 +150,11 @@ def load_library() -> ctypes.CDLL:
     lib.pob_gadget_template.restype = ctypes.c_int
     lib.pob_upload_inputs.argtypes = [vp, vp, vp, ctypes.c_uint32]
     lib.pob_upload_inputs_async.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
+    lib.pob_upload_inputs8.argtypes = [vp, vp, vp, vp, ctypes.c_uint32]
+    lib.pob_upload_inputs8_async.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
+    lib.pob_narrow_inputs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+    lib.pob_pack_json_batch8.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.c_uint32, ctypes.c_int, vp, vp, vp, vp, ctypes.c_char_p, ctypes.c_uint32]
     lib.pob_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
     lib.pob_pack_json.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, vp, vp, vp, ctypes.c_char_p, ctypes.c_uint32]
     lib.pob_pack_json_batch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64),
@@ -193,6 +201,7 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
+                    "pob_upload_inputs8", "pob_upload_inputs8_async", "pob_narrow_inputs", "pob_pack_json_batch8",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
                     "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
@@ -203,7 +212,19 @@ def plan_info(main: str) -> PobInfo:
     return plan_info_of(*parse_main(main))
 
 
+_plan_cache: dict = {}
+
+
 def plan_info_of(name: str, params) -> PobInfo:
+    """wire / class / input counts of an instantiation (the layout planner walks the whole circuit: cached per instantiation)"""
+    key = (name, tuple(int(v) for v in params))
+    if key in _plan_cache:
+        return _plan_cache[key]
+    info = _plan_cache[key] = _plan_info_uncached(name, params)
+    return info
+
+
+def _plan_info_uncached(name: str, params) -> PobInfo:
     circuit, cparams = circuit_of(name, params)
     info = PobInfo()
     rc = load_library().pob_plan_info(circuit, _limbs(cparams), len(cparams), ctypes.byref(info))
@@ -356,7 +377,21 @@ def _pack_gadget_inputs(name, params, inputs: Sequence[dict], info: PobInfo):
     return fr, sm, np.zeros(n, dtype=np.uint32)
 
 
-def pack_json(main, texts: Sequence[bytes | str], threads: int = 0, out: "PinnedInputs | None" = None, info: PobInfo | None = None):
+class TextBatch:
+    """n input.json texts as the (pointer, length) arrays the native loader takes, built once: a service that packs the same buffers again (bench.py cycles
+    its batches) does not pay Python's per-text handling per call"""
+
+    def __init__(self, texts: Sequence[bytes | str]):
+        self.raw = [t if isinstance(t, bytes) else (t.encode() if isinstance(t, str) else bytes(t)) for t in texts]
+        self.n = len(self.raw)
+        self.ptrs = (ctypes.c_char_p * self.n)(*self.raw)
+        self.lens = (ctypes.c_uint64 * self.n)(*[len(t) for t in self.raw])
+
+    def __len__(self):
+        return self.n
+
+
+def pack_json(main, texts: "Sequence[bytes | str] | TextBatch", threads: int = 0, out: "PinnedInputs | None" = None, info: PobInfo | None = None):
     """input.json TEXTS -> (fr, sm, forced) through the native loader (pob_pack_json_batch: hand-written parser, `threads` host
     threads, 0 = all cores) -- same acceptance and the same bits as pack_inputs on the parsed dicts; out = pinned arrays to fill in place.
     Needs no GPU."""
@@ -365,26 +400,83 @@ def pack_json(main, texts: Sequence[bytes | str], threads: int = 0, out: "Pinned
     n = len(texts)
     nfr, nsm = info.n_fr_inputs, info.n_sm_inputs
     if out is not None:
-        fr, sm, forced = out.fr, out.sm, out.forced
+        fr, sm, forced = out.fr, (None if out.compact else out.sm), out.forced
         assert fr.shape[0] == n
     else:
         fr = np.zeros((n, nfr, 32), dtype=np.uint8)
         sm = np.zeros((n, max(nsm, 1)), dtype=np.int32)
         forced = np.zeros(n, dtype=np.uint32)
-    raw = [t.encode() if isinstance(t, str) else bytes(t) for t in texts]
-    ptrs = (ctypes.c_char_p * n)(*raw)
-    lens = (ctypes.c_uint64 * n)(*[len(t) for t in raw])
+    tb = texts if isinstance(texts, TextBatch) else TextBatch(texts)
+    ptrs, lens = tb.ptrs, tb.lens
     circuit = 0 if name == "ProofOfBurn" else 1
     arr = (ctypes.c_uint64 * (4 * len(params)))()
     for i, v in enumerate(params):
         for k in range(4):
             arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
     err = ctypes.create_string_buffer(512)
+    if out is not None and out.compact:
+        # straight into the byte form (pob_pack_json_batch8); a witness with more than EXC_CAP values outside 0..255 sends the batch through the int32 form
+        rc = load_library().pob_pack_json_batch8(circuit, arr, len(params), ptrs, lens, n, threads, fr.ctypes.data, out.sm8.ctypes.data, out.exc.ctypes.data, forced.ctypes.data, err, 512)
+        out.bytes_ok = rc == 0
+        if rc == 0:
+            return fr, None, forced
+        if rc != E_RANGE:
+            msg = err.value.decode(errors="replace")
+            raise (KeyError if "missing [" in msg else ValueError)(msg)
+        out.ensure_sm()
+        sm = out.sm
     rc = load_library().pob_pack_json_batch(circuit, arr, len(params), ptrs, lens, n, threads, fr.ctypes.data, sm.ctypes.data, forced.ctypes.data, err, 512)
     if rc != 0:
         msg = err.value.decode(errors="replace")
         raise (KeyError if "missing [" in msg else ValueError)(msg)
     return fr, sm, forced
+
+
+def pack_json8(main, texts: Sequence[bytes | str], threads: int = 0):
+    """input.json TEXTS -> (fr, sm8, exc, forced): the native loader straight into the byte form (pob_pack_json_batch8), or None when a witness has more
+    than EXC_CAP small inputs outside 0..255 (then pack_json's int32 rows are the form to upload).  Needs no GPU."""
+    name, params = _main_of(main)
+    info = plan_info_of(name, params)
+    n, nfr, nsm = len(texts), info.n_fr_inputs, max(info.n_sm_inputs, 1)
+    fr = np.zeros((n, nfr, 32), dtype=np.uint8); sm8 = np.zeros((n, nsm), dtype=np.uint8); exc = np.zeros((n, EXC_CAP), dtype=EXC_DTYPE); forced = np.zeros(n, dtype=np.uint32)
+    tb = texts if isinstance(texts, TextBatch) else TextBatch(texts)
+    ptrs, lens = tb.ptrs, tb.lens
+    arr = (ctypes.c_uint64 * (4 * len(params)))()
+    for i, v in enumerate(params):
+        for k in range(4):
+            arr[4 * i + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    err = ctypes.create_string_buffer(512)
+    rc = load_library().pob_pack_json_batch8(0 if name == "ProofOfBurn" else 1, arr, len(params), ptrs, lens, n, threads, fr.ctypes.data, sm8.ctypes.data, exc.ctypes.data,
+                                             forced.ctypes.data, err, 512)
+    if rc == E_RANGE:
+        return None
+    if rc != 0:
+        msg = err.value.decode(errors="replace")
+        raise (KeyError if "missing [" in msg else ValueError)(msg)
+    return fr, sm8, exc, forced
+
+
+def widen_inputs(sm8: np.ndarray, exc: np.ndarray) -> np.ndarray:
+    """the int32 rows a byte-form batch stands for (what the device's widening pass writes)"""
+    sm = sm8.astype(np.int32)
+    w, e = np.nonzero(exc["k"] != EXC_NONE)
+    sm[w, exc["k"][w, e]] = exc["v"][w, e]
+    return sm
+
+
+def narrow_inputs(sm: np.ndarray):
+    """int32 rows [n][nsm] -> (sm8 uint8 [n][nsm], exc [n][EXC_CAP]) of the byte form, or None when a witness has more than EXC_CAP values outside 0..255
+    (pob_narrow_inputs; no GPU)"""
+    sm = np.ascontiguousarray(sm, dtype=np.int32)
+    n, nsm = sm.shape
+    sm8 = np.empty((n, nsm), dtype=np.uint8)
+    exc = np.empty((n, EXC_CAP), dtype=EXC_DTYPE)
+    rc = load_library().pob_narrow_inputs(sm.ctypes.data, n, nsm, sm8.ctypes.data, exc.ctypes.data)
+    if rc == E_RANGE:
+        return None
+    if rc != 0:
+        raise ValueError("pob_narrow_inputs")
+    return sm8, exc
 
 
 @dataclass
@@ -461,7 +553,7 @@ class WitnessCalculator:
         """list of input.json dicts -> (fr[n][nfr][32] uint8, sm[n][nsm] int32, forced_status[n]) (module-level pack_inputs)"""
         return pack_inputs((self.name, self.params), inputs, self.info)
 
-    def pack_json(self, texts: Sequence[bytes | str], threads: int = 0, out: "PinnedInputs | None" = None):
+    def pack_json(self, texts: "Sequence[bytes | str] | TextBatch", threads: int = 0, out: "PinnedInputs | None" = None):
         """input.json TEXTS -> (fr, sm, forced) through the native loader (module-level pack_json)"""
         return pack_json((self.name, self.params), texts, threads, out, self.info)
 
@@ -477,6 +569,29 @@ class WitnessCalculator:
         fr = np.ascontiguousarray(fr, dtype=np.uint8)
         sm = np.ascontiguousarray(sm, dtype=np.int32)
         self._ck(self.lib.pob_upload_inputs(self.h, fr.ctypes.data, sm.ctypes.data, n))
+        self._next = (n, np.array(forced, dtype=np.uint32) if forced is not None else np.zeros(n, dtype=np.uint32))
+
+    def upload_pinned_async(self, pin: "PinnedInputs", stream: int | None = None) -> int:
+        """service-loop upload of a PinnedInputs batch: the byte form when the batch holds it (pob_upload_inputs8_async: 11.4 KB per production witness on
+        the wire instead of 43.8), else the int32 rows; returns the bytes that cross PCIe"""
+        n = pin.fr.shape[0]
+        if n > self.max_batch:
+            raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
+        if pin.compact and pin.bytes_ok:
+            self._ck(self.lib.pob_upload_inputs8_async(self.h, pin.fr.ctypes.data, pin.sm8.ctypes.data, pin.exc.ctypes.data, n, ctypes.c_void_p(stream) if stream else None))
+            self._next = (n, np.array(pin.forced, dtype=np.uint32))
+            return pin.fr.nbytes + pin.sm8.nbytes + pin.exc.nbytes
+        self.upload_packed_async(pin.fr, pin.sm, pin.forced, stream)
+        return pin.fr.nbytes + pin.sm.nbytes
+
+    def upload_packed8(self, fr: np.ndarray, sm8: np.ndarray, exc: np.ndarray, forced: np.ndarray | None = None):
+        """synchronous upload of the byte form (pob_upload_inputs8; narrow_inputs makes it from int32 rows)"""
+        n = fr.shape[0]
+        if n > self.max_batch:
+            raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
+        fr = np.ascontiguousarray(fr, dtype=np.uint8); sm8 = np.ascontiguousarray(sm8, dtype=np.uint8); exc = np.ascontiguousarray(exc, dtype=EXC_DTYPE)
+        assert sm8.shape[0] == n and exc.shape == (n, EXC_CAP)
+        self._ck(self.lib.pob_upload_inputs8(self.h, fr.ctypes.data, sm8.ctypes.data, exc.ctypes.data, n))
         self._next = (n, np.array(forced, dtype=np.uint32) if forced is not None else np.zeros(n, dtype=np.uint32))
 
     def upload_packed_async(self, fr: np.ndarray, sm: np.ndarray, forced: np.ndarray | None = None, stream: int | None = None):
@@ -697,28 +812,55 @@ class WitnessCalculator:
 
 
 class PinnedInputs:
-    """packed inputs of one batch in pinned host memory (pob_host_alloc), the source of upload_packed_async"""
+    """packed inputs of one batch in pinned host memory (pob_host_alloc), the source of upload_pinned_async / upload_packed_async.
+    compact (default): the small inputs in the byte form -- sm8 [n][nsm] uint8 + exc [n][EXC_CAP] -- which pack_json fills natively and fill() narrows into;
+    the int32 rows (sm) are allocated only when a batch does not fit the byte form (bytes_ok False) or compact is off."""
 
-    def __init__(self, calc: "WitnessCalculator", n: int):
+    def __init__(self, calc: "WitnessCalculator", n: int, compact: bool = True):
         self.lib = calc.lib
-        nfr, nsm = int(calc.info.n_fr_inputs), max(int(calc.info.n_sm_inputs), 1)
+        self.n, self.nfr, self.nsm = n, int(calc.info.n_fr_inputs), max(int(calc.info.n_sm_inputs), 1)
+        self.compact = bool(compact) and int(calc.info.n_sm_inputs) > 0
+        self.bytes_ok = False
         self._p = []
-        arrs = []
-        for shape, dt in (((n, nfr, 32), np.uint8), ((n, nsm), np.int32)):
-            nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
-            p = ctypes.c_void_p()
-            if self.lib.pob_host_alloc(ctypes.byref(p), nbytes) != 0:
-                raise MemoryError("pob_host_alloc")
-            self._p.append(p)
-            arrs.append(np.frombuffer((ctypes.c_uint8 * nbytes).from_address(p.value), dtype=dt).reshape(shape))
-        self.fr, self.sm = arrs
+        self.fr = self._alloc((n, self.nfr, 32), np.uint8)
+        self.sm = self.sm8 = self.exc = None
+        if self.compact:
+            self.sm8 = self._alloc((n, self.nsm), np.uint8)
+            self.exc = self._alloc((n, EXC_CAP), EXC_DTYPE)
+        else:
+            self.sm = self._alloc((n, self.nsm), np.int32)
         self.forced = np.zeros(n, dtype=np.uint32)
+
+    def _alloc(self, shape, dt):
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        p = ctypes.c_void_p()
+        if self.lib.pob_host_alloc(ctypes.byref(p), nbytes) != 0:
+            raise MemoryError("pob_host_alloc")
+        self._p.append(p)
+        return np.frombuffer((ctypes.c_uint8 * nbytes).from_address(p.value), dtype=dt).reshape(shape)
+
+    def ensure_sm(self):
+        if self.sm is None:
+            self.sm = self._alloc((self.n, self.nsm), np.int32)
 
     def fill(self, fr, sm, forced=None):
         self.fr[...] = fr
-        self.sm[...] = sm
         self.forced[...] = 0 if forced is None else forced
+        if self.compact:
+            sm = np.ascontiguousarray(sm, dtype=np.int32)
+            rc = self.lib.pob_narrow_inputs(sm.ctypes.data, self.n, self.nsm, self.sm8.ctypes.data, self.exc.ctypes.data)
+            self.bytes_ok = rc == 0
+            if rc == 0:
+                return self
+            self.ensure_sm()
+        self.sm[...] = sm
         return self
+
+    def widened(self) -> np.ndarray:
+        """the int32 rows this batch stands for (what the device widens the byte form into)"""
+        if not (self.compact and self.bytes_ok):
+            return np.array(self.sm)
+        return widen_inputs(self.sm8, self.exc)
 
     def free(self):
         for p in self._p:

@@ -668,8 +668,8 @@ def test_reading_a_batch_does_not_stall_the_partner(pkg):
     a.pack_json([json.dumps(d) for d in batch.inputs], out=pin)
     still_running = 0
     for rnd in range(3):
-        a.upload_packed_async(pin.fr, pin.sm, pin.forced); a.generate(sa.cuda_stream)
-        b.upload_packed_async(pin.fr, pin.sm, pin.forced)
+        a.upload_pinned_async(pin); a.generate(sa.cuda_stream)
+        b.upload_pinned_async(pin)
         a.constraint_check(sa.cuda_stream); a.fetch_records()
         for _ in range(4):                              # (four generations of the same inputs: several times a's evaluation, whatever the box)
             b.generate(sb.cuda_stream)

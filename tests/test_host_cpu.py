@@ -190,6 +190,52 @@ def test_native_json_loader_equals_the_python_loader():
     assert all(np.array_equal(x, y) for x, y in zip(W.pack_inputs(main, batch.inputs), W.pack_json(main, [json.dumps(d) for d in batch.inputs])))
 
 
+def test_byte_form_of_the_small_inputs():
+    """pob_narrow_inputs / pob_pack_json_batch8 (round 5: bytes as bytes on the wire): narrowing then widening is the identity, a witness with more than
+    EXC_CAP values outside 0..255 is refused (never truncated), the loader's byte form stands for the rows of its int32 form on the loader's edge cases and on
+    production batches, and the persistent loader pool gives the same rows for any width, repeatedly and from two caller threads at once"""
+    import threading
+    from proof_of_burn_amd import inputs as gen
+    rng = np.random.default_rng(5)
+    sm = rng.integers(0, 256, size=(37, 2864), dtype=np.int32)
+    for w in range(37):
+        k = rng.choice(2864, size=w % (W.EXC_CAP + 1), replace=False)           # 0 .. EXC_CAP exceptions per witness, the last rows exactly EXC_CAP
+        sm[w, k] = rng.choice(np.array([256, 544, 2175, -1, -200, 0x7FFFFFFF, 1 << 20], dtype=np.int32), size=k.size)
+    nar = W.narrow_inputs(sm)
+    assert nar is not None and np.array_equal(W.widen_inputs(*nar), sm)
+    assert int((nar[1]["k"] != W.EXC_NONE).sum()) == int(((sm < 0) | (sm > 255)).sum())
+    over = sm.copy(); over[5, :W.EXC_CAP + 1] = 300
+    assert W.narrow_inputs(over) is None
+    fix = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
+    cases = _loader_cases()
+    texts = [json.dumps(d) for _, d in cases]
+    ref = W.pack_json(fix, texts, threads=1)
+    for threads in (1, 2, 7, 0):
+        got = W.pack_json8(fix, texts, threads=threads)
+        assert got is not None
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(W.widen_inputs(got[1], got[2]), ref[1]) and np.array_equal(got[3], ref[2]), threads
+    # a text with too many out-of-range bytes: the byte form refuses, the int32 form carries it
+    bad = json.loads(texts[0]); bad["layers"][0][:40] = [256] * 40
+    assert W.pack_json8(fix, [texts[0], json.dumps(bad)]) is None and W.pack_json(fix, [json.dumps(bad)])[1][0, 1] == 256
+    with pytest.raises(KeyError):
+        W.pack_json8(fix, [texts[0].replace('"numLayers"', '"numLayerz"')])
+    main = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
+    batch = gen.synthetic_batch(64, depth=10, seed=0xB0B, distinct_keys=2)
+    ptexts = [json.dumps(d) for d in batch.inputs]
+    pref = W.pack_json(main, ptexts, threads=1)
+    out = {}
+
+    def worker(tag):
+        for _ in range(3):
+            g = W.pack_json8(main, ptexts, threads=0)
+            out[tag] = np.array_equal(g[0], pref[0]) and np.array_equal(W.widen_inputs(g[1], g[2]), pref[1]) and np.array_equal(g[3], pref[2]) and out.get(tag, True)
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert out == {0: True, 1: True}
+    g = W.pack_json8(main, ptexts)
+    assert g[1].nbytes + g[2].nbytes + g[0].nbytes < 12 * 1024 * 64, "the byte form of a production witness is 11.4 KB"
+
+
 def test_stored_keep_maps():
     """the compressed O1-style keep maps under circuit_model/data/ (what the device-side reduced emission of the bench and the GPU tests
     reads): the stored Spend(31) map equals the one derived from the model now; the production map has the recorded size"""

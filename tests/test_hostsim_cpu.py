@@ -188,11 +188,12 @@ def test_service_loop_api_on_the_shim(pkg):
     a.set_partner(b)
     order = [list(range(len(inputs))), list(range(len(inputs)))[::-1], [2, 3, 0, 1] + list(range(4, len(inputs)))]
     pins = []
-    for o in order:
-        pin = pkg.PinnedInputs(a, len(o))
+    for k, o in enumerate(order):
+        pin = pkg.PinnedInputs(a, len(o), compact=(k != 1))      # batches 0 and 2 travel in the byte form (pob_upload_inputs8_async), batch 1 as int32 rows
         fr, sm, forced = a.pack_json([json.dumps(inputs[i]) for i in o], threads=2, out=pin)
         ref = a.pack([inputs[i] for i in o])
-        assert fr is pin.fr and all(np.array_equal(x, y) for x, y in zip(ref, (pin.fr, pin.sm, pin.forced)))
+        assert fr is pin.fr and all(np.array_equal(x, y) for x, y in zip(ref, (pin.fr, pin.widened(), pin.forced)))
+        assert pin.compact == (k != 1) and (pin.bytes_ok or not pin.compact)
         pins.append(pin)
     calcs, prev, got = [a, b], None, {}
 
@@ -208,7 +209,8 @@ def test_service_loop_api_on_the_shim(pkg):
         c = k % 2
         if prev is not None:
             finish(*prev)
-        calcs[c].upload_packed_async(pin.fr, pin.sm, pin.forced)
+        nbytes = calcs[c].upload_pinned_async(pin)
+        assert nbytes == pin.fr.nbytes + (pin.sm8.nbytes + pin.exc.nbytes if pin.compact else pin.sm.nbytes)
         calcs[c].generate()
         if k == 0:                                   # records of a batch whose evaluation has not run
             calcs[c].fetch_records()
@@ -217,7 +219,7 @@ def test_service_loop_api_on_the_shim(pkg):
         prev = (c, k)
     finish(*prev)
     # the probe is read one batch late, when the calculator has already been given its next batch (as the bench does)
-    calcs[0].upload_packed_async(pins[0].fr, pins[0].sm, pins[0].forced); calcs[0].generate()
+    calcs[0].upload_pinned_async(pins[0]); calcs[0].generate()
     assert calcs[0].probe_check_kernel(True, read=True) > 0
     for c in calcs:
         c.probe_check_kernel(False)
