@@ -75,6 +75,7 @@ void neg_mod(U256& v) {                                       // v <- (-v) mod p
     for (int i = 0; i < 4; i++) { const u128 d = (u128)P64[i] - v.l[i] - br; v.l[i] = (uint64_t)d; br = (d >> 127) & 1; }
 }
 
+
 struct Parser {
     const char* s; const char* e; std::string err;
     void ws() { while (s < e && (*s == ' ' || *s == '\n' || *s == '\t' || *s == '\r')) s++; }
@@ -162,6 +163,16 @@ struct Parser {
             // at the element where it was met (10 900 elements per production witness: the loop is the loader's rate)
             while (e - s > 16 && n < cap) {
                 const char* a = s;
+                // zero padding (a proof shorter than the circuit's maximum is padded with zeros, tests/main.py:65-178: 44 % of a 10-layer production input): eight "0, " at a time
+                if (*s == '0' && e - s > 40 && n + 8 <= cap) {
+                    uint64_t w0, w1, w2; memcpy(&w0, s, 8); memcpy(&w1, s + 8, 8); memcpy(&w2, s + 16, 8);
+                    // "0, 0, 0," | " 0, 0, 0" | ", 0, 0, " as little-endian words
+                    if (w0 == 0x2C30202C30202C30ULL && w1 == 0x30202C30202C3020ULL && w2 == 0x202C30202C30202CULL && (uint32_t)(uint8_t)s[24] - '0' <= 9) {
+                        for (int z = 0; z < 8; z++) dst[n + z] = 0;
+                        n += 8; s += 24;
+                        continue;
+                    }
+                }
                 uint32_t d = (uint32_t)(uint8_t)*s - '0';
                 if (d > 9) break;
                 uint32_t v = d; s++;
