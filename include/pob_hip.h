@@ -211,11 +211,19 @@ int pob_emit_queue(pob_handle h, uint32_t next_idx);
  *     every IsEqual [out | in[2]] over an IsZero:    IsZero.in === in[1] - in[0],   out === IsZero.out
  *     SubstringCheck's M[]:                          M[i+1] === M[i] + mainInput[i] * 256^i
  *     a derived copy of a STORED wire:               Pad.isEq[i] / isLast[i] / Selector.isEq[i] (stored) === the IsEqual child's out, its IsZero's out (derived)
- * enable = 1: every following O0 emission (pob_emit_begin / pob_emit_witness / pob_write_wtns; not the reduced form) is checked; the first one also
- * runs a recording pass that finds the sites.  pob_emit_selfcheck_result, called when the emission is complete: relations checked, relations skipped
- * because their wires straddle two windows, and the lowest wire whose relation does not hold (0xFFFFFFFF = none).  A witness emitted from a
- * corrupted resident vector (pob_debug_poke of an operand) violates the relations of the derived wires that consume the operand.             */
+ * enable = 1: every following emission (pob_emit_begin / pob_emit_witness / pob_write_wtns, and -- round 5 -- the reduced form, pob_emit_begin_reduced /
+ * pob_write_wtns_reduced: what a prover built at circom's default level consumes, .github/workflows/circuitscan.yml:29,36) is checked; the first one also
+ * runs a recording pass that finds the sites.  In the reduced form a site is evaluated where it lies among the KEPT wires (each wire through the keep
+ * bitmap, at its rank); a site with a dropped wire is skipped -- its relation holds between class representatives, which the map alone does not name.
+ * pob_emit_selfcheck_result, called when the emission is complete: relations checked, relations skipped (wires straddling two windows, dropped wires), and
+ * the lowest wire whose relation does not hold (0xFFFFFFFF = none): of THIS emission -- while the check is on, pob_emit_queue does not pre-make the next
+ * witness' window.  A witness emitted from a corrupted resident vector (pob_debug_poke of an operand) violates the relations of the derived wires that
+ * consume the operand.                                                                                                                          */
 int pob_emit_selfcheck(pob_handle h, int enable);
+/* Reduced emissions: the class representative of every O0 wire under the map that will be emitted (alias[w] = the kept wire that stands for w, w itself if it is kept;
+ * a wire pinned to the constant c < 2^30: -1 - c, to a larger constant: INT32_MIN; from circuit_model/o1.py O1Map), n_wires = n_witness.  With it a site whose wires were dropped is evaluated on their representatives --
+ * without it only the sites whose own wires are all kept are.  The array must stay valid and unchanged until the next reduced emission has begun; NULL clears it.  */
+int pob_emit_selfcheck_alias(pob_handle h, const int32_t* alias, uint64_t n_wires);
 int pob_emit_selfcheck_result(pob_handle h, uint64_t* checked, uint64_t* skipped, uint32_t* first_bad_wire);
 /* Measurement: `count` witnesses from `first_idx` on, back to back through the window pipeline into pinned host memory.          */
 int pob_emit_measure(pob_handle h, uint32_t first_idx, uint32_t count, uint64_t window_wires, double* seconds, uint64_t* bytes);

@@ -224,10 +224,26 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
     // filter[i] = prod_{j<i}(1 - isEq[j]) = [inLen >= i] (unsigned: an out-of-range inLen never hits); the evaluator re-reads it
     B f = P::is_gen ? p.ballot((uint32_t)inLen >= lo) : p.get(r.pad_flt + lo);
     B runE = 0, runL = 0, runF = 0, runPairE = 0, runPairL = 0, bits0 = 0, bits1 = 0;
-    for (uint32_t t = 0; t < cnt; t++) {
+    // the range's loads first, all of them in flight at once (round 5: as `put(in + i, get(src + i))` inside the loop every byte paid its own memory round trip -- two in
+    // the evaluator --, 17 us per wavefront for 32 dependent loads; the unit kind is a sixth of the G side's wave cycles in generation and in evaluation)
+    S vs[16];
+    if constexpr (P::is_count) { for (uint32_t t = 0; t < cnt; t++) p.put(r.in + (lo + t), (S)0); for (int q = 0; q < 16; q++) vs[q] = 0; }
+    else {
+        SmRef rr[16]; S sv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) rr[q] = r.in + (lo + ((uint32_t)q < cnt ? (uint32_t)q : cnt - 1));      // (a short last range repeats its last byte: same wire, same value)
+        const SmLoaded<16> h = sm_load(p, rr);
+#pragma unroll
+        for (int q = 0; q < 16; q++) sv[q] = p.get(src + (lo + ((uint32_t)q < cnt ? (uint32_t)q : cnt - 1)));
+        sm_commit(p, rr, h, sv);
+#pragma unroll
+        for (int q = 0; q < 16; q++) vs[q] = P::is_check ? h.s[q] : sv[q];        // the evaluator's later expressions see the STORED in[i]
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 16; t++) if (t < cnt) {
         const uint32_t i = lo + t;
         const Cur ce = cur_add(cE, FP_ISEQ_D, i), cl = cur_add(cL, FP_ISEQ_D, i);
-        const S v = p.put(r.in + i, p.get(src + i));
+        const S v = vs[t];
         const S xe = (S)((uint32_t)inLen - i), xl = (S)((uint32_t)last - i);
         iseq_derived(p, ce, (S)i, inLen); iseq_derived(p, cl, (S)i, last);      // IsEqual([i, inLen]), IsEqual([i, numBlocks*136 - 1]): operand wires derived
         const B e = p.ballot(xe == 0), l = p.ballot(xl == 0);

@@ -481,10 +481,14 @@ template <class P> GD void abs_range(P& p, Cur c0, uint32_t own_w, SmRef src, ui
     for (uint32_t i0 = lo; i0 < hi; i0 += 8) {
         const uint32_t cnt = hi - i0 < 8 ? hi - i0 : 8;
         B compact = 0;                                   // lane 8t + k = bit k of byte i0 + t
-        for (uint32_t t = 0; t < cnt; t++) {
+        S vs[8];                                         // the eight bytes' loads in flight together (a short last batch repeats its last byte)
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) vs[t] = p.get(src + (i0 + (t < cnt ? t : cnt - 1)));
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) if (t < cnt) {
             const uint32_t i = i0 + t;
             const Cur c = cur_add(c0, FP_ABITS8, i);
-            const S v = p.get(src + i);
+            const S v = vs[t];
             p.derived(own_w + i, v); p.derived(c.w, v); p.derived(c.w + 17, v);
             p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
             if constexpr (P::is_emit) {

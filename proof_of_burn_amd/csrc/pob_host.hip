@@ -105,41 +105,90 @@ __global__ void k_fr_inv_test(const uint32_t* in, uint32_t* out_kaliski, uint32_
 // (reference: circomlib comparators.circom IsZero `out <== -in*inv + 1; in*out === 0`, IsEqual `in[1] - in[0] ==> isz.in; isz.out ==> out`;
 //  substring_check.circom:45-49 `M[i+1] <== M[i] + mainInput[i] * 256^i`).  One thread per site; sites whose wires are not all inside the window are counted as
 // skipped by the host (IsZero / IsEqual) or here (M).  res[0] = lowest violated wire, res[1] = M sites skipped.
-__device__ __forceinline__ Fr sc_load(const uint8_t* win, uint32_t w0, uint32_t w) {
-    const uint32_t* q = (const uint32_t*)(win + (size_t)(w - w0) * 32);
+// where wire w lies in the window: O0 (rbits null) position w - w0; reduced witness: its rank among the kept wires - w0, false if the wire is dropped
+struct ScWin { const uint8_t* win; uint32_t w0, wn; const unsigned long long* rbits; const uint32_t* rpre; };
+__device__ __forceinline__ bool sc_pos(const ScWin& W, uint32_t w, uint32_t* pos) {
+    if (!W.rbits) { *pos = w - W.w0; return *pos < W.wn; }
+    const unsigned long long word = W.rbits[w >> 6];
+    if (!((word >> (w & 63)) & 1)) return false;
+    *pos = W.rpre[w >> 6] + (uint32_t)__popcll(word & ((1ull << (w & 63)) - 1)) - W.w0;
+    return *pos < W.wn;
+}
+__device__ __forceinline__ Fr sc_load(const ScWin& W, uint32_t pos) {
+    const uint32_t* q = (const uint32_t*)(W.win + (size_t)pos * 32);
     Fr c; for (int j = 0; j < 8; j++) c.l[j] = q[j];
     return fr_to_mont(c);
 }
-__global__ void __launch_bounds__(64) k_selfcheck_z(const uint8_t* win, uint32_t w0, const uint32_t* sites, uint32_t n, uint32_t* res) {
+// (a site with a wire outside the window -- or, in the reduced witness, a dropped wire: the relation then lives between class representatives the keep map alone does
+//  not name -- is skipped and counted in res[1])
+__global__ void __launch_bounds__(64) k_selfcheck_z(ScWin W, const uint32_t* sites, uint32_t n, uint32_t* res) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t s = sites[t], w = s & 0x7FFFFFFFu;                  // IsZero [out | in | inv] at w
-    const Fr out = sc_load(win, w0, w), in = sc_load(win, w0, w + 1), inv = sc_load(win, w0, w + 2);
+    uint32_t po, pi, pv, pe = 0, pa = 0, pb = 0;
+    bool have = sc_pos(W, w, &po) && sc_pos(W, w + 1, &pi) && sc_pos(W, w + 2, &pv);
+    if (have && (s >> 31)) have = sc_pos(W, w - 3, &pe) && sc_pos(W, w - 2, &pa) && sc_pos(W, w - 1, &pb);
+    if (!have) { atomicAdd(res + 1, 1u); return; }
+    const Fr out = sc_load(W, po), in = sc_load(W, pi), inv = sc_load(W, pv);
     bool ok = fr_eq(fr_mul(in, inv), fr_sub(fr_one_mont(), out)) && fr_is_zero(fr_mul(in, out));
     if (s >> 31) {                                                       // IsEqual [out | in[2]] at w - 3
-        const Fr eo = sc_load(win, w0, w - 3), a = sc_load(win, w0, w - 2), b = sc_load(win, w0, w - 1);
+        const Fr eo = sc_load(W, pe), a = sc_load(W, pa), b = sc_load(W, pb);
         ok = ok && fr_eq(in, fr_sub(b, a)) && fr_eq(eo, out);
     }
     if (!ok) atomicMin(res, w);
 }
-// copy constraints a === b between a derived wire and the stored wire it must equal (pairs {higher wire, lower wire}; both inside the window)
-__global__ void __launch_bounds__(64) k_selfcheck_c(const uint8_t* win, uint32_t w0, const uint32_t* sites, uint32_t n, uint32_t* res) {
+// copy constraints a === b between a derived wire and the stored wire it must equal (pairs {higher wire, lower wire})
+__global__ void __launch_bounds__(64) k_selfcheck_c(ScWin W, const uint32_t* sites, uint32_t n, uint32_t* res) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t a = sites[2 * t], b = sites[2 * t + 1];
-    if (b < w0) { atomicAdd(res + 1, 1u); return; }                     // (the lower wire lies in the window before: skipped and counted)
-    const uint4* p = (const uint4*)(win + (size_t)(a - w0) * 32); const uint4* q = (const uint4*)(win + (size_t)(b - w0) * 32);
+    uint32_t pa, pb;
+    if (!sc_pos(W, a, &pa) || !sc_pos(W, b, &pb)) { atomicAdd(res + 1, 1u); return; }      // (the lower wire lies in the window before, or one of the two is dropped)
+    const uint4* p = (const uint4*)(W.win + (size_t)pa * 32); const uint4* q = (const uint4*)(W.win + (size_t)pb * 32);
     const uint4 x0 = p[0], x1 = p[1], y0 = q[0], y1 = q[1];
     if (x0.x != y0.x || x0.y != y0.y || x0.z != y0.z || x0.w != y0.w || x1.x != y1.x || x1.y != y1.y || x1.z != y1.z || x1.w != y1.w) atomicMin(res, a);
 }
-__global__ void __launch_bounds__(64) k_selfcheck_m(const uint8_t* win, uint32_t w0, uint32_t wn, const uint32_t* sites, uint32_t n, const uint32_t* pow256, uint32_t* res) {
+__global__ void __launch_bounds__(64) k_selfcheck_m(ScWin W, const uint32_t* sites, uint32_t n, const uint32_t* pow256, uint32_t* res) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t wn1 = sites[3 * t], wb = sites[3 * t + 1], k = sites[3 * t + 2];
-    if (wn1 - 1 - w0 >= wn || wn1 - w0 >= wn || wb - w0 >= wn) { atomicAdd(res + 1, 1u); return; }
+    uint32_t pn, pp, pby;
+    if (!sc_pos(W, wn1, &pn) || !sc_pos(W, wn1 - 1, &pp) || !sc_pos(W, wb, &pby)) { atomicAdd(res + 1, 1u); return; }
     Fr pw; for (int j = 0; j < 8; j++) pw.l[j] = pow256[(size_t)k * 8 + j];                      // 256^k, Montgomery
-    const Fr next = sc_load(win, w0, wn1), prev = sc_load(win, w0, wn1 - 1), by = sc_load(win, w0, wb);
+    const Fr next = sc_load(W, pn), prev = sc_load(W, pp), by = sc_load(W, pby);
     if (!fr_eq(next, fr_add(prev, fr_mul(by, pw)))) atomicMin(res, wn1);
+}
+// the same relations on explicit wire lists (reduced witness): every wire of a site is kept (the host left the others out); a site is evaluated in the window that holds
+// its first wire -- if the others lie there too (else skipped: res[1]); res[2] counts the sites evaluated
+__global__ void __launch_bounds__(64) k_selfcheck_zr(ScWin W, const uint32_t* zw, uint32_t n, uint32_t* res) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t* w6 = zw + 6 * (size_t)t;                            // IsZero out, in, inv | IsEqual out, in[0], in[1] (0xFFFFFFFF: a bare IsZero)
+    uint32_t p[6];                                                      // (an entry with bit 31 set: a wire pinned to the small constant in its low bits -- not in the window at all)
+    if (!sc_pos(W, w6[0], &p[0])) return;
+    const bool iseq = w6[3] != 0xFFFFFFFFu;
+    auto pos = [&](int j) { if (w6[j] >> 31) { p[j] = w6[j]; return true; } return sc_pos(W, w6[j], &p[j]); };
+    bool have = pos(1) && pos(2);
+    if (have && iseq) have = pos(3) && pos(4) && pos(5);
+    if (!have) { atomicAdd(res + 1, 1u); return; }
+    atomicAdd(res + 2, 1u);
+    auto val = [&](int j) { if (p[j] >> 31) { Fr c = fr_zero(); c.l[0] = p[j] & 0x7FFFFFFFu; return fr_to_mont(c); } return sc_load(W, p[j]); };
+    const Fr out = val(0), in = val(1), inv = val(2);
+    bool ok = fr_eq(fr_mul(in, inv), fr_sub(fr_one_mont(), out)) && fr_is_zero(fr_mul(in, out));
+    if (iseq) { const Fr eo = val(3), a = val(4), b = val(5); ok = ok && fr_eq(in, fr_sub(b, a)) && fr_eq(eo, out); }
+    if (!ok) atomicMin(res, w6[0]);
+}
+__global__ void __launch_bounds__(64) k_selfcheck_mr(ScWin W, const uint32_t* mw, uint32_t n, const uint32_t* pow256, uint32_t* res) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t* w4 = mw + 4 * (size_t)t;                            // M[k+1], M[k], mainInput[k], k
+    uint32_t pn, pp, pby;
+    if (!sc_pos(W, w4[0], &pn)) return;
+    if (!sc_pos(W, w4[1], &pp) || !sc_pos(W, w4[2], &pby)) { atomicAdd(res + 1, 1u); return; }
+    atomicAdd(res + 2, 1u);
+    Fr pw; for (int j = 0; j < 8; j++) pw.l[j] = pow256[(size_t)w4[3] * 8 + j];
+    const Fr next = sc_load(W, pn), prev = sc_load(W, pp), by = sc_load(W, pby);
+    if (!fr_eq(next, fr_add(prev, fr_mul(by, pw)))) atomicMin(res, w4[0]);
 }
 __global__ void k_xor_word(uint64_t* p, uint64_t mask) { *p ^= mask; }
 __global__ void k_xor_u32(uint32_t* p, uint32_t mask) { *p ^= mask; }
@@ -240,6 +289,11 @@ struct pob_ctx {
         // self-check (pob_emit_selfcheck): site tables (sorted by wire), built once per handle by a recording pass of the emitter; d_sc_res: {lowest violated wire, M sites skipped}
         bool sc_on = false, sc_built = false; std::vector<uint32_t> sc_z, sc_m_next, sc_c_hi; uint32_t *d_sc_z = nullptr, *d_sc_m = nullptr, *d_sc_c = nullptr, *d_sc_res = nullptr;
         uint64_t sc_checked = 0, sc_skipped = 0;
+        // reduced witness: the sites as explicit wire lists, every wire replaced by its class representative (pob_emit_selfcheck_alias) and the sites with a wire that is
+        // not kept left out (counted in sc_red_host_skipped); built per map
+        std::vector<std::array<uint32_t, 3>> sc_ms; std::vector<std::array<uint32_t, 2>> sc_cs;
+        const int32_t* sc_alias = nullptr; uint64_t sc_alias_n = 0, sc_red_map = 0, sc_red_host_skipped = 0; uint32_t sc_red_nz = 0, sc_red_nm = 0;
+        uint32_t *d_sc_zr = nullptr, *d_sc_mr = nullptr;
         bool red = false; uint64_t map_id = 0, total = 0; std::vector<uint32_t> keep; unsigned long long* d_rbits = nullptr; uint32_t* d_rpre = nullptr;
     } em;
     // schedule
@@ -683,7 +737,7 @@ void pob_close(pob_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     void* ptrs[] = {h->d_bits, h->d_sm, h->d_fr, h->d_units, h->d_order, h->d_L, h->d_sponges, h->d_perm_sponge, h->d_perm_block, h->d_pos,
-                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_in_sm8[0], h->d_in_sm8[1], h->d_in_exc[0], h->d_in_exc[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_c, h->em.d_sc_res};
+                    h->d_inv, h->d_pow256, h->d_ktab, h->d_emit_ctr, h->d_in_fr[0], h->d_in_fr[1], h->d_in_sm[0], h->d_in_sm[1], h->d_in_sm8[0], h->d_in_sm8[1], h->d_in_exc[0], h->d_in_exc[1], h->d_status_raw, h->d_status, h->d_chk, h->d_bad, h->d_outputs, h->d_records, h->em.d_win[0], h->em.d_win[1], h->em.d_win[2], h->em.d_order, h->em.d_probe, h->em.d_rbits, h->em.d_rpre, h->em.d_sc_z, h->em.d_sc_m, h->em.d_sc_c, h->em.d_sc_res, h->em.d_sc_zr, h->em.d_sc_mr};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < pob_ctx::Emit::NSLOT; k++) {
         if (h->em.h_pin[k]) hipHostFree(h->em.h_pin[k]);
@@ -821,18 +875,23 @@ int pob_generate(pob_handle h, void* stream_) {
     const uint32_t G = (h->n + 63) / 64;
     if (h->upload_pending) { HIPC(hipStreamWaitEvent(st, h->ev_upload, 0)); h->upload_pending = false; }
     if (h->chk_ordered && h->chk_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_check_done, 0));      // the previous batch's evaluation still reads the vector this generation overwrites
+    if (h->gen_ordered && h->gen_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_gen_done, 0));        // ... and a previous generation on another stream still writes it
     h->chk_ordered = false;
     h->rec_slot ^= 1;                                   // this batch's records go to the other pinned buffer: the previous batch's stay readable
     if (h->inorder) {
         GArgs A = gargs(h);
         KArgs K = kargs(h);
-        launch_inputs(h, false, G, st);
+        static const int x_skip = getenv("POB_X_SKIP") ? atoi(getenv("POB_X_SKIP")) : 0;
+        static const int x_skipl = getenv("POB_X_SKIP_LEVELS") ? atoi(getenv("POB_X_SKIP_LEVELS")) : 0;      // EXPERIMENT: bit lv = the merged launch of level lv; bit 0 = k_inputs; x_skip & 256: Poseidon blocks, & 512: sponge chains
+        if (!(x_skipl & 1)) launch_inputs(h, false, G, st);
         size_t ki = 0;
         for (uint32_t lv = 1; lv <= h->nlevels; lv++) {
-            for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) { A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st); }
-            for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
+            for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) {
+                if (ls.cls == 4 ? (x_skip & 256) : ((x_skipl >> lv) & 1)) continue;
+                A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st);
+            }
+            for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { if (x_skip & 512) continue; K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
         }
-        static const int x_skip = getenv("POB_X_SKIP") ? atoi(getenv("POB_X_SKIP")) : 0;
         if (h->nperms && !(x_skip & 1)) { K.first = 0; launch_k_rounds(K, false, h->nperms, G, st); }
         HIPC(hipGetLastError());
         HIPC(hipEventRecord(h->ev_g_done, st));
@@ -1126,24 +1185,33 @@ static int emit_make_window(pob_ctx* h, uint32_t idx, uint64_t k, int slot) {
             else launch_k_emit_bits_red(Gp, E.d_win[slot], (uint32_t)lo2, (uint32_t)(r.b + (lo2 - r.w)), (uint32_t)(hi2 - lo2), idx % 64, E.d_rbits, E.d_rpre, (uint32_t)w0, (uint32_t)wn, st);
         }
     }
+    if (E.sc_on && E.red) {   // reduced witness: every site whose wires are all kept (through their class representatives), at their ranks (lists built in emit_start)
+        const ScWin W{E.d_win[slot], (uint32_t)w0, (uint32_t)wn, E.d_rbits, E.d_rpre};
+        uint32_t* res = E.d_sc_res; const uint32_t* zr = E.d_sc_zr; const uint32_t* mr = E.d_sc_mr; const uint32_t* pw = h->d_pow256; const uint32_t nz = E.sc_red_nz, nm = E.sc_red_nm;
+        if (nz) hipLaunchKernelGGL(k_selfcheck_zr, dim3((nz + 63) / 64), dim3(64), 0, st, W, zr, nz, res);
+        if (nm) hipLaunchKernelGGL(k_selfcheck_mr, dim3((nm + 63) / 64), dim3(64), 0, st, W, mr, nm, pw, res);
+    }
     if (E.sc_on && !E.red) {        // the derived wires' relations on the values just written into this window
-        const auto za = std::lower_bound(E.sc_z.begin(), E.sc_z.end(), (uint32_t)(w0 + 3), [](uint32_t s, uint32_t v) { return (s & 0x7FFFFFFFu) < v; });
-        const auto zb = std::lower_bound(za, E.sc_z.end(), (uint32_t)std::max<uint64_t>(w0 + wn, 2) - 2, [](uint32_t s, uint32_t v) { return (s & 0x7FFFFFFFu) < v; });
+        const ScWin W{E.d_win[slot], (uint32_t)w0, (uint32_t)wn, nullptr, nullptr};
+        uint32_t* res = E.d_sc_res;
+        // sites by the wire range of the window; the kernels skip (and count) a site one of whose wires is outside the window
+        const auto za = std::lower_bound(E.sc_z.begin(), E.sc_z.end(), (uint32_t)wire_lo, [](uint32_t s, uint32_t v) { return (s & 0x7FFFFFFFu) < v; });
+        const auto zb = std::lower_bound(za, E.sc_z.end(), (uint32_t)wire_hi, [](uint32_t s, uint32_t v) { return (s & 0x7FFFFFFFu) < v; });
         const uint32_t nz = (uint32_t)(zb - za);
-        const uint32_t* zs = E.d_sc_z + (za - E.sc_z.begin()); uint8_t* wbuf = E.d_win[slot]; uint32_t* res = E.d_sc_res;
-        if (nz) hipLaunchKernelGGL(k_selfcheck_z, dim3((nz + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, zs, nz, res);
+        const uint32_t* zs = E.d_sc_z + (za - E.sc_z.begin());          // (plain locals: the CPU shim's launch macro evaluates its arguments inside a by-copy lambda)
+        if (nz) hipLaunchKernelGGL(k_selfcheck_z, dim3((nz + 63) / 64), dim3(64), 0, st, W, zs, nz, res);
         E.sc_checked += nz;
-        // M sites whose M[k+1] lies in this window (the kernel skips and counts the ones whose other wires do not)
-        const auto ma = std::lower_bound(E.sc_m_next.begin(), E.sc_m_next.end(), (uint32_t)w0), mb = std::lower_bound(ma, E.sc_m_next.end(), (uint32_t)(w0 + wn));
+        // M sites whose M[k+1] lies in this window
+        const auto ma = std::lower_bound(E.sc_m_next.begin(), E.sc_m_next.end(), (uint32_t)wire_lo), mb = std::lower_bound(ma, E.sc_m_next.end(), (uint32_t)wire_hi);
         const uint32_t nm = (uint32_t)(mb - ma);
         const uint32_t* msites = E.d_sc_m + 3 * (ma - E.sc_m_next.begin()); const uint32_t* pw = h->d_pow256;
-        if (nm) hipLaunchKernelGGL(k_selfcheck_m, dim3((nm + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, (uint32_t)wn, msites, nm, pw, res);
+        if (nm) hipLaunchKernelGGL(k_selfcheck_m, dim3((nm + 63) / 64), dim3(64), 0, st, W, msites, nm, pw, res);
         E.sc_checked += nm;
         // copy sites whose HIGHER wire lies in this window
-        const auto ca = std::lower_bound(E.sc_c_hi.begin(), E.sc_c_hi.end(), (uint32_t)w0), cb = std::lower_bound(ca, E.sc_c_hi.end(), (uint32_t)(w0 + wn));
+        const auto ca = std::lower_bound(E.sc_c_hi.begin(), E.sc_c_hi.end(), (uint32_t)wire_lo), cb = std::lower_bound(ca, E.sc_c_hi.end(), (uint32_t)wire_hi);
         const uint32_t ncs = (uint32_t)(cb - ca);
         const uint32_t* csites = E.d_sc_c + 2 * (ca - E.sc_c_hi.begin());
-        if (ncs) hipLaunchKernelGGL(k_selfcheck_c, dim3((ncs + 63) / 64), dim3(64), 0, st, wbuf, (uint32_t)w0, csites, ncs, res);
+        if (ncs) hipLaunchKernelGGL(k_selfcheck_c, dim3((ncs + 63) / 64), dim3(64), 0, st, W, csites, ncs, res);
         E.sc_checked += ncs;
     }
     HIPC(hipGetLastError());
@@ -1251,7 +1319,7 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         if (!order.empty()) HIPC(hipMemcpy(E.d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
         E.probe_win = window_wires; E.probe_map = E.map_id;
     } else if (nwin_ > 64) { E.probe_win = 0; E.probe_map = E.map_id; }       // (too many windows for the probe's 64-bit masks: every unit runs for every window)
-    if (E.sc_on && !E.red && !E.sc_built) {
+    if (E.sc_on && !E.sc_built) {
         // site-recording pass: every emitting unit once with EmitP::sites set (nothing is written); the sites are layout constants of the handle
         const uint32_t cap = std::max(h->plan.total.q, 1u);
         uint32_t* d_rec = nullptr;
@@ -1272,25 +1340,63 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
         std::vector<std::array<uint32_t, 3>> ms(rec[1]);
         for (uint32_t i = 0; i < rec[1]; i++) for (int j = 0; j < 3; j++) ms[i][j] = rec[4 + (size_t)cap + 3 * (size_t)i + j];
         std::sort(ms.begin(), ms.end());
+        E.sc_ms = ms;
         E.sc_m_next.resize(ms.size());
         for (size_t i = 0; i < ms.size(); i++) E.sc_m_next[i] = ms[i][0];
         std::vector<std::array<uint32_t, 2>> cs(rec[2]);
         for (uint32_t i = 0; i < rec[2]; i++) for (int j = 0; j < 2; j++) cs[i][j] = rec[4 + 4 * (size_t)cap + 2 * (size_t)i + j];
         std::sort(cs.begin(), cs.end());
+        E.sc_cs = cs;
         E.sc_c_hi.resize(cs.size());
         for (size_t i = 0; i < cs.size(); i++) E.sc_c_hi[i] = cs[i][0];
         HIPC(hipMalloc(&E.d_sc_c, std::max<size_t>(cs.size(), 1) * 8));
         if (!cs.empty()) HIPC(hipMemcpy(E.d_sc_c, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
-        HIPC(hipMalloc(&E.d_sc_z, std::max<size_t>(E.sc_z.size(), 1) * 4)); HIPC(hipMalloc(&E.d_sc_m, std::max<size_t>(ms.size(), 1) * 12)); HIPC(hipMalloc(&E.d_sc_res, 8));
+        HIPC(hipMalloc(&E.d_sc_z, std::max<size_t>(E.sc_z.size(), 1) * 4)); HIPC(hipMalloc(&E.d_sc_m, std::max<size_t>(ms.size(), 1) * 12)); HIPC(hipMalloc(&E.d_sc_res, 16));
         if (!E.sc_z.empty()) HIPC(hipMemcpy(E.d_sc_z, E.sc_z.data(), E.sc_z.size() * 4, hipMemcpyHostToDevice));
         if (!ms.empty()) HIPC(hipMemcpy(E.d_sc_m, ms.data(), ms.size() * 12, hipMemcpyHostToDevice));
         E.sc_built = true;
     }
-    if (E.sc_on && !E.red) {
-        const uint32_t init[2] = {0xFFFFFFFFu, 0};
-        HIPC(hipMemcpyAsync(E.d_sc_res, init, 8, hipMemcpyHostToDevice, own_stream(h)));
+    if (E.sc_on) {
+        const uint32_t init[3] = {0xFFFFFFFFu, 0, 0};
+        HIPC(hipMemcpyAsync(E.d_sc_res, init, 12, hipMemcpyHostToDevice, own_stream(h)));
         HIPC(hipStreamSynchronize(own_stream(h)));
         E.sc_checked = 0; E.sc_skipped = 0;
+    }
+    if (E.sc_on && E.red && E.sc_red_map != E.map_id) {
+        // the sites of this map: every wire through its class representative (pob_emit_selfcheck_alias; without one a wire stands for itself), a site with a wire
+        // that is pinned to a constant or not kept is left out and counted; a copy site is a tautology between class members: counted as skipped
+        const bool have_alias = E.sc_alias && E.sc_alias_n == h->plan.total.w;
+        auto rep = [&](uint32_t w, uint32_t* out, bool may_be_const = true) -> bool {
+            int64_t r = w;
+            if (have_alias) {
+                r = E.sc_alias[w];
+                if (r < 0) {                                 // pinned to a constant: -1 - c for c < 2^30, INT32_MIN for a constant that does not fit
+                    if (!may_be_const || r == INT32_MIN) return false;
+                    *out = 0x80000000u | (uint32_t)(-1 - r); return true;
+                }
+            }
+            if (!std::binary_search(E.keep.begin(), E.keep.end(), (uint32_t)r)) return false;
+            *out = (uint32_t)r; return true;
+        };
+        std::vector<uint32_t> zr, mr; uint64_t left_out = E.sc_cs.size();
+        for (uint32_t s0 : E.sc_z) {
+            const uint32_t w = s0 & 0x7FFFFFFFu; uint32_t q[6] = {0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            bool ok = rep(w, &q[0], false) && rep(w + 1, &q[1]) && rep(w + 2, &q[2]);
+            if (ok && (s0 >> 31)) ok = rep(w - 3, &q[3]) && rep(w - 2, &q[4]) && rep(w - 1, &q[5]);
+            if (!ok) { left_out++; continue; }
+            zr.insert(zr.end(), q, q + 6);
+        }
+        for (const std::array<uint32_t, 3>& m3 : E.sc_ms) {
+            uint32_t q[4] = {0, 0, 0, m3[2]};
+            if (!(rep(m3[0], &q[0], false) && rep(m3[0] - 1, &q[1], false) && rep(m3[1], &q[2], false))) { left_out++; continue; }
+            mr.insert(mr.end(), q, q + 4);
+        }
+        if (E.d_sc_zr) { HIPC(hipFree(E.d_sc_zr)); E.d_sc_zr = nullptr; }
+        if (E.d_sc_mr) { HIPC(hipFree(E.d_sc_mr)); E.d_sc_mr = nullptr; }
+        HIPC(hipMalloc(&E.d_sc_zr, std::max<size_t>(zr.size(), 1) * 4)); HIPC(hipMalloc(&E.d_sc_mr, std::max<size_t>(mr.size(), 1) * 4));
+        if (!zr.empty()) HIPC(hipMemcpy(E.d_sc_zr, zr.data(), zr.size() * 4, hipMemcpyHostToDevice));
+        if (!mr.empty()) HIPC(hipMemcpy(E.d_sc_mr, mr.data(), mr.size() * 4, hipMemcpyHostToDevice));
+        E.sc_red_nz = (uint32_t)(zr.size() / 6); E.sc_red_nm = (uint32_t)(mr.size() / 4); E.sc_red_host_skipped = left_out; E.sc_red_map = E.map_id;
     }
     for (int k = 0; k < NS; k++) HIPC(hipEventRecord(E.ev_free[k], E.s_copy));
     E.win_wires = window_wires; E.nwin = nwin_; E.idx = idx; E.next_make = 0; E.next_take = 0; E.first_slot = 0; E.active = true;
@@ -1382,17 +1488,24 @@ int pob_emit_selfcheck(pob_handle h, int enable) {
     return POB_OK;
 }
 
+int pob_emit_selfcheck_alias(pob_handle h, const int32_t* alias, uint64_t n_wires) {
+    if (!h || (alias && n_wires != h->plan.total.w)) return POB_E_ARG;
+    h->em.sc_alias = alias; h->em.sc_alias_n = alias ? n_wires : 0; h->em.sc_red_map = 0;       // (the lists of the next reduced emission are rebuilt)
+    return POB_OK;
+}
+
 int pob_emit_selfcheck_result(pob_handle h, uint64_t* checked, uint64_t* skipped, uint32_t* first_bad_wire) {
     if (!h) return POB_E_ARG;
     pob_ctx::Emit& E = h->em;
-    if (!E.sc_on || !E.sc_built) { h->err = "no self-checked emission yet (pob_emit_selfcheck, then an O0 emission)"; return POB_E_STATE; }
+    if (!E.sc_on || !E.sc_built) { h->err = "no self-checked emission yet (pob_emit_selfcheck, then an emission)"; return POB_E_STATE; }
     HIPC(hipSetDevice(h->device));
     HIPC(hipStreamSynchronize(own_stream(h)));
-    uint32_t res[2];
-    HIPC(hipMemcpy(res, E.d_sc_res, 8, hipMemcpyDeviceToHost));
+    uint32_t res[3];
+    HIPC(hipMemcpy(res, E.d_sc_res, 12, hipMemcpyDeviceToHost));
     const uint64_t all = E.sc_z.size() + E.sc_m_next.size() + E.sc_c_hi.size();
-    if (checked) *checked = E.sc_checked - res[1];
-    if (skipped) *skipped = all - (E.sc_checked - res[1]);
+    const uint64_t done = E.red ? (uint64_t)res[2] : E.sc_checked - res[1];          // (reduced: the kernels count what they evaluate)
+    if (checked) *checked = done;
+    if (skipped) *skipped = all - done;
     if (first_bad_wire) *first_bad_wire = res[0];
     return POB_OK;
 }
@@ -1403,6 +1516,7 @@ int pob_emit_queue(pob_handle h, uint32_t next_idx) {
     if (!h->generated) { h->err = "nothing generated"; return POB_E_STATE; }
     if (next_idx >= h->n) { h->err = "witness index out of range"; return POB_E_STATE; }
     if (E.pre_made) return POB_OK;                      // (a first window is on its way already: one announcement at a time)
+    if (E.sc_on) return POB_OK;                         // self-checked emissions are not overlapped: the check's result names ONE witness (pob_emit_selfcheck_result)
     HIPC(hipSetDevice(h->device));
     { int rc = emit_statuses(h); if (rc) return rc; }
     if (E.status_host[next_idx] != 0) { h->err = "witness " + std::to_string(next_idx) + " failed an assert: nothing to emit"; return POB_E_STATE; }

@@ -186,6 +186,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.pob_debug_emit_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.pob_emit_selfcheck.argtypes = [vp, ctypes.c_int]
+    lib.pob_emit_selfcheck_alias.argtypes = [vp, vp, ctypes.c_uint64]
     lib.pob_set_inorder.argtypes = [vp, ctypes.c_int]
     lib.pob_emit_selfcheck_result.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     lib.pob_debug_fr_inv.argtypes = [ctypes.c_int, vp, ctypes.c_uint32, vp, vp]
@@ -204,7 +205,7 @@ EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_clo
                     "pob_upload_inputs8", "pob_upload_inputs8_async", "pob_narrow_inputs", "pob_pack_json_batch8",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_alias", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -695,17 +696,27 @@ class WitnessCalculator:
         self._ck(self.lib.pob_write_wtns(self.h, idx, os.fsencode(path)))
 
     def _keep_array(self, keep) -> np.ndarray:
-        """the map as a contiguous uint32 array, PINNED in the library (pob_reduced_map_pin: recognised by address afterwards instead of being
-        hashed per witness).  The array object the caller passed and its contiguous form stay referenced here while pinned, so the address
-        cannot be recycled for another map; a different object is a different map (hashed, validated, pinned in its turn)."""
-        keep = getattr(keep, "keep", keep)                 # circuit_model.o1.ReducedMap or a plain array of surviving O0 wire indices
-        held = getattr(self, "_pinned_map", None)
-        if held is not None and (held[0] is keep or held[1] is keep):
-            return held[1]
-        k = np.ascontiguousarray(keep, dtype=np.uint32)
-        self._ck(self.lib.pob_reduced_map_pin(self.h, k.ctypes.data, k.size))
-        self._pinned_map = (keep, k)
-        return k
+        """a ReducedMap (circuit_model/o1.py) or an array of kept O0 wire indices -> the PRIVATE, read-only uint32 copy the library has pinned
+        (pob_reduced_map_pin) for this map.  The library recognises a pinned map by address and length and then promises itself that its contents have not
+        changed, so what is pinned is never the caller's array (the caller may mutate it in place): a private copy, looked up by a digest of the caller's contents
+        (crc32 + adler32 over the 86 MB of the production map: ~40 ms per call, against ~9 ms of device-side hashing per emission that the pin saves and a silently stale map that it prevents)."""
+        import zlib
+        k = np.ascontiguousarray(getattr(keep, "keep", keep), dtype=np.uint32)
+        if k.ndim != 1 or k.size == 0:
+            raise ValueError("keep: a non-empty 1-D array of wire indices")
+        if not hasattr(self, "_keep_pins"):
+            self._keep_pins = {}             # digest of the contents -> the private read-only copy the library has pinned
+        if self._keep_pins.get(id(k)) is k:  # one of our own pinned copies handed back (witness_payload_reduced -> witness_windows): immutable, no digest needed
+            return k
+        key = (k.size, zlib.crc32(k), zlib.adler32(k))
+        own = self._keep_pins.get(key)
+        if own is None:
+            own = np.array(k, dtype=np.uint32, copy=True)
+            own.setflags(write=False)
+            self._ck(self.lib.pob_reduced_map_pin(self.h, own.ctypes.data, own.size))
+            self._keep_pins[key] = own
+            self._keep_pins[id(own)] = own
+        return own
 
     def write_wtns_reduced(self, idx: int, path: str, keep):
         """O1-style reduced .wtns (circuit_model.o1.reduce_map): only the surviving wires are expanded on the GPU and cross PCIe
@@ -734,8 +745,25 @@ class WitnessCalculator:
         self._ck(self.lib.pob_set_inorder(self.h, 1 if on else 0))
 
     def emit_selfcheck(self, enable: bool = True):
-        """every following O0 emission evaluates the derived wires' own relations on the values written into its windows (pob_emit_selfcheck)"""
+        """every following emission (O0 or reduced) evaluates the derived wires' own relations on the values written into its windows (pob_emit_selfcheck)"""
         self._ck(self.lib.pob_emit_selfcheck(self.h, 1 if enable else 0))
+
+    def emit_selfcheck_alias(self, alias):
+        """reduced emissions: the class representative of every O0 wire (circuit_model/o1.py O1Map or its .alias array; -1 = pinned to a constant), so that the check
+        evaluates a site whose wires were dropped on their representatives (pob_emit_selfcheck_alias); None clears it"""
+        if alias is None:
+            self._sc_alias = None
+            self._ck(self.lib.pob_emit_selfcheck_alias(self.h, None, 0))
+            return
+        if hasattr(alias, "const_wires"):        # an O1Map: representatives, and the constants coded as -1 - c (c < 2^30) / INT32_MIN
+            a = np.array(alias.alias, dtype=np.int64)
+            cv = np.array([(-1 - v) if v < (1 << 30) else -(1 << 31) for v in alias.const_values], dtype=np.int64)
+            a[np.asarray(alias.const_wires, dtype=np.int64)] = cv
+            a = a.astype(np.int32)
+        else:
+            a = np.ascontiguousarray(alias, dtype=np.int32)
+        self._sc_alias = a                       # (the library reads it when the next reduced emission begins)
+        self._ck(self.lib.pob_emit_selfcheck_alias(self.h, a.ctypes.data, a.size))
 
     def emit_selfcheck_result(self) -> dict:
         """of the last complete self-checked emission: relations checked / skipped (wires in two windows) and the lowest violated wire (None = none)"""

@@ -350,6 +350,58 @@ def test_failure_sets_match_oracle(pkg, depth):
     calc.close()
 
 
+def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
+    """reference tests/testcases/proof_of_burn.py:40-76 at the instantiation of circuits/main_proof_of_burn.circom:27: the ~45 mutations of _mutations on
+    ProofOfBurn(16,4,16,50,31,2,1e19,1e20), scattered over the three groups of ONE 130-witness batch of an IN-ORDER calculator (the schedule bench.py runs; a failing lane
+    must not disturb its neighbours): the fail set and the outputs equal the oracle's, the status of a failing witness is the lowest failing site (never above the
+    oracle's first one, equal to the track schedule's), every witness that passes evaluates clean, and the whole 6.9 GB payload of every VALID mutation is the oracle's"""
+    import random
+    import re
+    from proof_of_burn_amd import inputs as gen, witness as W
+    n = 130
+    batch = gen.synthetic_batch(n, depth=10, seed=0x5EED, distinct_keys=2)
+    cases = _mutations(batch.inputs[0], random.Random(11))
+    assert 40 <= len(cases) < n
+    inputs = list(batch.inputs)
+    pos = [(3 + 37 * i) % n for i in range(len(cases))]          # 37 is coprime to 130: distinct positions in all three groups
+    assert len(set(pos)) == len(cases)
+    for (label, inp), q in zip(cases, pos):
+        inputs[q] = inp
+    calc = pkg.WitnessCalculator(PROD, max_batch=n)
+    calc.set_inorder(True)
+    res = calc.calculate(inputs, check=True)
+    tracks = pkg.WitnessCalculator(PROD, max_batch=n)
+    res_t = tracks.calculate(inputs, check=True)
+    tracks.close()
+    assert [(r.status, r.outputs) for r in res] == [(r.status, r.outputs) for r in res_t], "the two schedules disagree about a witness"
+    code_of = {name: tid for tid, name in W._TPL.items()}
+    n_fail = n_valid_payloads = 0
+    is_case = set(pos)
+    for q in range(n):                                            # the untouched neighbours
+        if q not in is_case:
+            assert res[q].ok and res[q].outputs == [batch.commitments[q]] and res[q].check_status == 0 and res[q].bad_wire is None, q
+    for (label, inp), q in zip(cases, pos):
+        ora = O.run(PROD, inp)
+        r = res[q]
+        exp = None if ora.failed else ora.outputs()
+        assert (r.outputs if r.ok else None) == exp, f"{label}: GPU {r.outputs if r.ok else r.message()} vs oracle {exp if exp else ora.msg}"
+        if exp is None:
+            n_fail += 1
+            m = re.match(r"Failed assert in template (\w+) line (\d+)", ora.msg)
+            if m and m.group(1) in code_of and r.status != W.FAIL_INPUT_RANGE:      # (an input that does not fit its int32 row fails up front, whatever the circuit would say)
+                # the oracle stops at the FIRST failing site in execution order, the device reports the LOWEST failing site
+                assert r.status <= ((code_of[m.group(1)] << 12) | int(m.group(2))), f"{label}: {r.message()} vs oracle {ora.msg}"
+        else:
+            assert r.check_status == 0 and r.bad_wire is None, label
+            gpu, ref = calc.witness_payload(q), ora.witness_numpy()
+            assert np.array_equal(gpu, ref), f"{label}: first differing wire {_first_diff(gpu, ref)}"
+            n_valid_payloads += 1
+            del gpu, ref
+        del ora
+    assert n_fail > 15 and n_valid_payloads >= 8, (n_fail, n_valid_payloads)
+    calc.close()
+
+
 def test_max_depth_and_ragged_batches(pkg):
     """BASELINE config 5 shape: 16-layer proofs (byteSecurityRelax = 1, 3-zero-byte PoW) on the production instantiation;
     batch sizes that are not multiples of the 64-witness group; batch of one."""

@@ -438,6 +438,29 @@ def test_emit_selfcheck_on_written_values(pkg):
     assert np.array_equal(calc.witness_payload(0), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None      # the neighbouring witness is untouched
     calc.poke(cls, idx, 1, 1)
     assert np.array_equal(calc.witness_payload(1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
+    # the REDUCED (O1-style) witness is checked too (round 5): every site whose wires are all kept, at their ranks, through one window and through nine; the same poke
+    # is caught in what a prover built at circom's default level would consume
+    from proof_of_burn_amd.circuit_model.o1 import reduce_map
+    from proof_of_burn_amd.circuit_model.circuits import circuit
+    m = reduce_map(circuit("Spend(31)"))
+    full = ref.reshape(-1, 32)
+    red = calc.witness_payload_reduced(1, m)
+    r0 = calc.emit_selfcheck_result()                    # without the alias map: only the sites whose own wires all survive
+    assert np.array_equal(red.reshape(-1, 32), full[m.keep]) and r0["first_bad_wire"] is None
+    calc.emit_selfcheck_alias(m)                         # with it: every site through its class representatives
+    for window in (0, 30_000):
+        red = calc.witness_payload_reduced(1, m, window_wires=window) if window else calc.witness_payload_reduced(1, m)
+        assert np.array_equal(red.reshape(-1, 32), full[m.keep])
+        r = calc.emit_selfcheck_result()
+        # (one window: every IsZero / IsEqual site; nine windows: the sites whose representatives -- an operand's class may be represented far away -- share a window)
+        assert r["first_bad_wire"] is None and r["checked"] > (200 if window else 3000) and r["checked"] > r0["checked"] and r["skipped"] > 0, (r0, r)
+    calc.poke(cls, idx, 1, 1)
+    calc.witness_payload_reduced(1, m)
+    r = calc.emit_selfcheck_result()
+    assert r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 40_000, (wire, r)
+    calc.poke(cls, idx, 1, 1)
+    calc.witness_payload_reduced(1, m)
+    assert calc.emit_selfcheck_result()["first_bad_wire"] is None
     calc.emit_selfcheck(False)
     calc.close()
 
