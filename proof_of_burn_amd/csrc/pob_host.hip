@@ -1021,6 +1021,8 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         }
         launch_inputs(h, true, G, st);
         if (!forked && h->chk_narrow.count && !(x_skip & 4)) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
+        // (the four wide families -- RANGE, SELROW, LD, SC -- as ONE launch like the narrow ones: 1.60-1.68 / 1.45 ms per step with 4 / 8 in flight against 1.61-1.63 / 1.41-1.44
+        //  as four launches, profiles/round5_experiments.txt 7: nothing; not kept)
         for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B && !(x_skip & 8)) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         if (forked) HIPC(hipStreamWaitEvent(st, h->ev_join, 0));
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }

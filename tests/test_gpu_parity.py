@@ -603,6 +603,42 @@ def test_emit_selfcheck_on_written_values(pkg):
         calc.poke(cls, idx, 1, 1, group=1)
         assert not np.array_equal(got, ref) and r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 200_000, (kb, wire, r)
     assert np.array_equal(calc.witness_payload(n - 1), ref) and calc.emit_selfcheck_result()["first_bad_wire"] is None
+    # the reduced form of the same witness (the stored keep map, no class representatives given: the sites whose own wires all survive)
+    from proof_of_burn_amd.circuit_model import keepmap
+    keep, _ = keepmap.load(PROD)
+    red = calc.witness_payload_reduced(n - 1, keep)
+    r = calc.emit_selfcheck_result()
+    assert np.array_equal(red.reshape(-1, 32), ref.reshape(-1, 32)[keep]) and r["first_bad_wire"] is None, r
+    print("self-check of the reduced production witness without an alias map:", r)
+    calc.close()
+
+
+def test_emit_selfcheck_of_the_reduced_witness(pkg):
+    """the self-check on what a prover built at circom's default level consumes (.github/workflows/circuitscan.yml:29,36): the fixture instantiation's reduced witness with
+    the class representatives of circuit_model/o1.py -- every IsZero / IsEqual site is evaluated on representatives and constants, clean for a valid witness; a poked
+    KeccakBytes.inLen is caught in the reduced payload too"""
+    from proof_of_burn_amd.circuit_model.o1 import reduce_map
+    from proof_of_burn_amd.circuit_model.circuits import circuit
+    with open(os.path.join(ROOT, "tests", "golden", "test_pob_input.json")) as f:
+        inp = json.load(f)
+    m = reduce_map(circuit(POB_FIX))
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=66)
+    assert all(r.ok and r.check_status == 0 for r in calc.calculate([inp] * 66, check=True))
+    full = O.run(POB_FIX, inp).witness_numpy().reshape(-1, 32)
+    calc.emit_selfcheck(True)
+    calc.emit_selfcheck_alias(m)
+    red = calc.witness_payload_reduced(65, m)
+    r = calc.emit_selfcheck_result()
+    assert np.array_equal(red.reshape(-1, 32), full[m.keep]) and r["first_bad_wire"] is None and r["checked"] > 50_000, r
+    print("self-check of the reduced fixture witness:", r)
+    cls, idx, wire = calc.debug_ref("kb.inLen", 0)
+    calc.poke(cls, idx, 1, 1, group=1)
+    calc.witness_payload_reduced(65, m)
+    r = calc.emit_selfcheck_result()
+    calc.poke(cls, idx, 1, 1, group=1)
+    assert r["first_bad_wire"] is not None and wire < r["first_bad_wire"] < wire + 200_000, (wire, r)
+    calc.witness_payload_reduced(65, m)
+    assert calc.emit_selfcheck_result()["first_bad_wire"] is None
     calc.close()
 
 
