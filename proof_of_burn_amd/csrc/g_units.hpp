@@ -7,7 +7,9 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
     // the few long BN254 chains share their SIMDs with thousands of short light / Keccak waves: let the arbiter favour them
     if constexpr ((MASK & ~FAM_LIGHT) != 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
-    const uint32_t g = P::is_emit ? A.emit_group : blockIdx.y;
+    // grid = (groups, units): the group index runs fastest, so the units of a launch start in the order of the list (longest first, circuits.hpp cost) for ALL groups at
+    // once -- as (units, groups) the long units of the last groups started when everything of the groups before them had been dispatched: the launch's tail
+    const uint32_t g = P::is_emit ? A.emit_group : blockIdx.x, ux = blockIdx.y;
     P p;
     p.m.bits = A.bits + (uint64_t)g * A.bits_stride;
     p.m.sm = A.sm + (uint64_t)g * A.sm_stride;
@@ -27,9 +29,9 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
     p.decl_order = A.L->decl_order;
     if constexpr (P::is_gen) p.status = 0;
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false; }
-    if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.ctr = A.emit_counters; p.sites = A.emit_sites; p.sites_cap = A.emit_sites_cap; p.unit = A.order[A.first + blockIdx.x]; }
+    if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.ctr = A.emit_counters; p.sites = A.emit_sites; p.sites_cap = A.emit_sites_cap; p.unit = A.order[A.first + ux]; }
     for (int pass = 0;; pass++) {
-        const UnitDesc d = A.units[A.order[A.first + blockIdx.x]];      // (re-read for the replay: nothing of it stays live across the body)
+        const UnitDesc d = A.units[A.order[A.first + ux]];      // (re-read for the replay: nothing of it stays live across the body)
         if constexpr ((MASK & ~FAM_LIGHT) == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
         unit_run<P, MASK>(p, d, *A.L);
         if constexpr (P::is_check) {      // a lane-distributed run differed: replay the unit attributing wire by wire
@@ -47,5 +49,5 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
 // one launcher per kernel (each in its own translation unit, compiled in parallel)
 #define POB_DEFINE_G_LAUNCH(name, POL, MASK, WAVES)                                                                            \
     void name(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st) {                                             \
-        hipLaunchKernelGGL((g_units<POL, (MASK), WAVES>), dim3(nunits, ngroups), dim3(64), 0, st, A);                          \
+        hipLaunchKernelGGL((g_units<POL, (MASK), WAVES>), dim3(ngroups, nunits), dim3(64), 0, st, A);                          \
     }

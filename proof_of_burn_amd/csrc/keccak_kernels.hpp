@@ -53,6 +53,7 @@ __device__ __forceinline__ u64 lane_rotl(u64 v, int r, uint32_t lane) {
     uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ uint32_t lane_rotl(uint32_t v, int r, uint32_t lane) { return __shfl(v, (int)((lane - (uint32_t)r) & 63u), 64); }
 
 // Device side of the walker: V = the 64-witness mask of bit position `lane`.  arr / gate (the alias wires) are nothing here.
 struct DevIOBase {
@@ -172,9 +173,9 @@ template <class IO> HD void garr(IO& io, uint32_t off, const typename IO::V& o, 
     io.arr(off, o); io.arr(off + 64, a); io.arr(off + 128, b); io.gate(off + 192, o, a, b);
 }
 
-// the bare permutation round on the bit-sliced state (no wires)
-__device__ __forceinline__ void round_native(u64* a, int r, uint32_t lane) {
-    u64 c[5], d[5], b[25];
+// the bare permutation round on the bit-sliced state (no wires); W = u64: bit k of a Keccak lane for the 64 witnesses of a group, W = uint32_t: for 32 of them
+template <class W> __device__ __forceinline__ void round_native(W* a, int r, uint32_t lane) {
+    W c[5], d[5], b[25];
 #pragma unroll
     for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
 #pragma unroll
@@ -186,7 +187,7 @@ __device__ __forceinline__ void round_native(u64* a, int r, uint32_t lane) {
     for (int i = 0; i < 24; i++) b[KROT(i + 1)] = lane_rotl(a[KROT(i)], ((i + 1) * (i + 2) / 2) % 64, lane);
 #pragma unroll
     for (int i = 0; i < 25; i++) { const int y = i / 5 * 5; a[i] = b[i] ^ (~b[y + (i + 1) % 5] & b[y + (i + 2) % 5]); }
-    a[0] ^= ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~0ULL : 0ULL;
+    a[0] ^= ((KECCAK_RC_DEV[r] >> lane) & 1) ? ~(W)0 : (W)0;
 }
 
 // KeccakfRound(r) keccak.circom:290-297: every wire of the block, in O0 order, from the round input midRound[r].  The GATES (io.gx / io.ga /
@@ -370,6 +371,9 @@ template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) 
     }
 }
 
+// (round 5 tried TWO wavefronts per (group, sponge), each on the 32-bit half of every word -- 32-bit logic, one ds_bpermute per rotation: the header's 17-block chain
+//  0.433 -> 0.336 ms alone, but the step went from 1.57-1.60 / 1.39 to 1.67 / 1.52-1.53 ms with 4 / 8 in flight: twice the wavefronts storing 4-byte halves of every
+//  8-byte word is twice the store transactions on a write path the round expansion already saturates; profiles/round5_experiments.txt 8.  Not kept.)
 // Constraint evaluation of the same wires, LOCAL per permutation (every relation of Absorb/Final/Keccakf's own wires is
 // between stored wires, so no permutation needs to be recomputed): grid.x = (sponge, block), grid.y = group.
 __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(4) k_chain_check(KArgs A) {

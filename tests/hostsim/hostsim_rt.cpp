@@ -147,8 +147,8 @@ void hs_launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
     if (block.x > (uint32_t)MAXT || block.y != 1 || block.z != 1) { fprintf(stderr, "hostsim: unsupported block shape\n"); abort(); }
     gridDim = {grid.x, grid.y, grid.z}; blockDim = {block.x, 1, 1};
     body = &fn;
-    for (uint32_t by = 0; by < grid.y; by++) for (uint32_t bx = 0; bx < grid.x; bx++) {
-        blockIdx = {bx, by, 0};
+    for (uint32_t bz = 0; bz < grid.z; bz++) for (uint32_t by = 0; by < grid.y; by++) for (uint32_t bx = 0; bx < grid.x; bx++) {
+        blockIdx = {bx, by, bz};
         nthreads = (int)block.x; alive = nthreads;
         tag[0] = tag[1] = ~0ull;
         for (int t = 0; t < nthreads; t++) make_fiber(t);
