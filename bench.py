@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
     ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
     ap.add_argument("--x-kchk-sweep", default="", help="EXPERIMENT (round 5): comma-separated k_rounds_check variants, each run alone and in the loop with 4 and 8 in flight")
+    ap.add_argument("--main", choices=["proof_of_burn", "spend"], default="proof_of_burn", help="spend: the same service loop on Spend(31) (tests: small enough for the CPU shim)")
+    ap.add_argument("--shim", action="store_true", help="TESTS ONLY: run the loop on the CPU shim of the kernels (tests/hostsim) -- no GPU, no timing claims, no roofline; "
+                                                        "exercises the multi-rank plumbing (slices, pinned buffers, loader width, the records' all-gather) under gloo")
     ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records of the LAST batch (uint8 [N*B, 44]) to this .npy")
     args = ap.parse_args()
 
@@ -116,11 +119,35 @@ def main():
     from proof_of_burn_amd import witness as W
     from proof_of_burn_amd import distributed as D
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    MAIN_ = MAIN if args.main == "proof_of_burn" else "Spend(31)"
+    if args.shim:
+        # tests/hostsim: the product's kernels and host scheduler on CPU fibers; streams and events do not exist there (a launch runs synchronously)
+        import contextlib
+        from tests.hostsim import build as hb
+        W.LIB_PATH, W._lib = hb.build(), None
+
+        class cuda:
+            class Stream:
+                cuda_stream = 0
+                def __init__(self, *a, **k): pass
+                def wait_event(self, e): pass
+                def wait_stream(self, s): pass
+            class Event:
+                def __init__(self, *a, **k): self.t = 0.0
+                def record(self, s=None): self.t = time.perf_counter()
+                def elapsed_time(self, o): return (o.t - self.t) * 1e3
+            is_available = staticmethod(lambda: True); set_device = staticmethod(lambda d: None); synchronize = staticmethod(lambda: None)
+            stream = staticmethod(lambda s: contextlib.nullcontext())
+        os.environ.setdefault("POB_DIST_BACKEND", "gloo")
+    else:
+        cuda = torch.cuda
+    assert cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     rank, local_rank, world = D.init()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev_index = int(os.environ.get("POB_FORCE_DEVICE", local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
-    torch.cuda.set_device(dev_index)
+    cuda.set_device(dev_index)
+    # this rank's host threads next to its GPU, before any pinned buffer is allocated or the loader pool starts (a lone rank keeps the whole host)
+    bound_cpus = D.bind_rank_to_gpu_numa(local_rank, None if args.shim else dev_index) if world > 1 else None
     strong = args.total_batch > 0
     if strong:
         lo, hi = D.shard_bounds(args.total_batch, rank, world)
@@ -135,12 +162,15 @@ def main():
 
     # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
     t0 = time.time()
-    batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + first0,
-                                   pow_device=dev_index if args.depth > 12 else None) for b in range(NB)]
+    if args.main == "spend":
+        batches = [gen.synthetic_spend_batch(B, first=b * GB + first0) for b in range(NB)]
+    else:
+        batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + first0,
+                                       pow_device=dev_index if args.depth > 12 else None) for b in range(NB)]
     t_synth = (time.time() - t0) / NB
     NC = (max(2, args.pipeline) if INORDER else 2) if PIPE else 1
     LINK = PIPE and not INORDER
-    calcs = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(NC)]
+    calcs = [WitnessCalculator(MAIN_, max_batch=B, device=dev_index) for _ in range(NC)]
     if INORDER:
         for c in calcs:
             c.set_inorder(True)
@@ -160,13 +190,14 @@ def main():
     assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].widened(), pinned[0].forced))), "native loader differs from the Python loader"
     expect = [np.array([list(c.to_bytes(32, "little")) for c in bt.commitments], dtype=np.uint8) for bt in batches]
     # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
-    streams = [torch.cuda.Stream(device=dev_index, priority=-1) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
-    recs = [D.device_records(calcs[c], B) for c in range(NC)]
+    streams = [cuda.Stream(device=dev_index, priority=-1) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
+    records_of = D.host_records if args.shim else D.device_records
+    recs = [records_of(calcs[c], B) for c in range(NC)]
     if LINK:
         calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
-    gs = torch.cuda.Stream(device=dev_index)              # the record gather of the multi-GPU job: after the batch's evaluation, beside the next batch's work
+    gs = cuda.Stream(device=dev_index)              # the record gather of the multi-GPU job: after the batch's evaluation, beside the next batch's work
     gathered_ev = [None] * NC
-    gather_bad = torch.zeros(1, dtype=torch.int64, device=f"cuda:{dev_index}")      # witnesses of OTHER ranks with a non-clean record, accumulated on the device
+    gather_bad = torch.zeros(1, dtype=torch.int64, device="cpu" if args.shim else f"cuda:{dev_index}")      # witnesses of OTHER ranks with a non-clean record, accumulated on the device
     state = {"last_gather": None, "validated": 0, "kchk_ms": [], "h2d_bytes": 0}
     uploaded = [False] * NC
 
@@ -197,12 +228,12 @@ def main():
             calcs[c].fetch_records()
         if world > 1:
             gs.wait_stream(streams[c])
-            with torch.cuda.stream(gs):
+            with cuda.stream(gs):
                 out = D.gather_records(recs[c], total=GB if strong else None)
                 st, _ = D.unpack_records(out)
                 cs, bw = D.unpack_verdicts(out)
                 gather_bad.add_(((st != 0) | (cs != D.CLEAN) | (bw != D.CLEAN)).sum())
-                gathered_ev[c] = torch.cuda.Event(); gathered_ev[c].record(gs)
+                gathered_ev[c] = cuda.Event(); gathered_ev[c].record(gs)
                 state["last_gather"] = out
 
     def start(c, b):
@@ -242,10 +273,10 @@ def main():
             validate(*pend.pop(0))
 
     def fence():
-        torch.cuda.synchronize()
+        cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        cuda.synchronize()
 
     probing = False
     if args.warmup:
@@ -438,7 +469,7 @@ def main():
         for c in calcs:
             c.probe_check_kernel(True)
         n_before = len(calcs)
-        calcs.extend(extra); streams.extend(torch.cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
+        calcs.extend(extra); streams.extend(cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
         gathered_ev.extend([None] * len(extra)); uploaded.extend([False] * len(extra))
         work["NC"] = len(calcs)
         probing = True
@@ -464,7 +495,7 @@ def main():
         extra = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(8 - NC)]
         for c in extra:
             c.set_inorder(True)
-        calcs.extend(extra); streams.extend(torch.cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
+        calcs.extend(extra); streams.extend(cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
         gathered_ev.extend([None] * len(extra)); uploaded.extend([False] * len(extra))
         for c in calcs:
             c.probe_check_kernel(True)
@@ -497,6 +528,21 @@ def main():
         strong_slice = dict(leg(sl, 20), what=f"BASELINE config 4 as one GPU sees it: rank 0's slice (witnesses [0, {B})) of ONE global batch of {8 * B} split over 8 GPUs, per step; "
                                                f"the other ranks' slices and the all-gather of the 44-byte records need the node")
 
+    if args.shim or args.main != "proof_of_burn":
+        # the plumbing run of the tests: the loop, the slices and the gather have been exercised and validated; nothing is measured
+        if rank == 0:
+            print(json.dumps({"metric": "proof_of_burn witnesses/sec", "value": None, "unit": "witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "scaling": "strong" if strong else "weak", "data": "synthetic", "shim": bool(args.shim), "main": MAIN_,
+                              "config": {"workload": f"TEST RUN (not a measurement): {MAIN_}, batch {B} per rank, global {GB}", "validated_witnesses": validated_timed,
+                                         "h2d_bytes_per_step": int(h2d_per_step), "calculators_in_flight": NC, "bound_cpus": (len(bound_cpus) if bound_cpus else None),
+                                         "loader_threads_env": os.environ.get("POB_LOADER_THREADS"), "dist_backend": (dist.get_backend() if dist.is_initialized() else None)}}))
+        for c in calcs:
+            c.close()
+        for pin in pinned:
+            pin.free()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     groups = (B + 63) // 64
     stream0 = streams[0].cuda_stream
     # ---- roofline of the dominant kernel: Keccak round constraint evaluation, HBM-read bound.
@@ -513,13 +559,13 @@ def main():
     alone = launch_bytes / (t_chk * 1e-3) / 1e9
     in_step = launch_bytes / (kchk_in_step * 1e-3) / 1e9 if kchk_in_step else None
     # whole evaluation pass and whole step against the resident vector (write once, read once)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+    ev0, ev1 = cuda.Event(enable_timing=True), cuda.Event(enable_timing=True)
+    cuda.synchronize()
     ev0.record(streams[0])
     for _ in range(5):
         calcs[0].constraint_check(streams[0].cuda_stream)
     ev1.record(streams[0])
-    torch.cuda.synchronize()
+    cuda.synchronize()
     t_check_pass = ev0.elapsed_time(ev1) / 5
     resident = int(info.group_bytes) * groups
     traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
@@ -627,7 +673,7 @@ def main():
                        "canonical_bytes_per_witness": int(info.n_witness) * 32,
                        "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
                                                                                      + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                       "schedule": args.schedule, "calculators_in_flight": NC,
+                       "schedule": args.schedule, "calculators_in_flight": NC, "rank_bound_to_cpus": (len(bound_cpus) if bound_cpus else None),
                        "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,

@@ -363,6 +363,8 @@ uint32_t default_threads() {
     uint32_t n = 0;
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) n = (uint32_t)CPU_COUNT(&set);
+    const bool pinned = n && n < std::thread::hardware_concurrency();      // an affinity mask narrower than the machine: somebody placed this process
+    bool quota_cut = false;
     if (!n) n = std::thread::hardware_concurrency();
     if (!n) n = 1;
     // a container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us): more runnable threads than the quota are throttled, not faster (the GPU boxes of this project
@@ -372,10 +374,11 @@ uint32_t default_threads() {
         if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[32]; if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max")) quota = atol(q); fclose(f); }
         else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g);
             if (FILE* h2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h2, "%ld", &period) != 1) period = 100000; fclose(h2); } }
-        if (quota > 0 && period > 0) { const uint32_t q = (uint32_t)((quota + period - 1) / period); if (q && q < n) n = q; }
+        if (quota > 0 && period > 0) { const uint32_t q = (uint32_t)((quota + period - 1) / period); if (q && q < n) { n = q; quota_cut = true; } }      // (a quota is the container's: its ranks share it)
     }
     if (const char* e = getenv("POB_LOADER_THREADS")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int v = atoi(e); if (v > 1) n = n / (uint32_t)v ? n / (uint32_t)v : 1; }
+    // the ranks of a node share its cores: divide by LOCAL_WORLD_SIZE -- unless this process has been pinned to its share already (distributed.bind_rank_to_gpu_numa)
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int v = atoi(e); if (v > 1 && (!pinned || quota_cut)) n = n / (uint32_t)v ? n / (uint32_t)v : 1; }
     return n;
 }
 

@@ -262,7 +262,7 @@ struct pob_ctx {
     // inputs), pob_generate switches; ev_in_done[b] = the last generation / evaluation that read buffer b
     uint8_t* d_in_fr[2] = {nullptr, nullptr}; int32_t* d_in_sm[2] = {nullptr, nullptr}; int in_cur = 0, in_next = 0; uint32_t n_next = 0;
     hipEvent_t ev_in_done[2] = {nullptr, nullptr}; bool in_done_rec[2] = {false, false};
-    uint8_t* d_in_sm8[2] = {nullptr, nullptr}; pob_sm_exc_t* d_in_exc[2] = {nullptr, nullptr};      // staging of the byte form (pob_upload_inputs8*), allocated on first use
+    uint8_t* d_in_sm8[2] = {nullptr, nullptr}; pob_sm_exc_t* d_in_exc[2] = {nullptr, nullptr};      // staging of the byte form (pob_upload_inputs8*): 11 KB per witness and buffer
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
@@ -700,6 +700,10 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         HIPC(hipMalloc(&h->d_in_sm[k], std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
         HIPC(hipMemset(h->d_in_fr[k], 0, std::max<uint64_t>(npad * (uint64_t)pl.nfr_in * 32, 32)));
         HIPC(hipMemset(h->d_in_sm[k], 0, std::max<uint64_t>(npad * (uint64_t)pl.nsm_in * 4, 4)));
+        if (pl.nsm_in) {      // (allocated here, not on first use: a service loop's first byte-form upload must not pay a hipMalloc)
+            HIPC(hipMalloc(&h->d_in_sm8[k], npad * (uint64_t)pl.nsm_in + 16));
+            HIPC(hipMalloc(&h->d_in_exc[k], npad * POB_EXC_CAP * sizeof(pob_sm_exc_t)));
+        }
         HIPC(hipEventCreateWithFlags(&h->ev_in_done[k], hipEventDisableTiming));
     }
     HIPC(hipMalloc(&h->d_status_raw, npad * 4)); HIPC(hipMalloc(&h->d_status, npad * 4));
@@ -815,11 +819,6 @@ int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_
 static int upload8(pob_ctx* h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n, hipStream_t su, bool async) {
     const int t = h->in_cur ^ 1;
     const uint64_t nsm = h->plan.nsm_in;
-    if (nsm && !h->d_in_sm8[t]) {
-        const uint64_t npad = ((uint64_t)h->max_batch + 63) / 64 * 64;
-        HIPC(hipMalloc(&h->d_in_sm8[t], npad * nsm + 16));
-        HIPC(hipMalloc(&h->d_in_exc[t], npad * POB_EXC_CAP * sizeof(pob_sm_exc_t)));
-    }
     if (async) { if (h->upload_pending) HIPC(hipStreamWaitEvent(su, h->ev_upload, 0)); if (h->in_done_rec[t]) HIPC(hipStreamWaitEvent(su, h->ev_in_done[t], 0)); }
     else { if (h->upload_pending) HIPC(hipEventSynchronize(h->ev_upload)); if (h->in_done_rec[t]) HIPC(hipEventSynchronize(h->ev_in_done[t])); }
     if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));

@@ -187,6 +187,20 @@ def synthetic_batch(n: int, depth: int = 10, seed: int = 0xB0B, distinct_keys: i
     return out
 
 
+def synthetic_spend_batch(n: int, seed: int = 0x5BE4D, first: int = 0, amount_bytes: int = 31) -> Batch:
+    """witnesses [first, first + n) of a synthetic Spend(amount_bytes) batch (spend.circom:32-53): witness g depends only on (seed, g); commitment =
+    PublicCommitment([coin, withdrawnBalance, remainingCoin, extraCommitment]) with coin = Poseidon(COIN_PREFIX, burnKey, balance)"""
+    out = Batch(distinct_keys=n, depth=0)
+    for w in range(first, first + n):
+        rng = random.Random(seed * 7919 + w)
+        key, balance = rng.randrange(P), rng.randrange(1, 256 ** min(amount_bytes, 12))
+        withdrawn, extra = rng.randrange(balance + 1), rng.randrange(P)
+        coin, rem = poseidon(POSEIDON_PREFIX + 2, key, balance), poseidon(POSEIDON_PREFIX + 2, key, balance - withdrawn)
+        out.inputs.append({"burnKey": str(key), "balance": str(balance), "withdrawnBalance": str(withdrawn), "extraCommitment": str(extra)})
+        out.commitments.append(expected_commitment([coin, withdrawn, rem, extra]))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Real account proof -> input.json (reference tests/main.py:65-178, which obtains the proof from a JSON-RPC node)
 def rlp_decode(data: bytes):

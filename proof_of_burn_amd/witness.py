@@ -857,6 +857,8 @@ class PinnedInputs:
             self.exc = self._alloc((n, EXC_CAP), EXC_DTYPE)
         else:
             self.sm = self._alloc((n, self.nsm), np.int32)
+            if int(calc.info.n_sm_inputs) == 0:
+                self.sm[...] = 0             # (the dummy column of a circuit without small inputs: the loader never writes it)
         self.forced = np.zeros(n, dtype=np.uint32)
 
     def _alloc(self, shape, dt):

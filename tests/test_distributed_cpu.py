@@ -1,5 +1,6 @@
 """N>1 plumbing on CPU: world_size-2 gloo run of the slice-per-rank sharding and the single result all-gather
 (proof_of_burn_amd/distributed.py).  The GPU path uses the same functions with backend "nccl" (= RCCL)."""
+import json
 import os
 import subprocess
 import sys
@@ -226,6 +227,39 @@ def test_eight_ranks_uneven_global_batch(tmp_path):
     script = tmp_path / "world8_worker.py"
     script.write_text(WORLD8_WORKER % (ROOT, lib, ROOT))
     _run_two_ranks(script, world=8, timeout=560)
+
+
+def _run_bench_ranks(world, extra, timeout=280):
+    """bench.py as the driver launches it for N > 1 (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_* in the environment), on the CPU shim"""
+    port = D.free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), POB_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shim", "--main", "spend", "--steps", "3", "--warmup", "1",
+           "--no-single", "--no-emission", "--no-extra-legs", "--no-cpu-baseline"] + extra
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for r in range(world)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, e[-2000:])
+    lines = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs[:1]]
+    assert all(not [ln for ln in o.splitlines() if ln.strip() and not ln.startswith("[Gloo]")] for o, _ in outs[1:]), "only rank 0 prints the line"
+    return lines[0]
+
+
+@pytest.mark.timeout(600)
+def test_bench_py_eight_ranks_on_the_shim_weak_and_strong():
+    """`bench.py --gpus 8` end to end under gloo, every rank the real service loop (four in-order calculators over consecutive batches, pinned inputs through the native
+    loader, byte-form upload, records validated per batch, ONE all-gather of the records per batch, the other ranks' records counted on arrival) on the CPU shim with
+    Spend(31): weak (64 witnesses per rank) and BASELINE config 4's strong split with a remainder (one global batch of 509 witnesses: slices of 64 and 63); every
+    rank binds itself to its share of the host's CPUs and the loader's width follows"""
+    from tests.hostsim import build as hb
+    hb.build()
+    weak = _run_bench_ranks(8, ["--batch", "64"])
+    assert weak["shim"] and weak["n_gpus"] == 8 and weak["scaling"] == "weak" and weak["config"]["validated_witnesses"] == 3 * 64
+    assert weak["config"]["dist_backend"] == "gloo" and weak["config"]["calculators_in_flight"] == 4
+    ncpu = len(os.sched_getaffinity(0))
+    assert weak["config"]["bound_cpus"] == (ncpu // 8 if ncpu >= 8 else None)
+    strong = _run_bench_ranks(8, ["--total-batch", "509"])
+    assert strong["scaling"] == "strong" and strong["config"]["validated_witnesses"] == 3 * 64      # rank 0's slice of 509 = 64 (ranks 5..7: 63)
+    assert "global 509" in strong["config"]["workload"]
 
 
 def test_init_refuses_a_job_without_a_port(monkeypatch):
