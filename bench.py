@@ -105,7 +105,6 @@ def main():
     ap.add_argument("--probe-after", action="store_true", help="record the HIP events around the Keccak round evaluation kernel in 16 extra steps after the timed region instead of inside it")
     ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
     ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
-    ap.add_argument("--x-kchk-sweep", default="", help="EXPERIMENT (round 5): comma-separated k_rounds_check variants, each run alone and in the loop with 4 and 8 in flight")
     ap.add_argument("--main", choices=["proof_of_burn", "spend"], default="proof_of_burn", help="spend: the same service loop on Spend(31) (tests: small enough for the CPU shim)")
     ap.add_argument("--shim", action="store_true", help="TESTS ONLY: run the loop on the CPU shim of the kernels (tests/hostsim) -- no GPU, no timing claims, no roofline; "
                                                         "exercises the multi-rank plumbing (slices, pinned buffers, loader width, the records' all-gather) under gloo")
@@ -489,37 +488,6 @@ def main():
             c.close()
         del calcs[n_before:], streams[n_before:], recs[n_before:], gathered_ev[n_before:], uploaded[n_before:]
         work["NC"] = NC
-    if args.x_kchk_sweep:
-        import ctypes
-        lib = ctypes.CDLL(W.LIB_PATH)
-        extra = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(8 - NC)]
-        for c in extra:
-            c.set_inorder(True)
-        calcs.extend(extra); streams.extend(cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
-        gathered_ev.extend([None] * len(extra)); uploaded.extend([False] * len(extra))
-        for c in calcs:
-            c.probe_check_kernel(True)
-        sweep = []
-        for rnd in range(2):
-            for ent in args.x_kchk_sweep.split(","):
-                v, gw, cw = (int(x) for x in (ent.split("/") + ["0", "0"])[:3])
-                lib.pob_x_set_kchk(v); lib.pob_x_set_kwaves(0, gw); lib.pob_x_set_kwaves(1, cw)
-                row = {"variant": ent, "round": rnd, "alone_ms": round(calcs[0].time_kernel(1, iters=8, stream=streams[0].cuda_stream), 4),
-                       "gen_alone_ms": round(calcs[0].time_kernel(0, iters=8, stream=streams[0].cuda_stream), 4)}
-                for nc in (4, 8):
-                    work["NC"] = nc
-                    probing = True
-                    run(nc); fence()
-                    state.update(validated=0, kchk_ms=[])
-                    t1 = time.perf_counter()
-                    run(64, k0=nc); fence()
-                    d = time.perf_counter() - t1
-                    probing = False
-                    row[f"step_ms_{nc}"] = round(d / 64 * 1e3, 4); row[f"kchk_ms_{nc}"] = round(float(np.mean(state["kchk_ms"])), 4)
-                sweep.append(row)
-                print("SWEEP", json.dumps(row), file=sys.stderr, flush=True)
-        print(json.dumps({"sweep": sweep}))
-        return
     if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch:
         probing = False
         deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=dev_index) for b in range(2)]
@@ -570,7 +538,7 @@ def main():
     resident = int(info.group_bytes) * groups
     traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
-        pmc_file = next(p for p in ("round4_pmc_k_rounds.json",) if os.path.exists(os.path.join(ROOT, "profiles", p)))      # (rounds 1-3 measured the full-layout kernel: not this one)
+        pmc_file = next(p for p in ("round5_pmc_k_rounds.json",) if os.path.exists(os.path.join(ROOT, "profiles", p)))      # (rounds 1-4 measured other kernels: not this one)
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups / pmc["groups"])
@@ -591,7 +559,7 @@ def main():
                 "bytes_per_launch": launch_bytes, "rounds_per_wavefront": kr,
                 "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
                                     f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
-                "gen_kernel": {"kernel": "k_rounds_gen, alone (4 rounds per wavefront: 4 x 76 arrays written, midRound[r0] read)", "achieved": round(info.n_perms * 6 * (4 * 76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
+                "gen_kernel": {"kernel": "k_rounds_gen, alone (8 rounds per wavefront: 8 x 76 arrays written, midRound[r0] read)", "achieved": round(info.n_perms * 3 * (8 * 76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
                                "avg_ms": round(t_gen, 4)},
                 "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,
                                "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),

@@ -5,21 +5,14 @@ void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngro
     if (check) hipLaunchKernelGGL(k_chain_check, dim3(nsponges, ngroups), dim3(64), 0, st, K);
     else hipLaunchKernelGGL(k_chain<false>, dim3(nsponges, ngroups), dim3(64), 0, st, K);
 }
-// EXPERIMENT SWITCH (round 5, to be removed): generation rounds per wavefront
-static int g_kgen = 8;
-extern "C" void pob_x_set_kchk(int) {}
-extern "C" void pob_x_set_kwaves(int which, int v) { if (which == 0 && v > 0) g_kgen = v; }
 int pob_kchk_rounds() { return POB_KCHK_ROUNDS; }
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st) {
-    // evaluation: POB_KCHK_ROUNDS rounds per wavefront, 4 wavefronts per SIMD (124 VGPRs), 12 arrays requested ahead (round 5 sweep: 3 / 4 / 6 / 8 rounds and 8-24
-    // arrays ahead are within 3 % of each other alone and in the step; 5 wavefronts per SIMD spill; profiles/round5_experiments.txt)
+    // evaluation: POB_KCHK_ROUNDS (4) rounds per wavefront, 4 wavefronts per SIMD (124 VGPRs, no scratch), 12 arrays requested ahead.  Round 5's sweep, alone / in the step:
+    // 3 / 4 / 6 / 8 rounds and 8-24 arrays ahead are within 3 % of each other; without the ring (the compiler's one load per wait) the same alone; 5 wavefronts per SIMD spill
+    // and lose 40 %; a persistent grid of ONE wavefront per SIMD saturates HBM alone (0.261 ms) and is slower in the step (profiles/round5_experiments.txt 1-2).
+    // generation: 8 rounds per wavefront (1 / 2 / 4 / 8: 0.329 / 0.302 / 0.283 / 0.261 ms alone: midRound[r0] is read once per chunk; experiments 3)
     if (check) hipLaunchKernelGGL((k_rounds_check<true, POB_KCHK_ROUNDS, 4, 12>), dim3(nperms * (24 / POB_KCHK_ROUNDS), ngroups), dim3(64), 0, st, K);
-    else switch (g_kgen) {
-        case 1: hipLaunchKernelGGL(k_rounds_gen<1>, dim3(nperms * 24, ngroups), dim3(64), 0, st, K); break;
-        case 2: hipLaunchKernelGGL(k_rounds_gen<2>, dim3(nperms * 12, ngroups), dim3(64), 0, st, K); break;
-        case 8: hipLaunchKernelGGL(k_rounds_gen<8>, dim3(nperms * 3, ngroups), dim3(64), 0, st, K); break;
-        default: hipLaunchKernelGGL(k_rounds_gen<4>, dim3(nperms * 6, ngroups), dim3(64), 0, st, K); break;
-    }
+    else hipLaunchKernelGGL(k_rounds_gen<POB_KGEN_ROUNDS>, dim3(nperms * (24 / POB_KGEN_ROUNDS), ngroups), dim3(64), 0, st, K);
 }
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st) {
     uint32_t blocks = (count + 255) / 256; if (blocks > 8192) blocks = 8192;

@@ -437,6 +437,7 @@ template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
 // fetched once (round 4's one-round items fetched every state twice: 126 arrays per round).
 #define KR_CHECK_ARRAYS(kr) (101u * (kr) + 25u)
 #define POB_KCHK_ROUNDS 4
+#define POB_KGEN_ROUNDS 8
 template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) {
     static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
     const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;

@@ -317,7 +317,6 @@ struct pob_ctx {
     // dependency path): every unit of a level, of whatever track, goes out in one launch per kernel class, then the level's sponges; the round expansion of
     // every sponge is ONE launch at the end (nothing of the generation reads it).
     bool inorder = false;
-    hipStream_t s_eval_side = nullptr;                  // EXPERIMENT (POB_X_EVAL_FORK): the narrow evaluation kernel beside the rest of the evaluation
     struct LSeg { uint32_t level, cls, first, count; };
     Seg chk_narrow{0, 0, 0, 0};                          // in-order evaluation: the units of the four narrow families, one launch
     std::vector<LSeg> lsegs;                            // generation launches in level order (cls: generation class; first / count into `order`)
@@ -880,18 +879,13 @@ int pob_generate(pob_handle h, void* stream_) {
     if (h->inorder) {
         GArgs A = gargs(h);
         KArgs K = kargs(h);
-        static const int x_skip = getenv("POB_X_SKIP") ? atoi(getenv("POB_X_SKIP")) : 0;
-        static const int x_skipl = getenv("POB_X_SKIP_LEVELS") ? atoi(getenv("POB_X_SKIP_LEVELS")) : 0;      // EXPERIMENT: bit lv = the merged launch of level lv; bit 0 = k_inputs; x_skip & 256: Poseidon blocks, & 512: sponge chains
-        if (!(x_skipl & 1)) launch_inputs(h, false, G, st);
+        launch_inputs(h, false, G, st);
         size_t ki = 0;
         for (uint32_t lv = 1; lv <= h->nlevels; lv++) {
-            for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) {
-                if (ls.cls == 4 ? (x_skip & 256) : ((x_skipl >> lv) & 1)) continue;
-                A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st);
-            }
-            for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { if (x_skip & 512) continue; K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
+            for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) { A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st); }
+            for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
         }
-        if (h->nperms && !(x_skip & 1)) { K.first = 0; launch_k_rounds(K, false, h->nperms, G, st); }
+        if (h->nperms) { K.first = 0; launch_k_rounds(K, false, h->nperms, G, st); }
         HIPC(hipGetLastError());
         HIPC(hipEventRecord(h->ev_g_done, st));
         { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
@@ -1003,27 +997,15 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         if (!h->plan.sponges.empty()) {
             KArgs K = kargs(h); K.first = 0;
             if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
-            static const int x_skip2 = getenv("POB_X_SKIP") ? atoi(getenv("POB_X_SKIP")) : 0;
-            if (!(x_skip2 & 2)) launch_k_rounds(K, true, h->nperms, G, st);
+            launch_k_rounds(K, true, h->nperms, G, st);
             if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
-            if (!(x_skip2 & 64)) launch_k_chain(K, true, h->nperms, G, st);
-        }
-        static const int x_skip = getenv("POB_X_SKIP") ? atoi(getenv("POB_X_SKIP")) : 0;
-        static const int x_fork = getenv("POB_X_EVAL_FORK") ? atoi(getenv("POB_X_EVAL_FORK")) : 0;
-        bool forked = false;
-        if (x_fork && h->chk_narrow.count) {
-            if (!h->s_eval_side) { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi); HIPC(hipStreamCreateWithPriority(&h->s_eval_side, hipStreamNonBlocking, x_fork == 2 ? hi : lo)); }
-            HIPC(hipStreamWaitEvent(h->s_eval_side, h->ev_gen_done, 0));
-            A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, h->s_eval_side);
-            HIPC(hipEventRecord(h->ev_join, h->s_eval_side));
-            forked = true;
+            launch_k_chain(K, true, h->nperms, G, st);
         }
         launch_inputs(h, true, G, st);
-        if (!forked && h->chk_narrow.count && !(x_skip & 4)) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
-        // (the four wide families -- RANGE, SELROW, LD, SC -- as ONE launch like the narrow ones: 1.60-1.68 / 1.45 ms per step with 4 / 8 in flight against 1.61-1.63 / 1.41-1.44
-        //  as four launches, profiles/round5_experiments.txt 7: nothing; not kept)
-        for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B && !(x_skip & 8)) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
-        if (forked) HIPC(hipStreamWaitEvent(st, h->ev_join, 0));
+        // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
+        //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
+        if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
+        for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));

@@ -5,7 +5,7 @@
 gfx950 correction (MI355X_MICROARCH.md "HBM"): FETCH_SIZE counts 64 B per 128-B request of a coalesced stream, i.e. exactly
 half the bytes -> doubled here (calibrated on this kernel family in round 3: the full-layout kernel streamed 27 GB that cannot sit in the 256 MB L3
 and read 0.51 x raw); WRITE_SIZE is used as reported (it matched the algorithmic write bytes to 0.2 %).  Round 4: the compact round blocks (76 stored
-arrays of 64 wires per block instead of 1 604)."""
+arrays of 64 wires per block instead of 1 604).  Round 5: a wavefront covers several consecutive rounds; every resident array is counted once."""
 import json
 import sqlite3
 import sys
@@ -26,17 +26,19 @@ def per_launch(path, counter, kernel_like):
 
 
 def main(fetch_db, write_db, out):
-    chk = per_launch(fetch_db, "FETCH_SIZE", "%k_roundsILb1%")
-    gen = per_launch(write_db, "WRITE_SIZE", "%k_roundsILb0%")
+    chk = per_launch(fetch_db, "FETCH_SIZE", "%k_rounds_check%")
+    gen = per_launch(write_db, "WRITE_SIZE", "%k_rounds_gen%")
     groups = chk["groups"]
-    perms_rounds = chk["grid_x_threads"] // 64
+    KCHK, KGEN = 4, 8                          # rounds per wavefront (keccak_kernels.hpp POB_KCHK_ROUNDS / POB_KGEN_ROUNDS)
+    chunks = chk["grid_x_threads"] // 64       # (permutation, chunk) items of the evaluation launch
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --batch %d" % (groups * 64),
         "groups": groups,
         "k_rounds_check": {"fetch_size_kb_raw": chk["avg_kb"], "hbm_read_bytes_per_launch": chk["avg_kb"] * 1024 * 2,
-                           "algorithmic_bytes_per_launch": perms_rounds * groups * (76 + 50) * 64 * 8},      # the 76 stored arrays of a round block + midRound[r] + midRound[r+1]
+                           # every resident array of a chunk once: midRound[r0] + per round the 76 stored gate outputs and the stored midRound[r+1]
+                           "algorithmic_bytes_per_launch": chunks * groups * (101 * KCHK + 25) * 64 * 8, "rounds_per_wavefront": KCHK},
         "k_rounds_gen": {"write_size_kb_raw": gen["avg_kb"], "hbm_write_bytes_per_launch": gen["avg_kb"] * 1024,
-                         "algorithmic_bytes_per_launch": (gen["grid_x_threads"] // 64) * groups * 76 * 64 * 8},                  # the 76 stored arrays
+                         "algorithmic_bytes_per_launch": (gen["grid_x_threads"] // 64) * groups * KGEN * 76 * 64 * 8, "rounds_per_wavefront": KGEN},      # the 76 stored arrays of each round
     }
     for k in ("k_rounds_check", "k_rounds_gen"):
         d = res[k]
