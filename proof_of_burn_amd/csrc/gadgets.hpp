@@ -801,7 +801,9 @@ template <class P> GD SmRef gMask(P& p, int n, SmRef src, S count) {
     B fr[4] = {0, 0, 0, 0};
     const BitRef f = gFilter(p, n, count, fr);                   // n <= 256
     const uint32_t ln = p.lane_id();
-    if constexpr (P::is_check) {        // (filter[] <== Filter.out, in[] <== src[], out = filter * in: all on STORED wires, plain loop)
+    // (filter[] <== Filter.out, in[] <== src[], out = filter * in.  The evaluator: all on STORED wires, plain loop.  n > 256 -- gadget mains only, the production
+    //  circuits stay below 105 -- takes the same per-wire loop in every policy: the lane-distributed runs below carry 4 x 64 filter bits)
+    if (P::is_check || n > 256) {
         (void)ln;
         for (int i = 0; i < n; i++) {
             const B fb = p.put(flt + (uint32_t)i, p.get(f + (uint32_t)i));

@@ -114,7 +114,8 @@ LARGE_MAINS = ["SubstringCheck(136, 31)", "RlpMerklePatriciaTrieLeaf(32, 31)", "
                "Poseidon(4)", "KeccakBytes(4)", "PublicCommitment(4)", "Divide(30)", "IsInRange(30)", "Mask(139)", "CountBytes(31)", "Fit(32, 31)", "Fit(104, 136)",
                "AssertBits(253)", "AssertByteString(136)", "Num2BitsSafe(255)", "Num2BitsSafe(253)", "LittleEndianBytes2Num(31)", "BigEndianBytes2Num(31)",
                "Bytes2Nibbles(32)", "Nibbles2Bytes(33)", "RlpInteger(31)", "RlpEmptyAccount(31)", "LeafDetector(136)", "Filter(64)", "Reverse(31)", "Flatten(6, 32)",
-               "AssertLessEqThan(30)", "AssertLessThan(16)", "AssertGreaterEqThan(16)", "ConcatFixed4(32, 32, 32, 8)"]
+               "AssertLessEqThan(30)", "AssertLessThan(16)", "AssertGreaterEqThan(16)", "ConcatFixed4(32, 32, 32, 8)",
+               "Mask(300)", "Concat(300, 5)"]        # (beyond 256 entries: Mask's filter[] runs carry 4 x 64 bits, larger ones take the per-wire loop -- advisor, round 4)
 
 
 def differential(pkg, s, n: int = 48, seed: int = 11) -> list:
