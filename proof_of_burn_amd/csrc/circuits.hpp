@@ -44,6 +44,8 @@ enum UnitKind : uint32_t {
     CK_SL_ROWS,          // rows [a1, a2) of the ShiftLeft(a0) block at cur, IsEqual children from cursor (a3, a4, a5) on (gShiftLeftRows)
     CK_N2BE,             // Num2BigEndianBytes(a0) at cur; a1,a2 = source FR wire; a3,a4,a5 = caller's copy of out[] (w, i, present);
                          // also a GENERATION unit (same stage as its composite): a6,a7 = a wire of an earlier stage with the source's value
+    CK_CAT,              // child a0 (0 Mask(A), 1 Mask(B), 2 ShiftRight, 3 the sums) of the Concat(a1, a2) block whose first wire / SM rank are a3 / a4; cur = the child (gConcatPart)
+    CK_RL_B2, CK_RL_B3,  // U_RL_B's evaluation cut at stored wires (keyLen / accLen; pkLen / valLen): the value / key prefixes, Concat(3 + 33, 2 + 4 + amountBytes + 66) + the leaf copies
     // generation-only unit (UNIT_GEN): the Poseidon(a0 - 1) block at cur with the state spread over lanes (poseidon_wide.hpp);
     // a1 = prefix index, a2..a4 = FR ranks of inputs 1.., a5 = FR rank subtracted from the last input, a6 = FR rank of the caller's copy
     U_POS_WIDE,
@@ -63,7 +65,7 @@ HD constexpr uint32_t fam_of(uint32_t k) {
     return (k == U_KB_RANGE || k == U_ABS_RANGE) ? F_RANGE
          : k == U_KB_SELROW ? F_SELROW
          : (k == U_LD_HEAD || k == U_LD_SELR || k == U_LD_TAIL || k == U_POB_LASTLAYER_RANGE || k == U_SC_SUMS) ? F_LD
-         : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B || k == CK_SR_COLS || k == CK_SL_ROWS) ? F_RL
+         : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B || k == CK_SR_COLS || k == CK_SL_ROWS || k == CK_RL_B2 || k == CK_RL_B3 || k == CK_CAT) ? F_RL
          : (k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE) ? F_SC
          : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG || k == U_POS_WIDE) ? F_POS
          : (k == U_GM || k == U_GM_INPUT) ? F_GM
@@ -372,6 +374,29 @@ template <class P> GD void kb_post(P& p, const KBRefs& r) {
 
 #include "gadget_mains.hpp"
 
+// U_RL_B's second and third part (merkle_patricia_trie_leaf.circom:166-188): the value / key prefixes and their copies | Concat + the leaf copies.  Generation and emission
+// run them inside U_RL_B; the evaluator as units of their own from the stored lengths.
+template <class P> GD void rl_b_prefixes(P& p, const RlRefs& R, const PobParams& prm, S kl, S& pl, S& vl) {
+    const int ab = 32, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxKey = 1 + ab;
+    const S al = p.get(R.accLen);
+    p.put(R.val, 0xb8); p.put(R.val + 1, al);
+    copy_n(p, R.val + 2, R.acc, maxAcc);
+    vl = p.put(R.valLen, 2 + al);
+    p.put(R.pk, 0xf8); p.put(R.pk + 1, (kl + 1) + vl); p.put(R.pk + 2, 0x80 + kl);
+    copy_n(p, R.pk + 3, R.key, maxKey);
+    pl = p.put(R.pkLen, 3 + kl);
+}
+template <class P, class MR> GD void rl_b_concat(P& p, const RlRefs& R, const MR& M, const PobParams& prm, S pl, S vl) {
+    const int ab = 32, bb = prm.amountBytes, maxAcc = 4 + bb + 66, maxVal = 2 + maxAcc, maxKey = 1 + ab, maxPK = 2 + 1 + maxKey, maxOut = maxPK + maxVal;
+    p.cur = R.c_concat;
+    S cl;
+    SmRef c;
+    if constexpr (P::is_check) c = gConcatHead(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl);          // (its children: CK_CAT units)
+    else c = gConcat(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl, true);
+    { copy_n(p, R.o, c, (int)(maxOut)); copy_n(p, M.leaf, c, (int)(maxOut)); }
+    p.put(M.leafLen, p.put(R.ol, cl));
+}
+
 // ---------------------------------------------------------------------------- unit bodies
 // ONE switch over every unit kind; a kernel instantiates it with the MASK of the families it serves and the other cases
 // compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
@@ -627,7 +652,9 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         p.put(A.pn + 1, nb + 66);
         p.cur = A.c_concat;
         S clen;
-        SmRef cc = gConcat(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen, true);
+        SmRef cc;
+        if constexpr (P::is_check) cc = gConcatHead(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen);       // (its children: CK_CAT units)
+        else cc = gConcat(p, 4 + N, 66, A.pn, pl, A.sc, (S)66, clen, true);
         { copy_n(p, A.ea_o, cc, (int)(maxAcc)); copy_n(p, R.acc, cc, (int)(maxAcc)); }
         p.put(R.accLen, p.put(A.ea_ol, clen));
     } break;
@@ -655,19 +682,13 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         { copy_n(p, R.t_o, by, (int)(ab + 1)); copy_n(p, R.key, by, (int)(ab + 1)); }
         const S kl = p.put(R.keyLen, p.put(R.t_ol, 1 + q));
         gAssertGreaterEqThanS(p, 16, kl, (S)2);
-        const S al = p.get(R.accLen);
-        p.put(R.val, 0xb8); p.put(R.val + 1, al);
-        copy_n(p, R.val + 2, R.acc, maxAcc);
-        const S vl = p.put(R.valLen, 2 + al);
-        p.put(R.pk, 0xf8); p.put(R.pk + 1, (kl + 1) + vl); p.put(R.pk + 2, 0x80 + kl);
-        copy_n(p, R.pk + 3, R.key, maxKey);
-        const S pl = p.put(R.pkLen, 3 + kl);
-        p.cur = R.c_concat;
-        S cl;
-        SmRef c = gConcat(p, maxPK, maxVal, R.pk, pl, R.val, vl, cl, true);
-        { copy_n(p, R.o, c, (int)(maxOut)); copy_n(p, M.leaf, c, (int)(maxOut)); }
-        p.put(M.leafLen, p.put(R.ol, cl));
+        // the evaluator runs the rest as two wavefronts of their own (CK_RL_B2, CK_RL_B3): every relation below is between stored wires, and this unit was the longest
+        // of the narrow evaluation kernel (0.24 ms alone)
+        if constexpr (!P::is_check) { S pl, vl; rl_b_prefixes(p, R, prm, kl, pl, vl); rl_b_concat(p, R, M, prm, pl, vl); }
     } break;
+    UCASE(CK_CAT) { gConcatPart(p, (int)d.a[0], (int)d.a[1], (int)d.a[2], d.a[3], d.a[4]); } break;
+    UCASE(CK_RL_B2) { S pl, vl; rl_b_prefixes(p, L.rl, prm, p.get(L.rl.keyLen), pl, vl); } break;
+    UCASE(CK_RL_B3) { rl_b_concat(p, L.rl, M, prm, p.get(L.rl.pkLen), p.get(L.rl.valLen)); } break;
     UCASE(U_POW_POST) {           // :73-79
         B fr[4] = {0, 0, 0, 0};
         const BitRef f = gFilter(p, 32, p.get(L.pw.mzb), fr);
@@ -995,7 +1016,7 @@ struct Plan {
     }
     void record(uint32_t kind, uint32_t stage, Cur cur, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0, uint32_t a5 = 0, uint32_t a6 = 0, uint32_t a7 = 0) {
         UnitDesc d; d.kind = kind; d.stage = stage; d.cur = cur; d.cost = 0; d.a[0] = a0; d.a[1] = a1; d.a[2] = a2; d.a[3] = a3; d.a[4] = a4; d.a[5] = a5; d.a[6] = a6; d.a[7] = a7;
-        d.flags = (kind == CK_POS_SEG || kind == CK_SR_COLS || kind == CK_SL_ROWS) ? UNIT_CHECK      // sub-blocks the evaluator runs on their own
+        d.flags = (kind == CK_POS_SEG || kind == CK_SR_COLS || kind == CK_SL_ROWS || kind == CK_RL_B2 || kind == CK_RL_B3 || kind == CK_CAT) ? UNIT_CHECK      // sub-blocks the evaluator runs on their own
                 : kind == CK_N2BE ? (UNIT_GEN | UNIT_CHECK)                                            // ... and the generator too
                 : kind == U_POS_WIDE ? UNIT_GEN
                 : kind == U_SC_M ? UNIT_EMIT                                                           // (M[]: derived wires, rebuilt by the emitter only)
@@ -1037,6 +1058,11 @@ struct Plan {
         CountP q; q.nnotes = 0;
         unit_run_all(q, d, L);
         take_notes(q, stage);
+    }
+    // the children of the Concat(La, Lb) block at c0 as evaluator units (gadgets.hpp gConcatPart)
+    void cat_units(uint32_t stage, Cur c0, int La, int Lb) {
+        Cur cc[3]; concat_cursors(p, c0, La, Lb, cc);
+        for (uint32_t part = 0; part < 4; part++) record(CK_CAT, stage, cc[part < 3 ? part : 2], part, (uint32_t)La, (uint32_t)Lb, c0.w, c0.s);
     }
     // AssertByteString(N)(src) as range units; p.cur = start of the AssertByteString block
     void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32) {
@@ -1250,8 +1276,11 @@ struct Plan {
                 p.cur = keep;
                 record_composite(U_RL_ACC_B, TC + 2, L.ra.c_cb);
                 record_composite(U_RL_ACC_C, TC + 3, L.ra.c_concat);          // long serial unit
+                cat_units(TC + 3, L.ra.c_concat, 4 + prm.amountBytes, 66);
             }
             record_composite(U_RL_B, TR + 2, R.c_mux);
+            record(CK_RL_B2, TR + 2, R.c_mux); record(CK_RL_B3, TR + 2, R.c_concat);
+            cat_units(TR + 2, R.c_concat, 2 + 1 + 33, 2 + 4 + prm.amountBytes + 66);
             p.cur = chk.cur;
         }
         proof_of_work_checker(TB + 2);                         // :211 (inputs only; in step with BurnAddressHash so that the two sponges share their launches)

@@ -884,6 +884,55 @@ template <class P> GD SmRef gConcat(P& p, int La, int Lb, SmRef a, S aLen, SmRef
     return o;
 }
 
+// ---- Concat(A, B) for the EVALUATOR of a composite unit, cut at stored wires (round 5): the composite keeps the head -- own copies, lengths, the two asserts --, the
+// children run as wavefronts of their own: Mask(A) + maskedA[] | Mask(B) + maskedB[] | ShiftRight(B, A) | shiftedB[] / out[] / outLen.  Every relation of a part is between
+// stored wires; a part finds the block's own wires from the block's first (wire, SM rank) and its child from the cursor the planner recorded for it (concat_cursors).
+struct ConcatOwn { SmRef o, ol, ia, ial, ib, ibl, mA, mB, sB; };
+HD ConcatOwn concat_own(uint32_t w0, uint32_t s0, int La, int Lb) {
+    ConcatOwn c; uint32_t k = 0;
+    auto take = [&](uint32_t n) { SmRef r = {w0 + k, s0 + k}; k += n; return r; };
+    c.o = take(La + Lb); c.ol = take(1); c.ia = take(La); c.ial = take(1); c.ib = take(Lb); c.ibl = take(1); c.mA = take(La); c.mB = take(Lb); c.sB = take(La + Lb);
+    return c;
+}
+// the head, in place of gConcat, for a policy whose parts run elsewhere; the cursor is left behind the asserts (nothing after the head uses it)
+template <class P> GD SmRef gConcatHead(P& p, int La, int Lb, SmRef a, S aLen, SmRef b, S bLen, S& outLen) {
+    const ConcatOwn c = concat_own(p.cur.w, p.cur.s, La, Lb);
+    p.sms(2 * (La + Lb) + 2 * La + 2 * Lb + 3);
+    copy_n(p, c.ia, a, La);
+    aLen = p.put(c.ial, aLen);
+    copy_n(p, c.ib, b, Lb);
+    bLen = p.put(c.ibl, bLen);
+    gAssertLessEqThanS(p, 16, aLen, (S)La);
+    gAssertLessEqThanS(p, 16, bLen, (S)Lb);
+    outLen = p.get(c.ol);                                     // (outLen <== aLen + bLen is the last part's relation)
+    return c.o;
+}
+// part 0: Mask(A) at p.cur | 1: Mask(B) | 2: ShiftRight(B, A) | 3: the sums (p.cur = the ShiftRight block: its out[] comes first)
+template <class P> GD void gConcatPart(P& p, int part, int La, int Lb, uint32_t w0, uint32_t s0) {
+    const ConcatOwn c = concat_own(w0, s0, La, Lb);
+    const S aLen = p.get(c.ial);
+    if (part == 0) { SmRef x = gMask(p, La, c.ia, aLen); copy_n(p, c.mA, x, La); }
+    else if (part == 1) { SmRef x = gMask(p, Lb, c.ib, p.get(c.ibl)); copy_n(p, c.mB, x, Lb); }
+    else if (part == 2) gShiftRight(p, Lb, La, c.mB, aLen, true);
+    else {
+        const SmRef x = {p.cur.w, p.cur.s};
+        for (int i = 0; i < La + Lb; i++) {
+            const S sv = p.put(c.sB + (uint32_t)i, p.get(x + (uint32_t)i));
+            p.put(c.o + (uint32_t)i, i < La ? p.get(c.mA + (uint32_t)i) + sv : sv);
+        }
+        p.put(c.ol, aLen + p.get(c.ibl));
+    }
+}
+// where the three children of the Concat block at c0 begin (host planner: a counting walk)
+template <class CP> inline void concat_cursors(const CP& proto, Cur c0, int La, int Lb, Cur out[3]) {
+    CP q; q.cur = c0; q.decl_order = proto.decl_order;
+    q.sms(2 * (La + Lb) + 2 * La + 2 * Lb + 3);
+    gAssertLessEqThanS(q, 16, 0, (S)La); gAssertLessEqThanS(q, 16, 0, (S)Lb);
+    out[0] = q.cur; { SmRef z = {0, 0}; gMask(q, La, z, 0); }
+    out[1] = q.cur; { SmRef z = {0, 0}; gMask(q, Lb, z, 0); }
+    out[2] = q.cur;
+}
+
 // ============================================================================ circuits/utils/convert.circom
 // LittleEndianBytes2Num(N<=31) :12-26  [out | in[N]] || AssertByteString(N)
 template <class P> GD F gLittleEndianBytes2NumF(P& p, int N, SmRef src) {

@@ -25,7 +25,7 @@ import numpy as np
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpob_hip.so")
+LIB_PATH = os.environ.get("POB_LIB_PATH") or os.path.join(_HERE, "csrc", "libpob_hip.so")      # (POB_LIB_PATH: another BUILD of the same library, for A/B runs on one box)
 
 POB_FR_INPUTS = ["burnKey", "actualBalance", "intendedBalance", "revealAmount", "burnExtraCommitment", "_proofExtraCommitment"]
 POB_SM_INPUTS = ["numLeafAddressNibbles", "layers", "layerLens", "numLayers", "blockHeader", "blockHeaderLen", "byteSecurityRelax"]

@@ -353,7 +353,8 @@ def test_gadget_mains_at_production_sizes(pkg):
     """a few templates at the parameters the production circuit uses, seeded random inputs against the oracle (the full list runs on the GPU)"""
     from tests import gadget_cases as GC
     bad, total = [], 0
-    for main in ("SubstringCheck(136, 31)", "RlpMerklePatriciaTrieLeaf(32, 31)", "Concat(36, 103)", "Pad(4, 136)", "SelectorArray2D(5, 4, 16)", "Num2BitsSafe(253)", "LeafDetector(136)"):
+    for main in ("SubstringCheck(136, 31)", "RlpMerklePatriciaTrieLeaf(32, 31)", "Concat(36, 103)", "Pad(4, 136)", "SelectorArray2D(5, 4, 16)", "Num2BitsSafe(253)", "LeafDetector(136)",
+                 "Mask(300)", "Concat(300, 5)"):          # (beyond 256 entries Mask's lane-distributed filter[] runs do not reach: the per-wire loop, advisor round 4)
         b, nok = GC.differential(pkg, {"main": main}, n=5, seed=5)
         bad += b
         total += nok

@@ -11,7 +11,7 @@ MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
 KINDS = ("U_POB_INPUT U_POB_RANGE U_POB_LAYER_ASSERT U_POB_HDR_ASSERT U_POB_POSEIDONS U_BAH_PRE U_BAH_POST U_KB_HEAD U_KB_RANGE U_KB_SELROW "
          "U_KB_POST U_POB_N2B U_PC_PRE U_PC_POST U_POB_LASTLAYER U_POB_LASTLAYER_RANGE U_POB_LASTLEN U_POB_LEAF U_POB_LAYER_POST U_SC_M U_SC_RANGE "
          "U_SC_SUMS U_POB_LASTLEAF U_RL_A U_RL_SLROW U_RL_ACC U_RL_B U_POW_PRE U_POW_POST U_POB_FINAL U_ABS_RANGE U_LD_HEAD U_LD_SELR U_LD_TAIL "
-         "U_POB_INPUT_FR U_RL_ACC_B U_RL_ACC_C U_SP_INPUT U_SP_HEAD U_SC_MI CK_POS_SEG CK_SR_COLS CK_SL_ROWS CK_N2BE U_POS_WIDE").split()      # = circuits.hpp UnitKind, from 1
+         "U_POB_INPUT_FR U_RL_ACC_B U_RL_ACC_C U_SP_INPUT U_SP_HEAD U_SC_MI CK_POS_SEG CK_SR_COLS CK_SL_ROWS CK_N2BE CK_CAT CK_RL_B2 CK_RL_B3 U_POS_WIDE").split()      # = circuits.hpp UnitKind, from 1
 FAMS = "F_MISC F_RANGE F_SELROW F_LD F_RL F_SC F_POS F_N2B".split()
 
 
