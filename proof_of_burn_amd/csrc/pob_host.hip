@@ -78,13 +78,19 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32
 static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st);
 // pob_upload_inputs8*: the byte rows widened into the int32 rows every kernel reads (four values per thread when the row length allows aligned words), then the
 // exception slots on top (values outside 0..255: lengths, deliberately out-of-range test inputs)
-__global__ void __launch_bounds__(256) k_widen_sm8(const uint8_t* sm8, int32_t* sm, uint64_t total, uint32_t vec) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (vec) {
-        if (t * 4 >= total) return;
-        const uint32_t w = ((const uint32_t*)sm8)[t];
-        ((uint4*)sm)[t] = make_uint4(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24);
-    } else if (t < total) sm[t] = (int32_t)sm8[t];
+__global__ void __launch_bounds__(256) k_widen_sm8(const uint8_t* sm8, int32_t* sm, uint64_t total) {
+    // 16 bytes per thread and step (one 16-byte load, four 16-byte stores), grid-stride: a few thousand wavefronts -- with four values per thread the pass was 174 k
+    // wavefronts per batch that competed for wave slots with whatever ran beside the upload (the round evaluation of the previous batch: the host enqueues the two together)
+    const uint64_t nvec = total / 16;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 w = ((const uint4*)sm8)[t];
+        uint4* o = (uint4*)sm + 4 * t;
+        o[0] = make_uint4(w.x & 255u, (w.x >> 8) & 255u, (w.x >> 16) & 255u, w.x >> 24);
+        o[1] = make_uint4(w.y & 255u, (w.y >> 8) & 255u, (w.y >> 16) & 255u, w.y >> 24);
+        o[2] = make_uint4(w.z & 255u, (w.z >> 8) & 255u, (w.z >> 16) & 255u, w.z >> 24);
+        o[3] = make_uint4(w.w & 255u, (w.w >> 8) & 255u, (w.w >> 16) & 255u, w.w >> 24);
+    }
+    if (blockIdx.x == 0) for (uint64_t t = nvec * 16 + threadIdx.x; t < total; t += blockDim.x) sm[t] = (int32_t)sm8[t];      // (a row length that is no multiple of 16)
 }
 __global__ void __launch_bounds__(256) k_apply_exc(const pob_sm_exc_t* exc, int32_t* sm, uint32_t n, uint32_t nsm) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -824,9 +830,9 @@ static int upload8(pob_ctx* h, const uint8_t* fr_inputs, const uint8_t* sm8, con
     if (nsm) {
         HIPC(hipMemcpyAsync(h->d_in_sm8[t], sm8, (uint64_t)n * nsm, hipMemcpyHostToDevice, su));
         HIPC(hipMemcpyAsync(h->d_in_exc[t], exc, (uint64_t)n * POB_EXC_CAP * sizeof(pob_sm_exc_t), hipMemcpyHostToDevice, su));
-        const uint64_t total = (uint64_t)n * nsm; const uint32_t vec = total % 4 == 0;
-        const uint64_t threads = vec ? total / 4 : total;
-        hipLaunchKernelGGL(k_widen_sm8, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, su, h->d_in_sm8[t], h->d_in_sm[t], total, vec);
+        const uint64_t total = (uint64_t)n * nsm;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total / 16 + 255) / 256 + 1, 1024);
+        hipLaunchKernelGGL(k_widen_sm8, dim3(blocks), dim3(256), 0, su, h->d_in_sm8[t], h->d_in_sm[t], total);
         hipLaunchKernelGGL(k_apply_exc, dim3((n * POB_EXC_CAP + 255) / 256), dim3(256), 0, su, h->d_in_exc[t], h->d_in_sm[t], n, (uint32_t)nsm);
         HIPC(hipGetLastError());
     }
