@@ -146,7 +146,7 @@ def main():
     dev_index = int(os.environ.get("POB_FORCE_DEVICE", local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
     cuda.set_device(dev_index)
     # this rank's host threads next to its GPU, before any pinned buffer is allocated or the loader pool starts (a lone rank keeps the whole host)
-    bound_cpus = D.bind_rank_to_gpu_numa(local_rank, None if args.shim else dev_index) if world > 1 else None
+    bound_cpus = D.bind_rank_to_gpu_numa(local_rank, None if args.shim else dev_index) if (world > 1 or os.environ.get("POB_BIND_NUMA") == "1") else None
     strong = args.total_batch > 0
     if strong:
         lo, hi = D.shard_bounds(args.total_batch, rank, world)
