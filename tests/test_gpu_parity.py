@@ -478,6 +478,16 @@ def test_max_depth_config5_payload_and_bench(pkg):
     gpu = calc.witness_payload(2)
     ref = ora.witness_numpy()
     assert np.array_equal(gpu, ref), f"first differing wire {_first_diff(gpu, ref)}"
+    # a 16-layer proof through the input producer (reference tests/main.py:65-178): the unpadded nodes and the header, as eth_getProof and the block RPC return them,
+    # through from_account_proof -- the leaf's hex-prefix parse, the state-root position, the padding -- give the same input.json, and that one the same witness
+    inp = deep.inputs[1]
+    nodes = [bytes(inp["layers"][i][:inp["layerLens"][i]]) for i in range(inp["numLayers"])]
+    assert len(nodes) == 16
+    again = gen.from_account_proof(nodes, bytes(inp["blockHeader"][:inp["blockHeaderLen"]]), int(inp["burnKey"]), int(inp["actualBalance"]), int(inp["intendedBalance"]),
+                                   int(inp["revealAmount"]), int(inp["burnExtraCommitment"]), int(inp["_proofExtraCommitment"]), inp["byteSecurityRelax"])
+    assert {k: (v if isinstance(v, list) else int(v)) for k, v in again.items()} == {k: (v if isinstance(v, list) else int(v)) for k, v in inp.items()}
+    r = calc.calculate([again], check=True)[0]
+    assert r.ok and r.outputs == [deep.commitments[1]] and r.check_status == 0 and r.bad_wire is None
     calc.close()
     line = _run_bench(["--gpus", "1", "--depth", "16", "--batch", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single",
                        "--distinct-keys", "2", "--distinct-batches", "2"])
