@@ -554,9 +554,9 @@ def test_production_batch_payloads_beyond_group_0(pkg):
     calc.close()
 
 
-@pytest.mark.parametrize("depth", [8, 9, 10, 16])
+@pytest.mark.parametrize("depth", [2, 8, 9, 10, 15, 16])
 def test_production_payload_across_depths(pkg, depth):
-    """production instantiation, proofs of depth 8 / 9 / 10 / 16 (the derived and alias wires are data-dependent): the whole O0 payload of a
+    """production instantiation, proofs of depth 2 / 8 / 9 / 10 / 15 / 16 (the derived and alias wires are data-dependent): the whole O0 payload of a
     witness of group 1 against the oracle"""
     from proof_of_burn_amd import inputs as gen
     n = 66
