@@ -74,7 +74,10 @@ def bind_rank_to_gpu_numa(local_rank: int, device_index: int | None = None, loca
         cpus = allowed[local_rank * len(allowed) // local_world:(local_rank + 1) * len(allowed) // local_world]
     if not cpus:
         return None
-    os.sched_setaffinity(0, cpus)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:                     # (a container that forbids it: the rank runs where the launcher put it)
+        return None
     return cpus
 
 
