@@ -220,9 +220,11 @@ int pob_emit_queue(pob_handle h, uint32_t next_idx);
  * witness' window.  A witness emitted from a corrupted resident vector (pob_debug_poke of an operand) violates the relations of the derived wires that
  * consume the operand.                                                                                                                          */
 int pob_emit_selfcheck(pob_handle h, int enable);
-/* Reduced emissions: the class representative of every O0 wire under the map that will be emitted (alias[w] = the kept wire that stands for w, w itself if it is kept;
- * a wire pinned to the constant c < 2^30: -1 - c, to a larger constant: INT32_MIN; from circuit_model/o1.py O1Map), n_wires = n_witness.  With it a site whose wires were dropped is evaluated on their representatives --
- * without it only the sites whose own wires are all kept are.  The array must stay valid and unchanged until the next reduced emission has begun; NULL clears it.  */
+/* Reduced emissions: the class representative of every O0 wire under the map that will be emitted (alias[w] = the kept wire that stands for w, w itself if
+ * it is kept; a wire pinned to the constant c < 2^30: -1 - c, to a larger constant: INT32_MIN; from circuit_model/o1.py O1Map), n_wires = n_witness.  With
+ * it a site whose wires were dropped is evaluated on their representatives, without it only the sites whose own wires are all kept are.  The library keeps
+ * the POINTER and reads the array whenever a reduced emission begins with a map whose site lists it has not built yet: the array must stay valid and
+ * unchanged for as long as it is set -- until it is replaced, cleared (NULL) or the handle is closed.                                              */
 int pob_emit_selfcheck_alias(pob_handle h, const int32_t* alias, uint64_t n_wires);
 int pob_emit_selfcheck_result(pob_handle h, uint64_t* checked, uint64_t* skipped, uint32_t* first_bad_wire);
 /* Measurement: `count` witnesses from `first_idx` on, back to back through the window pipeline into pinned host memory.          */
