@@ -383,8 +383,8 @@ def main():
                "steps": n_e2e, "ms_per_step": round(dte / n_e2e * 1e3, 3), "value": round(GB * n_e2e / dte, 1), "unit": "witnesses/s", "validated_witnesses": n_e2e * B,
                "loader_ms_per_batch": round(loader_ms, 3), "loader_witnesses_per_s": round(B / max(loader_ms, 1e-9) * 1e3, 1), "host_waited_for_loader_ms_per_step": round(stall / n_e2e * 1e3, 3),
                "bound": ("loader: the device loop waited for the packer most of every step -- host CPU time, see loader_cpu" if stall > 0.3 * dte else "device (the loader keeps ahead)"),
-               "loader_cpu": {"host_cpus_visible": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(), "what": "one production input.json (40 KB of text, 10 900 values) takes ~30 us of one core; "
-                              "a batch of 1 024 is ~31 ms of CPU time, so a host that grants this process Q CPUs packs at most Q / 0.031 batches per second"}}
+               "loader_cpu": {"host_cpus_visible": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(), "what": "one production input.json (40 KB of text, 10 900 values) takes ~14 us of one core; "
+                              "a batch of 1 024 is ~14 ms of CPU time, so a host that grants this process Q CPUs packs at most Q / 0.014 batches per second"}}
 
     # ---- the bare kernel pipeline (what round 2's bench timed): the same two calculators and batches, but the inputs stay resident (no
     # per-batch H2D), no records are read per batch and nothing is validated inside the loop -- the results are checked once afterwards.

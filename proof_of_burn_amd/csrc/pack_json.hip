@@ -15,6 +15,9 @@
 // batch of 1 024 texts is 0.5 ms of parsing on the cores of a GPU box -- starting and joining threads per call cost more than that) and write straight
 // into the caller's (pinned) arrays.  Default width: the CPUs this process may run on (its affinity mask: a rank pinned to its GPU's NUMA node
 // gets that node's cores) divided by LOCAL_WORLD_SIZE when a launcher set it, so that the ranks of a node do not each start a full-width loader.
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -162,8 +165,60 @@ struct Parser {
             // -- one tight loop per run of such elements (1-9 digits, no leading zero, then ',' + optional blanks or ']'); anything else falls to the general path below
             // at the element where it was met (10 900 elements per production witness: the loop is the loader's rate)
             while (e - s > 16 && n < cap) {
+#if defined(__SSE2__)
+                // zero padding (a proof shorter than the circuit's maximum is padded with zeros, tests/main.py:65-178: 44 % of a 10-layer production input): sixteen
+                // "0, " (json.dumps) or eight "0," (JSON.stringify) per step
+                while (*s == '0' && s[1] == ',' && e - s > 64 && n + 16 <= cap) {
+                    const __m128i x0 = _mm_loadu_si128((const __m128i*)s);
+                    if (s[2] == ' ') {
+                        const __m128i x1 = _mm_loadu_si128((const __m128i*)(s + 16)), x2 = _mm_loadu_si128((const __m128i*)(s + 32));
+                        const __m128i p0 = _mm_setr_epi8('0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0');
+                        const __m128i p1 = _mm_setr_epi8(',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',');
+                        const __m128i p2 = _mm_setr_epi8(' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ', '0', ',', ' ');
+                        const __m128i eq = _mm_and_si128(_mm_and_si128(_mm_cmpeq_epi8(x0, p0), _mm_cmpeq_epi8(x1, p1)), _mm_cmpeq_epi8(x2, p2));
+                        if (_mm_movemask_epi8(eq) != 0xFFFF || (uint32_t)(uint8_t)s[48] - '0' > 9) break;
+                        memset(dst + n, 0, 64); n += 16; s += 48;
+                    } else {
+                        const __m128i pc = _mm_setr_epi8('0', ',', '0', ',', '0', ',', '0', ',', '0', ',', '0', ',', '0', ',', '0', ',');
+                        if (_mm_movemask_epi8(_mm_cmpeq_epi8(x0, pc)) != 0xFFFF || (uint32_t)(uint8_t)s[16] - '0' > 9) break;
+                        memset(dst + n, 0, 32); n += 8; s += 16;
+                    }
+                }
+                // 64 bytes of text at a time: bit masks of the digits, commas and blanks; every comma below the first other character closes an element whose start
+                // follows from the comma before it, so the elements' positions come from mask arithmetic (a cycle or two each) and their values are computed
+                // independently of one another -- the one-element loop below walks a chain of load -> classify -> advance, 15 cycles per element
+                if (e - s > 80 && n + 33 <= cap && (uint32_t)(uint8_t)*s - '0' <= 9) {
+                    uint64_t D = 0, C = 0, S = 0;
+                    for (int k = 0; k < 4; k++) {
+                        const __m128i x = _mm_loadu_si128((const __m128i*)(s + 16 * k));
+                        const __m128i dg = _mm_sub_epi8(x, _mm_set1_epi8('0'));
+                        D |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(dg, _mm_set1_epi8(9)), dg)) << (16 * k);
+                        C |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, _mm_set1_epi8(','))) << (16 * k);
+                        S |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, _mm_set1_epi8(' '))) << (16 * k);
+                    }
+                    const uint64_t O = ~(D | C | S);
+                    uint64_t Cm = O ? C & ((1ULL << __builtin_ctzll(O)) - 1) : C;
+                    unsigned start = 0; bool stop = false;
+                    while (Cm) {
+                        const unsigned p = (unsigned)__builtin_ctzll(Cm), len = p - start;
+                        uint32_t w; memcpy(&w, s + start, 4);
+                        const uint32_t t = w ^ 0x30303030u, mask = (1u << len) - 1;
+                        if (len - 1u >= 3u || (((uint32_t)(D >> start)) & mask) != mask || (len > 1 && (t & 0xFF) == 0)) { stop = true; break; }
+                        const uint32_t y = (t & ((1u << (8 * len)) - 1)) << (8 * (3 - len));               // hundreds | tens | units in bytes 0 | 1 | 2
+                        dst[n++] = (int32_t)((y & 0xFF) * 100 + ((y >> 8) & 0xFF) * 10 + (y >> 16));
+                        start = p + 1 + (unsigned)(((S >> p) >> 1) & 1);
+                        Cm &= Cm - 1;
+                    }
+                    s += start;
+                    if (start) {                                    // at the next element (or at whatever follows the last comma taken: the loops below decide)
+                        if (*s == ' ') s++;
+                        if ((uint32_t)(uint8_t)*s - '0' <= 9) { if (!stop) continue; }
+                        else { ws(); if (s < e && ((uint32_t)(uint8_t)*s - '0' > 9)) goto general; }
+                    }
+                }
+#endif
                 const char* a = s;
-                // zero padding (a proof shorter than the circuit's maximum is padded with zeros, tests/main.py:65-178: 44 % of a 10-layer production input): eight "0, " at a time
+                // (the zero padding without SSE2: eight "0, " at a time)
                 if (*s == '0' && e - s > 40 && n + 8 <= cap) {
                     uint64_t w0, w1, w2; memcpy(&w0, s, 8); memcpy(&w1, s + 8, 8); memcpy(&w2, s + 16, 8);
                     // "0, 0, 0," | " 0, 0, 0" | ", 0, 0, " as little-endian words
@@ -368,7 +423,7 @@ uint32_t default_threads() {
     if (!n) n = std::thread::hardware_concurrency();
     if (!n) n = 1;
     // a container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us): more runnable threads than the quota are throttled, not faster (the GPU boxes of this project
-    // show 256 CPUs and grant 16: 32 threads parse one batch in 2.9 ms, 64 in 10 ms)
+    // show 256 CPUs and grant 16: 64 threads took 10 ms for a batch that 32 parsed in 2.9 ms)
     {
         long quota = -1, period = 100000;
         if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[32]; if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max")) quota = atol(q); fclose(f); }
@@ -384,8 +439,24 @@ uint32_t default_threads() {
 
 // one int32 row -> bytes + exception slots; false: more than POB_EXC_CAP values outside 0..255
 bool narrow_row(const int32_t* row, uint32_t nsm, uint8_t* b, pob_sm_exc_t* ex) {
-    uint32_t ne = 0;
-    for (uint32_t k = 0; k < nsm; k++) {
+    uint32_t ne = 0, k0 = 0;
+#if defined(__SSE2__)
+    for (; k0 + 16 <= nsm; k0 += 16) {                        // sixteen values at a time while all of them are bytes (all but a handful of a witness' 10 900 are)
+        const __m128i a = _mm_loadu_si128((const __m128i*)(row + k0)), c = _mm_loadu_si128((const __m128i*)(row + k0 + 4));
+        const __m128i d = _mm_loadu_si128((const __m128i*)(row + k0 + 8)), f = _mm_loadu_si128((const __m128i*)(row + k0 + 12));
+        const __m128i hi = _mm_andnot_si128(_mm_set1_epi32(255), _mm_or_si128(_mm_or_si128(a, c), _mm_or_si128(d, f)));
+        if (_mm_movemask_epi8(_mm_cmpeq_epi32(hi, _mm_setzero_si128())) == 0xFFFF) {
+            _mm_storeu_si128((__m128i*)(b + k0), _mm_packus_epi16(_mm_packs_epi32(a, c), _mm_packs_epi32(d, f)));
+            continue;
+        }
+        for (uint32_t k = k0; k < k0 + 16; k++) {
+            const int32_t v = row[k];
+            if ((uint32_t)v < 256u) b[k] = (uint8_t)v;
+            else { b[k] = 0; if (ne < POB_EXC_CAP) { ex[ne].k = k; ex[ne].v = v; } ne++; }
+        }
+    }
+#endif
+    for (uint32_t k = k0; k < nsm; k++) {
         const int32_t v = row[k];
         if ((uint32_t)v < 256u) b[k] = (uint8_t)v;
         else { b[k] = 0; if (ne < POB_EXC_CAP) { ex[ne].k = k; ex[ne].v = v; } ne++; }

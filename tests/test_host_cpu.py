@@ -190,6 +190,78 @@ def test_native_json_loader_equals_the_python_loader():
     assert all(np.array_equal(x, y) for x, y in zip(W.pack_inputs(main, batch.inputs), W.pack_json(main, [json.dumps(d) for d in batch.inputs])))
 
 
+def test_native_json_loader_array_paths_fuzz():
+    """the loader's array fast paths (64-byte mask stage, zero-run skip, one-element loop, general path) against json.loads + the Python loader on texts assembled
+    element by element: every mix of separators (", " | "," | " ," | newlines), zero runs of every length across the 48- / 24- / 16-byte skips, numbers of 1-12
+    digits, strings, negatives, nested rows -- and the forms json.loads refuses (leading zeros, fractions, exponents, a trailing comma, two commas): refused by both"""
+    import copy
+    import random
+    fix = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
+    with open(os.path.join(ROOT, "tests", "golden", "test_pob_input.json")) as f:
+        base = json.load(f)
+    rng = random.Random(0xA77A)
+    nlay, nrow = len(base["layers"]), len(base["layers"][0])
+
+    def element(kind, bad_ok):
+        r = rng.random()
+        if not bad_ok and r >= 0.96:
+            r = 0.0
+        if kind == "bytes" or r < 0.80:
+            return str(rng.choice((0, 0, 0, rng.randrange(10), rng.randrange(100), rng.randrange(256))))
+        if r < 0.86:
+            return str(rng.choice((256, 999, 1000, 54321, 2 ** 31 - 1, 2 ** 31, 10 ** 11 + 7)))
+        if r < 0.90:
+            return '"%d"' % rng.randrange(300)
+        if r < 0.93:
+            return str(-rng.randrange(1, 300))
+        if r < 0.96:
+            return rng.choice(("true", "false"))
+        if rng.random() < 0.98:
+            return "0"
+        return rng.choice(("00", "01", "1.5", "2e1", "1E2", "-0", " 7", "0x10", ""))           # most of these are not JSON (or not integers)
+
+    def text_of(kind, seps, zero_run):
+        rows = []
+        bad_ok = kind != "bytes" and rng.random() < 0.5
+        for _ in range(nlay):
+            el = [element(kind, bad_ok) for _ in range(nrow)]
+            if zero_run:
+                a = rng.randrange(nrow - zero_run); el[a:a + zero_run] = ["0"] * zero_run
+            row = ""
+            for i, x in enumerate(el):
+                row += x + (rng.choice(seps) if i + 1 < nrow else "")
+            rows.append("[" + row + rng.choice(("", " ", "", "", ",", "")) + "]" if kind == "hostile" else "[" + row + "]")
+        flat_form = kind != "bytes" and rng.random() < 0.2
+        body = ("[" + ", ".join(r[1:-1] for r in rows) + "]") if flat_form else "[" + rng.choice((", ", ",", ",\n ")).join(rows) + "]"
+        d = copy.deepcopy(base); d["layers"] = "@@"
+        return json.dumps(d).replace('"@@"', body)
+    n_ok = n_refused = 0
+    for it in range(400):
+        kind = ("bytes", "mixed", "hostile")[it % 3]
+        seps = [(", ",), (",",), (", ", ","), (", ", " ,", ",  ", ",\n", ", \t", " , ")][it % 4]
+        zero_run = rng.choice((0, 0, 1, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100))
+        text = text_of(kind, seps, zero_run)
+        try:
+            want = W.pack_inputs(fix, [json.loads(text)])
+        except (ValueError, TypeError, KeyError):
+            want = None
+        try:
+            got = W.pack_json(fix, [text])
+        except (ValueError, KeyError):
+            got = None
+        if want is None:
+            assert got is None, f"text {it}: json.loads / the Python loader refuse it, the native loader accepted it"
+            n_refused += 1
+            continue
+        assert got is not None, f"text {it} ({kind}, {seps}): refused by the native loader only"
+        assert all(np.array_equal(x, y) for x, y in zip(want, got)), f"text {it} ({kind}, {seps}, zero run {zero_run})"
+        n_ok += 1
+        if kind == "bytes":
+            g8 = W.pack_json8(fix, [text])
+            assert g8 is not None and np.array_equal(W.widen_inputs(g8[1], g8[2]), want[1])
+    assert n_ok > 150 and n_refused > 40, (n_ok, n_refused)
+
+
 def test_byte_form_of_the_small_inputs():
     """pob_narrow_inputs / pob_pack_json_batch8 (round 5: bytes as bytes on the wire): narrowing then widening is the identity, a witness with more than
     EXC_CAP values outside 0..255 is refused (never truncated), the loader's byte form stands for the rows of its int32 form on the loader's edge cases and on
