@@ -474,24 +474,32 @@ int pack_batch(const Shape& sh, const char* const* json, const uint64_t* len, ui
     uint32_t nt = threads > 0 ? (uint32_t)threads : default_threads();
     if (nt > (n + 3) / 4) nt = (n + 3) / 4;                        // at least four texts (~0.5 ms of parsing) per thread: waking a sleeping worker costs tens of microseconds
     if (nt == 0) nt = 1;
-    std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu), overflow(0);
+    std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu), overflow(0), oom(0);
     std::vector<std::string> errs(nt);
     const uint32_t smw = sh.nsm ? sh.nsm : 1;                      // (witness.py keeps one dummy column for circuits without small inputs)
     const bool narrow = sm8 != nullptr;
     std::function<void(uint32_t)> work = [&](uint32_t t) {
-        std::vector<int32_t> row(narrow ? smw : 0);                // byte form: the int32 row of the text being parsed (43 KB: stays in the core's cache)
-        for (;;) {
-            const uint32_t i = next.fetch_add(1);
-            if (i >= n) return;
-            std::string em;
-            int32_t* dst = narrow ? row.data() : (sm ? sm + (uint64_t)i * smw : nullptr);
-            if (!pack_one(sh, json[i], len[i], fr + (uint64_t)i * sh.nfr * 32, sh.nsm ? dst : nullptr, forced + i, em)) {
-                uint32_t cur = bad.load();
-                while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
-                if (errs[t].empty()) errs[t] = "input " + std::to_string(i) + ": " + em;
-            } else if (narrow && sh.nsm) {
-                if (!narrow_row(row.data(), sh.nsm, sm8 + (uint64_t)i * sh.nsm, exc + (uint64_t)i * POB_EXC_CAP)) overflow.store(1);
+        uint32_t i = 0;
+        try {                                                        // (an exception must not leave a pool thread: std::terminate would take the caller's process with it)
+            std::vector<int32_t> row(narrow ? smw : 0);            // byte form: the int32 row of the text being parsed (43 KB: stays in the core's cache)
+            for (;;) {
+                i = next.fetch_add(1);
+                if (i >= n) return;
+                std::string em;
+                int32_t* dst = narrow ? row.data() : (sm ? sm + (uint64_t)i * smw : nullptr);
+                if (!pack_one(sh, json[i], len[i], fr + (uint64_t)i * sh.nfr * 32, sh.nsm ? dst : nullptr, forced + i, em)) {
+                    uint32_t cur = bad.load();
+                    while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+                    if (errs[t].empty()) errs[t] = "input " + std::to_string(i) + ": " + em;
+                } else if (narrow && sh.nsm) {
+                    if (!narrow_row(row.data(), sh.nsm, sm8 + (uint64_t)i * sh.nsm, exc + (uint64_t)i * POB_EXC_CAP)) overflow.store(1);
+                }
             }
+        } catch (...) {                                              // out of memory while parsing: the batch is refused
+            const uint32_t at = i < n ? i : 0;
+            uint32_t cur = bad.load();
+            while (at < cur && !bad.compare_exchange_weak(cur, at)) {}
+            oom.store(1);
         }
     };
     {
@@ -499,6 +507,7 @@ int pack_batch(const Shape& sh, const char* const* json, const uint64_t* len, ui
         std::lock_guard<std::mutex> lk(P.call_mu);
         P.run(nt - 1, work);
     }
+    if (oom.load()) { put_err(err, errcap, "out of memory in the loader"); return POB_E_ARG; }
     if (bad.load() != 0xFFFFFFFFu) { for (const std::string& m : errs) if (!m.empty()) { put_err(err, errcap, m); break; } return POB_E_ARG; }
     if (overflow.load()) { put_err(err, errcap, "a witness has more than POB_EXC_CAP small inputs outside 0..255: use the int32 form for this batch"); return POB_E_RANGE; }
     return POB_OK;
