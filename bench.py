@@ -276,7 +276,10 @@ def main():
     def fence():
         cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[dev_index])         # (this rank's GPU, said explicitly: without it the barrier guesses the device from the rank)
+            else:
+                dist.barrier()
         cuda.synchronize()
 
     probing = False
