@@ -2,23 +2,28 @@
 """bench.py -- proof_of_burn witnesses/s on N MI355X GPUs (BASELINE.json metric).
 
 A "step" = one batch through the hot path as a SERVICE LOOP would run it: the batch's packed inputs go H2D from pinned memory
-(pob_upload_inputs_async), every wire of the O0 witness is generated (resident in HBM in the compact typed layout), the per-gate
+(pob_upload_inputs8_async), every wire of the O0 witness is generated (resident in HBM in the compact typed layout), the per-gate
 constraint evaluation reads that resident vector back, the per-witness result records {status, evaluator verdict, commitment} are packed
 AFTER the evaluation, copied to pinned host memory and VALIDATED on the host (every record of every batch: status 0, evaluator clean,
 commitment equal to the host-side formula) -- all of it inside the timed region.  Consecutive batches carry DIFFERENT inputs
-(--distinct-batches of them, cycled).  The loop keeps --pipeline (4) IN-ORDER calculators in flight, each on a stream of its own, on consecutive
+(--distinct-batches of them, cycled).  The loop keeps --pipeline IN-ORDER calculators in flight, each on a stream of its own, on consecutive
 batches (pob_set_inorder: a calculator's whole batch in dependency order on one stream); --schedule tracks is round 3's
 two-calculator pipeline.  Workload at N=1: BASELINE.json configs[2] -- batch = 1024 proof_of_burn witnesses of the
 production instantiation ProofOfBurn(16,4,16,50,31,2,1e19,1e20) on synthetic 10-layer MPT proofs; for N > 1 every rank gets its own 1024
 (weak scaling; --total-batch B splits ONE global batch over the ranks instead: BASELINE config 4 as written), one slice per GPU, no
 data-path collective except ONE all-gather of the 44-byte result records per batch.
 
+Launch forms (both are tested):
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                      WORLD_SIZE unset: bench.py starts its N ranks itself (one process per GPU, rendezvous on 127.0.0.1:free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Structure: `ServiceLoop` is the loop (calculators, streams, pinned inputs, counters); every leg of the report is a function that takes it.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,8 +33,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job n
 
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+DEFAULT_DEPTH = 8                                                    # in-order calculators in flight (the fastest depth measured: profiles/round6_experiments.txt)
+PMC_FILES = ("round6_pmc_k_rounds.json", "round5_pmc_k_rounds.json")
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline (the oracle, test infrastructure: this leg only)
 def _cpu_worker(args):
     """one CPU-baseline process: k witnesses on the C oracle (a restatement of the circom-emitted calculator), single thread"""
     main, inputs, commitments = args
@@ -83,25 +91,29 @@ def cpu_baseline(batch, info, single_samples: int, budget_s: float = 25.0):
                       f"single_thread = {single_samples} witnesses on one warm process"}
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ command line, self-launch
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=180, help="timed batches (180 x ~1.9 ms = a 0.35 s timed region)")
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=180, help="timed batches (180 x ~1.5 ms = a 0.27 s timed region)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="witnesses per GPU per step (weak scaling)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: ONE global batch of this many witnesses per step, split over the ranks (BASELINE config 4: 8192)")
     ap.add_argument("--schedule", choices=["inorder", "tracks"], default="inorder",
                     help="inorder: every calculator enqueues its whole batch in dependency order on ONE stream (pob_set_inorder) and --pipeline of them are in flight; "
                          "tracks: round 2-3's schedule, two linked calculators (pob_set_partner) whose tracks run on the device's side streams")
-    ap.add_argument("--pipeline", type=int, default=-1, help="calculators in flight, each on consecutive batches (default: 4 in-order ones / 2 linked track ones; 0 = one calculator, no pipeline)")
+    ap.add_argument("--pipeline", type=int, default=-1, help=f"calculators in flight, each on consecutive batches (default: {DEFAULT_DEPTH} in-order ones / 2 linked track ones; 0 = one calculator, no pipeline)")
+    ap.add_argument("--streaming-stream", type=int, default=0, choices=[0, 1],
+                    help="1: the two HBM-saturating Keccak round kernels of every in-order calculator on the device's ONE streaming stream (pob_set_inorder(h, 2)), the rest of each batch beside them")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
     ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
     ap.add_argument("--cpu-samples", type=int, default=2, help="witnesses timed single-threaded on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurements")
-    ap.add_argument("--no-single", action="store_true", help="skip the single-calculator steps after the timed region")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the depth16 / strong_slice legs after the timed region")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-calculator / e2e / bare-pipeline legs after the timed region")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the other-depths / depth16 / strong_slice legs after the timed region")
+    ap.add_argument("--other-depths", default="4,12", help="pipeline depths measured beside the default one after the timed region (rank 0 of a 1-GPU run)")
     ap.add_argument("--probe-after", action="store_true", help="record the HIP events around the Keccak round evaluation kernel in 16 extra steps after the timed region instead of inside it")
     ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
     ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
@@ -109,423 +121,409 @@ def main():
     ap.add_argument("--shim", action="store_true", help="TESTS ONLY: run the loop on the CPU shim of the kernels (tests/hostsim) -- no GPU, no timing claims, no roofline; "
                                                         "exercises the multi-rank plumbing (slices, pinned buffers, loader width, the records' all-gather) under gloo")
     ap.add_argument("--dump-results", default=None, help="rank 0 writes the gathered records of the LAST batch (uint8 [N*B, 44]) to this .npy")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from proof_of_burn_amd import WitnessCalculator, PinnedInputs, TextBatch, inputs as gen
-    from proof_of_burn_amd import witness as W
-    from proof_of_burn_amd import distributed as D
 
-    MAIN_ = MAIN if args.main == "proof_of_burn" else "Spend(31)"
-    if args.shim:
-        # tests/hostsim: the product's kernels and host scheduler on CPU fibers; streams and events do not exist there (a launch runs synchronously)
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here, one process per GPU, with the environment torch.distributed.run would give
+    them (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1 and a port the kernel says is free).  Rank 0 inherits stdout, so the ONE
+    JSON line is this command's output; the other ranks' stdout goes to stderr.  Any rank failing ends the job with its exit code (the others are terminated)."""
+    from proof_of_burn_amd.distributed import free_port
+    n = args.gpus
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), POB_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=None if r == 0 else sys.stderr) for r in range(n)]
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ the job's environment: device API, ranks
+class _ShimCuda:
+    """tests/hostsim: the product's kernels and host scheduler on CPU fibers; streams and events do not exist there (a launch runs synchronously)"""
+    class Stream:
+        cuda_stream = 0
+        def __init__(self, *a, **k): pass
+        def wait_event(self, e): pass
+        def wait_stream(self, s): pass
+    class Event:
+        def __init__(self, *a, **k): self.t = 0.0
+        def record(self, s=None): self.t = time.perf_counter()
+        def elapsed_time(self, o): return (o.t - self.t) * 1e3
+    is_available = staticmethod(lambda: True)
+    set_device = staticmethod(lambda d: None)
+    synchronize = staticmethod(lambda: None)
+
+    @staticmethod
+    def stream(s):
         import contextlib
-        from tests.hostsim import build as hb
-        W.LIB_PATH, W._lib = hb.build(), None
+        return contextlib.nullcontext()
 
-        class cuda:
-            class Stream:
-                cuda_stream = 0
-                def __init__(self, *a, **k): pass
-                def wait_event(self, e): pass
-                def wait_stream(self, s): pass
-            class Event:
-                def __init__(self, *a, **k): self.t = 0.0
-                def record(self, s=None): self.t = time.perf_counter()
-                def elapsed_time(self, o): return (o.t - self.t) * 1e3
-            is_available = staticmethod(lambda: True); set_device = staticmethod(lambda d: None); synchronize = staticmethod(lambda: None)
-            stream = staticmethod(lambda s: contextlib.nullcontext())
-        os.environ.setdefault("POB_DIST_BACKEND", "gloo")
-    else:
-        cuda = torch.cuda
-    assert cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    rank, local_rank, world = D.init()
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    dev_index = int(os.environ.get("POB_FORCE_DEVICE", local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
-    cuda.set_device(dev_index)
-    # this rank's host threads next to its GPU, before any pinned buffer is allocated or the loader pool starts (a lone rank keeps the whole host)
-    bound_cpus = D.bind_rank_to_gpu_numa(local_rank, None if args.shim else dev_index) if (world > 1 or os.environ.get("POB_BIND_NUMA") == "1") else None
-    strong = args.total_batch > 0
-    if strong:
-        lo, hi = D.shard_bounds(args.total_batch, rank, world)
-        B, first0, GB = hi - lo, lo, args.total_batch                   # this rank's slice of every global batch
-    else:
-        B, first0, GB = args.batch, rank * args.batch, world * args.batch
-    INORDER = args.schedule == "inorder"
-    if args.pipeline < 0:
-        args.pipeline = 4 if INORDER else 2
-    PIPE = bool(args.pipeline)
-    NB = 1 if args.dbg_no_upload else max(1, args.distinct_batches)
 
-    # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
-    t0 = time.time()
-    if args.main == "spend":
-        batches = [gen.synthetic_spend_batch(B, first=b * GB + first0) for b in range(NB)]
-    else:
-        batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + first0,
-                                       pow_device=dev_index if args.depth > 12 else None) for b in range(NB)]
-    t_synth = (time.time() - t0) / NB
-    NC = (max(2, args.pipeline) if INORDER else 2) if PIPE else 1
-    LINK = PIPE and not INORDER
-    calcs = [WitnessCalculator(MAIN_, max_batch=B, device=dev_index) for _ in range(NC)]
-    if INORDER:
-        for c in calcs:
-            c.set_inorder(True)
-    info = calcs[0].info
-    # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch); the Python packer beside it
-    texts = [TextBatch([json.dumps(inp).encode() for inp in bt.inputs]) for bt in batches]
-    pinned = [PinnedInputs(calcs[0], B) for _ in range(NB)]
-    calcs[0].pack_json(texts[0], out=pinned[0])            # (first call: the loader pool's threads start, first touch of the texts)
-    t0 = time.time()
-    for rep in range(3):
-        for b in range(NB):
-            calcs[0].pack_json(texts[b], out=pinned[b])
-    t_pack_native = (time.time() - t0) / (3 * NB)
-    t0 = time.time()
-    ref = calcs[0].pack(batches[0].inputs[:min(B, 128)])
-    t_pack_py = (time.time() - t0) / min(B, 128) * B
-    assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].widened(), pinned[0].forced))), "native loader differs from the Python loader"
-    expect = [np.array([list(c.to_bytes(32, "little")) for c in bt.commitments], dtype=np.uint8) for bt in batches]
-    # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
-    streams = [cuda.Stream(device=dev_index, priority=-1) for _ in range(NC)]     # (not the legacy default stream: it synchronises with every blocking stream)
-    records_of = D.host_records if args.shim else D.device_records
-    recs = [records_of(calcs[c], B) for c in range(NC)]
-    if LINK:
-        calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
-    gs = cuda.Stream(device=dev_index)              # the record gather of the multi-GPU job: after the batch's evaluation, beside the next batch's work
-    gathered_ev = [None] * NC
-    gather_bad = torch.zeros(1, dtype=torch.int64, device="cpu" if args.shim else f"cuda:{dev_index}")      # witnesses of OTHER ranks with a non-clean record, accumulated on the device
-    state = {"last_gather": None, "validated": 0, "kchk_ms": [], "h2d_bytes": 0}
-    uploaded = [False] * NC
+class Job:
+    """ranks, device, the device API (torch.cuda or the tests' shim) and the job-wide reductions"""
 
-    work = {"pinned": pinned, "expect": expect, "NC": NC}    # the input batches the loop cycles through and the calculators in flight (the extra legs swap in their own)
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from proof_of_burn_amd import distributed as D
+        from proof_of_burn_amd import witness as W
+        self.args, self.torch, self.dist, self.D, self.W = args, torch, dist, D, W
+        if args.shim:
+            from tests.hostsim import build as hb
+            W.LIB_PATH, W._lib = hb.build(), None
+            os.environ.setdefault("POB_DIST_BACKEND", "gloo")
+            self.cuda = _ShimCuda
+        else:
+            self.cuda = torch.cuda
+        assert self.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+        self.rank, self.local_rank, self.world = D.init()
+        assert self.world == args.gpus, f"WORLD_SIZE={self.world} but --gpus {args.gpus}"
+        self.dev = int(os.environ.get("POB_FORCE_DEVICE", self.local_rank))     # (test hook: several ranks on one GPU with POB_DIST_BACKEND=gloo)
+        self.cuda.set_device(self.dev)
+        # this rank's host threads next to its GPU, before any pinned buffer is allocated or the loader pool starts (a lone rank keeps the whole host)
+        self.bound_cpus = D.bind_rank_to_gpu_numa(self.local_rank, None if args.shim else self.dev) if (self.world > 1 or os.environ.get("POB_BIND_NUMA") == "1") else None
+        self.strong = args.total_batch > 0
+        if self.strong:
+            lo, hi = D.shard_bounds(args.total_batch, self.rank, self.world)
+            self.B, self.first0, self.GB = hi - lo, lo, args.total_batch          # this rank's slice of every global batch
+        else:
+            self.B, self.first0, self.GB = args.batch, self.rank * args.batch, self.world * args.batch
+        self.backend = dist.get_backend() if dist.is_initialized() else None
 
-    def validate(c, b):
+    def fence(self):
+        self.cuda.synchronize()
+        if self.world > 1:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.dev])         # (this rank's GPU, said explicitly: without it the barrier guesses the device from the rank)
+            else:
+                self.dist.barrier()
+        self.cuda.synchronize()
+
+    def _tensor(self, vals):
+        return self.torch.tensor(vals, dtype=self.torch.float64, device="cpu" if self.backend == "gloo" else "cuda")
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.world == 1:
+            return seconds
+        t = self._tensor([seconds])
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ranks(self, value: float):
+        """the value of every rank, in rank order"""
+        if self.world == 1:
+            return [value]
+        out = self._tensor([0.0] * self.world)
+        self.dist.all_gather_into_tensor(out, self._tensor([value]))
+        return [float(x) for x in out.cpu()]
+
+
+# ------------------------------------------------------------------------------------------------ the service loop
+class ServiceLoop:
+    """`depth` calculators in flight on consecutive batches.  Per batch, all inside run(): H2D of the packed inputs from pinned memory, generate, constraint evaluation, records into
+    pinned host memory, every record validated on the host; at N > 1 one all-gather of the device records.  Pipeline: batch k is generated by calculator k % depth while batch k-1 is
+    evaluated by the one before; the host validates the oldest batch after it has enqueued the newest, so the device never waits for the host."""
+
+    def __init__(self, job: Job, main: str, depth: int, inorder: bool = True, streaming_stream: bool = False):
+        import numpy as np
+        from proof_of_burn_amd import WitnessCalculator
+        self.job, self.np, self.main = job, np, main
+        self.B, self.depth, self.inorder = job.B, max(1, depth), inorder
+        self.link = (not inorder) and depth > 1
+        cuda, D = job.cuda, job.D
+        self.calcs = [WitnessCalculator(main, max_batch=self.B, device=job.dev) for _ in range(self.depth)]
+        if inorder:
+            for c in self.calcs:
+                c.set_inorder(2 if streaming_stream else 1)
+        # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
+        self.streams = [cuda.Stream(device=job.dev, priority=-1) for _ in self.calcs]     # (not the legacy default stream: it synchronises with every blocking stream)
+        records_of = D.host_records if job.args.shim else D.device_records
+        self.recs = [records_of(c, self.B) for c in self.calcs]
+        if self.link:
+            self.calcs[0].set_partner(self.calcs[1]); self.calcs[1].set_partner(self.calcs[0])
+        self.gs = cuda.Stream(device=job.dev)              # the record gather of the multi-GPU job: after the batch's evaluation, beside the next batch's work
+        self.gathered_ev = [None] * self.depth
+        self.gather_bad = job.torch.zeros(1, dtype=job.torch.int64, device="cpu" if job.args.shim else f"cuda:{job.dev}")      # witnesses of OTHER ranks with a non-clean record
+        self.last_gather = None
+        self.uploaded = [False] * self.depth
+        self.pinned, self.expect = [], []                   # the input batches the loop cycles through (set_inputs)
+        self.active = self.depth                            # calculators the loop uses (the single / tracks legs use fewer)
+        self.upload_each, self.fetch_each, self.probing = not job.args.dbg_no_upload, not job.args.dbg_no_fetch, False
+        self.validated = self.h2d_bytes = 0
+        self.kchk_ms = []
+        self.host_s = {"t_gen": 0.0, "t_chk": 0.0, "t_wait": 0.0}
+
+    # ---- inputs
+    def set_inputs(self, pinned, expect):
+        self.pinned, self.expect = list(pinned), list(expect)
+
+    def reset_counters(self):
+        self.validated = self.h2d_bytes = 0
+        self.kchk_ms = []
+        for k in self.host_s:
+            self.host_s[k] = 0.0
+
+    def probe(self, on: bool):
+        """HIP events around the dominant kernel (Keccak round evaluation) of every evaluation from here on"""
+        self.probing = on
+        for c in self.calcs:
+            c.probe_check_kernel(on)
+
+    # ---- one batch
+    def start(self, c: int, pin):
+        calc, st = self.calcs[c], self.streams[c]
+        if self.upload_each or not self.uploaded[c]:
+            # H2D from pinned memory on the device's upload stream (byte form: 11.4 KB per witness), right in front of the generation that reads it.  (Sending a calculator's
+            # NEXT batch on its way right after its generate -- the inputs are double-buffered -- was measured: 1.74 against 1.61-1.63 ms per step; round-5 experiments 14)
+            self.h2d_bytes += calc.upload_pinned_async(pin)
+            self.uploaded[c] = True
+        if self.gathered_ev[c] is not None:
+            st.wait_event(self.gathered_ev[c])                             # the gather of THIS calculator's previous batch has read its records
+        _t = time.perf_counter()
+        calc.generate(st.cuda_stream)
+        self.host_s["t_gen"] += time.perf_counter() - _t
+
+    def finish(self, c: int):
+        """evaluation of calculator c's batch, its records (now with the verdict) to the host and to the other ranks"""
+        job, D, cuda = self.job, self.job.D, self.job.cuda
+        calc, st = self.calcs[c], self.streams[c]
+        _t = time.perf_counter()
+        calc.constraint_check(st.cuda_stream)
+        self.host_s["t_chk"] += time.perf_counter() - _t
+        if self.fetch_each:
+            calc.fetch_records()
+        if job.world > 1:
+            self.gs.wait_stream(st)
+            with cuda.stream(self.gs):
+                out = D.gather_records(self.recs[c], total=job.GB if job.strong else None)
+                status, _ = D.unpack_records(out)
+                cs, bw = D.unpack_verdicts(out)
+                self.gather_bad.add_(((status != 0) | (cs != D.CLEAN) | (bw != D.CLEAN)).sum())
+                self.gathered_ev[c] = cuda.Event(); self.gathered_ev[c].record(self.gs)
+                self.last_gather = out
+
+    def validate(self, c: int, b: int):
         """every record of the batch calculator c has just finished: host-visible, checked before the clock stops"""
-        if args.dbg_no_fetch:
-            state["validated"] += B
+        np, W = self.np, self.job.W
+        if not self.fetch_each:
+            self.validated += self.B
             return
         _t = time.perf_counter()
-        rec = calcs[c].wait_records()
-        state["t_wait"] = state.get("t_wait", 0.0) + time.perf_counter() - _t
-        assert rec.shape[0] == B
+        rec = self.calcs[c].wait_records()
+        self.host_s["t_wait"] += time.perf_counter() - _t
+        assert rec.shape[0] == self.B
         assert not rec["status"].any(), ("a witness failed", np.nonzero(rec["status"])[0][:4], rec["status"][np.nonzero(rec["status"])[0][:4]])
         assert (rec["check_status"] == W.CLEAN).all() and (rec["bad_wire"] == W.CLEAN).all(), "the constraint evaluator flagged a witness (or did not run)"
-        assert np.array_equal(rec["commitment"], work["expect"][b]), "commitment mismatch"
-        state["validated"] += B
-        if probing:
-            state["kchk_ms"].append(calcs[c].probe_check_kernel(True, read=True))
+        assert np.array_equal(rec["commitment"], self.expect[b]), "commitment mismatch"
+        self.validated += self.B
+        if self.probing:
+            self.kchk_ms.append(self.calcs[c].probe_check_kernel(True, read=True))
 
-    def finish(c):
-        """evaluation of calculator c's batch, its records (now with the verdict) to the host and to the other ranks"""
-        _t = time.perf_counter()
-        calcs[c].constraint_check(streams[c].cuda_stream)
-        state["t_chk"] = state.get("t_chk", 0.0) + time.perf_counter() - _t
-        if not args.dbg_no_fetch:
-            calcs[c].fetch_records()
-        if world > 1:
-            gs.wait_stream(streams[c])
-            with cuda.stream(gs):
-                out = D.gather_records(recs[c], total=GB if strong else None)
-                st, _ = D.unpack_records(out)
-                cs, bw = D.unpack_verdicts(out)
-                gather_bad.add_(((st != 0) | (cs != D.CLEAN) | (bw != D.CLEAN)).sum())
-                gathered_ev[c] = cuda.Event(); gathered_ev[c].record(gs)
-                state["last_gather"] = out
-
-    def start(c, b):
-        pin = work["pinned"][b]
-        if not (args.dbg_no_upload and uploaded[c]):
-            # H2D from pinned memory on the device's upload stream (byte form: 11.4 KB per witness), right in front of the generation that reads it.  (Sending a calculator's
-            # NEXT batch on its way right after its generate -- the inputs are double-buffered -- was measured: 1.74 against 1.61-1.63 ms per step; experiments 14)
-            state["h2d_bytes"] += calcs[c].upload_pinned_async(pin)
-            uploaded[c] = True
-        if gathered_ev[c] is not None:
-            streams[c].wait_event(gathered_ev[c])                         # the gather of THIS calculator's previous batch has read its records
-        _t = time.perf_counter()
-        calcs[c].generate(streams[c].cuda_stream)
-        state["t_gen"] = state.get("t_gen", 0.0) + time.perf_counter() - _t
-
-    def run(nsteps, k0=0):
-        """nsteps batches through the service loop, fill and drain included: every batch is uploaded, generated, evaluated, fetched and validated
-        inside the call.  Pipeline: batch k is generated by calculator k % NC while batch k-1 is evaluated by the one before; the host validates
-        the oldest batch after it has enqueued the newest, so the device never waits for the host."""
-        pend = []                                         # (calculator, distinct batch) enqueued but not yet validated, oldest first
-        prev = None
-        nc = work["NC"]
+    # ---- the loop
+    def run(self, nsteps: int, k0: int = 0, source=None):
+        """nsteps batches, fill and drain included: every batch is uploaded, generated, evaluated, fetched and validated inside the call.
+        source(k) -> the pinned inputs of batch k (default: the loop's own, cycled); it may block (the e2e leg waits for its loader there) and returns its stall"""
+        nc, nb = self.active, max(1, len(self.pinned))
+        pend, prev, stall = [], None, 0.0           # pend: (calculator, distinct batch) enqueued but not yet validated, oldest first
         for k in range(k0, k0 + nsteps):
-            c, b = k % nc, k % len(work["pinned"])
+            c, b = k % nc, k % nb
             if nc > 1:
                 if prev is not None:
-                    finish(prev[0]); pend.append(prev)
-                start(c, b)
+                    self.finish(prev[0]); pend.append(prev)
+                if source is not None:
+                    _t = time.perf_counter(); pin = source(k); stall += time.perf_counter() - _t
+                else:
+                    pin = self.pinned[b]
+                self.start(c, pin)
                 prev = (c, b)
                 while len(pend) > nc - 1:
-                    validate(*pend.pop(0))
+                    self.validate(*pend.pop(0))
             else:
-                start(c, b)
-                finish(c); pend.append((c, b))
-                validate(*pend.pop(0))
+                self.start(c, source(k) if source is not None else self.pinned[b])
+                self.finish(c); pend.append((c, b))
+                self.validate(*pend.pop(0))
         if prev is not None:
-            finish(prev[0]); pend.append(prev)
+            self.finish(prev[0]); pend.append(prev)
         while pend:
-            validate(*pend.pop(0))
+            self.validate(*pend.pop(0))
+        return stall
 
-    def fence():
-        cuda.synchronize()
-        if world > 1:
-            if dist.get_backend() == "nccl":
-                dist.barrier(device_ids=[dev_index])         # (this rank's GPU, said explicitly: without it the barrier guesses the device from the rank)
-            else:
-                dist.barrier()
-        cuda.synchronize()
+    def timed(self, nsteps: int, warm: int, k0: int = 0, source=None):
+        """warm untimed steps, fence, nsteps timed steps, fence: (seconds: the max over the ranks, this rank's seconds, source stall)"""
+        if warm:
+            self.run(warm, k0=k0, source=source)
+        self.job.fence()
+        self.reset_counters()
+        t0 = time.perf_counter()
+        stall = self.run(nsteps, k0=k0 + warm, source=source)
+        self.job.fence()
+        mine = time.perf_counter() - t0
+        assert self.validated == nsteps * self.B, "not every batch was validated inside the timed region"
+        return self.job.max_over_ranks(mine), mine, stall
 
-    probing = False
-    if args.warmup:
-        run(args.warmup)
-    fence()
-    if not args.probe_after and not args.dbg_no_fetch:
-        probing = True
-        for c in calcs:
-            c.probe_check_kernel(True)                    # HIP events around the dominant kernel of every evaluation from here on
-    state.update(validated=0, h2d_bytes=0, t_gen=0.0, t_chk=0.0, t_wait=0.0)
-    t0 = time.perf_counter()
-    run(args.steps, k0=args.warmup)
-    fence()
-    dt = time.perf_counter() - t0
-    host_ms = {k: round(state[k] / args.steps * 1e3, 3) for k in ("t_gen", "t_chk", "t_wait")}
-    assert state["validated"] == args.steps * B, "not every batch was validated inside the timed region"
-    validated_timed = state["validated"]
-    h2d_per_step = state["h2d_bytes"] // max(args.steps, 1)
-    probe_steps = 0
-    if args.probe_after and not args.dbg_no_fetch:
-        # the dominant kernel as it runs IN the service loop: the same loop for a few more batches with HIP events around each of its launches
-        # (outside the timed region: timing events make the runtime time-stamp every dispatch of the queue)
-        probing = True
-        for c in calcs:
-            c.probe_check_kernel(True)
-        probe_steps = 16
-        run(probe_steps, k0=args.warmup + args.steps)
-        fence()
-    probing = False
-    for c in calcs:
-        c.probe_check_kernel(False)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        assert int(gather_bad.item()) == 0, "a gathered record of some rank is not clean"
-        rec_all = state["last_gather"].cpu()
-        assert int(rec_all.shape[0]) == GB
-        mine = rec_all[first0:first0 + B].numpy() if strong else rec_all[rank * B:(rank + 1) * B].numpy()
-        assert np.array_equal(mine[:, 12:], expect[(args.warmup + args.steps + probe_steps - 1) % NB]), "gathered records differ from this rank's commitments"
-        if rank == 0 and args.dump_results:
-            np.save(args.dump_results, rec_all.numpy())
-    elif rank == 0 and args.dump_results:
-        np.save(args.dump_results, recs[(args.warmup + args.steps + probe_steps - 1) % NC].cpu().numpy())
-    kchk_in_step = float(np.mean(state["kchk_ms"])) if state["kchk_ms"] else None
-
-    # ---- the path from input.json TEXT, in the clock (reference Makefile:4-5: the calculator's unit of work starts at the JSON file): the same service loop, but every
-    # batch is parsed from its texts by the native loader (pob_pack_json_batch8 on the persistent loader pool) INSIDE the timed region -- a host thread packs batch k + 2
-    # into a ring of pinned buffers while the device works on batches k, k - 1, ... ; the loop waits for the packer only if it has fallen behind
-    e2e = None
-    if PIPE and INORDER and not args.no_single and not args.dbg_no_fetch:
-        from concurrent.futures import ThreadPoolExecutor
-        ring = [PinnedInputs(calcs[0], B) for _ in range(NC + 3)]
-        ex = ThreadPoolExecutor(1)
-        t_pack_busy = [0.0]
-
-        def pack(k):
-            _t = time.perf_counter()
-            calcs[0].pack_json(texts[k % NB], out=ring[k % len(ring)])
-            t_pack_busy[0] += time.perf_counter() - _t
-            return ring[k % len(ring)]
-
-        def run_e2e(nsteps, k0):
-            fut = {k: ex.submit(pack, k) for k in range(k0, min(k0 + 2, k0 + nsteps))}
-            pend, prev, t_stall = [], None, 0.0
-            for k in range(k0, k0 + nsteps):
-                c = k % NC
-                if prev is not None:
-                    finish(prev[0]); pend.append(prev)
-                _t = time.perf_counter()
-                pin = fut.pop(k).result()
-                t_stall += time.perf_counter() - _t
-                if k + 2 < k0 + nsteps:
-                    fut[k + 2] = ex.submit(pack, k + 2)       # its ring slot held batch k - NC - 1: validated below before this call returns to it
-                state["h2d_bytes"] += calcs[c].upload_pinned_async(pin)
-                if gathered_ev[c] is not None:
-                    streams[c].wait_event(gathered_ev[c])
-                calcs[c].generate(streams[c].cuda_stream)
-                prev = (c, k % NB)
-                while len(pend) > NC - 1:
-                    validate(*pend.pop(0))
-            finish(prev[0]); pend.append(prev)
-            while pend:
-                validate(*pend.pop(0))
-            return t_stall
-        run_e2e(NC + 2, 0); fence()
-        state.update(validated=0); t_pack_busy[0] = 0.0
-        n_e2e = max(args.steps, 40)
-        t1 = time.perf_counter()
-        stall = run_e2e(n_e2e, NC + 2); fence()
-        dte = time.perf_counter() - t1
-        assert state["validated"] == n_e2e * B
-        if world > 1:
-            te = torch.tensor([dte], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            dte = float(te.item())
-        ex.shutdown()
-        for pin_ in ring:
-            pin_.free()
-        loader_ms = t_pack_busy[0] / n_e2e * 1e3
-        e2e = {"what": "the same service loop with the loader inside the timed region: input.json TEXT -> pob_pack_json_batch8 (persistent host thread pool, byte form straight into pinned "
-                       "memory) -> H2D -> generate -> evaluate -> records validated; a host thread parses batch k + 2 while the device works on batch k",
-               "steps": n_e2e, "ms_per_step": round(dte / n_e2e * 1e3, 3), "value": round(GB * n_e2e / dte, 1), "unit": "witnesses/s", "validated_witnesses": n_e2e * B,
-               "loader_ms_per_batch": round(loader_ms, 3), "loader_witnesses_per_s": round(B / max(loader_ms, 1e-9) * 1e3, 1), "host_waited_for_loader_ms_per_step": round(stall / n_e2e * 1e3, 3),
-               "bound": ("loader: the device loop waited for the packer most of every step -- host CPU time, see loader_cpu" if stall > 0.3 * dte else "device (the loader keeps ahead)"),
-               "loader_cpu": {"host_cpus_visible": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(), "what": "one production input.json (40 KB of text, 10 900 values) takes ~14 us of one core; "
-                              "a batch of 1 024 is ~14 ms of CPU time, so a host that grants this process Q CPUs packs at most Q / 0.014 batches per second"}}
-
-    # ---- the bare kernel pipeline (what round 2's bench timed): the same two calculators and batches, but the inputs stay resident (no
-    # per-batch H2D), no records are read per batch and nothing is validated inside the loop -- the results are checked once afterwards.
-    # Same run, same box: the difference to `value` is what the service loop costs.
-    bare = None
-    if PIPE and not args.no_single and not args.dbg_no_fetch:
-        args.dbg_no_upload = args.dbg_no_fetch = True
-        run(4)
-        fence()
-        t1 = time.perf_counter()
-        run(20, k0=4)
-        fence()
-        dtb = time.perf_counter() - t1
-        args.dbg_no_upload = args.dbg_no_fetch = False
-        for c in calcs:
-            res = c.results(with_check=True)
-            assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res)
-        if world > 1:
-            tb = torch.tensor([dtb], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-            dtb = float(tb.item())
-        bare = {"what": "round 2's timed loop on this build: inputs resident, no per-batch upload / record read-back / host validation; 20 batches after the timed region",
-                "value": round(GB * 20 / dtb, 1), "ms_per_step": round(dtb / 20 * 1e3, 3)}
-
-    # ---- the same service loop without the pipeline (one calculator), 10 batches: reported beside `value`, same run, same box
-    single = tracks_pipeline = None
-    if PIPE and not args.no_single:
-        def timed(nsteps):
-            run(2)
-            fence()
-            t1 = time.perf_counter()
-            run(nsteps)
-            fence()
-            d = time.perf_counter() - t1
-            if world > 1:
-                tm = torch.tensor([d], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                d = float(tm.item())
-            return {"value": round(GB * nsteps / d, 1), "ms_per_step": round(d / nsteps * 1e3, 3)}
-        # the same service loop on ONE calculator with the track schedule (the lowest latency for a lone batch), and on round 3's pipeline (two linked track calculators)
-        if LINK:
-            calcs[0].set_partner(None)
-        for c in calcs[:2]:
-            c.set_inorder(False)
-        work["NC"] = 1
-        single = dict(timed(10), what="one calculator per GPU, track schedule, no pipeline (bench.py --schedule tracks --pipeline 0): 10 batches of the same service loop after the timed region")
-        calcs[0].set_partner(calcs[1]); calcs[1].set_partner(calcs[0])
-        work["NC"] = 2
-        tracks_pipeline = dict(timed(20), what="round 3's schedule on this build (bench.py --schedule tracks): two linked track calculators (pob_set_partner), 20 batches after the timed region")
-        if not LINK:
-            calcs[0].set_partner(None)
-            for c in calcs[:2]:
-                c.set_inorder(True)
-        work["NC"] = NC
-
-    # ---- extra legs, same calculators, same service loop, after the timed region (rank 0 of a 1-GPU run):
-    #   depth16       BASELINE config 5's shape on one GPU: batches of 16-layer proofs (byteSecurityRelax = 1, 3-zero-byte proof of work)
-    #   strong_slice  BASELINE config 4 as one GPU sees it: this GPU's slice of ONE global batch of 8192 split over 8 GPUs (witnesses 0..1023 of it)
-    def leg(batches_, steps_):
-        pins = [PinnedInputs(calcs[0], B) for _ in batches_]
-        for pin_, bt_ in zip(pins, batches_):
-            calcs[0].pack_json([json.dumps(inp).encode() for inp in bt_.inputs], out=pin_)
-        work.update(pinned=pins, expect=[np.array([list(c.to_bytes(32, "little")) for c in bt_.commitments], dtype=np.uint8) for bt_ in batches_])
-        run(4)
-        fence()
-        state.update(validated=0)
-        t1 = time.perf_counter()
-        run(steps_, k0=4)
-        fence()
-        dtl = time.perf_counter() - t1
-        assert state["validated"] == steps_ * B
-        work.update(pinned=pinned, expect=expect)
-        for pin_ in pins:
-            pin_.free()
-        return {"ms_per_step": round(dtl / steps_ * 1e3, 3), "value": round(B * steps_ / dtl, 1), "unit": "witnesses/s", "steps": steps_, "batch": B, "validated_witnesses": steps_ * B}
-    depth16 = strong_slice = deeper = None
-    if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch and INORDER and PIPE:
-        # the same loop with EIGHT calculators in flight, 96 steps: what a longer-running service reaches (fill and drain weigh (N - 1) / K of a K-step run, and the
-        # round evaluation kernel shares the machine with more launches: its in-step time is reported beside the throughput)
-        extra = [WitnessCalculator(MAIN, max_batch=B, device=dev_index) for _ in range(8 - NC)] if NC < 8 else []
-        for c in extra:
-            c.set_inorder(True); c.probe_check_kernel(True)
-        for c in calcs:
-            c.probe_check_kernel(True)
-        n_before = len(calcs)
-        calcs.extend(extra); streams.extend(cuda.Stream(device=dev_index, priority=-1) for _ in extra); recs.extend(D.device_records(c, B) for c in extra)
-        gathered_ev.extend([None] * len(extra)); uploaded.extend([False] * len(extra))
-        work["NC"] = len(calcs)
-        probing = True
-        run(len(calcs)); fence()
-        state.update(validated=0, kchk_ms=[])
-        t1 = time.perf_counter()
-        run(96, k0=len(calcs)); fence()
-        dtd = time.perf_counter() - t1
-        probing = False
-        k8 = float(np.mean(state["kchk_ms"]))
-        deeper = {"what": f"{len(calcs)} in-order calculators in flight, 96 steps of the same service loop after the timed region", "calculators_in_flight": len(calcs), "steps": 96,
-                  "ms_per_step": round(dtd / 96 * 1e3, 3), "value": round(B * 96 / dtd, 1), "unit": "witnesses/s", "validated_witnesses": state["validated"],
-                  "round_evaluation_ms_in_step": round(k8, 4)}
-        for c in calcs:
-            c.probe_check_kernel(False)
-        for c in extra:
+    def close(self):
+        for c in self.calcs:
             c.close()
-        del calcs[n_before:], streams[n_before:], recs[n_before:], gathered_ev[n_before:], uploaded[n_before:]
-        work["NC"] = NC
-    if rank == 0 and world == 1 and not strong and not args.no_extra_legs and not args.dbg_no_fetch:
-        probing = False
-        deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=dev_index) for b in range(2)]
-        depth16 = dict(leg(deep, 20), what=f"BASELINE config 5's shape on one GPU: batch={B} of 16-layer (max-depth) MPT proofs per step, same service loop, 2 distinct batches cycled")
-        sl = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * 8 * B) for b in range(2)]
-        strong_slice = dict(leg(sl, 20), what=f"BASELINE config 4 as one GPU sees it: rank 0's slice (witnesses [0, {B})) of ONE global batch of {8 * B} split over 8 GPUs, per step; "
-                                               f"the other ranks' slices and the all-gather of the 44-byte records need the node")
 
-    if args.shim or args.main != "proof_of_burn":
-        # the plumbing run of the tests: the loop, the slices and the gather have been exercised and validated; nothing is measured
-        if rank == 0:
-            print(json.dumps({"metric": "proof_of_burn witnesses/sec", "value": None, "unit": "witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "scaling": "strong" if strong else "weak", "data": "synthetic", "shim": bool(args.shim), "main": MAIN_,
-                              "config": {"workload": f"TEST RUN (not a measurement): {MAIN_}, batch {B} per rank, global {GB}", "validated_witnesses": validated_timed,
-                                         "h2d_bytes_per_step": int(h2d_per_step), "calculators_in_flight": NC, "bound_cpus": (len(bound_cpus) if bound_cpus else None),
-                                         "loader_threads_env": os.environ.get("POB_LOADER_THREADS"), "dist_backend": (dist.get_backend() if dist.is_initialized() else None)}}))
-        for c in calcs:
-            c.close()
-        for pin in pinned:
-            pin.free()
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    groups = (B + 63) // 64
-    stream0 = streams[0].cuda_stream
-    # ---- roofline of the dominant kernel: Keccak round constraint evaluation, HBM-read bound.
-    # algorithmic bytes per launch = every wire of every KeccakfRound block as resident (8 B per BIT wire per 64 witnesses)
-    #                                + the round input/output states it is checked against.
-    t_chk = calcs[0].time_kernel(1, iters=5, stream=stream0)
-    t_gen = calcs[0].time_kernel(0, iters=5, stream=stream0)
+
+def _rate(job, loop, seconds, steps, **extra):
+    return dict({"ms_per_step": round(seconds / steps * 1e3, 3), "value": round(job.GB * steps / seconds, 1), "unit": "witnesses/s", "steps": steps, "batch": loop.B,
+                 "validated_witnesses": steps * loop.B}, **extra)
+
+
+def _expect(np, batch):
+    return np.array([list(c.to_bytes(32, "little")) for c in batch.commitments], dtype=np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ legs after the timed region
+def leg_e2e_from_json(job, loop, texts, nsteps):
+    """the path from input.json TEXT, in the clock (reference Makefile:4-5: the calculator's unit of work starts at the JSON file): the same service loop, but every batch is
+    parsed from its texts by the native loader (pob_pack_json_batch8 on the persistent loader pool) INSIDE the timed region -- a host thread packs batch k + 2 into a ring of
+    pinned buffers while the device works on batches k, k - 1, ...; the loop waits for the packer only if it has fallen behind"""
+    from concurrent.futures import ThreadPoolExecutor
+    from proof_of_burn_amd import PinnedInputs
+    NC, NB, calc0 = loop.active, len(texts), loop.calcs[0]
+    ring = [PinnedInputs(calc0, loop.B) for _ in range(NC + 3)]
+    ex = ThreadPoolExecutor(1)
+    busy = [0.0]
+    fut = {}
+
+    def pack(k):
+        _t = time.perf_counter()
+        calc0.pack_json(texts[k % NB], out=ring[k % len(ring)])
+        busy[0] += time.perf_counter() - _t
+        return ring[k % len(ring)]
+
+    def make_source(k_end):
+        def source(k):
+            if k not in fut:                                 # the first batches of a run: nothing was packed ahead
+                fut[k] = ex.submit(pack, k)
+                if k + 1 < k_end:
+                    fut[k + 1] = ex.submit(pack, k + 1)
+            pin = fut.pop(k).result()
+            if k + 2 < k_end and k + 2 not in fut:
+                fut[k + 2] = ex.submit(pack, k + 2)          # its ring slot held batch k - NC - 1: validated before the loop returns to it
+            return pin
+        return source
+    warm = NC + 2
+    loop.run(warm, k0=0, source=make_source(warm)); job.fence()
+    loop.reset_counters(); busy[0] = 0.0
+    t1 = time.perf_counter()
+    stall = loop.run(nsteps, k0=warm, source=make_source(warm + nsteps)); job.fence()
+    dte = job.max_over_ranks(time.perf_counter() - t1)
+    assert loop.validated == nsteps * loop.B
+    ex.shutdown()
+    for pin in ring:
+        pin.free()
+    loader_ms = busy[0] / nsteps * 1e3
+    return {"what": "the same service loop with the loader inside the timed region: input.json TEXT -> pob_pack_json_batch8 (persistent host thread pool, byte form straight into pinned "
+                    "memory) -> H2D -> generate -> evaluate -> records validated; a host thread parses batch k + 2 while the device works on batch k",
+            "steps": nsteps, "ms_per_step": round(dte / nsteps * 1e3, 3), "value": round(job.GB * nsteps / dte, 1), "unit": "witnesses/s", "validated_witnesses": nsteps * loop.B,
+            "loader_ms_per_batch": round(loader_ms, 3), "loader_witnesses_per_s": round(loop.B / max(loader_ms, 1e-9) * 1e3, 1), "host_waited_for_loader_ms_per_step": round(stall / nsteps * 1e3, 3),
+            "bound": ("loader: the device loop waited for the packer most of every step -- host CPU time, see loader_cpu" if stall > 0.3 * dte else "device (the loader keeps ahead)"),
+            "loader_cpu": {"host_cpus_visible": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(), "what": "a batch of 1 024 production input.json texts (40 KB, 10 900 values each) is "
+                           "loader_ms_per_batch x the loader's threads of CPU time; a host that grants this process Q CPUs packs at most Q / that many batches per second"}}
+
+
+def leg_kernel_pipeline_only(job, loop):
+    """the bare kernel pipeline (what round 2's bench timed): the same calculators and batches, but the inputs stay resident (no per-batch H2D), no records are read per batch
+    and nothing is validated inside the loop -- the results are checked once afterwards.  Same run, same box: the difference to `value` is what the service loop costs."""
+    loop.upload_each = loop.fetch_each = False
+    loop.run(loop.active); job.fence()
+    loop.reset_counters()
+    t1 = time.perf_counter()
+    loop.run(20, k0=loop.active); job.fence()
+    dtb = job.max_over_ranks(time.perf_counter() - t1)
+    loop.upload_each, loop.fetch_each = not job.args.dbg_no_upload, not job.args.dbg_no_fetch
+    for c in loop.calcs[:loop.active]:
+        res = c.results(with_check=True)
+        assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res)
+    return {"what": "round 2's timed loop on this build: inputs resident, no per-batch upload / record read-back / host validation; 20 batches after the timed region",
+            "value": round(job.GB * 20 / dtb, 1), "ms_per_step": round(dtb / 20 * 1e3, 3)}
+
+
+def legs_track_schedule(job, loop):
+    """the same service loop on ONE calculator with the track schedule (the lowest latency for a lone batch), and on round 3's pipeline (two linked track calculators)"""
+    def timed(n):
+        s, _, _ = loop.timed(n, 2)
+        return {"value": round(job.GB * n / s, 1), "ms_per_step": round(s / n * 1e3, 3)}
+    if loop.link:
+        loop.calcs[0].set_partner(None)
+    for c in loop.calcs[:2]:
+        c.set_inorder(0)
+    loop.active = 1
+    single = dict(timed(10), what="one calculator per GPU, track schedule, no pipeline (bench.py --schedule tracks --pipeline 0): 10 batches of the same service loop after the timed region")
+    loop.calcs[0].set_partner(loop.calcs[1]); loop.calcs[1].set_partner(loop.calcs[0])
+    loop.active = 2
+    tracks = dict(timed(20), what="round 3's schedule on this build (bench.py --schedule tracks): two linked track calculators (pob_set_partner), 20 batches after the timed region")
+    if not loop.link:
+        loop.calcs[0].set_partner(None)
+        for c in loop.calcs[:2]:
+            c.set_inorder(2 if job.args.streaming_stream else 1)
+    loop.active = loop.depth
+    return single, tracks
+
+
+def leg_other_depth(job, main, depth, pinned, expect, nsteps=96):
+    """the same service loop with another number of in-order calculators in flight: throughput and the round evaluation kernel's in-step duration"""
+    np = __import__("numpy")
+    lp = ServiceLoop(job, main, depth, True, bool(job.args.streaming_stream))
+    lp.set_inputs(pinned, expect)
+    lp.run(depth + 2); job.fence()
+    lp.probe(True)
+    s, _, _ = lp.timed(nsteps, 2, k0=depth + 2)
+    k = float(np.mean(lp.kchk_ms)) if lp.kchk_ms else None
+    lp.probe(False)
+    lp.close()
+    return _rate(job, lp, s, nsteps, what=f"{depth} in-order calculators in flight, {nsteps} steps of the same service loop after the timed region",
+                 calculators_in_flight=depth, round_evaluation_ms_in_step=(round(k, 4) if k else None))
+
+
+def leg_other_inputs(job, loop, texts_of, batches, nsteps, what):
+    """the same loop on other input batches.  They are packed into the loop's OWN pinned buffers (the ones the timed region read: round 5's leg allocated fresh ones and measured
+    17 % slower on the driver's box, pinning artefact or not), warmed with depth + 4 steps, and the original batches are packed back afterwards."""
+    np = loop.np
+    calc0 = loop.calcs[0]
+    keep_expect = loop.expect
+    n = min(len(batches), len(loop.pinned))
+    for pin, bt in zip(loop.pinned[:n], batches[:n]):
+        calc0.pack_json([json.dumps(inp).encode() for inp in bt.inputs], out=pin)
+    keep_pinned = loop.pinned
+    loop.set_inputs(keep_pinned[:n], [_expect(np, bt) for bt in batches[:n]])
+    s, _, _ = loop.timed(nsteps, loop.depth + 4)
+    loop.set_inputs(keep_pinned, keep_expect)
+    for pin, tx in zip(loop.pinned, texts_of):
+        calc0.pack_json(tx, out=pin)
+    return _rate(job, loop, s, nsteps, what=what)
+
+
+def leg_roofline(job, loop, info, kchk_in_step, ms_step, probe_steps):
+    """roofline of the dominant kernel: Keccak round constraint evaluation, HBM-read bound.  Algorithmic bytes per launch = every resident array the launch covers, once."""
+    cuda, args = job.cuda, job.args
+    groups = (loop.B + 63) // 64
+    calc0, st0 = loop.calcs[0], loop.streams[0]
+    t_chk = calc0.time_kernel(1, iters=5, stream=st0.cuda_stream)
+    t_gen = calc0.time_kernel(0, iters=5, stream=st0.cuda_stream)
     # a wavefront of k_rounds_check covers k = info.kchk_rounds consecutive rounds of a permutation: midRound[r0] once, then per round the 76 stored gate-output
-    # arrays + the stored midRound[r+1] (which stays in registers as the next round's input): 101 k + 25 arrays of 512 B, every resident array of the chunk
-    # counted ONCE (round 4's one-round items fetched -- and counted -- every state twice: 126 arrays per round)
+    # arrays + the stored midRound[r+1] (which stays in registers as the next round's input): 101 k + 25 arrays of 512 B, every resident array of the chunk counted ONCE
     kr = int(info.kchk_rounds)
     launch_bytes = info.n_perms * (24 // kr) * (101 * kr + 25) * 64 * 8 * groups
     launch_bytes_r4 = info.n_perms * 24 * 126 * 64 * 8 * groups
@@ -534,131 +532,256 @@ def main():
     # whole evaluation pass and whole step against the resident vector (write once, read once)
     ev0, ev1 = cuda.Event(enable_timing=True), cuda.Event(enable_timing=True)
     cuda.synchronize()
-    ev0.record(streams[0])
+    ev0.record(st0)
     for _ in range(5):
-        calcs[0].constraint_check(streams[0].cuda_stream)
-    ev1.record(streams[0])
+        calc0.constraint_check(st0.cuda_stream)
+    ev1.record(st0)
     cuda.synchronize()
     t_check_pass = ev0.elapsed_time(ev1) / 5
     resident = int(info.group_bytes) * groups
     traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
-        pmc_file = next(p for p in ("round5_pmc_k_rounds.json",) if os.path.exists(os.path.join(ROOT, "profiles", p)))      # (rounds 1-4 measured other kernels: not this one)
+        pmc_file = next(p for p in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", p)))
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups / pmc["groups"])
     except Exception:
         pass
-    ms_step = dt / args.steps * 1e3
     # `achieved` / `frac`: the kernel as it runs IN the timed loop (HIP events on its own stream around every launch, averaged over the timed
-    # steps), i.e. beside the other batch's generation; `frac_alone`: the same kernel alone on an idle device (5 back-to-back launches)
-    roofline = {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
-                "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
-                "measured": ((f"in {probe_steps} more batches of the same pipelined service loop right after the timed region" if args.probe_after else "in the timed region, every step")
-                             + ": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel)") if in_step else "alone",
-                "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
-                "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
-                "traffic": traffic,
-                "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
-                "bytes_per_launch": launch_bytes, "rounds_per_wavefront": kr,
-                "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
-                                    f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
-                "gen_kernel": {"kernel": "k_rounds_gen, alone (8 rounds per wavefront: 8 x 76 arrays written, midRound[r0] read)", "achieved": round(info.n_perms * 3 * (8 * 76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
-                               "avg_ms": round(t_gen, 4)},
-                "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,
-                               "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),
-                               "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "step": {"what": "generate (write the resident vector once) + evaluate (read it once) per timed step", "bytes": 2 * resident,
-                         "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    # steps), i.e. beside the other batches' kernels; `frac_alone`: the same kernel alone on an idle device (5 back-to-back launches)
+    return {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
+            "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
+            "measured": ((f"in {probe_steps} more batches of the same pipelined service loop right after the timed region" if args.probe_after else "in the timed region, every step")
+                         + f": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel); {loop.depth} calculators in flight"
+                         + (", the round kernels of all of them on the device's one streaming stream" if args.streaming_stream else "")) if in_step else "alone",
+            "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
+            "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
+            "traffic": traffic,
+            "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
+            "bytes_per_launch": launch_bytes, "rounds_per_wavefront": kr,
+            "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
+                                f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
+            "gen_kernel": {"kernel": "k_rounds_gen, alone (8 rounds per wavefront: 8 x 76 arrays written, midRound[r0] read)", "achieved": round(info.n_perms * 3 * (8 * 76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
+                           "avg_ms": round(t_gen, 4)},
+            "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone", "bytes": resident,
+                           "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),
+                           "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "step": {"what": "generate (write the resident vector once) + evaluate (read it once) per timed step", "bytes": 2 * resident,
+                     "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
-    # ---- .wtns emission (the step after the path): the O0 payload and the reduced (O1-style) one, through the window pipeline into pinned memory
-    emission = None
-    if rank == 0 and not args.no_emission:
-        cold_s, cold_b = calcs[0].emit_throughput(0, count=1)              # first emission of this calculator: allocates the windows (2 x 256 MiB device + pinned), probe pass
-        sec, nbytes = calcs[0].emit_throughput(1, count=2)
-        emission = {"what": "canonical 32 B/wire payload expanded on the GPU in 256 MiB windows, D2H double-buffered into pinned memory; steady state = 2 witnesses back to back "
-                            "after a first one that set the buffers up (first_witness_ms includes hipHostMalloc of 512 MiB and the probe pass)",
-                    "GB_per_s": round(nbytes / sec / 1e9, 2), "ms_per_witness": round(sec / 2 * 1e3, 1), "bytes_per_witness": nbytes // 2,
-                    "first_witness_ms": round(cold_s * 1e3, 1)}
-        try:
-            from proof_of_burn_amd.circuit_model import keepmap
-            keep, _ = keepmap.load(MAIN)
-            calcs[0].emit_throughput(0, count=1, keep=keep, window_wires=1 << 24)
-            rsec, rbytes = calcs[0].emit_throughput(1, count=4, keep=keep, window_wires=1 << 24)
-            emission["reduced"] = {"what": "O1-style reduced witness (circuit_model/o1.py map, stored under circuit_model/data/): only the kept wires are expanded and copied "
-                                           "(pob_emit_begin_reduced), 4 witnesses back to back after a first one",
-                                   "kept_wires": int(keep.size), "of": int(info.n_witness), "ms_per_witness": round(rsec / 4 * 1e3, 2),
-                                   "GB_per_s": round(rbytes / rsec / 1e9, 2), "bytes_per_witness": rbytes // 4}
-        except FileNotFoundError:
-            pass
 
-    # ---- BASELINE config 2: ONE witness of the fixture (tests/test_pob_input.json, instantiation of tests/testcases/proof_of_burn.py:53) end to end:
-    # input.json text -> loader -> upload -> generate -> constraint evaluation -> verdict on the host -> the whole 2.06 GB .wtns payload in pinned memory
-    latency = None
+def leg_emission(calc0, info):
+    """.wtns emission (the step after the path): the O0 payload and the reduced (O1-style) one, through the window pipeline into pinned memory"""
+    cold_s, _ = calc0.emit_throughput(0, count=1)              # first emission of this calculator: allocates the windows (3 x 256 MiB device + pinned), probe pass
+    sec, nbytes = calc0.emit_throughput(1, count=2)
+    emission = {"what": "canonical 32 B/wire payload expanded on the GPU in 256 MiB windows, D2H double-buffered into pinned memory; steady state = 2 witnesses back to back "
+                        "after a first one that set the buffers up (first_witness_ms includes hipHostMalloc of the windows and the probe pass)",
+                "GB_per_s": round(nbytes / sec / 1e9, 2), "ms_per_witness": round(sec / 2 * 1e3, 1), "bytes_per_witness": nbytes // 2,
+                "first_witness_ms": round(cold_s * 1e3, 1)}
+    try:
+        from proof_of_burn_amd.circuit_model import keepmap
+        keep, _ = keepmap.load(MAIN)
+        calc0.emit_throughput(0, count=1, keep=keep, window_wires=1 << 24)
+        rsec, rbytes = calc0.emit_throughput(1, count=4, keep=keep, window_wires=1 << 24)
+        emission["reduced"] = {"what": "O1-style reduced witness (circuit_model/o1.py map, stored under circuit_model/data/): only the kept wires are expanded and copied "
+                                       "(pob_emit_begin_reduced), 4 witnesses back to back after a first one",
+                               "kept_wires": int(keep.size), "of": int(info.n_witness), "ms_per_witness": round(rsec / 4 * 1e3, 2),
+                               "GB_per_s": round(rbytes / rsec / 1e9, 2), "bytes_per_witness": rbytes // 4}
+    except FileNotFoundError:
+        pass
+    return emission
+
+
+def leg_single_witness_latency(job):
+    """BASELINE config 2: ONE witness of the fixture (tests/test_pob_input.json, instantiation of tests/testcases/proof_of_burn.py:53) end to end:
+    input.json text -> loader -> upload -> generate -> constraint evaluation -> verdict on the host -> the whole 2.06 GB .wtns payload in pinned memory"""
+    from proof_of_burn_amd import WitnessCalculator, PinnedInputs
+    W = job.W
     fix_json = os.path.join(ROOT, "tests", "golden", "test_pob_input.json")
-    if rank == 0 and world == 1 and not args.no_emission and os.path.exists(fix_json):
-        FIX = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
-        with open(fix_json, "rb") as f:
-            text = f.read()
-        one = WitnessCalculator(FIX, max_batch=1, device=dev_index)
-        pin1 = PinnedInputs(one, 1)
+    if not os.path.exists(fix_json):
+        return None
+    FIX = "ProofOfBurn(4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)"
+    with open(fix_json, "rb") as f:
+        text = f.read()
+    one = WitnessCalculator(FIX, max_batch=1, device=job.dev)
+    pin1 = PinnedInputs(one, 1)
 
-        def once():
-            ta = time.perf_counter()
-            one.pack_json([text], threads=1, out=pin1)
-            one.upload_pinned_async(pin1)
-            one.generate(); one.constraint_check(); one.fetch_records()
-            rec = one.wait_records()
-            tb = time.perf_counter()
-            assert rec["status"][0] == 0 and rec["check_status"][0] == W.CLEAN
-            nb = sum(v.size for _, v in one.witness_windows(0))
-            return tb - ta, time.perf_counter() - tb, nb, int.from_bytes(rec["commitment"][0].tobytes(), "little")
-        once()                                            # (first call: buffers, probe pass)
-        runs = [once() for _ in range(3)]
-        best = min(runs, key=lambda r: r[0] + r[1])
-        latency = {"what": "BASELINE config 2: one witness of tests/test_pob_input.json on " + FIX + ": input.json text -> verdict on the host (load, H2D, generate, evaluate, "
-                           "records), then the whole canonical .wtns payload streamed into pinned host memory; best of 3 after one warm-up",
-                   "ms_to_verdict": round(best[0] * 1e3, 3), "ms_emit_payload": round(best[1] * 1e3, 2), "payload_bytes": int(best[2]),
-                   "ms_total": round((best[0] + best[1]) * 1e3, 2), "commitment": str(best[3])}
-        pin1.free(); one.close()
+    def once():
+        ta = time.perf_counter()
+        one.pack_json([text], threads=1, out=pin1)
+        one.upload_pinned_async(pin1)
+        one.generate(); one.constraint_check(); one.fetch_records()
+        rec = one.wait_records()
+        tb = time.perf_counter()
+        assert rec["status"][0] == 0 and rec["check_status"][0] == W.CLEAN
+        nb = sum(v.size for _, v in one.witness_windows(0))
+        return tb - ta, time.perf_counter() - tb, nb, int.from_bytes(rec["commitment"][0].tobytes(), "little")
+    once()                                            # (first call: buffers, probe pass)
+    best = min((once() for _ in range(3)), key=lambda r: r[0] + r[1])
+    pin1.free(); one.close()
+    return {"what": "BASELINE config 2: one witness of tests/test_pob_input.json on " + FIX + ": input.json text -> verdict on the host (load, H2D, generate, evaluate, "
+                    "records), then the whole canonical .wtns payload streamed into pinned host memory; best of 3 after one warm-up",
+            "ms_to_verdict": round(best[0] * 1e3, 3), "ms_emit_payload": round(best[1] * 1e3, 2), "payload_bytes": int(best[2]),
+            "ms_total": round((best[0] + best[1]) * 1e3, 2), "commitment": str(best[3])}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batches[0], info, args.cpu_samples)
 
-    if rank == 0:
-        value = GB * args.steps / dt
-        line = {
-            "metric": "proof_of_burn witnesses/sec", "value": round(value, 1), "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "u64 bit-sliced lanes + BN254 Fr (8x32-bit Montgomery)", "data": "synthetic",
-            "config": {"workload": (f"global batch={GB} split over {world} GPUs" if strong else f"batch={B}/GPU") + f" proof_of_burn witnesses per step, {MAIN}, synthetic "
-                                   f"{args.depth}-layer MPT proofs ({args.distinct_keys} distinct PoW burn keys tiled, {NB} distinct input batches cycled); per step, inside the timed "
-                                   f"region: H2D of the packed inputs from pinned memory, generate, per-gate constraint evaluation, records {{status, verdict, commitment}} D2H, "
-                                   f"every record validated on the host" + (", one all-gather of the records" if world > 1 else ""),
-                       "wires_per_witness": int(info.n_witness), "resident_bytes_per_witness": int(info.group_bytes // 64),
-                       "wire_classes": {"stored_bit": int(info.n_bit), "stored_sm": int(info.n_sm), "stored_fr": int(info.n_fr), "derived": int(info.n_derived),
-                                        "alias": int(info.n_alias), "constant_one": 1,
-                                        "what": "stored: resident in HBM (8 B per BIT wire, 256 B per SM wire, 2 KiB per FR wire, per 64 witnesses); derived: functions of stored wires, "
-                                                "rebuilt by the emitter; alias: Keccak round-block wires that ARE another stored wire (copy / rotated / negated / constant), expanded by the emitter"},
-                       "full_layout_round3": {"resident_bytes_per_witness": 27225718, "ms_per_step": 11.257, "witnesses_per_s": 90963, "what": "BENCH_r03.json: every wire of the Keccak round blocks stored"},
-                       "canonical_bytes_per_witness": int(info.n_witness) * 32,
-                       "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
-                                                                                     + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                       "schedule": args.schedule, "calculators_in_flight": NC, "rank_bound_to_cpus": (len(bound_cpus) if bound_cpus else None),
-                       "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
-                       "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
-                       "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,
-                       "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),
-                       "json_to_packed": {"what": "input.json texts -> packed rows (byte form) in pinned memory, pob_pack_json_batch8 on the persistent loader pool (bit-equal to the Python loader on a sample of this batch)",
-                                          "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
-            "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "tracks_pipeline": tracks_pipeline, "kernel_pipeline_only": bare, "single_witness_latency": latency,
-            "depth16": depth16, "strong_slice": strong_slice, "deeper_pipeline": deeper, "e2e_from_json": e2e,
-        }
-        print(json.dumps(line))
-    for c in calcs:
-        c.close()
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
+    from proof_of_burn_amd import PinnedInputs, TextBatch, inputs as gen
+    job = Job(args)
+    torch, dist = job.torch, job.dist
+    rank, world, B, GB = job.rank, job.world, job.B, job.GB
+    MAIN_ = MAIN if args.main == "proof_of_burn" else "Spend(31)"
+    INORDER = args.schedule == "inorder"
+    if args.pipeline < 0:
+        args.pipeline = DEFAULT_DEPTH if INORDER else 2
+    PIPE = bool(args.pipeline)
+    NC = (max(2, args.pipeline) if INORDER else 2) if PIPE else 1
+    NB = 1 if args.dbg_no_upload else max(1, args.distinct_batches)
+
+    # ---- synthetic inputs (seeded): global batch b holds witnesses [b*GB, (b+1)*GB) of the global sequence; witness g depends only on (seed, g)
+    t0 = time.time()
+    if args.main == "spend":
+        batches = [gen.synthetic_spend_batch(B, first=b * GB + job.first0) for b in range(NB)]
+    else:
+        batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + job.first0,
+                                       pow_device=job.dev if args.depth > 12 else None) for b in range(NB)]
+    t_synth = (time.time() - t0) / NB
+    loop = ServiceLoop(job, MAIN_, NC, INORDER, bool(args.streaming_stream))
+    calc0 = loop.calcs[0]
+    info = calc0.info
+    # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch8); the Python packer beside it
+    texts = [TextBatch([json.dumps(inp).encode() for inp in bt.inputs]) for bt in batches]
+    pinned = [PinnedInputs(calc0, B) for _ in range(NB)]
+    calc0.pack_json(texts[0], out=pinned[0])            # (first call: the loader pool's threads start, first touch of the texts)
+    t0 = time.time()
+    for rep in range(3):
+        for b in range(NB):
+            calc0.pack_json(texts[b], out=pinned[b])
+    t_pack_native = (time.time() - t0) / (3 * NB)
+    t0 = time.time()
+    ref = calc0.pack(batches[0].inputs[:min(B, 128)])
+    t_pack_py = (time.time() - t0) / min(B, 128) * B
+    assert all(np.array_equal(x, y[:min(B, 128)]) for x, y in zip(ref, (pinned[0].fr, pinned[0].widened(), pinned[0].forced))), "native loader differs from the Python loader"
+    expect = [_expect(np, bt) for bt in batches]
+    loop.set_inputs(pinned, expect)
+
+    # ---- the timed region: W untimed warm-up steps, fence, K timed steps, fence
+    if args.warmup:
+        loop.run(args.warmup)
+    job.fence()
+    if not args.probe_after and loop.fetch_each:
+        loop.probe(True)
+    loop.reset_counters()
+    t0 = time.perf_counter()
+    loop.run(args.steps, k0=args.warmup)
+    job.fence()
+    dt_mine = time.perf_counter() - t0
+    assert loop.validated == args.steps * B, "not every batch was validated inside the timed region"
+    host_ms = {k: round(v / args.steps * 1e3, 3) for k, v in loop.host_s.items()}
+    validated_timed, h2d_per_step = loop.validated, loop.h2d_bytes // max(args.steps, 1)
+    probe_steps = 0
+    if args.probe_after and loop.fetch_each:
+        # the dominant kernel as it runs IN the service loop: the same loop for a few more batches with HIP events around each of its launches
+        loop.probe(True)
+        probe_steps = 16
+        loop.run(probe_steps, k0=args.warmup + args.steps)
+        job.fence()
+    kchk_in_step = float(np.mean(loop.kchk_ms)) if loop.kchk_ms else None
+    loop.probe(False)
+    dt = job.max_over_ranks(dt_mine)
+    rank_ms = [s / args.steps * 1e3 for s in job.all_ranks(dt_mine)]
+    last_k = args.warmup + args.steps + probe_steps - 1
+    if world > 1:
+        assert int(loop.gather_bad.item()) == 0, "a gathered record of some rank is not clean"
+        rec_all = loop.last_gather.cpu()
+        assert int(rec_all.shape[0]) == GB
+        mine = rec_all[job.first0:job.first0 + B].numpy() if job.strong else rec_all[rank * B:(rank + 1) * B].numpy()
+        assert np.array_equal(mine[:, 12:], expect[last_k % NB]), "gathered records differ from this rank's commitments"
+        if rank == 0 and args.dump_results:
+            np.save(args.dump_results, rec_all.numpy())
+    elif rank == 0 and args.dump_results:
+        np.save(args.dump_results, loop.recs[last_k % NC].cpu().numpy())
+    ms_step = dt / args.steps * 1e3
+
+    # ---- legs after the timed region, same run, same box
+    e2e = bare = single = tracks_pipeline = None
+    if PIPE and INORDER and not args.no_single and loop.fetch_each:
+        e2e = leg_e2e_from_json(job, loop, texts, max(args.steps, 40))
+    if PIPE and not args.no_single and loop.fetch_each:
+        bare = leg_kernel_pipeline_only(job, loop)
+    if PIPE and not args.no_single:
+        single, tracks_pipeline = legs_track_schedule(job, loop)
+    depths, depth16, strong_slice = {}, None, None
+    lone = rank == 0 and world == 1 and not job.strong and not args.no_extra_legs and loop.fetch_each and not args.shim and args.main == "proof_of_burn"
+    if lone and INORDER and PIPE:
+        for d in [int(x) for x in args.other_depths.split(",") if x.strip()]:
+            if d != NC and d >= 2:
+                depths[str(d)] = leg_other_depth(job, MAIN_, d, pinned, expect)
+    if lone:
+        # depth16: BASELINE config 5's shape on one GPU (16-layer proofs, byteSecurityRelax = 1, 3-zero-byte proof of work); strong_slice: BASELINE config 4 as one GPU sees it
+        deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=job.dev) for b in range(2)]
+        depth16 = leg_other_inputs(job, loop, texts, deep, max(40, args.steps),
+                                   f"BASELINE config 5's shape on one GPU: batch={B} of 16-layer (max-depth) MPT proofs per step, same service loop and pinned buffers, 2 distinct batches cycled")
+        sl = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * 8 * B) for b in range(2)]
+        strong_slice = leg_other_inputs(job, loop, texts, sl, max(40, args.steps),
+                                        f"BASELINE config 4 as one GPU sees it: rank 0's slice (witnesses [0, {B})) of ONE global batch of {8 * B} split over 8 GPUs, per step; "
+                                        f"the other ranks' slices and the all-gather of the 44-byte records need the node")
+
+    ranks = {"rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "dist_backend": job.backend,
+             "launched_by": "bench.py itself" if os.environ.get("POB_SELF_LAUNCHED") else ("a launcher (torch.distributed.run / the environment)" if world > 1 else "single process"),
+             "ms_per_step_min": round(min(rank_ms), 3), "ms_per_step_max": round(max(rank_ms), 3)}
+    if args.shim or args.main != "proof_of_burn":
+        # the plumbing run of the tests: the loop, the slices and the gather have been exercised and validated; nothing is measured
+        if rank == 0:
+            print(json.dumps({"metric": "proof_of_burn witnesses/sec", "value": None, "unit": "witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "scaling": "strong" if job.strong else "weak", "data": "synthetic", "shim": bool(args.shim), "main": MAIN_, "ranks": ranks,
+                              "config": {"workload": f"TEST RUN (not a measurement): {MAIN_}, batch {B} per rank, global {GB}", "validated_witnesses": validated_timed,
+                                         "h2d_bytes_per_step": int(h2d_per_step), "calculators_in_flight": NC, "bound_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
+                                         "loader_threads_env": os.environ.get("POB_LOADER_THREADS"), "dist_backend": job.backend}}), flush=True)
+    else:
+        roofline = leg_roofline(job, loop, info, kchk_in_step, ms_step, probe_steps)
+        emission = leg_emission(calc0, info) if rank == 0 and not args.no_emission else None
+        latency = leg_single_witness_latency(job) if rank == 0 and world == 1 and not args.no_emission else None
+        cpu = cpu_baseline(batches[0], info, args.cpu_samples) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
+        if rank == 0:
+            deeper = depths.get("12") or (next(iter(depths.values())) if depths else None)
+            line = {
+                "metric": "proof_of_burn witnesses/sec", "value": round(GB * args.steps / dt, 1), "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if job.strong else "weak",
+                "vs_baseline": None, "dtype": "u64 bit-sliced lanes + BN254 Fr (8x32-bit Montgomery)", "data": "synthetic",
+                "config": {"workload": (f"global batch={GB} split over {world} GPUs" if job.strong else f"batch={B}/GPU") + f" proof_of_burn witnesses per step, {MAIN}, synthetic "
+                                       f"{args.depth}-layer MPT proofs ({args.distinct_keys} distinct PoW burn keys tiled, {NB} distinct input batches cycled); per step, inside the timed "
+                                       f"region: H2D of the packed inputs from pinned memory, generate, per-gate constraint evaluation, records {{status, verdict, commitment}} D2H, "
+                                       f"every record validated on the host" + (", one all-gather of the records" if world > 1 else ""),
+                           "wires_per_witness": int(info.n_witness), "resident_bytes_per_witness": int(info.group_bytes // 64),
+                           "wire_classes": {"stored_bit": int(info.n_bit), "stored_sm": int(info.n_sm), "stored_fr": int(info.n_fr), "derived": int(info.n_derived),
+                                            "alias": int(info.n_alias), "constant_one": 1,
+                                            "what": "stored: resident in HBM (8 B per BIT wire, 256 B per SM wire, 2 KiB per FR wire, per 64 witnesses); derived: functions of stored wires, "
+                                                    "rebuilt by the emitter; alias: Keccak round-block wires that ARE another stored wire (copy / rotated / negated / constant), expanded by the emitter"},
+                           "full_layout_round3": {"resident_bytes_per_witness": 27225718, "ms_per_step": 11.257, "witnesses_per_s": 90963, "what": "BENCH_r03.json: every wire of the Keccak round blocks stored"},
+                           "canonical_bytes_per_witness": int(info.n_witness) * 32,
+                           "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
+                                                                                         + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
+                           "schedule": args.schedule, "calculators_in_flight": NC, "streaming_stream": bool(args.streaming_stream), "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
+                           "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
+                           "rccl_ranks": ranks["rccl_ranks"], "dist_backend": job.backend,
+                           "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,
+                           "json_to_packed_witnesses_per_s": round(B / max(t_pack_native, 1e-9), 1),
+                           "json_to_packed": {"what": "input.json texts -> packed rows (byte form) in pinned memory, pob_pack_json_batch8 on the persistent loader pool (bit-equal to the Python loader on a sample of this batch)",
+                                              "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
+                "ranks": ranks,
+                "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "tracks_pipeline": tracks_pipeline, "kernel_pipeline_only": bare, "single_witness_latency": latency,
+                "depth16": depth16, "strong_slice": strong_slice, "deeper_pipeline": deeper, "other_depths": depths or None, "e2e_from_json": e2e,
+            }
+            print(json.dumps(line), flush=True)
+    loop.close()
     for pin in pinned:
         pin.free()
     if world > 1:

@@ -201,9 +201,10 @@ struct Parser {
                     unsigned start = 0; bool stop = false;
                     while (Cm) {
                         const unsigned p = (unsigned)__builtin_ctzll(Cm), len = p - start;
+                        if (len - 1u >= 3u) { stop = true; break; }          // (first: a run of up to 63 characters in front of the comma would shift by >= 32 below)
                         uint32_t w; memcpy(&w, s + start, 4);
                         const uint32_t t = w ^ 0x30303030u, mask = (1u << len) - 1;
-                        if (len - 1u >= 3u || (((uint32_t)(D >> start)) & mask) != mask || (len > 1 && (t & 0xFF) == 0)) { stop = true; break; }
+                        if ((((uint32_t)(D >> start)) & mask) != mask || (len > 1 && (t & 0xFF) == 0)) { stop = true; break; }
                         const uint32_t y = (t & ((1u << (8 * len)) - 1)) << (8 * (3 - len));               // hundreds | tens | units in bytes 0 | 1 | 2
                         dst[n++] = (int32_t)((y & 0xFF) * 100 + ((y >> 8) & 0xFF) * 10 + (y >> 16));
                         start = p + 1 + (unsigned)(((S >> p) >> 1) & 1);
@@ -211,8 +212,8 @@ struct Parser {
                     }
                     s += start;
                     if (start) {                                    // at the next element (or at whatever follows the last comma taken: the loops below decide)
-                        if (*s == ' ') s++;
-                        if ((uint32_t)(uint8_t)*s - '0' <= 9) { if (!stop) continue; }
+                        if (s < e && *s == ' ') s++;
+                        if (s < e && (uint32_t)(uint8_t)*s - '0' <= 9) { if (!stop) continue; }
                         else { ws(); if (s < e && ((uint32_t)(uint8_t)*s - '0' > 9)) goto general; }
                     }
                 }
@@ -235,7 +236,7 @@ struct Parser {
                 if (s - a > 9 || (s - a > 1 && *a == '0')) { s = a; break; }
                 char c = *s;
                 if (c == ' ') { const char* q = s; while (e - q > 1 && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++; c = *q; if (c == ',' || c == ']') s = q; }
-                if (c == ',') { dst[n++] = (int32_t)v; s++; if (*s == ' ') s++; if ((uint32_t)(uint8_t)*s - '0' > 9) { ws(); if (s < e && ((uint32_t)(uint8_t)*s - '0' > 9)) goto general; } continue; }
+                if (c == ',') { dst[n++] = (int32_t)v; s++; if (s < e && *s == ' ') s++; if (s >= e || (uint32_t)(uint8_t)*s - '0' > 9) { ws(); if (s < e && ((uint32_t)(uint8_t)*s - '0' > 9)) goto general; } continue; }
                 if (c == ']') { dst[n++] = (int32_t)v; s++; return true; }
                 s = a; break;                                  // a fraction, an exponent, a longer number: the general path decides
             }
@@ -433,7 +434,15 @@ uint32_t default_threads() {
     }
     if (const char* e = getenv("POB_LOADER_THREADS")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }
     // the ranks of a node share its cores: divide by LOCAL_WORLD_SIZE -- unless this process has been pinned to its share already (distributed.bind_rank_to_gpu_numa)
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int v = atoi(e); if (v > 1 && (!pinned || quota_cut)) n = n / (uint32_t)v ? n / (uint32_t)v : 1; }
+    // -- a mask narrower than the machine is not enough for that: a job-wide cpuset / taskset that all ranks share looks the same.  The rank holds its share when
+    // bind_rank_to_gpu_numa said so (POB_RANK_BOUND=1) or when its mask is no wider than the machine divided by the ranks.
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) {
+        const int v = atoi(e);
+        const char* b = getenv("POB_RANK_BOUND");
+        const uint32_t hw = std::thread::hardware_concurrency();
+        const bool has_share = pinned && ((b && b[0] == '1') || (v > 0 && hw && n <= hw / (uint32_t)v));
+        if (v > 1 && (!has_share || quota_cut)) n = n / (uint32_t)v ? n / (uint32_t)v : 1;
+    }
     return n;
 }
 
@@ -507,7 +516,7 @@ int pack_batch(const Shape& sh, const char* const* json, const uint64_t* len, ui
         std::lock_guard<std::mutex> lk(P.call_mu);
         P.run(nt - 1, work);
     }
-    if (oom.load()) { put_err(err, errcap, "out of memory in the loader"); return POB_E_ARG; }
+    if (oom.load()) { put_err(err, errcap, "out of memory in the loader"); return POB_E_NOMEM; }      // (not POB_E_ARG: the input may be fine)
     if (bad.load() != 0xFFFFFFFFu) { for (const std::string& m : errs) if (!m.empty()) { put_err(err, errcap, m); break; } return POB_E_ARG; }
     if (overflow.load()) { put_err(err, errcap, "a witness has more than POB_EXC_CAP small inputs outside 0..255: use the int32 form for this batch"); return POB_E_RANGE; }
     return POB_OK;

@@ -323,6 +323,11 @@ struct pob_ctx {
     // dependency path): every unit of a level, of whatever track, goes out in one launch per kernel class, then the level's sponges; the round expansion of
     // every sponge is ONE launch at the end (nothing of the generation reads it).
     bool inorder = false;
+    // in-order calculators with the device's ONE streaming stream (pob_set_inorder(h, 2)): the two HBM-saturating Keccak round kernels of every such calculator of the device --
+    // round expansion at the end of the generation, round evaluation -- go onto the pool's streaming stream in the order the host enqueues them, so that no two of them
+    // ever share the memory system; everything else of the batch stays on the caller's stream and runs BESIDE them (no launch of the evaluation's G side reads a round block,
+    // and the sponge-chain evaluation reads what k_chain wrote).  ev_kgen: the round expansion of the last generation is done; ev_k_done: the round evaluation.
+    bool heavy = false, kgen_rec = false; hipEvent_t ev_kgen = nullptr;
     struct LSeg { uint32_t level, cls, first, count; };
     Seg chk_narrow{0, 0, 0, 0};                          // in-order evaluation: the units of the four narrow families, one launch
     std::vector<LSeg> lsegs;                            // generation launches in level order (cls: generation class; first / count into `order`)
@@ -668,6 +673,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_g_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_k_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_gen_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_check_done, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&h->ev_kgen, hipEventDisableTiming));
     for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < Plan::MAX_TRACKS; t++) {        // (streams for every track slot: the evaluation uses tracks 1 and 2's whatever the circuit)
@@ -773,6 +779,7 @@ void pob_close(pob_handle h) {
     if (h->ev_rounds_fork) hipEventDestroy(h->ev_rounds_fork);
     if (h->ev_g_done) hipEventDestroy(h->ev_g_done);
     if (h->ev_k_done) hipEventDestroy(h->ev_k_done);
+    if (h->ev_kgen) hipEventDestroy(h->ev_kgen);
     for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
     for (pob_ctx::Track& T : h->tracks) {
@@ -881,6 +888,7 @@ int pob_generate(pob_handle h, void* stream_) {
     if (h->chk_ordered && h->chk_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_check_done, 0));      // the previous batch's evaluation still reads the vector this generation overwrites
     if (h->gen_ordered && h->gen_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_gen_done, 0));        // ... and a previous generation on another stream still writes it
     h->chk_ordered = false;
+    if (h->kgen_rec) { HIPC(hipStreamWaitEvent(st, h->ev_kgen, 0)); h->kgen_rec = false; }             // (streaming-stream mode) ... and its round expansion reads the states the sponge chains overwrite
     h->rec_slot ^= 1;                                   // this batch's records go to the other pinned buffer: the previous batch's stay readable
     if (h->inorder) {
         GArgs A = gargs(h);
@@ -891,9 +899,16 @@ int pob_generate(pob_handle h, void* stream_) {
             for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) { A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st); }
             for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
         }
-        if (h->nperms) { K.first = 0; launch_k_rounds(K, false, h->nperms, G, st); }
-        HIPC(hipGetLastError());
         HIPC(hipEventRecord(h->ev_g_done, st));
+        if (h->nperms) {
+            K.first = 0;
+            if (h->heavy && h->stream_k != st) {      // the round expansion leaves the calculator's stream: behind the G side, in order with every other calculator's round kernels
+                HIPC(hipStreamWaitEvent(h->stream_k, h->ev_g_done, 0));
+                launch_k_rounds(K, false, h->nperms, G, h->stream_k);
+                HIPC(hipEventRecord(h->ev_kgen, h->stream_k)); h->kgen_rec = true;
+            } else launch_k_rounds(K, false, h->nperms, G, st);
+        }
+        HIPC(hipGetLastError());
         { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true; h->gen_stream = st; h->gen_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st)); h->in_done_rec[h->in_cur] = true;
@@ -1000,11 +1015,15 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // one stream: the Keccak round evaluation (the batch's one bandwidth-bound kernel) first, then the sponge chains, the inputs and the eight families
         // (the round evaluation on a high-priority stream of the device, forked and joined per batch, was measured: 4 / 6 / 8 / 12 calculators in flight
         //  2.39 / 2.04 / 1.91 / 2.14 ms per step against 2.19 / 2.09 / 1.87 / 2.07 here, the kernel 0.49-0.74 against 0.42-0.80 ms: nothing; removed)
+        const bool on_k = h->heavy && h->kgen_rec && h->stream_k != st && !h->plan.sponges.empty();      // streaming-stream mode: the round evaluation follows this batch's round expansion there
         if (!h->plan.sponges.empty()) {
             KArgs K = kargs(h); K.first = 0;
-            if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
-            launch_k_rounds(K, true, h->nperms, G, st);
-            if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
+            hipStream_t sk = on_k ? h->stream_k : st;
+            if (!on_k && h->kgen_rec) { HIPC(hipStreamWaitEvent(st, h->ev_kgen, 0)); h->kgen_rec = false; }
+            if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }
+            launch_k_rounds(K, true, h->nperms, G, sk);
+            if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
+            if (on_k) HIPC(hipEventRecord(h->ev_k_done, sk));
             launch_k_chain(K, true, h->nperms, G, st);
         }
         launch_inputs(h, true, G, st);
@@ -1012,12 +1031,14 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
         if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
         for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        if (on_k) { HIPC(hipStreamWaitEvent(st, h->ev_k_done, 0)); h->kgen_rec = false; }      // the records carry the round evaluation's verdict too (and behind this point the round expansion is done as well)
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));
         HIPC(hipGetLastError());
         return POB_OK;
     }
+    if (h->kgen_rec) { HIPC(hipStreamWaitEvent(st, h->ev_kgen, 0)); h->kgen_rec = false; }
     static const uint32_t side_plan[2][5] = {{F_N2B, F_SC, F_LD, F_RANGE, F_GM}, {F_RL, F_POS, F_MISC, F_SELROW, F_COUNT}};      // (F_GM: gadget-level mains only; F_COUNT: no family)
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
@@ -1074,7 +1095,7 @@ int pob_set_partner(pob_handle h, pob_handle partner) {
 int pob_set_inorder(pob_handle h, int on) {
     if (!h) return POB_E_ARG;
     if (on && h->partner) { h->err = "an in-order calculator has no partner: unlink first (pob_set_partner(h, NULL))"; return POB_E_STATE; }
-    h->inorder = on != 0;
+    h->inorder = on != 0; h->heavy = on == 2;
     return POB_OK;
 }
 
@@ -1083,6 +1104,7 @@ int pob_sync(pob_handle h) {
     HIPC(hipSetDevice(h->device));
     // this handle's work only: its last generation / evaluation (the side streams are joined into those events) and its copies
     if (h->gen_done_rec) HIPC(hipEventSynchronize(h->ev_gen_done));
+    if (h->kgen_rec) HIPC(hipEventSynchronize(h->ev_kgen));
     if (h->check_done_rec && h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
     HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;
@@ -1238,7 +1260,7 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
     pob_ctx::Emit& E = h->em;
     const int NS = pob_ctx::Emit::NSLOT;
     // this handle's work only (a partner handle may be busy): the generation of the batch
-    HIPC(hipEventSynchronize(h->ev_gen_done));
+    HIPC(hipEventSynchronize(h->ev_gen_done)); if (h->kgen_rec) HIPC(hipEventSynchronize(h->ev_kgen));
     if (h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
     {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
         int rc = emit_statuses(h); if (rc) return rc;

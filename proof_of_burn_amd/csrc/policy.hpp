@@ -134,6 +134,7 @@ struct CountP : PolBase {
     HD void run_put(uint32_t n, uint32_t, uint32_t, B) { nput += n; nb += n; }
     HD void run_derived(uint32_t, uint32_t, B) {}      // n DERIVED BIT wires as a lane-distributed run (lane k: wire index, that wire's 64-witness mask): the emitter only
     HD B run_bcast(B, uint32_t) { return 0; }
+    HD B xpose64(uint32_t, uint32_t, uint32_t) { return 0; }
     HD B run_set(B run, uint32_t, B) { return run; }
     HD B run_perm(B run, uint32_t) { return run; }
 };
@@ -166,15 +167,14 @@ template <class P, int N> HD __attribute__((always_inline)) void sm_commit(P& p,
 // decomposition (Num2Bits and everything copied from it) is built ONCE from the witnesses' canonical values and then written /
 // verified as runs -- no wire of it is ever read back.
 struct BV { B r[4]; };
+// The decomposition of the 64 witnesses' canonical values IS a bit-matrix transposition: lane l holds the 64-bit word x_l (two limbs) and lane k must end up with
+// the mask whose bit l is bit k of x_l.  p.xpose64 does it across the lanes (device: six butterfly stages, one ds_bpermute each -- DevPol::xpose64); rounds 1-5 built
+// the run from 254 ballots, each a compare into an SGPR pair and two selects under a per-lane `lane == k` mask (another 64 SGPR pairs, hoisted and spilled:
+// 3.6-5.5 k spilled SGPRs in the kernels that decompose field elements).
 template <class P> HD __attribute__((always_inline)) BV bv_from_canon(P& p, const F& c, int n) {
-    BV v; v.r[0] = v.r[1] = v.r[2] = v.r[3] = 0;
+    BV v;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        for (int k = 0; k < 32; k++) {
-            const int idx = 32 * j + k;
-            if (idx < n) v.r[j >> 1] = p.run_set(v.r[j >> 1], (uint32_t)(idx & 63), p.ballot((c.l[j] >> k) & 1));
-        }
-    }
+    for (int q = 0; q < 4; q++) v.r[q] = (64 * q < n) ? p.xpose64(c.l[2 * q], c.l[2 * q + 1], (uint32_t)(n - 64 * q)) : 0;
     return v;
 }
 // wires dst + 0 .. n-1 := bits 0 .. n-1
@@ -332,6 +332,29 @@ struct DevPol : PolBase {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)run);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)(run >> 32));
         return ((B)hi << 32) | lo;
+    }
+    // 64 x 64 bit-matrix transposition across the wavefront: in: this lane's (witness') 64-bit word lo | hi << 32; out: lane k holds the mask whose bit l is bit k of
+    // lane l's word -- the lane-distributed run of the 64 BIT wires "bit k of the value", lanes k >= n zeroed.  Butterfly over j = 32, 16, .., 1: the lanes l and l ^ j
+    // exchange the off-diagonal j x j blocks; each lane needs 32 of its partner's 64 bits, packed into ONE word per stage (one ds_bpermute).
+    __device__ __forceinline__ B xpose64(uint32_t lo, uint32_t hi, uint32_t n) {
+        {   // j = 32: the off-diagonal blocks are whole words
+            const bool up = m.lane & 32;
+            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((m.lane ^ 32u) << 2), (int)(up ? lo : hi));
+            if (up) lo = got; else hi = got;
+        }
+#pragma unroll
+        for (int st = 0; st < 5; st++) {
+            const uint32_t j = 16u >> st;
+            const uint32_t mk = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;      // bit positions with (pos & j) == 0
+            const bool up = m.lane & j;
+            // what the partner needs of this lane: its columns of the other half, both words packed into one
+            const uint32_t send = up ? ((lo & mk) | ((hi & mk) << j)) : (((lo & ~mk) >> j) | (hi & ~mk));
+            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((m.lane ^ j) << 2), (int)send);
+            if (up) { lo = (lo & ~mk) | (got & mk); hi = (hi & ~mk) | ((got & ~mk) >> j); }
+            else { lo = (lo & mk) | ((got & mk) << j); hi = (hi & mk) | (got & ~mk); }
+        }
+        const B r = ((B)hi << 32) | lo;
+        return m.lane < n ? r : 0;
     }
     __device__ __forceinline__ B get(BitRef r) { return ld(r); }
     __device__ __forceinline__ S get(SmRef r) { return ld(r); }

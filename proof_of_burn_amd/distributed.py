@@ -78,6 +78,7 @@ def bind_rank_to_gpu_numa(local_rank: int, device_index: int | None = None, loca
         os.sched_setaffinity(0, cpus)
     except OSError:                     # (a container that forbids it: the rank runs where the launcher put it)
         return None
+    os.environ["POB_RANK_BOUND"] = "1"  # (read by the loader pool's width: this rank holds ITS share of the host, csrc/pack_json.hip default_threads)
     return cpus
 
 

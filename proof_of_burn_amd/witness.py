@@ -123,7 +123,7 @@ class PobInfo(ctypes.Structure):
 RECORD_DTYPE = np.dtype([("status", "<u4"), ("check_status", "<u4"), ("bad_wire", "<u4"), ("commitment", "u1", (32,))])
 NOT_EVALUATED, CLEAN = 0xFFFFFFFE, 0xFFFFFFFF
 # the byte form of the small inputs (include/pob_hip.h pob_upload_inputs8): per witness POB_EXC_CAP exception slots {index, int32 value}, unused = POB_EXC_NONE
-EXC_CAP, EXC_NONE, E_RANGE = 32, 0xFFFFFFFF, -6
+EXC_CAP, EXC_NONE, E_RANGE, E_NOMEM = 32, 0xFFFFFFFF, -6, -3
 EXC_DTYPE = np.dtype([("k", "<u4"), ("v", "<i4")])
 
 _lib = None
@@ -422,15 +422,22 @@ def pack_json(main, texts: "Sequence[bytes | str] | TextBatch", threads: int = 0
         if rc == 0:
             return fr, None, forced
         if rc != E_RANGE:
-            msg = err.value.decode(errors="replace")
-            raise (KeyError if "missing [" in msg else ValueError)(msg)
+            _raise_loader(rc, err)
         out.ensure_sm()
         sm = out.sm
     rc = load_library().pob_pack_json_batch(circuit, arr, len(params), ptrs, lens, n, threads, fr.ctypes.data, sm.ctypes.data, forced.ctypes.data, err, 512)
     if rc != 0:
-        msg = err.value.decode(errors="replace")
-        raise (KeyError if "missing [" in msg else ValueError)(msg)
+        _raise_loader(rc, err)
     return fr, sm, forced
+
+
+def _raise_loader(rc: int, err):
+    """the loader's error as the exception the Python loader raises for the same input: a missing / unexpected key is a KeyError, a malformed value a ValueError; running out of
+    memory (POB_E_NOMEM) says nothing about the input and is a MemoryError"""
+    msg = err.value.decode(errors="replace")
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    raise (KeyError if "missing [" in msg else ValueError)(msg)
 
 
 def pack_json8(main, texts: Sequence[bytes | str], threads: int = 0):
@@ -452,8 +459,7 @@ def pack_json8(main, texts: Sequence[bytes | str], threads: int = 0):
     if rc == E_RANGE:
         return None
     if rc != 0:
-        msg = err.value.decode(errors="replace")
-        raise (KeyError if "missing [" in msg else ValueError)(msg)
+        _raise_loader(rc, err)
     return fr, sm8, exc, forced
 
 
@@ -698,24 +704,24 @@ class WitnessCalculator:
     def _keep_array(self, keep) -> np.ndarray:
         """a ReducedMap (circuit_model/o1.py) or an array of kept O0 wire indices -> the PRIVATE, read-only uint32 copy the library has pinned
         (pob_reduced_map_pin) for this map.  The library recognises a pinned map by address and length and then promises itself that its contents have not
-        changed, so what is pinned is never the caller's array (the caller may mutate it in place): a private copy, looked up by a digest of the caller's contents
-        (crc32 + adler32 over the 86 MB of the production map: ~40 ms per call, against ~9 ms of device-side hashing per emission that the pin saves and a silently stale map that it prevents)."""
+        changed, so what is pinned is never the caller's array (the caller may mutate it in place): a private copy, recognised by a digest of the caller's contents
+        (crc32 + adler32 over the 86 MB of the production map: ~40 ms per call, against ~9 ms of device-side hashing per emission that the pin saves and a silently stale map
+        that it prevents) AND an element-wise comparison on a digest hit.  The library holds ONE pin, so this object keeps ONE copy: the map pinned last (a second map
+        replaces it -- an earlier map handed in again is copied and pinned again, never served from a stale cache entry that the library would hash on every emission)."""
         import zlib
         k = np.ascontiguousarray(getattr(keep, "keep", keep), dtype=np.uint32)
         if k.ndim != 1 or k.size == 0:
             raise ValueError("keep: a non-empty 1-D array of wire indices")
-        if not hasattr(self, "_keep_pins"):
-            self._keep_pins = {}             # digest of the contents -> the private read-only copy the library has pinned
-        if self._keep_pins.get(id(k)) is k:  # one of our own pinned copies handed back (witness_payload_reduced -> witness_windows): immutable, no digest needed
+        cur = getattr(self, "_keep_pin", None)           # (digest, the private read-only copy the library has pinned)
+        if cur is not None and k is cur[1]:              # our own pinned copy handed back (witness_payload_reduced -> witness_windows): immutable, no digest needed
             return k
         key = (k.size, zlib.crc32(k), zlib.adler32(k))
-        own = self._keep_pins.get(key)
-        if own is None:
-            own = np.array(k, dtype=np.uint32, copy=True)
-            own.setflags(write=False)
-            self._ck(self.lib.pob_reduced_map_pin(self.h, own.ctypes.data, own.size))
-            self._keep_pins[key] = own
-            self._keep_pins[id(own)] = own
+        if cur is not None and cur[0] == key and np.array_equal(cur[1], k):
+            return cur[1]
+        own = np.array(k, dtype=np.uint32, copy=True)
+        own.setflags(write=False)
+        self._ck(self.lib.pob_reduced_map_pin(self.h, own.ctypes.data, own.size))
+        self._keep_pin = (key, own)
         return own
 
     def write_wtns_reduced(self, idx: int, path: str, keep):
@@ -740,9 +746,11 @@ class WitnessCalculator:
             buf = (ctypes.c_uint8 * (32 * wn.value)).from_address(p.value)
             yield w0.value, np.frombuffer(buf, dtype=np.uint8)
 
-    def set_inorder(self, on: bool = True):
-        """every launch of this calculator on the caller's stream, in dependency order, no side streams (pob_set_inorder): for jobs that keep several calculators in flight"""
-        self._ck(self.lib.pob_set_inorder(self.h, 1 if on else 0))
+    def set_inorder(self, on=True):
+        """every launch of this calculator on the caller's stream, in dependency order, no side streams (pob_set_inorder): for jobs that keep several calculators in flight.
+        on = 2: the same, but the two HBM-saturating Keccak round kernels (expansion, evaluation) of every such calculator of the device share the device's one streaming stream,
+        in the order they are enqueued: they never run beside each other, the rest of each batch runs beside them"""
+        self._ck(self.lib.pob_set_inorder(self.h, int(on)))
 
     def emit_selfcheck(self, enable: bool = True):
         """every following emission (O0 or reduced) evaluates the derived wires' own relations on the values written into its windows (pob_emit_selfcheck)"""

@@ -233,7 +233,7 @@ def _run_bench_ranks(world, extra, timeout=280):
     """bench.py as the driver launches it for N > 1 (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_* in the environment), on the CPU shim"""
     port = D.free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), POB_DIST_BACKEND="gloo")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shim", "--main", "spend", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shim", "--main", "spend", "--steps", "3", "--warmup", "1", "--pipeline", "4",
            "--no-single", "--no-emission", "--no-extra-legs", "--no-cpu-baseline"] + extra
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for r in range(world)]
     outs = [p.communicate(timeout=timeout) for p in procs]
@@ -260,6 +260,28 @@ def test_bench_py_eight_ranks_on_the_shim_weak_and_strong():
     strong = _run_bench_ranks(8, ["--total-batch", "509"])
     assert strong["scaling"] == "strong" and strong["config"]["validated_witnesses"] == 3 * 64      # rank 0's slice of 509 = 64 (ranks 5..7: 63)
     assert "global 509" in strong["config"]["workload"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_py_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 8 ...` with NO launcher and no WORLD_SIZE / RANK / MASTER_* in the environment (the way the driver starts the N = 1 bench): bench.py starts
+    its eight ranks itself (bench.launch_ranks), rank 0 prints the ONE JSON line on the command's stdout, the records of all ranks are gathered per batch"""
+    from tests.hostsim import build as hb
+    hb.build()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["POB_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--shim", "--main", "spend", "--steps", "3", "--warmup", "1", "--batch", "64", "--pipeline", "4",
+           "--no-single", "--no-emission", "--no-extra-legs", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks"]["rccl_ranks"] == 8 and d["ranks"]["dist_backend"] == "gloo" and d["ranks"]["launched_by"] == "bench.py itself"
+    assert d["config"]["validated_witnesses"] == 3 * 64 and d["ranks"]["ms_per_step_min"] <= d["ranks"]["ms_per_step_max"]
+    # a rank that dies takes the job down with its exit code instead of leaving seven ranks waiting at the rendezvous
+    bad = subprocess.run(cmd + ["--total-batch", "3"], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)      # 3 witnesses over 8 ranks: empty slices are refused
+    assert bad.returncode != 0
 
 
 def test_init_refuses_a_job_without_a_port(monkeypatch):
