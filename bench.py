@@ -103,8 +103,8 @@ def parse_args(argv=None):
                     help="inorder: every calculator enqueues its whole batch in dependency order on ONE stream (pob_set_inorder) and --pipeline of them are in flight; "
                          "tracks: round 2-3's schedule, two linked calculators (pob_set_partner) whose tracks run on the device's side streams")
     ap.add_argument("--pipeline", type=int, default=-1, help=f"calculators in flight, each on consecutive batches (default: {DEFAULT_DEPTH} in-order ones / 2 linked track ones; 0 = one calculator, no pipeline)")
-    ap.add_argument("--streaming-stream", type=int, default=0, choices=[0, 1],
-                    help="1: the two HBM-saturating Keccak round kernels of every in-order calculator on the device's ONE streaming stream (pob_set_inorder(h, 2)), the rest of each batch beside them")
+    ap.add_argument("--fused", type=int, default=1, choices=[0, 1],
+                    help="1 (default): in-order calculators with fused launches (pob_set_inorder(h, 3): independent kernels of a batch share a launch); 0: one launch per kernel, round 5's schedule")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
     ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
@@ -242,7 +242,7 @@ class ServiceLoop:
     pinned host memory, every record validated on the host; at N > 1 one all-gather of the device records.  Pipeline: batch k is generated by calculator k % depth while batch k-1 is
     evaluated by the one before; the host validates the oldest batch after it has enqueued the newest, so the device never waits for the host."""
 
-    def __init__(self, job: Job, main: str, depth: int, inorder: bool = True, streaming_stream: bool = False):
+    def __init__(self, job: Job, main: str, depth: int, inorder: bool = True, fused: bool = True):
         import numpy as np
         from proof_of_burn_amd import WitnessCalculator
         self.job, self.np, self.main = job, np, main
@@ -252,7 +252,7 @@ class ServiceLoop:
         self.calcs = [WitnessCalculator(main, max_batch=self.B, device=job.dev) for _ in range(self.depth)]
         if inorder:
             for c in self.calcs:
-                c.set_inorder(2 if streaming_stream else 1)
+                c.set_inorder(3 if fused else 1)
         # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
         self.streams = [cuda.Stream(device=job.dev, priority=-1) for _ in self.calcs]     # (not the legacy default stream: it synchronises with every blocking stream)
         records_of = D.host_records if job.args.shim else D.device_records
@@ -477,7 +477,7 @@ def legs_track_schedule(job, loop):
     if not loop.link:
         loop.calcs[0].set_partner(None)
         for c in loop.calcs[:2]:
-            c.set_inorder(2 if job.args.streaming_stream else 1)
+            c.set_inorder(3 if job.args.fused else 1)
     loop.active = loop.depth
     return single, tracks
 
@@ -485,7 +485,7 @@ def legs_track_schedule(job, loop):
 def leg_other_depth(job, main, depth, pinned, expect, nsteps=96):
     """the same service loop with another number of in-order calculators in flight: throughput and the round evaluation kernel's in-step duration"""
     np = __import__("numpy")
-    lp = ServiceLoop(job, main, depth, True, bool(job.args.streaming_stream))
+    lp = ServiceLoop(job, main, depth, True, bool(job.args.fused))
     lp.set_inputs(pinned, expect)
     lp.run(depth + 2); job.fence()
     lp.probe(True)
@@ -554,7 +554,7 @@ def leg_roofline(job, loop, info, kchk_in_step, ms_step, probe_steps):
             "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
             "measured": ((f"in {probe_steps} more batches of the same pipelined service loop right after the timed region" if args.probe_after else "in the timed region, every step")
                          + f": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel); {loop.depth} calculators in flight"
-                         + (", the round kernels of all of them on the device's one streaming stream" if args.streaming_stream else "")) if in_step else "alone",
+                         + (", fused launches: the events bracket the launch the kernel shares with the wide evaluation families" if args.fused else "")) if in_step else "alone",
             "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
             "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
             "traffic": traffic,
@@ -653,7 +653,7 @@ def main():
         batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + job.first0,
                                        pow_device=job.dev if args.depth > 12 else None) for b in range(NB)]
     t_synth = (time.time() - t0) / NB
-    loop = ServiceLoop(job, MAIN_, NC, INORDER, bool(args.streaming_stream))
+    loop = ServiceLoop(job, MAIN_, NC, INORDER, bool(args.fused))
     calc0 = loop.calcs[0]
     info = calc0.info
     # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch8); the Python packer beside it
@@ -769,7 +769,7 @@ def main():
                            "canonical_bytes_per_witness": int(info.n_witness) * 32,
                            "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
                                                                                          + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                           "schedule": args.schedule, "calculators_in_flight": NC, "streaming_stream": bool(args.streaming_stream), "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
+                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused), "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
                            "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                            "rccl_ranks": ranks["rccl_ranks"], "dist_backend": job.backend,
                            "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,

@@ -223,9 +223,13 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
     const S last = (S)((uint32_t)nb * 136u - 1u);
     const Cur cE = r.c_loop, cL = cur_add(cE, FP_ISEQ_D, m), cN = cur_add(cL, FP_ISEQ_D, m), cF = cur_add(cN, FP_N2B8, m);
     const uint32_t flat_o_w = cF.w, flat_i_w = cF.w + 8 * m;
-    // filter[i] = prod_{j<i}(1 - isEq[j]) = [inLen >= i] (unsigned: an out-of-range inLen never hits); the evaluator re-reads it
-    B f = P::is_gen ? p.ballot((uint32_t)inLen >= lo) : p.get(r.pad_flt + lo);
-    B runE = 0, runL = 0, runF = 0, runPairE = 0, runPairL = 0, bits0 = 0, bits1 = 0;
+    // filter[i] = prod_{j<i}(1 - isEq[j]) = [inLen >= i] (unsigned: an out-of-range inLen never hits); the evaluator re-reads it.
+    // Every bit of the range is first THIS witness' bit of a per-lane word (isEq / isLast / filter: bit t = byte lo + t; the byte's own bits: eight per byte), and the words
+    // become the lane-distributed runs of the wires by bit-matrix transpositions across the wavefront (policy.hpp xpose64) -- rounds 1-5 built every run from one ballot and
+    // two selects under a `lane == k` mask per wire: 40 SGPR pairs per byte.
+    bool fl = P::is_gen ? ((uint32_t)inLen >= lo) : p.bit(p.get(r.pad_flt + lo));
+    uint32_t wE = 0, wL = 0, wF = 0, wPE = 0, wPL = 0;
+    B wb0 = 0, wb1 = 0;
     // the range's loads first, all of them in flight at once (round 5: as `put(in + i, get(src + i))` inside the loop every byte paid its own memory round trip -- two in
     // the evaluator --, 17 us per wavefront for 32 dependent loads; the unit kind is a sixth of the G side's wave cycles in generation and in evaluation)
     S vs[16];
@@ -246,22 +250,19 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
         const uint32_t i = lo + t;
         const Cur ce = cur_add(cE, FP_ISEQ_D, i), cl = cur_add(cL, FP_ISEQ_D, i);
         const S v = vs[t];
-        const S xe = (S)((uint32_t)inLen - i), xl = (S)((uint32_t)last - i);
         iseq_derived(p, ce, (S)i, inLen); iseq_derived(p, cl, (S)i, last);      // IsEqual([i, inLen]), IsEqual([i, numBlocks*136 - 1]): operand wires derived
-        const B e = p.ballot(xe == 0), l = p.ballot(xl == 0);
-        f &= ~e;
-        const S pv = (p.bit(f) ? v : 0) + (S)p.bit(e) + (p.bit(l) ? 0x80 : 0);
+        const bool e = (uint32_t)inLen == i, l = (uint32_t)last == i;
+        fl = fl && !e;
+        const S pv = (fl ? v : 0) + (S)e + (l ? 0x80 : 0);
         p.derived(r.pad_in_w + i, v); p.derived(r.pad_o_w + i, pv); p.derived(r.padded_w + i, pv); p.derived(cN.w + 9 * i + 8, pv);   // (derived copies)
-        p.require(p.ballot((uint32_t)pv < 256u), FAILCODE(T_NUM2BITS, 38));
-        runE = p.run_set(runE, t, e); runL = p.run_set(runL, t, l); runF = p.run_set(runF, t, f);
-        runPairE = p.run_set(p.run_set(runPairE, 2 * t, e), 2 * t + 1, e);
-        runPairL = p.run_set(p.run_set(runPairL, 2 * t, l), 2 * t + 1, l);
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            const B b = p.ballot(((uint32_t)pv >> k) & 1);
-            if (t < 8) bits0 = p.run_set(bits0, 8 * t + k, b); else bits1 = p.run_set(bits1, 8 * (t - 8) + k, b);
-        }
+        p.require_lane((uint32_t)pv < 256u, FAILCODE(T_NUM2BITS, 38));
+        wE |= (uint32_t)e << t; wL |= (uint32_t)l << t; wF |= (uint32_t)fl << t;
+        wPE |= (e ? 3u : 0u) << (2 * t); wPL |= (l ? 3u : 0u) << (2 * t);
+        if (t < 8) wb0 |= (B)((uint32_t)pv & 0xffu) << (8 * t); else wb1 |= (B)((uint32_t)pv & 0xffu) << (8 * (t - 8));
     }
+    const B runE = p.xpose64(wE, 0, cnt), runL = p.xpose64(wL, 0, cnt), runF = p.xpose64(wF, 0, cnt);
+    const B runPairE = p.xpose64(wPE, 0, 2 * cnt), runPairL = p.xpose64(wPL, 0, 2 * cnt);
+    const B bits0 = p.xpose(wb0, 64), bits1 = cnt > 8 ? p.xpose(wb1, 64) : 0;
     p.run_put(cnt, r.pad_isEq.w + lo + ln, r.pad_isEq.i + lo + ln, runE);
     p.run_put(cnt, r.pad_flt.w + lo + 1 + ln, r.pad_flt.i + lo + 1 + ln, runF);
     p.run_put(cnt, r.pad_isLast.w + lo + ln, r.pad_isLast.i + lo + ln, runL);
@@ -927,25 +928,25 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         // allowed[i] = prod_{j<i}(1 - isLastIndex[j]) = [mainLen - sl + 1 >= i] (unsigned); the evaluator re-reads it
         const uint32_t lastIdx = (uint32_t)(mainLen - (S)sl + 1);
         const uint32_t ln = p.lane_id(), cnt = hi - lo;                      // cnt <= 32
-        B allowed = P::is_gen ? p.ballot(lastIdx >= lo) : p.get(sc.alw + lo);
+        bool allowed = P::is_gen ? (lastIdx >= lo) : p.bit(p.get(sc.alw + lo));
         // Per position: IsEqual([i, lastIndex]) and IsEqual([subNum * 256^i, M[i+sl] - M[i]]) -- 12 wires: 4 BIT outputs (IsEqual.out, IsZero.out
         // twice) and 8 DERIVED operand wires (policy.hpp), i.e. nothing but bits is stored, and exists[i] needs no field arithmetic: it is
         // [subNum == the 31 bytes from position i] on a sliding window (gadgets.hpp sc_window; rounds 1-2 stored M[] and the four field-element
         // operands and ran a Montgomery batch inversion per unit through the witness' own slots: 2.3 GB per batch).
         // The bits leave as lane-distributed runs: isLastIndex[], allowed[], exists[] (one wire per position) and the children's outputs
         // (four per position, consecutive BIT ranks: 16 positions per run).
-        B runIsl = 0, runAlw = 0, runEx = 0, runC0 = 0, runC1 = 0;
+        uint32_t wIsl = 0, wAlw = 0, wEx = 0;                                 // this witness' bits of the range (bit t = position lo + t): transposed into runs below
+        B wC0 = 0, wC1 = 0;
         F ddL = fr_zero();                                                   // (emitter: lane t <- position lo + t's IsZero operand of the emitted witness)
         Fr win = sc_window(p, src, lo, sl);
         for (uint32_t t = 0; t < cnt; t++) {
             const uint32_t i = lo + t;
             const S nxt = i + sl < (uint32_t)LB ? p.get(src + (i + sl)) : 0;    // (the byte that enters the window next is requested before this position's compares)
-            const B e = p.ballot(fr_eq(win, subC)), last = p.ballot(i == lastIdx);
-            allowed &= ~last;
-            runIsl = p.run_set(runIsl, t, last); runAlw = p.run_set(runAlw, t, allowed); runEx = p.run_set(runEx, t, e);
-            const uint32_t k = 4 * (t & 15);
-            if (t < 16) runC0 = p.run_set(p.run_set(p.run_set(p.run_set(runC0, k, last), k + 1, last), k + 2, e), k + 3, e);
-            else runC1 = p.run_set(p.run_set(p.run_set(p.run_set(runC1, k, last), k + 1, last), k + 2, e), k + 3, e);
+            const bool e = fr_eq(win, subC), last = i == lastIdx;
+            allowed = allowed && !last;
+            wIsl |= (uint32_t)last << t; wAlw |= (uint32_t)allowed << t; wEx |= (uint32_t)e << t;
+            const B four = (B)((last ? 3u : 0u) | (e ? 12u : 0u)) << (4 * (t & 15));
+            if (t < 16) wC0 |= four; else wC1 |= four;
             if constexpr (P::is_emit) {
                 const Cur c = cur_add(cur_add(sc.c_loop, FP_ISEQ_S, i), FP_ISEQ_F, i);
                 iseq_derived(p, c, (S)i, (S)lastIdx);
@@ -960,6 +961,8 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
             const F inv = fr_is_zero(ddL) ? fr_zero() : fr_inv(ddL);
             if (ln < cnt) p.w32(cur_add(cur_add(sc.c_loop, FP_ISEQ_S, lo + ln), FP_ISEQ_F, lo + ln).w + 11, fr_from_mont(inv), (fr_is_zero(ddL) ? 3 : 2) | 4);      // (counted: pob_debug_emit_counters)
         }
+        const B runIsl = p.xpose64(wIsl, 0, cnt), runAlw = p.xpose64(wAlw, 0, cnt), runEx = p.xpose64(wEx, 0, cnt);
+        const B runC0 = p.xpose(wC0, 64), runC1 = cnt > 16 ? p.xpose(wC1, 64) : 0;
         p.run_put(cnt, sc.isl.w + lo + ln, sc.isl.i + lo + ln, runIsl);
         p.run_put(cnt, sc.alw.w + lo + 1 + ln, sc.alw.i + lo + 1 + ln, runAlw);
         p.run_put(cnt, sc.ex.w + lo + ln, sc.ex.i + lo + ln, runEx);

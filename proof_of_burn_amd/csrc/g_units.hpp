@@ -3,13 +3,13 @@
 #include "kernels_common.hpp"
 
 // MASK = families (circuits.hpp Fam) this kernel serves; WAVES = waves per SIMD it is compiled for (VGPR budget 512 / WAVES)
-template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(64, WAVES) g_units(GArgs A) {
+// the BODY: a device function of the launch arguments and the (group, position in the launch's unit list) of its wavefront, so that a launch can carry the wavefronts of
+// several independent kernels (the fused launches of g_gen_all.hip / g_gen_poswide.hip / g_check_wide.hip / g_check_narrow.hip)
+template <class P, uint32_t MASK> __device__ __forceinline__ void g_units_body(const GArgs& A, uint32_t g_in, uint32_t ux) {
     // the few long BN254 chains share their SIMDs with thousands of short light / Keccak waves: let the arbiter favour them
     if constexpr ((MASK & ~FAM_LIGHT) != 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
-    // grid = (groups, units): the group index runs fastest, so the units of a launch start in the order of the list (longest first, circuits.hpp cost) for ALL groups at
-    // once -- as (units, groups) the long units of the last groups started when everything of the groups before them had been dispatched: the launch's tail
-    const uint32_t g = P::is_emit ? A.emit_group : blockIdx.x, ux = blockIdx.y;
+    const uint32_t g = P::is_emit ? A.emit_group : g_in;
     P p;
     p.m.bits = A.bits + (uint64_t)g * A.bits_stride;
     p.m.sm = A.sm + (uint64_t)g * A.sm_stride;
@@ -46,6 +46,9 @@ template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(6
         if (p.bad_wire != 0xFFFFFFFFu) atomicMin(&A.bad_wire[g * 64 + lane], p.bad_wire);
     }
 }
+// grid = (groups, units): the group index runs fastest, so the units of a launch start in the order of the list (longest first, circuits.hpp cost) for ALL groups at
+// once -- as (units, groups) the long units of the last groups started when everything of the groups before them had been dispatched: the launch's tail
+template <class P, uint32_t MASK, int WAVES> __global__ void __launch_bounds__(64, WAVES) g_units(GArgs A) { g_units_body<P, MASK>(A, blockIdx.x, blockIdx.y); }
 // one launcher per kernel (each in its own translation unit, compiled in parallel)
 #define POB_DEFINE_G_LAUNCH(name, POL, MASK, WAVES)                                                                            \
     void name(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st) {                                             \

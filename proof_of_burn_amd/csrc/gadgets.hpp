@@ -480,7 +480,7 @@ template <class P> GD void abs_range(P& p, Cur c0, uint32_t own_w, SmRef src, ui
     const uint32_t ln = p.lane_id();
     for (uint32_t i0 = lo; i0 < hi; i0 += 8) {
         const uint32_t cnt = hi - i0 < 8 ? hi - i0 : 8;
-        B compact = 0;                                   // lane 8t + k = bit k of byte i0 + t
+        B compact = 0, wc = 0;                           // lane 8t + k = bit k of byte i0 + t (wc: this witness' eight bytes, transposed below)
         S vs[8];                                         // the eight bytes' loads in flight together (a short last batch repeats its last byte)
 #pragma unroll
         for (uint32_t t = 0; t < 8; t++) vs[t] = p.get(src + (i0 + (t < cnt ? t : cnt - 1)));
@@ -491,19 +491,17 @@ template <class P> GD void abs_range(P& p, Cur c0, uint32_t own_w, SmRef src, ui
             const S v = vs[t];
             p.derived(own_w + i, v); p.derived(c.w, v); p.derived(c.w + 17, v);
             p.require(p.ballot((uint32_t)v < 256u), FAILCODE(T_NUM2BITS, 38));
-            if constexpr (P::is_emit) {
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) compact = p.run_set(compact, 8 * t + k, p.ballot(((uint32_t)v >> k) & 1));
-            }
+            if constexpr (P::is_emit) wc |= (B)((uint32_t)v & 0xffu) << (8 * t);
         }
         if constexpr (P::is_emit) {
+            compact = p.xpose(wc, 64);
             for (uint32_t h2 = 0; h2 < 2 && 4 * h2 < cnt; h2++) {       // bytes i0 + 4*h2 .. +3: 16 wires each (bits[8] then out[8])
                 const uint32_t nb = cnt - 4 * h2 < 4 ? cnt - 4 * h2 : 4;
                 const uint32_t t = 4 * h2 + (ln >> 4), q = ln & 15, i = i0 + t;
                 const B x = p.run_perm(compact, 8 * t + (q & 7));
                 p.run_derived(16 * nb, c0.w + 18 * i + 1 + q, x);
             }
-        } else { (void)compact; (void)ln; }
+        } else { (void)compact; (void)wc; (void)ln; }
     }
 }
 
@@ -570,13 +568,14 @@ template <class P> GD BitRef gFilter(P& p, int N, S in, B* oruns = nullptr) {
                                                                  //  instruction cache -- and no dynamically indexed register array)
     for (uint32_t k0 = 0; k0 < (uint32_t)N; k0 += 32) {
         const uint32_t n = (uint32_t)N - k0 < 32 ? (uint32_t)N - k0 : 32, r = k0 >> 6, l0 = k0 & 63;
-        B runE = 0, runO = 0, runK = 0, kp = 0;
-        for (uint32_t t = 0; t < n; t++) {
-            const B e = p.ballot((uint32_t)in == k0 + t), ob = p.ballot((uint32_t)in > k0 + t);
-            runE = p.run_set(runE, t, e); runO = p.run_set(runO, t, ob);
-            runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
-            kp = p.run_set(kp, l0 + t, ob);
-        }
+        // this witness' bits of the 32 entries: isEq[k0 + t] = [in == k0 + t], out[k0 + t] = [in > k0 + t] (unsigned); transposed into the wires' runs
+        const uint32_t d = (uint32_t)in - k0, nmask = n < 32 ? (1u << n) - 1u : 0xFFFFFFFFu;
+        const bool above = (uint32_t)in >= k0;
+        const uint32_t wE = (above && d < n) ? 1u << d : 0u;
+        const uint32_t wO = !above ? 0u : d >= 32 ? nmask : ((1u << d) - 1u) & nmask;
+        const B wK = (above && d < n) ? (B)3 << (2 * d) : 0;
+        const B runE = p.xpose64(wE, 0, n), runO = p.xpose64(wO, 0, n), runK = p.xpose(wK, 2 * n);
+        const B kp = oruns ? p.xpose((B)wO << l0, 64) : 0;
         if (r == 0) keep0 |= kp; else if (r == 1) keep1 |= kp; else if (r == 2) keep2 |= kp; else keep3 |= kp;
         p.run_put(n, isEq.w + k0 + ln, isEq.i + k0 + ln, runE);
         p.run_put(n, o.w + k0 + ln, o.i + k0 + ln, runO);
@@ -648,12 +647,10 @@ template <class P> GD void sel_range(P& p, const SelBlk& sb, SmRef src, uint32_t
     const uint32_t ln = p.lane_id();
     for (uint32_t i0 = lo; i0 < hi; i0 += 32) {
         const uint32_t n = hi - i0 < 32 ? hi - i0 : 32;
-        B runE = 0, runK = 0;
-        for (uint32_t t = 0; t < n; t++) {
-            const B e = p.ballot((uint32_t)select == i0 + t);
-            runE = p.run_set(runE, t, e);
-            runK = p.run_set(p.run_set(runK, 2 * t, e), 2 * t + 1, e);
-        }
+        // this witness' bits of the 32 entries (isEq[i0 + t] = [select == i0 + t]; the children's two outputs: two bits per entry), transposed into the wires' runs
+        const uint32_t d = (uint32_t)select - i0;
+        const bool hit = (uint32_t)select >= i0 && d < n;
+        const B runE = p.xpose64(hit ? 1u << d : 0u, 0, n), runK = p.xpose(hit ? (B)3 << (2 * d) : 0, 2 * n);
         p.run_put(n, sb.isEq.w + i0 + ln, sb.isEq.i + i0 + ln, runE);
         p.run_derived(2 * n, sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), runK);      // IsEqual.out / IsZero.out of child i: copies of isEq[i]
         if constexpr (P::is_emit) { if (ln < 2 * n) p.site_c(sb.kids.w + 6 * (i0 + (ln >> 1)) + 3 * (ln & 1), sb.isEq.w + i0 + (ln >> 1)); }

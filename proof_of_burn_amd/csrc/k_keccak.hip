@@ -1,4 +1,5 @@
 #include <stdlib.h>
+#define POB_KECCAK_TU
 #include "keccak_kernels.hpp"
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st) {
     // check: nsponges is the number of PERMUTATIONS (local evaluation, one wavefront per (sponge, block))

@@ -20,7 +20,7 @@
 #define POB_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
 
-__device__ __constant__ u64 KECCAK_RC_DEV[24] = {
+static __device__ __constant__ u64 KECCAK_RC_DEV[24] = {
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
     0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
     0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
@@ -324,10 +324,12 @@ static inline bool keccak_round_alias_table(uint16_t* tab) {
 // Sponge chain (Final/Absorb, keccak.circom:304-349): everything of Keccak(n)/Final(n)/Absorb x n EXCEPT the 24 round
 // blocks and the output selector: Keccak.in, Final.in, Final.s[0..n], Absorb own wires + 17 XorArrays, Keccakf in/out/midRound.
 // (<= 128 VGPRs: the small sponges of a side track must fit the slot a k_rounds wave frees, see g_gen_heavy_small.hip)
-template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) {
+// (every kernel of this file is a BODY -- a device function of the launch arguments and the (item, group) of its wavefront -- plus a __global__ wrapper, so that a launch
+//  can carry the wavefronts of several independent kernels: fused launches, g_*.hip)
+template <bool CHECK> __device__ __forceinline__ void chain_body(const KArgs A, uint32_t bx, uint32_t by) {
     const uint32_t lane = threadIdx.x;
-    const SpongeDesc sp = A.sponges[A.first + blockIdx.x];
-    u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    const SpongeDesc sp = A.sponges[A.first + bx];
+    u64* G = A.bits + (uint64_t)by * A.group_stride;
     u64 st[25], bad = 0;
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = 0;
@@ -367,21 +369,22 @@ template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) 
     if (CHECK) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
-        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w);
+        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[by * 64 + lane], sp.abs_w);
     }
 }
+template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) { chain_body<CHECK>(A, blockIdx.x, blockIdx.y); }
 
 // (round 5 tried TWO wavefronts per (group, sponge), each on the 32-bit half of every word -- 32-bit logic, one ds_bpermute per rotation: the header's 17-block chain
 //  0.433 -> 0.336 ms alone, but the step went from 1.57-1.60 / 1.39 to 1.67 / 1.52-1.53 ms with 4 / 8 in flight: twice the wavefronts storing 4-byte halves of every
 //  8-byte word is twice the store transactions on a write path the round expansion already saturates; profiles/round5_experiments.txt 8.  Not kept.)
 // Constraint evaluation of the same wires, LOCAL per permutation (every relation of Absorb/Final/Keccakf's own wires is
 // between stored wires, so no permutation needs to be recomputed): grid.x = (sponge, block), grid.y = group.
-__global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(4) k_chain_check(KArgs A) {
+__device__ __forceinline__ void chain_check_body(const KArgs A, uint32_t bx, uint32_t by) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t pi = A.first + blockIdx.x;
+    const uint32_t pi = A.first + bx;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t b = A.perm_block[pi];
-    const u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    const u64* G = A.bits + (uint64_t)by * A.group_stride;
     const uint32_t Ab = sp.abs_b + b * ABSORB_BITS, Kf = Ab + AB_KECCAKF;
     u64 bad = 0;
     // (one state word's ~17 loads per iteration: unrolled, all 400 loads are hoisted -- 256 VGPRs, or 556 B of scratch at 128)
@@ -406,14 +409,17 @@ __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(4) k_chain_check(KArgs 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
-    if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
+    if ((bad >> lane) & 1) atomicMin(&A.bad_wire[by * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
 }
+#ifdef POB_KECCAK_TU          // (the non-template kernels are defined in ONE translation unit, k_keccak.hip; the bodies and the template kernels wherever they are used)
+__global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(4) k_chain_check(KArgs A) { chain_check_body(A, blockIdx.x, blockIdx.y); }
+#endif
 
 // Generation: one wavefront per (permutation, KR consecutive rounds, group).  Reads midRound[r0] (written by k_chain), writes the 76 gate-output arrays of
 // each of its rounds (38.9 KB per 64 witnesses and round; rounds 1-3 stored all 102 656 wires of the block: 821 KB).  grid = ((24 / KR) x permutations, groups)
-template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
+template <int KR> __device__ __forceinline__ void rounds_gen_body(const KArgs A, uint32_t x, uint32_t y) {
     static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
-    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
+    const uint32_t lane = threadIdx.x;
     const uint32_t pi = A.first + x / (24 / KR), r0 = x % (24 / KR) * KR;
     const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
     const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
@@ -430,6 +436,7 @@ template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
         io.st += KR_BITS;
     }
 }
+template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) { rounds_gen_body<KR>(A, blockIdx.x, blockIdx.y); }
 
 // Constraint evaluation: one wavefront per (permutation, KR consecutive rounds, group).  It loads midRound[r0] once, then per round the 76 stored
 // gate outputs and the stored midRound[r+1] (101 arrays = 51 712 B per 64 witnesses), checks every XOR / AND gate of the round on stored operands and
@@ -438,34 +445,36 @@ template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) {
 #define KR_CHECK_ARRAYS(kr) (101u * (kr) + 25u)
 #define POB_KCHK_ROUNDS 4
 #define POB_KGEN_ROUNDS 8
-template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) {
-    static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
-    __builtin_amdgcn_s_setprio(3);       // beside the other calculators' kernels its loads issue first (experiment 15: 5-10 % less time in the step, the step itself unchanged)
-    const uint32_t lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
-    const uint32_t pi = A.first + x / (24 / KR), r0 = x % (24 / KR) * KR;
-    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
-    const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
-    const u64* G = A.bits + (uint64_t)y * A.group_stride;
-    CheckIOT<NT, DP> io; io.lane = lane; io.bad = 0;
-    const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0;
-#pragma unroll
-    for (int i = 0; i < 25; i++) io.s[i] = io.ldw(mid + 64 * i + lane);
-    io.st = G + Ab + AB_DIRECT + r0 * KR_BITS;
-#pragma unroll 1
-    for (uint32_t r = r0; r < r0 + KR; r++) {
-        mid += 1600; io.out_ = mid;
-        io.begin_round();
-        round_walk(io, (int)r);
-        io.st += KR_BITS;
-        if (__any(io.bad != 0)) {       // (corrupted vectors only) which witnesses, and the round block the mismatch belongs to
-            u64 bad = io.bad;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
-            if ((bad >> lane) & 1) atomicMin(&A.bad_wire[y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
-            io.bad = 0;
-        }
-    }
-}
+// (the body is a MACRO, not a device function like the other kernels': inlined from a function -- by value, by reference, with or without lifetime markers -- the same
+//  statements compile to 128 VGPRs + 112 spilled where the kernel's own scope gives 127 and no scratch; the ring of prefetched arrays is that sensitive to the allocator)
+#define POB_ROUNDS_CHECK_BODY(A, X_, Y_, NT, KR, DP) do { \
+    static_assert(24 % (KR) == 0, "a chunk does not straddle two permutations"); \
+    __builtin_amdgcn_s_setprio(3);       /* beside the other calculators' kernels its loads issue first (experiment 15: 5-10 % less time in the step, the step itself unchanged) */ \
+    const uint32_t lane = threadIdx.x; \
+    const uint32_t pi = (A).first + (X_) / (24 / (KR)), r0 = (X_) % (24 / (KR)) * (KR); \
+    const SpongeDesc sp = (A).sponges[(A).perm_sponge[pi]]; \
+    const uint32_t Ab = sp.abs_b + (A).perm_block[pi] * ABSORB_BITS; \
+    const u64* G = (A).bits + (uint64_t)(Y_) * (A).group_stride; \
+    CheckIOT<NT, DP> io; io.lane = lane; io.bad = 0; \
+    const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0; \
+    _Pragma("unroll") \
+    for (int i = 0; i < 25; i++) io.s[i] = io.ldw(mid + 64 * i + lane); \
+    io.st = G + Ab + AB_DIRECT + r0 * KR_BITS; \
+    _Pragma("unroll 1") \
+    for (uint32_t r = r0; r < r0 + (KR); r++) { \
+        mid += 1600; io.out_ = mid; \
+        io.begin_round(); \
+        round_walk(io, (int)r); \
+        io.st += KR_BITS; \
+        if (__any(io.bad != 0)) {       /* (corrupted vectors only) which witnesses, and the round block the mismatch belongs to */ \
+            u64 bad = io.bad; \
+            _Pragma("unroll") \
+            for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); } \
+            if ((bad >> lane) & 1) atomicMin(&(A).bad_wire[(Y_) * 64 + lane], sp.abs_w + (A).perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES); \
+            io.bad = 0; \
+        } \
+    } } while (0)
+template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) { POB_ROUNDS_CHECK_BODY(A, blockIdx.x, blockIdx.y, NT, KR, DP); }
 
 // the 64-witness word of the wire at offset o of an Absorb block whose storage starts at BIT rank ab (A = this group's slab); *neg: the
 // wire is the complement of that word
@@ -481,6 +490,7 @@ __device__ __forceinline__ u64 absorb_wire_word(const u64* A, uint32_t ab, uint3
     if (slot == KS_ZERO) return 0;
     return ((KECCAK_RC_DEV[r] >> k) & 1) ? ~0ULL : 0ULL;
 }
+#ifdef POB_KECCAK_TU
 // .wtns expansion of the wires [o0, o0 + count) of ONE Absorb block for witness `sel` of a group: stored wires directly, alias wires through
 // the table (keccak_round_alias_table)
 __global__ void __launch_bounds__(256) k_emit_absorb(const u64* G, uint8_t* out, uint32_t ab, uint32_t o0, uint32_t count, uint32_t sel, const uint16_t* tab) {
@@ -531,3 +541,4 @@ __global__ void __launch_bounds__(256) k_emit_bits_red(const u64* G, uint8_t* ou
         q[0] = make_uint4(v, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
     }
 }
+#endif  // POB_KECCAK_TU

@@ -323,16 +323,15 @@ struct pob_ctx {
     // dependency path): every unit of a level, of whatever track, goes out in one launch per kernel class, then the level's sponges; the round expansion of
     // every sponge is ONE launch at the end (nothing of the generation reads it).
     bool inorder = false;
-    // in-order calculators with the device's ONE streaming stream (pob_set_inorder(h, 2)): the two HBM-saturating Keccak round kernels of every such calculator of the device --
-    // round expansion at the end of the generation, round evaluation -- go onto the pool's streaming stream in the order the host enqueues them, so that no two of them
-    // ever share the memory system; everything else of the batch stays on the caller's stream and runs BESIDE them (no launch of the evaluation's G side reads a round block,
-    // and the sponge-chain evaluation reads what k_chain wrote).  ev_kgen: the round expansion of the last generation is done; ev_k_done: the round evaluation.
-    bool heavy = false, kgen_rec = false; hipEvent_t ev_kgen = nullptr;
-    struct LSeg { uint32_t level, cls, first, count; };
+    // FUSED launches (pob_set_inorder(h, 3), what bench.py runs): independent kernels of the batch share a launch -- the Poseidon blocks with the sponge chain that does not
+    // depend on them, slices of the round expansion with the generation levels behind that chain, the round evaluation with the wide evaluation families, the sponge-chain
+    // evaluation with the narrow families -- so that a calculator's stream is a shorter chain of fuller launches.  gen_plan[0]: one launch per kernel (round 5), [1]: fused.
+    bool fused = false;
+    struct GenLaunch { uint32_t kind, cls, first, count, k_first, k_count; };
+    enum { GL_UNITS = 0, GL_CHAIN = 1, GL_POS_CHAIN = 2, GL_UNITS_ROUNDS = 3, GL_ROUNDS = 4 };
+    std::vector<GenLaunch> gen_plan[2];
+    Seg chk_wide{0, 0, 0, 0};                            // fused evaluation: the units of the four wide families (RANGE, SELROW, LD, SC), one list, longest first
     Seg chk_narrow{0, 0, 0, 0};                          // in-order evaluation: the units of the four narrow families, one launch
-    std::vector<LSeg> lsegs;                            // generation launches in level order (cls: generation class; first / count into `order`)
-    struct LK { uint32_t level, sp_first, sp_count; };
-    std::vector<LK> lksegs;                             // sponge-chain launches per level
     uint32_t nlevels = 0;
     bool generated = false; uint64_t gen_count = 0;
     // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
@@ -576,13 +575,22 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         if (sg.count) h->chk_segs.push_back(sg);
     }
 
-    {   // ---- levels of the in-order schedule.  G units of global stage sid = node (sid, G); its sponges = node (sid, K) one level later.
-        //      A stage depends on the stage before it in its track, on the stage its track forked after, and on the last stage of every track joined before it.
+    // ---- levels of the in-order schedule.  G units of global stage sid = node (sid, G); its sponges = node (sid, K) one level later.
+    //      A stage depends on the stage before it in its track, on the stage its track forked after, and on the last stage of every track joined before it.
+    //      Two plans: [0] one launch per kernel; [1] fused launches (pob_ctx::fused).  In the fused plan of the ProofOfBurn circuit the Poseidon blocks (side track 1, first
+    //      stage) are held back to the level of the main track's first sponge chain -- header and layers, 17 blocks: the longest chain -- and share its launch; the units
+    //      that continue from the blocks' outputs follow one level later than they could (they have the slack: the side tracks join the main track well behind it).
+    for (int variant = 0; variant < 2; variant++) {
+        const bool fused = variant == 1;
         const uint32_t NS = (pl.max_stage / Plan::TRACK_STRIDE + 1) * Plan::TRACK_STRIDE;
         std::vector<int> lvl_end(NS, 0), lvl_g(NS, 0);
         std::vector<char> has_g(NS, 0), has_k(NS, 0);
         for (const pob_ctx::Seg& sg : h->segs) has_g[sg.stage] = 1;
         for (const pob_ctx::KSeg& ks : h->ksegs) has_k[ks.stage] = 1;
+        uint32_t pos_stage = 0xFFFFFFFFu;                 // the stage of the Poseidon blocks to hold back (fused plan, ProofOfBurn: track 1's first stage), chain_stage: the chain they join
+        const uint32_t chain_stage = 2;
+        if (fused && circuit == POB_CIRCUIT_PROOF_OF_BURN && chain_stage < NS && has_k[chain_stage])
+            for (const pob_ctx::Seg& sg : h->segs) if (sg.lds == 4 && sg.stage / Plan::TRACK_STRIDE == 1) pos_stage = sg.stage;
         std::vector<int> track_end(Plan::MAX_TRACKS, 0);
         // tracks in an order in which every fork parent and every joined track is complete when needed: a track is joined only by a lower-numbered track and
         // forked from a lower-numbered one, so resolve iteratively until nothing changes (the graph is tiny)
@@ -593,6 +601,7 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
                     const uint32_t sid = t * Plan::TRACK_STRIDE + s2;
                     if (sid >= NS) break;
                     for (uint32_t u = 1; u < pl.ntracks; u++) if (pl.track_join[u] == sid) cur = std::max(cur, track_end[u]);
+                    if (sid == pos_stage) cur = std::max(cur, lvl_end[chain_stage] - 1);      // (the whole stage moves: its other units are the five range checks of the inputs)
                     if (has_g[sid]) { cur += 1; lvl_g[sid] = cur; }
                     if (has_k[sid]) cur += 1;
                     lvl_end[sid] = cur;
@@ -602,29 +611,69 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         }
         int nlev = 0;
         for (uint32_t sid = 0; sid < NS; sid++) nlev = std::max(nlev, lvl_end[sid]);
-        h->nlevels = (uint32_t)nlev;
+        if (!fused) h->nlevels = (uint32_t)nlev;
+        std::vector<pob_ctx::GenLaunch>& plan = h->gen_plan[variant];
+        std::vector<uint32_t> sp_perm0(pl.sponges.size() + 1, 0);           // first permutation of every sponge in the flattened list
+        for (size_t i2 = 0; i2 < pl.sponges.size(); i2++) sp_perm0[i2 + 1] = sp_perm0[i2] + pl.sponges[i2].n;
         for (int lv = 1; lv <= nlev; lv++) {
             // (one launch per class -- BN254 | SubstringCheck | light -- instead of the merged one: 2.24 ms per step against 2.04 with 4 calculators in flight, 1.83 against 1.72
             //  with 8, two interleaved pairs on one box: profiles/round4_experiments.txt 10)
+            pob_ctx::GenLaunch pos{pob_ctx::GL_UNITS, 4, 0, 0, 0, 0};
             for (uint32_t cls : {4u, 5u, (uint32_t)CLS_ALL}) {     // the lane-spread Poseidon blocks (a level's longest pole) first, gadget mains, then EVERYTHING else in one launch
-                pob_ctx::LSeg ls{(uint32_t)lv, cls, (uint32_t)h->order.size(), 0};
+                pob_ctx::GenLaunch gl{pob_ctx::GL_UNITS, cls, (uint32_t)h->order.size(), 0, 0, 0};
                 for (const pob_ctx::Seg& sg : h->segs) if ((cls == CLS_ALL ? (sg.lds == 0 || sg.lds == 1 || sg.lds == 3) : sg.lds == cls) && has_g[sg.stage] && lvl_g[sg.stage] == lv)
-                    for (uint32_t j = 0; j < sg.count; j++) h->order.push_back(h->order[sg.first + j]);
-                ls.count = (uint32_t)h->order.size() - ls.first;
-                std::stable_sort(h->order.begin() + ls.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
-                if (ls.count) h->lsegs.push_back(ls);
+                    for (uint32_t j2 = 0; j2 < sg.count; j2++) h->order.push_back(h->order[sg.first + j2]);
+                gl.count = (uint32_t)h->order.size() - gl.first;
+                std::stable_sort(h->order.begin() + gl.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
+                if (!gl.count) continue;
+                if (cls == 4 && fused) pos = gl;                   // held for the level's first chain launch (below); launched by itself if the level has none
+                else plan.push_back(gl);
             }
-            for (const pob_ctx::KSeg& ks : h->ksegs) if (lvl_end[ks.stage] == lv) h->lksegs.push_back({(uint32_t)lv, ks.sp_first, ks.sp_count});
+            for (const pob_ctx::KSeg& ks : h->ksegs) if (lvl_end[ks.stage] == lv) {
+                if (pos.count) { plan.push_back({pob_ctx::GL_POS_CHAIN, 4, pos.first, pos.count, ks.sp_first, ks.sp_count}); pos.count = 0; }
+                else plan.push_back({pob_ctx::GL_CHAIN, 0, 0, 0, ks.sp_first, ks.sp_count});
+            }
+            if (pos.count) plan.push_back(pos);
+        }
+        // the round expansion: [0] ONE launch at the end (nothing of the generation reads a round block); [1] the permutations of the LARGEST chain launch ride along with the
+        // unit launches behind it, shared out by the launches' longest unit (the planner's cost estimate: a launch lasts as long as its longest unit), the rest at the end
+        if (h->nperms) {
+            size_t big = plan.size(); uint32_t big_n = 0;
+            if (fused) for (size_t a = 0; a < plan.size(); a++) if (plan[a].kind == pob_ctx::GL_CHAIN || plan[a].kind == pob_ctx::GL_POS_CHAIN) {
+                const uint32_t n = sp_perm0[plan[a].k_first + plan[a].k_count] - sp_perm0[plan[a].k_first];
+                if (n > big_n) { big_n = n; big = a; }
+            }
+            std::vector<size_t> carriers; uint64_t wsum = 0;
+            // (the estimate counts wires written, and beyond a few thousand of them a unit's run stores make it look longer than it is: capped, so that the one launch with the
+            //  burn-address composite does not take nine tenths of the expansion -- measured durations of these launches: 0.12, 0.17, 0.01, 0.05, 0.06, 0.21, 0.03, 0.02 ms)
+            auto weight = [&](size_t a) { return (uint64_t)std::min<uint32_t>(pl.units[h->order[plan[a].first]].cost, 4000u) + 1; };
+            for (size_t a = big + 1; a < plan.size(); a++) if (plan[a].kind == pob_ctx::GL_UNITS && plan[a].cls == CLS_ALL) { carriers.push_back(a); wsum += weight(a); }
+            uint32_t done0 = 0, done1 = 0;                       // the permutations [done0, done1) have been given to carriers
+            if (big_n && !carriers.empty()) {
+                const uint32_t p0 = sp_perm0[plan[big].k_first];
+                uint32_t given = 0; uint64_t wacc = 0;
+                for (size_t c = 0; c < carriers.size(); c++) {
+                    wacc += weight(carriers[c]);
+                    const uint32_t upto = c + 1 == carriers.size() ? big_n : (uint32_t)((uint64_t)big_n * wacc / wsum);
+                    if (upto > given) { pob_ctx::GenLaunch& gl = plan[carriers[c]]; gl.kind = pob_ctx::GL_UNITS_ROUNDS; gl.k_first = p0 + given; gl.k_count = upto - given; given = upto; }
+                }
+                done0 = p0; done1 = p0 + big_n;
+            }
+            if (done0 > 0) plan.push_back({pob_ctx::GL_ROUNDS, 0, 0, 0, 0, done0});
+            if (done1 < h->nperms) plan.push_back({pob_ctx::GL_ROUNDS, 0, 0, 0, done1, h->nperms - done1});
         }
         if (getenv("POB_DEBUG_LEVELS")) {       // (diagnostic: the in-order launch list with the unit kinds of every launch)
-            for (const pob_ctx::LSeg& ls : h->lsegs) {
-                fprintf(stderr, "level %2u class %u: %5u units:", ls.level, ls.cls, ls.count);
-                std::vector<uint32_t> kinds(U_KIND_COUNT, 0);
-                for (uint32_t j = 0; j < ls.count; j++) kinds[pl.units[h->order[ls.first + j]].kind]++;
-                for (uint32_t k = 0; k < U_KIND_COUNT; k++) if (kinds[k]) fprintf(stderr, " %u x kind %u", kinds[k], k);
+            fprintf(stderr, "---- in-order launch plan %d (%s), %d levels\n", variant, fused ? "fused" : "one launch per kernel", nlev);
+            for (const pob_ctx::GenLaunch& gl : plan) {
+                fprintf(stderr, "kind %u class %u: %5u units, sponges / permutations [%u, +%u)", gl.kind, gl.cls, gl.count, gl.k_first, gl.k_count);
+                if (gl.count && gl.kind != pob_ctx::GL_CHAIN && gl.kind != pob_ctx::GL_ROUNDS) {
+                    fprintf(stderr, " longest unit cost %u:", pl.units[h->order[gl.first]].cost);
+                    std::vector<uint32_t> kinds(U_KIND_COUNT, 0);
+                    for (uint32_t j2 = 0; j2 < gl.count; j2++) kinds[pl.units[h->order[gl.first + j2]].kind]++;
+                    for (uint32_t k = 0; k < U_KIND_COUNT; k++) if (kinds[k]) fprintf(stderr, " %u x kind %u", kinds[k], k);
+                }
                 fprintf(stderr, "\n");
             }
-            for (const pob_ctx::LK& lk : h->lksegs) fprintf(stderr, "level %2u sponges: %u (first %u)\n", lk.level, lk.sp_count, lk.sp_first);
         }
     }
 
@@ -636,6 +685,16 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         }
         h->chk_narrow.count = (uint32_t)h->order.size() - h->chk_narrow.first;
         std::stable_sort(h->order.begin() + h->chk_narrow.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
+    }
+
+    {   // fused evaluation: the four wide families as ONE list (they share a launch with the round evaluation, g_check_wide.hip), longest unit first
+        h->chk_wide = pob_ctx::Seg{0, 0, (uint32_t)h->order.size(), 0};
+        for (uint32_t u = 0; u < pl.units.size(); u++) {
+            const uint32_t f = fam_of(pl.units[u].kind);
+            if ((pl.units[u].flags & UNIT_CHECK) && (f == F_RANGE || f == F_SELROW || f == F_LD || f == F_SC)) h->order.push_back(u);
+        }
+        h->chk_wide.count = (uint32_t)h->order.size() - h->chk_wide.first;
+        std::stable_sort(h->order.begin() + h->chk_wide.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
     }
 
     HIPC(hipSetDevice(device));
@@ -673,7 +732,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
     HIPC(hipEventCreateWithFlags(&h->ev_rounds_fork, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_g_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_k_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_gen_done, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_check_done, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&h->ev_kgen, hipEventDisableTiming));
     for (pob_ctx::KSeg& ks : h->ksegs) HIPC(hipEventCreateWithFlags(&ks.ev_done, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (uint32_t t = 1; t < Plan::MAX_TRACKS; t++) {        // (streams for every track slot: the evaluation uses tracks 1 and 2's whatever the circuit)
@@ -779,7 +837,6 @@ void pob_close(pob_handle h) {
     if (h->ev_rounds_fork) hipEventDestroy(h->ev_rounds_fork);
     if (h->ev_g_done) hipEventDestroy(h->ev_g_done);
     if (h->ev_k_done) hipEventDestroy(h->ev_k_done);
-    if (h->ev_kgen) hipEventDestroy(h->ev_kgen);
     for (pob_ctx::KSeg& ks : h->ksegs) if (ks.ev_done) hipEventDestroy(ks.ev_done);
     if (h->stream) hipStreamDestroy(h->stream);
     for (pob_ctx::Track& T : h->tracks) {
@@ -888,26 +945,22 @@ int pob_generate(pob_handle h, void* stream_) {
     if (h->chk_ordered && h->chk_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_check_done, 0));      // the previous batch's evaluation still reads the vector this generation overwrites
     if (h->gen_ordered && h->gen_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_gen_done, 0));        // ... and a previous generation on another stream still writes it
     h->chk_ordered = false;
-    if (h->kgen_rec) { HIPC(hipStreamWaitEvent(st, h->ev_kgen, 0)); h->kgen_rec = false; }             // (streaming-stream mode) ... and its round expansion reads the states the sponge chains overwrite
     h->rec_slot ^= 1;                                   // this batch's records go to the other pinned buffer: the previous batch's stay readable
     if (h->inorder) {
         GArgs A = gargs(h);
         KArgs K = kargs(h);
         launch_inputs(h, false, G, st);
-        size_t ki = 0;
-        for (uint32_t lv = 1; lv <= h->nlevels; lv++) {
-            for (const pob_ctx::LSeg& ls : h->lsegs) if (ls.level == lv) { A.first = ls.first; launch_g_gen(A, ls.cls, ls.count, G, st); }
-            for (; ki < h->lksegs.size() && h->lksegs[ki].level == lv; ki++) { K.first = h->lksegs[ki].sp_first; launch_k_chain(K, false, h->lksegs[ki].sp_count, G, st); }
+        for (const pob_ctx::GenLaunch& gl : h->gen_plan[h->fused ? 1 : 0]) {
+            A.first = gl.first; K.first = gl.k_first;
+            switch (gl.kind) {
+            case pob_ctx::GL_UNITS: launch_g_gen(A, gl.cls, gl.count, G, st); break;
+            case pob_ctx::GL_CHAIN: launch_k_chain(K, false, gl.k_count, G, st); break;
+            case pob_ctx::GL_POS_CHAIN: launch_pos_chain(A, K, gl.count, gl.k_count, G, st); break;
+            case pob_ctx::GL_UNITS_ROUNDS: launch_gen_level(A, K, gl.count, gl.k_count, G, st); break;
+            default: launch_k_rounds(K, false, gl.k_count, G, st); break;
+            }
         }
         HIPC(hipEventRecord(h->ev_g_done, st));
-        if (h->nperms) {
-            K.first = 0;
-            if (h->heavy && h->stream_k != st) {      // the round expansion leaves the calculator's stream: behind the G side, in order with every other calculator's round kernels
-                HIPC(hipStreamWaitEvent(h->stream_k, h->ev_g_done, 0));
-                launch_k_rounds(K, false, h->nperms, G, h->stream_k);
-                HIPC(hipEventRecord(h->ev_kgen, h->stream_k)); h->kgen_rec = true;
-            } else launch_k_rounds(K, false, h->nperms, G, st);
-        }
         HIPC(hipGetLastError());
         { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_gen_done, st)); h->gen_done_rec = true; h->gen_stream = st; h->gen_ordered = true;
@@ -1015,30 +1068,37 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // one stream: the Keccak round evaluation (the batch's one bandwidth-bound kernel) first, then the sponge chains, the inputs and the eight families
         // (the round evaluation on a high-priority stream of the device, forked and joined per batch, was measured: 4 / 6 / 8 / 12 calculators in flight
         //  2.39 / 2.04 / 1.91 / 2.14 ms per step against 2.19 / 2.09 / 1.87 / 2.07 here, the kernel 0.49-0.74 against 0.42-0.80 ms: nothing; removed)
-        const bool on_k = h->heavy && h->kgen_rec && h->stream_k != st && !h->plan.sponges.empty();      // streaming-stream mode: the round evaluation follows this batch's round expansion there
-        if (!h->plan.sponges.empty()) {
-            KArgs K = kargs(h); K.first = 0;
-            hipStream_t sk = on_k ? h->stream_k : st;
-            if (!on_k && h->kgen_rec) { HIPC(hipStreamWaitEvent(st, h->ev_kgen, 0)); h->kgen_rec = false; }
-            if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }
-            launch_k_rounds(K, true, h->nperms, G, sk);
-            if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
-            if (on_k) HIPC(hipEventRecord(h->ev_k_done, sk));
-            launch_k_chain(K, true, h->nperms, G, st);
+        KArgs K = kargs(h); K.first = 0;
+        const bool sponges = !h->plan.sponges.empty();
+        if (h->fused) {
+            // two launches: the round evaluation interleaved with the wide families' units | the narrow families' units with the sponge-chain evaluation behind them
+            if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
+            A.first = h->chk_wide.first;
+            if (h->chk_wide.count || sponges) launch_check_wide(A, K, h->chk_wide.count, sponges ? h->nperms : 0, G, st);
+            if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
+            launch_inputs(h, true, G, st);
+            A.first = h->chk_narrow.first;
+            if (h->chk_narrow.count || sponges) launch_check_narrow_chain(A, K, h->chk_narrow.count, sponges ? h->nperms : 0, G, st);
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == F_GM) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        } else {
+            if (sponges) {
+                if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
+                launch_k_rounds(K, true, h->nperms, G, st);
+                if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
+                launch_k_chain(K, true, h->nperms, G, st);
+            }
+            launch_inputs(h, true, G, st);
+            // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
+            //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
+            if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         }
-        launch_inputs(h, true, G, st);
-        // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
-        //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
-        if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
-        for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
-        if (on_k) { HIPC(hipStreamWaitEvent(st, h->ev_k_done, 0)); h->kgen_rec = false; }      // the records carry the round evaluation's verdict too (and behind this point the round expansion is done as well)
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));
         HIPC(hipGetLastError());
         return POB_OK;
     }
-    if (h->kgen_rec) { HIPC(hipStreamWaitEvent(st, h->ev_kgen, 0)); h->kgen_rec = false; }
     static const uint32_t side_plan[2][5] = {{F_N2B, F_SC, F_LD, F_RANGE, F_GM}, {F_RL, F_POS, F_MISC, F_SELROW, F_COUNT}};      // (F_GM: gadget-level mains only; F_COUNT: no family)
     // side streams: the generation's (idle during a lone handle's evaluation); in pipeline mode -- the partner generates meanwhile -- the
     // pool's two evaluation streams
@@ -1095,7 +1155,7 @@ int pob_set_partner(pob_handle h, pob_handle partner) {
 int pob_set_inorder(pob_handle h, int on) {
     if (!h) return POB_E_ARG;
     if (on && h->partner) { h->err = "an in-order calculator has no partner: unlink first (pob_set_partner(h, NULL))"; return POB_E_STATE; }
-    h->inorder = on != 0; h->heavy = on == 2;
+    h->inorder = on != 0; h->fused = (on & 2) != 0;
     return POB_OK;
 }
 
@@ -1104,7 +1164,6 @@ int pob_sync(pob_handle h) {
     HIPC(hipSetDevice(h->device));
     // this handle's work only: its last generation / evaluation (the side streams are joined into those events) and its copies
     if (h->gen_done_rec) HIPC(hipEventSynchronize(h->ev_gen_done));
-    if (h->kgen_rec) HIPC(hipEventSynchronize(h->ev_kgen));
     if (h->check_done_rec && h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
     HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;
@@ -1260,7 +1319,7 @@ static int emit_start(pob_ctx* h, uint32_t idx, uint64_t window_wires) {
     pob_ctx::Emit& E = h->em;
     const int NS = pob_ctx::Emit::NSLOT;
     // this handle's work only (a partner handle may be busy): the generation of the batch
-    HIPC(hipEventSynchronize(h->ev_gen_done)); if (h->kgen_rec) HIPC(hipEventSynchronize(h->ev_kgen));
+    HIPC(hipEventSynchronize(h->ev_gen_done));
     if (h->evaluated) HIPC(hipEventSynchronize(h->ev_check_done));
     {   // like the reference binary, no witness is written for an input that failed an assert (tests/test.py:65-68)
         int rc = emit_statuses(h); if (rc) return rc;

@@ -123,6 +123,7 @@ struct CountP : PolBase {
     HD B ballot(bool) { return 0; }
     HD bool bit(B) { return false; }
     HD void require(B, uint32_t) {}
+    HD void require_lane(bool, uint32_t) {}              // the assert on this lane's own predicate (no ballot)
     HD F kconst(uint32_t) { return fr_zero(); }   // Poseidon table entry (Montgomery)
     HD F k256(uint32_t) { return fr_zero(); }     // 256^i (Montgomery)
     HD F k256r(uint32_t) { return fr_zero(); }    // 256^i * R (so that fr_mul(plain small integer, k256r(i)) is Montgomery(small * 256^i))
@@ -135,6 +136,7 @@ struct CountP : PolBase {
     HD void run_derived(uint32_t, uint32_t, B) {}      // n DERIVED BIT wires as a lane-distributed run (lane k: wire index, that wire's 64-witness mask): the emitter only
     HD B run_bcast(B, uint32_t) { return 0; }
     HD B xpose64(uint32_t, uint32_t, uint32_t) { return 0; }
+    HD B xpose(B, uint32_t) { return 0; }
     HD B run_set(B run, uint32_t, B) { return run; }
     HD B run_perm(B run, uint32_t) { return run; }
 };
@@ -356,6 +358,7 @@ struct DevPol : PolBase {
         const B r = ((B)hi << 32) | lo;
         return m.lane < n ? r : 0;
     }
+    __device__ __forceinline__ B xpose(B word, uint32_t n) { return xpose64((uint32_t)word, (uint32_t)(word >> 32), n); }      // bit t of this witness' word -> lane t's 64-witness mask
     __device__ __forceinline__ B get(BitRef r) { return ld(r); }
     __device__ __forceinline__ S get(SmRef r) { return ld(r); }
     // SM wire base + k with a PER-WITNESS k (generation shortcuts that index by a witness value)
@@ -395,6 +398,7 @@ struct GenP : DevPol {
     __device__ __forceinline__ F hint(FrRef r, const F& v) { st(r, v); return v; }
     __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
+    __device__ __forceinline__ void require_lane(bool ok, uint32_t code) { if (!ok && status == 0) status = code; }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
         pob_v2i q; q.x = (int)(uint32_t)x; q.y = (int)(uint32_t)(x >> 32);
         __builtin_amdgcn_raw_buffer_store_b64(q, m.rs_bits, (int)run_off(n, i), 0, 0);
@@ -437,6 +441,7 @@ struct CheckP : DevPol {
     __device__ __forceinline__ F hint(FrRef r, const F&) { return ld(r); }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
+    __device__ __forceinline__ void require_lane(bool ok, uint32_t code) { if (!ok && status == 0) status = code; }
     // lane-distributed runs: a run's difference is folded into `rdiff` when the NEXT run's load has been issued (one load is
     // always in flight).  Only if a unit ends with rdiff != 0 (corrupted vector) it is replayed with `attribute` set, which
     // resolves every run on the spot and finds the lowest mismatching wire of each witness.
@@ -534,6 +539,7 @@ struct EmitP : DevPol {
     }
     __device__ __forceinline__ void raw_put(FrRef, const F&) {}
     __device__ __forceinline__ void require(B, uint32_t) {}
+    __device__ __forceinline__ void require_lane(bool, uint32_t) {}
     // derived BIT wires: lane k < n writes wire w (its own) from the mask x it holds
     __device__ __forceinline__ void run_derived(uint32_t n, uint32_t w, B x) { if (m.lane < n) { Fr c = {{(uint32_t)((x >> sel) & 1), 0, 0, 0, 0, 0, 0, 0}}; w32(w, c); } }
     __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B) {

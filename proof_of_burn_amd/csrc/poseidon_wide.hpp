@@ -153,11 +153,11 @@ template <int T> __device__ __forceinline__ void posw_run(const GArgs& A, const 
     }
 }
 
-// grid = (8 * nunits, ngroups): blockIdx.x = 8 * unit + witness slice
-__global__ void __launch_bounds__(64, 1) k_poseidon_wide(GArgs A) {
+// bx = 8 * unit + witness slice (unit = position in the launch's list), g = group
+__device__ __forceinline__ void poswide_body(const GArgs& A, uint32_t bx, uint32_t g) {
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = threadIdx.x, g = blockIdx.y;
-    const UnitDesc* dp = A.units + POB_UNI(A.order[A.first + (blockIdx.x >> 3)]);
+    const uint32_t lane = threadIdx.x;
+    const UnitDesc* dp = A.units + POB_UNI(A.order[A.first + (bx >> 3)]);
     const int T = (int)POB_UNI(dp->a[0]);
     const PosWDesc d = {POB_UNI(dp->cur.f), POB_UNI(dp->a[1]), POB_UNI(dp->a[2]), POB_UNI(dp->a[3]), POB_UNI(dp->a[4]), POB_UNI(dp->a[5]), POB_UNI(dp->a[6])};
     const PosOff k = pos_off(T);
@@ -168,10 +168,12 @@ __global__ void __launch_bounds__(64, 1) k_poseidon_wide(GArgs A) {
     uint32_t* frp = A.fr + (uint64_t)g * A.fr_stride;
     const uint64_t nf = A.fr_stride * 4;
     W.rs = __builtin_amdgcn_make_buffer_rsrc(frp, 0, (int)(nf > 0xFFFFF000ull ? 0xFFFFF000ull : nf), 0x00020000);
-    W.slot4 = (8 * (blockIdx.x & 7u) + (lane >> 3)) * 4;
+    W.slot4 = (8 * (bx & 7u) + (lane >> 3)) * 4;
     W.act = (lane & 7u) < (uint32_t)T;
     W.ktab = g_lds; W.kbase = k.C;
     if (T == 3) posw_run<3>(A, d, W, lane); else if (T == 4) posw_run<4>(A, d, W, lane); else posw_run<5>(A, d, W, lane);
 }
+// grid = (8 * nunits, ngroups)
+__global__ void __launch_bounds__(64, 1) k_poseidon_wide(GArgs A) { poswide_body(A, blockIdx.x, blockIdx.y); }
 static_assert(POS_TABLE_LEN - POS_OFF_C_5 >= POS_OFF_C_5 - POS_OFF_C_4 && POS_TABLE_LEN - POS_OFF_C_5 >= POS_OFF_C_4 - POS_OFF_C_3, "the T = 5 constants are the largest set");
 #define POSW_LDS_BYTES ((POS_TABLE_LEN - POS_OFF_C_5) * 32u)

@@ -748,8 +748,8 @@ class WitnessCalculator:
 
     def set_inorder(self, on=True):
         """every launch of this calculator on the caller's stream, in dependency order, no side streams (pob_set_inorder): for jobs that keep several calculators in flight.
-        on = 2: the same, but the two HBM-saturating Keccak round kernels (expansion, evaluation) of every such calculator of the device share the device's one streaming stream,
-        in the order they are enqueued: they never run beside each other, the rest of each batch runs beside them"""
+        on = 3: the same with FUSED launches -- independent kernels of the batch share a launch (the Poseidon blocks with the header's sponge chain, slices of the round
+        expansion with the levels behind it, the round evaluation with the wide evaluation families, the chain evaluation with the narrow ones)"""
         self._ck(self.lib.pob_set_inorder(self.h, int(on)))
 
     def emit_selfcheck(self, enable: bool = True):

@@ -368,7 +368,7 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
     for (label, inp), q in zip(cases, pos):
         inputs[q] = inp
     calc = pkg.WitnessCalculator(PROD, max_batch=n)
-    calc.set_inorder(True)
+    calc.set_inorder(3)                                          # in order, fused launches: the schedule bench.py runs
     res = calc.calculate(inputs, check=True)
     tracks = pkg.WitnessCalculator(PROD, max_batch=n)
     res_t = tracks.calculate(inputs, check=True)
@@ -669,8 +669,8 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
     ref.close()
     calcs = [pkg.WitnessCalculator(PROD, max_batch=n) for _ in range(4)]
     streams = [torch.cuda.Stream() for _ in calcs]
-    for c in calcs:
-        c.set_inorder(True)
+    for k, c in enumerate(calcs):
+        c.set_inorder(3 if k % 2 else 1)         # (1: one launch per kernel; 3: fused launches -- what bench.py runs: calculators 1 and 3, one of them emits the payload below)
     for rnd in range(2):
         for k, c in enumerate(calcs):
             c.upload(batches[(k + rnd) % 3].inputs)
@@ -680,9 +680,14 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
             got = [(r.status, r.outputs, r.check_status, r.bad_wire) for r in c.results(with_check=True)]
             assert got == want[(k + rnd) % 3], (rnd, k)
     ora = O.run(PROD, batches[0].inputs[n - 1])
-    idx0 = next(k for k in range(4) if (k + 1) % 3 == 0)         # the calculator that holds batch 0 after round 1
+    idx0 = next(k for k in range(4) if (k + 1) % 3 == 0)         # the calculator that holds batch 0 after round 1 (k = 2: one launch per kernel)
     gpu = calcs[idx0].witness_payload(n - 1)
     assert np.array_equal(gpu, ora.witness_numpy()), f"first differing wire {_first_diff(gpu, ora.witness_numpy())}"
+    # ... and the same batch generated by a calculator with FUSED launches: every wire of the same witness again
+    calcs[1].upload(batches[0].inputs); calcs[1].generate(streams[1].cuda_stream); calcs[1].constraint_check(streams[1].cuda_stream)
+    assert [(r.status, r.outputs, r.check_status, r.bad_wire) for r in calcs[1].results(with_check=True)] == want[0]
+    gpu = calcs[1].witness_payload(n - 1)
+    assert np.array_equal(gpu, ora.witness_numpy()), f"fused launches: first differing wire {_first_diff(gpu, ora.witness_numpy())}"
     for c in calcs:
         c.close()
 
@@ -701,7 +706,7 @@ def test_generation_and_evaluation_on_different_streams(pkg):
     ref.close()
     assert want[1][70][0] != 0 and all(w[0] == 0 and w[2] == 0 for w in want[0])
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    for inorder in (False, True):
+    for inorder in (0, 1, 3):
         c = pkg.WitnessCalculator(PROD, max_batch=n)
         c.set_inorder(inorder)
         for rnd in range(2):

@@ -471,10 +471,12 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
     of the stage graph in one launch per kernel class).  The shim executes launches one after the other in enqueue order -- which is exactly what an in-order stream
     does -- so a level that ran ahead of something it reads would show here: reference outputs, evaluator clean, payload == the oracle's, for Spend(31), the fixture
     instantiation (all tracks) and a Keccak gadget main"""
-    for main, suite in (("Spend(31)", "test_spend"), (POB_FIX, "test_proof_of_burn")):
+    for main, suite, mode in (("Spend(31)", "test_spend", 1), ("Spend(31)", "test_spend", 3), (POB_FIX, "test_proof_of_burn", 1), (POB_FIX, "test_proof_of_burn", 3)):
+        # mode 3: FUSED launches (the Poseidon blocks with the header's sponge chain, slices of the round expansion with the levels behind it, the round evaluation interleaved
+        # with the wide evaluation families, the chain evaluation behind the narrow ones): the same wires from fewer, fuller launches
         s = _suite(suite)
         calc = pkg.WitnessCalculator(main, max_batch=8)
-        calc.set_inorder(True)
+        calc.set_inorder(mode)
         for rnd in range(2):                                # (twice: the second batch reuses every buffer)
             res = calc.calculate([c["input"] for c in s["cases"]], check=True)
             assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
@@ -498,8 +500,10 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
     from tests import gadget_cases as GC
     by_name = {s["main"]: s for s in GC.gadget_suites()}
     s = by_name["PublicCommitment(2)"] if "PublicCommitment(2)" in by_name else next(v for k, v in by_name.items() if k.startswith("PublicCommitment"))
-    calc = pkg.WitnessCalculator(s["main"], max_batch=len(s["cases"]))
-    calc.set_inorder(True)
-    res = calc.calculate([c["input"] for c in s["cases"]], check=True)
-    assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
-    calc.close()
+    for mode in (1, 3):
+        calc = pkg.WitnessCalculator(s["main"], max_batch=len(s["cases"]))
+        calc.set_inorder(mode)
+        res = calc.calculate([c["input"] for c in s["cases"]], check=True)
+        assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
+        assert all(r.check_status == 0 and r.bad_wire is None for r in res if r.ok)
+        calc.close()

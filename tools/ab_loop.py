@@ -19,7 +19,7 @@ import bench as BM
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--label", default="new")
-    ap.add_argument("--points", default="4:0,8:0,12:0", help="depth:streaming_stream, ...")
+    ap.add_argument("--points", default="4:0,8:0,12:0", help="depth:fused, ...")
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--depth", type=int, default=10)
@@ -36,7 +36,7 @@ def main():
     points = [tuple(int(x) for x in p.split(":")) for p in a.points.split(",")]
     for r in range(a.rounds):
         for depth, ss in points:
-            args.streaming_stream = ss
+            args.fused = ss
             lp = BM.ServiceLoop(job, BM.MAIN, depth, True, bool(ss))
             if pinned is None:
                 pinned = [PinnedInputs(lp.calcs[0], B) for _ in batches]
@@ -63,7 +63,7 @@ def main():
                 t_gen = span(lambda: c0.generate(st0.cuda_stream))
                 fams = {f: round(c0.time_kernel(300 + f, iters=5, stream=st0.cuda_stream), 4) for f in range(8)}
                 extra = f" | alone: evaluation {t_eval:.3f} ms generation {t_gen:.3f} ms K_CHK {c0.time_kernel(1, iters=5, stream=st0.cuda_stream):.4f} K_GEN {c0.time_kernel(0, iters=5, stream=st0.cuda_stream):.4f} families {fams}"
-            print(f"round {r} {a.label} depth {depth} ss {ss}: {s / a.steps * 1e3:.3f} ms/step  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
+            print(f"round {r} {a.label} depth {depth} fused {ss}: {s / a.steps * 1e3:.3f} ms/step  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
             lp.close()
             del lp
     for pin in pinned:

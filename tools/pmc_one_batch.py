@@ -11,8 +11,8 @@ from proof_of_burn_amd import WitnessCalculator, inputs as gen  # noqa: E402
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
 batch = gen.synthetic_batch(1024, depth=10, seed=0xB0B, distinct_keys=16)
 calc = WitnessCalculator(MAIN, max_batch=1024)
-if os.environ.get("POB_PMC_INORDER", "1") == "1":
-    calc.set_inorder(True)          # the schedule bench.py runs (one launch per level, merged narrow evaluation kernel)
+if os.environ.get("POB_PMC_INORDER", "3") != "0":
+    calc.set_inorder(int(os.environ.get("POB_PMC_INORDER", "3")))          # 3: the schedule bench.py runs (in order, fused launches); 1: one launch per kernel
 for _ in range(2):
     res = calc.calculate(batch.inputs, check=True)
     assert all(r.ok and r.check_status == 0 for r in res)

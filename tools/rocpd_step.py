@@ -7,6 +7,9 @@ import sys
 
 
 def short(n):
+    for key, lab in (('k_gen_level', 'gGEN+K_GEN'), ('k_pos_chain', 'pos+chainG'), ('k_check_wide', 'K_CHK+wide'), ('k_check_narrow', 'narrow+chainC')):      # fused launches (round 6)
+        if key in n:
+            return lab
     if 'k_rounds' in n:
         return 'K_CHK' if 'k_rounds_check' in n else 'K_GEN'
     if 'g_units' in n:
