@@ -672,6 +672,10 @@ def main():
     expect = [_expect(np, bt) for bt in batches]
     loop.set_inputs(pinned, expect)
 
+    # ---- setup: every calculator of the loop passes one batch (a calculator's first pass touches its buffers for the first time and creates its stream's hardware queue; with W
+    #      warm-up steps fewer than calculators in flight some of them would do that inside the timed region)
+    loop.run(NC)
+    job.fence()
     # ---- the timed region: W untimed warm-up steps, fence, K timed steps, fence
     if args.warmup:
         loop.run(args.warmup)
@@ -769,7 +773,8 @@ def main():
                            "canonical_bytes_per_witness": int(info.n_witness) * 32,
                            "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
                                                                                          + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused), "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
+                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused),
+                           "setup": f"before the {args.warmup} warm-up steps every one of the {NC} calculators has passed one batch (first touch of its buffers, its stream's hardware queue)", "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
                            "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                            "rccl_ranks": ranks["rccl_ranks"], "dist_backend": job.backend,
                            "input_synthesis_s_per_batch": round(t_synth, 2), "host_ms_per_step": host_ms,

@@ -146,10 +146,8 @@ int pob_set_partner(pob_handle h, pob_handle partner);
  * on = 1 -- IN ORDER: every launch of the calculator goes to the caller's stream, in dependency order, with no side stream and no event (a cross-stream hand-over
  * costs 0.1-0.3 ms on this runtime, a dependent kernel boundary on one stream 1.5 us): the units of every track that are ready at the same depth of the stage graph
  * leave in ONE launch.  A batch takes longer by itself; a job that keeps several calculators in flight, each on a stream of its own, fills the machine with them.
- * on = 3 -- IN ORDER with FUSED launches (what bench.py runs): independent kernels of the batch share a launch -- the lane-spread Poseidon blocks with the sponge chain
- * that does not depend on them, slices of the Keccak round expansion with the generation levels behind that chain, the Keccak round evaluation interleaved with the
- * wide evaluation families, the sponge-chain evaluation behind the narrow families: the same wavefronts in 16 + 3 launches instead of 18 + 8, the calculator's
- * stream a third shorter.  Same wires, same records.                                                                                      */
+ * on = 3 -- IN ORDER with the FUSED launch (what bench.py runs): the lane-spread Poseidon blocks share a launch with the sponge chain that does not depend on them
+ * (header and layers); the units that continue from the blocks' outputs follow one level later.  A lone batch's launches: 3.03 -> 2.61 ms; same wires, same records. */
 int pob_set_inorder(pob_handle h, int on);
 
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.

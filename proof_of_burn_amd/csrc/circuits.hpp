@@ -51,6 +51,8 @@ enum UnitKind : uint32_t {
     U_POS_WIDE,
     // gadget-level mains (gadget_mains.hpp): a0 = template, a1..a4 = its parameters | the packed inputs of a main planned from split units
     U_GM, U_GM_INPUT,
+    U_PC_COPY,           // PublicCommitment: the 32 bytes of input a0 through every copy the template makes of them (in[][], AssertByteString, Flatten in / out, Fit in / out, the Keccak block); a0 = N: the zero padding
+    U_LD_COPY,           // LeafDetector a0: layer[a1 .. a2) <== the source bytes (the head's 544-byte copy as range units: in the head it was 68 dependent batches of loads)
     U_KIND_COUNT
 };
 enum : uint32_t { UNIT_GEN = 1, UNIT_CHECK = 2, UNIT_EMIT = 4 };      // UnitDesc.flags: generation / constraint evaluation / .wtns emission
@@ -64,7 +66,7 @@ enum Fam : uint32_t { F_MISC = 0, F_RANGE, F_SELROW, F_LD, F_RL, F_SC, F_POS, F_
 HD constexpr uint32_t fam_of(uint32_t k) {
     return (k == U_KB_RANGE || k == U_ABS_RANGE) ? F_RANGE
          : k == U_KB_SELROW ? F_SELROW
-         : (k == U_LD_HEAD || k == U_LD_SELR || k == U_LD_TAIL || k == U_POB_LASTLAYER_RANGE || k == U_SC_SUMS) ? F_LD
+         : (k == U_LD_HEAD || k == U_LD_SELR || k == U_LD_TAIL || k == U_LD_COPY || k == U_POB_LASTLAYER_RANGE || k == U_SC_SUMS) ? F_LD
          : (k == U_RL_A || k == U_RL_SLROW || k == U_RL_ACC_B || k == U_RL_ACC_C || k == U_RL_B || k == CK_SR_COLS || k == CK_SL_ROWS || k == CK_RL_B2 || k == CK_RL_B3 || k == CK_CAT) ? F_RL
          : (k == U_POB_LAYER_POST || k == U_SC_M || k == U_SC_RANGE) ? F_SC
          : (k == U_POB_POSEIDONS || k == U_BAH_PRE || k == U_SP_HEAD || k == CK_POS_SEG || k == U_POS_WIDE) ? F_POS
@@ -159,7 +161,7 @@ struct CircuitLayout {
     PobMain pm; SpendMain sm;
     Fr prefix[3];                 // POSEIDON_PREFIX + 0/1/2 (constants.circom:3-14), Montgomery
     struct { SmRef nibbles; FrRef in; SmRef addressBytes, block, hash; uint32_t kb; } bah;
-    struct { FrRef out; SmRef in, flat, block, hash, reduced; uint32_t kb; int N, nb; } pc;
+    struct { FrRef out; SmRef in, flat, block, hash, reduced; uint32_t kb; int N, nb; SmRef fl_o, fl_i, fit_o, fit_i; Cur c_abs; } pc;      // (fl_* / fit_*: Flatten's and Fit's own [out | in]; c_abs: the first AssertByteString(32) block)
     struct { FrRef in; SmRef mzb, keyBytes, raBytes, becBytes, eip, hin, block, keccak; BitRef sbz; uint32_t kb; } pw;
     struct { SmRef out; uint32_t arr_w, sel_w, T_w; Cur c_sel0; } ll;    // SelectorArray1D(L, 136*NB) of :142 (arrays / select / arraysT: derived wires)
     RlRefs rl;
@@ -398,6 +400,16 @@ template <class P, class MR> GD void rl_b_concat(P& p, const RlRefs& R, const MR
     p.put(M.leafLen, p.put(R.ol, cl));
 }
 
+// PublicCommitment(N) between its own wires (declared by the planner) and KeccakBytes: AssertByteString(32) x N, Flatten(N, 32) [out | in], Fit(32 N, 136 nb) [out | in] -- the
+// places of their wires (the bytes are written by U_PC_COPY units)
+template <class P> GD void L_pc_declare(P& p, CircuitLayout& L, int N) {
+    const Cur c_abs = p.cur;
+    for (int j = 0; j < N; j++) { p.dvs(32); p.cur = cur_add(p.cur, FP_ABITS8, 32); }
+    const SmRef fl_o = p.sms(32 * N), fl_i = p.sms(32 * N);
+    const SmRef fit_o = p.sms(136 * L.pc.nb), fit_i = p.sms(32 * N);
+    if (P::is_count) { L.pc.c_abs = c_abs; L.pc.fl_o = fl_o; L.pc.fl_i = fl_i; L.pc.fit_o = fit_o; L.pc.fit_i = fit_i; }
+}
+
 // ---------------------------------------------------------------------------- unit bodies
 // ONE switch over every unit kind; a kernel instantiates it with the MASK of the families it serves and the other cases
 // compile to nothing.  LIGHT families touch only BIT/SM wires (few VGPRs -> 8 waves/SIMD, which is what hides the load latency of
@@ -448,23 +460,47 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
     } break;
     UCASE(U_KB_SELROW) { kb_selrow(p, L.kbs[d.a[0]], d.a[1], d.a[2], d.a[3]); } break;
     UCASE(U_KB_POST) { kb_post(p, L.kbs[d.a[0]]); } break;
-    UCASE(U_PC_PRE) {             // PublicCommitment(N) public_commitment.circom:18-36 up to the sponge
+    UCASE(U_PC_PRE) {             // PublicCommitment(N) public_commitment.circom:18-36 up to the sponge: the wires' places and KeccakBytes' head; the BYTES travel in U_PC_COPY units
         const int N = L.pc.N;
-        for (int j = 0; j < N; j++) {
+        L_pc_declare(p, L, N);
+        KBRefs r = L.kbs[L.pc.kb];
+        kb_head(p, L.pc.nb, (S)(32 * N), r);
+        if (P::is_count) L.kbs[L.pc.kb] = r;
+    } break;
+    UCASE(U_PC_COPY) {            // the 32 bytes of input a0: in[a0][] <== the caller's bytes, AssertByteString(32), Flatten [out | in], flat, Fit [out | in], block -- seven copies of the same
+                                 // values, requested together (as one serial unit the head was 370 dependent memory round trips: 0.17 ms, a generation level of its own)
+        const uint32_t N = (uint32_t)L.pc.N, j = d.a[0], nblk = 136u * (uint32_t)L.pc.nb;
+        if (j < N) {
             SmRef src;
             if (L.circuit == 2) src = L.pc.in + 32 * j;      // PublicCommitment(N) as the main: in[][] holds the packed inputs already (U_GM_INPUT)
             else if (L.circuit == 0) src = j == 0 ? M.blockRoot : j == 1 ? M.nullifierBytes : j == 2 ? M.remainingCoinBytes : j == 3 ? M.revealAmountBytes : j == 4 ? M.burnExtraCommitmentBytes : M.extraCommitmentBytes;
             else src = j == 0 ? L.sm.coinBytes : j == 1 ? L.sm.withdrawnBalanceBytes : j == 2 ? L.sm.remainingCoinBytes : L.sm.extraCommitmentBytes;
-            for (int i = 0; i < 32; i++) p.put(L.pc.in + (32 * j + i), p.get(src + i));
+            auto dst_of = [&](uint32_t a) -> SmRef {       // (a uniform select chain: an array of references indexed by the loop counter would live in scratch)
+                const SmRef b = a == 0 ? L.pc.in : a == 1 ? L.pc.fl_i : a == 2 ? L.pc.fl_o : a == 3 ? L.pc.flat : a == 4 ? L.pc.fit_i : a == 5 ? L.pc.fit_o : L.pc.block;
+                return b + 32 * j;
+            };
+#pragma unroll 1
+            for (uint32_t h2 = 0; h2 < 2; h2++) {
+                S v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = p.get(src + (16 * h2 + q));
+#pragma unroll 1
+                for (uint32_t a = 0; a < 7; a++) {
+                    const SmRef dst = dst_of(a);
+                    SmRef rr[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) rr[q] = dst + (16 * h2 + q);
+                    const SmLoaded<16> h = sm_load(p, rr);
+                    sm_commit(p, rr, h, v);
+                }
+            }
+            // AssertByteString(32)(in[j]): [ | in[32]] || AssertBits(8) x 32 -- derived wires, functions of the bytes
+            const Cur fp = {32u + 32u * 18u, 0, 0, 0, 32u + 32u * 18u};
+            const Cur cj = cur_add(L.pc.c_abs, fp, j);
+            abs_range(p, Cur{cj.w + 32, cj.b, cj.s, cj.f, cj.q + 32}, cj.w, L.pc.in + 32 * j, 0, 32);
+        } else {
+            for (uint32_t i = 32 * N; i < nblk; i++) { p.put(L.pc.fit_o + i, 0); p.put(L.pc.block + i, 0); }      // Fit(32 N, 136 nb) pads with zeros
         }
-        for (int j = 0; j < N; j++) gAssertByteString(p, 32, L.pc.in + 32 * j);
-        SmRef f = gFlattenS(p, 32 * N, L.pc.in);
-        copy_n(p, L.pc.flat, f, (int)(32 * N));
-        f = gFitS(p, 32 * N, 136 * L.pc.nb, L.pc.flat);
-        copy_n(p, L.pc.block, f, (int)(136 * L.pc.nb));
-        KBRefs r = L.kbs[L.pc.kb];
-        kb_head(p, L.pc.nb, (S)(32 * N), r);
-        if (P::is_count) L.kbs[L.pc.kb] = r;
     } break;
     UCASE(U_POB_LASTLAYER) {      // :142-143 SelectorArray1D(L, LB): the select input; selectors run as range units
         p.derived(L.ll.sel_w, p.get(M.numLayers) - 1);
@@ -534,7 +570,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         R.keyPrefixIsValid = p.bits(1); R.keyIsMultiByte = p.bits(1); R.keyExtraLen = p.sms(1); R.keyLen = p.sms(1); R.valueWrapperPrefix = p.sms(1);
         R.valueWrapperPrefixIsB8 = p.bits(1); R.valueWrapperLen = p.sms(1); R.valuePrefix = p.sms(1); R.valuePrefixIsF8 = p.bits(1);
         R.valueLen = p.sms(1); R.isValueWrapperLenConsistent = p.bits(1); R.isKeyValueLenEqualWithLayerLen = p.bits(1);
-        copy_n(p, R.layer, R.src, (int)(N));
+        // (layer[] <== the source bytes: U_LD_COPY range units)
         const S layerLen = p.put(R.ll, p.get(R.len_src));
         gAssertLessEqThanS(p, 16, layerLen, (S)N);
         p.put(R.leafPrefixIsF8, gIsEqualS(p, p.get(R.src), (S)0xf8));
@@ -558,6 +594,10 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         { B m[7] = {0, 0, 0, 0, 0, 0, 0}; p.cur = R.c_mand; CountP q; q.cur = p.cur; q.decl_order = p.decl_order; MultiANDg<CountP, 7>::run(q, m); R.c_end = q.cur; }
         p.cur = R.c_end;
         if (P::is_count) L.lds[d.a[0]] = R;
+    } break;
+    UCASE(U_LD_COPY) {            // LeafDetector.layer[a1 .. a2) <== layer bytes (merkle_patricia_trie_leaf.circom:248: the template's own input array)
+        const LdRefs& R = L.lds[d.a[0]];
+        copy_n(p, R.layer + d.a[1], R.src + d.a[1], (int)(d.a[2] - d.a[1]));
     } break;
     UCASE(U_LD_SELR) {            // entries [a2, a3) of selector a1 of LeafDetector a0: bits only (gadgets.hpp sel_range); the last range also writes out
         const LdRefs& R = L.lds[d.a[0]];
@@ -1122,6 +1162,7 @@ struct Plan {
         L.lds[inst].src = src; L.lds[inst].len_src = len; L.lds[inst].dst = dst;
         unit(U_LD_HEAD, stage, inst);
         expect_cursor("LeafDetector", p.cur, chk.cur);
+        for (uint32_t lo = 0; lo < N; lo += 32) record(U_LD_COPY, stage, p.cur, inst, lo, std::min(lo + 32, N));
         for (uint32_t k = 0; k < 4; k++) for (uint32_t lo = 0; lo < N; lo += 34) record(U_LD_SELR, stage + 1, p.cur, inst, k, lo, std::min(lo + 34, N));
         record(U_LD_TAIL, stage + 2, p.cur, inst);
     }
@@ -1151,7 +1192,15 @@ struct Plan {
         L.pc.N = N; L.pc.nb = N * 32 / 136 + ((N * 32) % 136 != 0);
         L.pc.out = p.frs(1); L.pc.in = p.sms(32 * N); L.pc.flat = p.sms(32 * N); L.pc.block = p.sms(136 * L.pc.nb); L.pc.hash = p.sms(32); L.pc.reduced = p.sms(31);
         L.pc.kb = L.nkb++; L.kbs[L.pc.kb].mb = L.pc.nb;
-        unit(U_PC_PRE, pre_stage);
+        {   // the monolithic statement (public_commitment.circom:22-36) must end where the split units say it ends
+            CountP chk; chk.cur = p.cur; chk.decl_order = p.decl_order;
+            for (int j = 0; j < N; j++) gAssertByteString(chk, 32, L.pc.in + 32 * j);
+            gFlattenS(chk, 32 * N, L.pc.in); gFitS(chk, 32 * N, 136 * L.pc.nb, L.pc.flat);
+            unit(U_PC_PRE, pre_stage);
+            for (int j = 0; j <= N; j++) record(U_PC_COPY, pre_stage, p.cur, (uint32_t)j);
+            KBRefs r2 = L.kbs[L.pc.kb]; kb_head(chk, L.pc.nb, (S)(32 * N), r2);
+            expect_cursor("PublicCommitment", p.cur, chk.cur);
+        }
         kb_ranges(L.pc.kb, pre_stage + 1, L.pc.block);
         keccak_tail(L.pc.kb, pre_stage + 1, L.pc.hash, true);
         unit(U_PC_POST, pre_stage + 4);
@@ -1200,7 +1249,6 @@ struct Plan {
         M.substringCheckers = p.bits(Ln - 1); M.layerKeccaks = p.sms(32 * Ln); M.reducedLayerKeccaks = p.sms(31 * Ln); M.isLeaf = p.bits(Ln);
         M.isLastLayerLeaf = p.bits(1); M.leaf = p.sms(139); M.leafLen = p.sms(1);
         nfr_in = 6; nsm_in = 1 + Ln * LB + Ln + 1 + HBy + 2;
-        const uint32_t in0 = M.numLeafAddressNibbles.i;      // SM inputs are contiguous SM ranks from here (U_POB_INPUT)
 
         // main track: 0 inputs + KeccakBytes heads | 1 KeccakBytes byte ranges | 2 sponges A | 3 output selector rows, posts
         //             | 5 consumers (SubstringCheck, PublicCommitment) | 6 ... | 10 final ===          (side tracks: see above)
@@ -1215,7 +1263,7 @@ struct Plan {
         unit(U_POB_POSEIDONS, TB + 2, 1);
         burn_address_hash(TB + 2);                             // :119
         L.kb_hdr = L.nkb++;
-        keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot, M.blockHeaderLen.i - in0 + 1);       // :122
+        keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122  (the length: the input's WIRE -- the input kernel runs ahead of every stage; a batch in the byte form has no packed int32 rows to read)
         for (int j = 0; j < 5; j++) unit(U_POB_N2B, TN + 1, j);                                    // :132-136
         public_commitment(6, TQ + 1);                                                           // :137  (track 6: pre 1, ranges 2, sponge 3, rows/post 4, commitment 5)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
@@ -1233,7 +1281,7 @@ struct Plan {
         L.nsc = Ln;
         for (int i = 0; i < Ln; i++) {                                                          // :157-181
             leaf_detector(i, TP + 1, M.layers + i * LB, M.layerLens + i, M.isLeaf + i);
-            keccak_bytes(L.kb_layer0 + i, prm.NB, 0, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i, (M.layerLens + i).i - in0 + 1);
+            keccak_bytes(L.kb_layer0 + i, prm.NB, 0, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i);
             const Cur start = p.cur;
             unit(U_POB_LAYER_POST, 5, i);
             if (i > 0) {

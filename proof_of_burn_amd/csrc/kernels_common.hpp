@@ -57,11 +57,8 @@ void launch_g_emit_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStre
 void launch_g_gen_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_emit_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-// fused launches of the in-order schedule: independent kernels of one calculator whose wavefronts share a launch (g_gen_all.hip, g_gen_poswide.hip, g_check_wide.hip, g_check_narrow.hip)
-void launch_gen_level(const GArgs& A, const KArgs& K, uint32_t nunits, uint32_t nperms, uint32_t ngroups, hipStream_t st);          // a level's units + the round expansion of nperms permutations from K.first
-void launch_pos_chain(const GArgs& A, const KArgs& K, uint32_t npos, uint32_t nsponges, uint32_t ngroups, hipStream_t st);          // npos Poseidon blocks + nsponges sponge chains from K.first
-void launch_check_wide(const GArgs& A, const KArgs& K, uint32_t nunits, uint32_t nperms, uint32_t ngroups, hipStream_t st);         // the wide evaluation families' units + the round evaluation of nperms permutations, interleaved
-void launch_check_narrow_chain(const GArgs& A, const KArgs& K, uint32_t nunits, uint32_t nperms, uint32_t ngroups, hipStream_t st); // the narrow families' units + the sponge-chain evaluation of nperms permutations
+// fused launch of the in-order schedule: npos Poseidon blocks + nsponges sponge chains from K.first in one launch (g_gen_poswide.hip)
+void launch_pos_chain(const GArgs& A, const KArgs& K, uint32_t npos, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
 int pob_kchk_rounds();        // rounds per wavefront of the round evaluation (k_keccak.hip)

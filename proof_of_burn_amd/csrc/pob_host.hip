@@ -76,6 +76,44 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32
     if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
 }
 static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st);
+// The same from the BYTE FORM of a batch (pob_upload_inputs8*: u8 rows + POB_EXC_CAP exception slots per witness), in ONE pass: a workgroup reads 64 witnesses x 128 inputs as
+// bytes (32 per thread), widens them into an LDS tile, lays the group's exception slots that fall into its 128 inputs over the tile, and writes (CHECK: compares) the 128 SM
+// rows, lane = witness.  Rounds 4-5 widened the whole batch into an int32 copy of the packed inputs first (k_widen_sm8 + k_apply_exc on the upload stream: 11 MB read, 45 MB
+// written) and transposed that copy (45 MB read, 45 MB written): per batch two launches and 90 MB of traffic that this pass does not have.  grid = (ceil(nsm / 128), groups).
+#define IN8_K 128
+template <bool CHECK> __global__ void __launch_bounds__(256) k_inputs8(const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t nsm, uint32_t n, int32_t* sm, uint64_t sm_stride, uint32_t s0,
+                                                                        uint32_t w0, uint32_t* bad_wire) {
+    int32_t* t = (int32_t*)g_lds;                         // [64 witnesses][IN8_K + 1]
+    const uint32_t tid = threadIdx.x, k0 = blockIdx.x * IN8_K, g = blockIdx.y;
+    {   // bytes: thread = (witness row, 32-byte segment)
+        const uint32_t row = tid >> 2, seg = tid & 3u, wg = g * 64 + row, kb = k0 + 32 * seg;
+        const uint8_t* src = sm8 + (uint64_t)wg * nsm + kb;
+        int32_t* d = t + row * (IN8_K + 1) + 32 * seg;
+        if (wg < n && kb + 32 <= nsm && (nsm & 3u) == 0) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) { const uint32_t w = ((const uint32_t*)src)[j]; d[4 * j] = (int32_t)(w & 255u); d[4 * j + 1] = (int32_t)((w >> 8) & 255u); d[4 * j + 2] = (int32_t)((w >> 16) & 255u); d[4 * j + 3] = (int32_t)(w >> 24); }
+        } else {
+            for (uint32_t j = 0; j < 32; j++) d[j] = (wg < n && kb + j < nsm) ? (int32_t)src[j] : 0;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 64 * POB_EXC_CAP; i += 256) {          // the group's exception slots (values outside 0..255: the lengths, deliberately out-of-range test inputs)
+        const uint32_t row = i / POB_EXC_CAP, wg = g * 64 + row;
+        if (wg >= n) continue;
+        const pob_sm_exc_t e = exc[(uint64_t)wg * POB_EXC_CAP + i % POB_EXC_CAP];
+        if (e.k < nsm && e.k - k0 < IN8_K) t[row * (IN8_K + 1) + (e.k - k0)] = e.v;
+    }
+    __syncthreads();
+    const uint32_t lane = tid & 63u, q = tid >> 6;
+    int32_t* dst = sm + (uint64_t)g * sm_stride + (uint64_t)(s0 + k0) * 64;
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t kk = 32 * q; kk < 32 * q + 32 && k0 + kk < nsm; kk++) {
+        const int32_t v = t[lane * (IN8_K + 1) + kk];
+        if (CHECK) { if (dst[kk * 64 + lane] != v && bad == 0xFFFFFFFFu) bad = w0 + k0 + kk; }
+        else dst[kk * 64 + lane] = v;
+    }
+    if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
+}
 // pob_upload_inputs8*: the byte rows widened into the int32 rows every kernel reads (four values per thread when the row length allows aligned words), then the
 // exception slots on top (values outside 0..255: lengths, deliberately out-of-range test inputs)
 __global__ void __launch_bounds__(256) k_widen_sm8(const uint8_t* sm8, int32_t* sm, uint64_t total) {
@@ -269,6 +307,7 @@ struct pob_ctx {
     uint8_t* d_in_fr[2] = {nullptr, nullptr}; int32_t* d_in_sm[2] = {nullptr, nullptr}; int in_cur = 0, in_next = 0; uint32_t n_next = 0;
     hipEvent_t ev_in_done[2] = {nullptr, nullptr}; bool in_done_rec[2] = {false, false};
     uint8_t* d_in_sm8[2] = {nullptr, nullptr}; pob_sm_exc_t* d_in_exc[2] = {nullptr, nullptr};      // staging of the byte form (pob_upload_inputs8*): 11 KB per witness and buffer
+    bool in_bytes[2] = {false, false};                  // buffer b holds its batch in the byte form only (ProofOfBurn: the inputs' wires are written straight from it, k_inputs8; d_in_sm[b] is stale)
     uint32_t *d_status_raw = nullptr, *d_status = nullptr, *d_chk = nullptr, *d_bad = nullptr, *d_records = nullptr; uint8_t* d_outputs = nullptr;
     // streaming .wtns emission: two device windows + two pinned host windows, window k+1 is expanded and copied while the caller
     // consumes window k (pob_emit_begin / pob_emit_next)
@@ -323,14 +362,16 @@ struct pob_ctx {
     // dependency path): every unit of a level, of whatever track, goes out in one launch per kernel class, then the level's sponges; the round expansion of
     // every sponge is ONE launch at the end (nothing of the generation reads it).
     bool inorder = false;
-    // FUSED launches (pob_set_inorder(h, 3), what bench.py runs): independent kernels of the batch share a launch -- the Poseidon blocks with the sponge chain that does not
-    // depend on them, slices of the round expansion with the generation levels behind that chain, the round evaluation with the wide evaluation families, the sponge-chain
-    // evaluation with the narrow families -- so that a calculator's stream is a shorter chain of fuller launches.  gen_plan[0]: one launch per kernel (round 5), [1]: fused.
+    // FUSED launch (pob_set_inorder(h, 3), what bench.py runs): the lane-spread Poseidon blocks share a launch with the sponge chain that does not depend on them (header and
+    // layers: the longest chain) -- two launches of a few hundred wavefronts each, both a long serial chain per wavefront, neither near any throughput limit: side by side
+    // they take the longer one's time.  gen_plan[0]: one launch per kernel (round 5), [1]: with the fused launch.
+    // (Round 6 also fused the bandwidth-bound kernels with latency-bound ones -- slices of the round expansion with the levels behind the chain, the round evaluation
+    //  interleaved with the wide evaluation families, the chain evaluation behind the narrow families: such a launch lasts about the SUM of its parts (a latency-bound
+    //  wavefront makes next to no progress while the memory system is saturated), the loop did not move; removed.  profiles/round6_experiments.txt)
     bool fused = false;
     struct GenLaunch { uint32_t kind, cls, first, count, k_first, k_count; };
-    enum { GL_UNITS = 0, GL_CHAIN = 1, GL_POS_CHAIN = 2, GL_UNITS_ROUNDS = 3, GL_ROUNDS = 4 };
+    enum { GL_UNITS = 0, GL_CHAIN = 1, GL_POS_CHAIN = 2, GL_ROUNDS = 4 };
     std::vector<GenLaunch> gen_plan[2];
-    Seg chk_wide{0, 0, 0, 0};                            // fused evaluation: the units of the four wide families (RANGE, SELROW, LD, SC), one list, longest first
     Seg chk_narrow{0, 0, 0, 0};                          // in-order evaluation: the units of the four narrow families, one launch
     uint32_t nlevels = 0;
     bool generated = false; uint64_t gen_count = 0;
@@ -408,6 +449,13 @@ static void launch_g_emit(const GArgs& A, uint32_t cls, uint32_t nunits, hipStre
 static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st) {
     if (h->circuit != POB_CIRCUIT_PROOF_OF_BURN || !h->plan.nsm_in) return;
     const SmRef r0 = h->plan.L.pm.numLeafAddressNibbles;  // the small inputs are contiguous SM ranks / wire indices from here (declaration order)
+    if (h->in_bytes[h->in_cur]) {
+        const dim3 grid8((h->plan.nsm_in + IN8_K - 1) / IN8_K, G);
+        const size_t lds = 64 * (IN8_K + 1) * 4;
+        if (check) hipLaunchKernelGGL(k_inputs8<true>, grid8, dim3(256), lds, st, h->d_in_sm8[h->in_cur], h->d_in_exc[h->in_cur], h->plan.nsm_in, h->n, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
+        else hipLaunchKernelGGL(k_inputs8<false>, grid8, dim3(256), lds, st, h->d_in_sm8[h->in_cur], h->d_in_exc[h->in_cur], h->plan.nsm_in, h->n, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
+        return;
+    }
     const dim3 grid((h->plan.nsm_in + 63) / 64, G);
     if (check) hipLaunchKernelGGL(k_inputs<true>, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
     else hipLaunchKernelGGL(k_inputs<false>, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
@@ -613,8 +661,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         for (uint32_t sid = 0; sid < NS; sid++) nlev = std::max(nlev, lvl_end[sid]);
         if (!fused) h->nlevels = (uint32_t)nlev;
         std::vector<pob_ctx::GenLaunch>& plan = h->gen_plan[variant];
-        std::vector<uint32_t> sp_perm0(pl.sponges.size() + 1, 0);           // first permutation of every sponge in the flattened list
-        for (size_t i2 = 0; i2 < pl.sponges.size(); i2++) sp_perm0[i2 + 1] = sp_perm0[i2] + pl.sponges[i2].n;
         for (int lv = 1; lv <= nlev; lv++) {
             // (one launch per class -- BN254 | SubstringCheck | light -- instead of the merged one: 2.24 ms per step against 2.04 with 4 calculators in flight, 1.83 against 1.72
             //  with 8, two interleaved pairs on one box: profiles/round4_experiments.txt 10)
@@ -635,33 +681,8 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
             }
             if (pos.count) plan.push_back(pos);
         }
-        // the round expansion: [0] ONE launch at the end (nothing of the generation reads a round block); [1] the permutations of the LARGEST chain launch ride along with the
-        // unit launches behind it, shared out by the launches' longest unit (the planner's cost estimate: a launch lasts as long as its longest unit), the rest at the end
-        if (h->nperms) {
-            size_t big = plan.size(); uint32_t big_n = 0;
-            if (fused) for (size_t a = 0; a < plan.size(); a++) if (plan[a].kind == pob_ctx::GL_CHAIN || plan[a].kind == pob_ctx::GL_POS_CHAIN) {
-                const uint32_t n = sp_perm0[plan[a].k_first + plan[a].k_count] - sp_perm0[plan[a].k_first];
-                if (n > big_n) { big_n = n; big = a; }
-            }
-            std::vector<size_t> carriers; uint64_t wsum = 0;
-            // (the estimate counts wires written, and beyond a few thousand of them a unit's run stores make it look longer than it is: capped, so that the one launch with the
-            //  burn-address composite does not take nine tenths of the expansion -- measured durations of these launches: 0.12, 0.17, 0.01, 0.05, 0.06, 0.21, 0.03, 0.02 ms)
-            auto weight = [&](size_t a) { return (uint64_t)std::min<uint32_t>(pl.units[h->order[plan[a].first]].cost, 4000u) + 1; };
-            for (size_t a = big + 1; a < plan.size(); a++) if (plan[a].kind == pob_ctx::GL_UNITS && plan[a].cls == CLS_ALL) { carriers.push_back(a); wsum += weight(a); }
-            uint32_t done0 = 0, done1 = 0;                       // the permutations [done0, done1) have been given to carriers
-            if (big_n && !carriers.empty()) {
-                const uint32_t p0 = sp_perm0[plan[big].k_first];
-                uint32_t given = 0; uint64_t wacc = 0;
-                for (size_t c = 0; c < carriers.size(); c++) {
-                    wacc += weight(carriers[c]);
-                    const uint32_t upto = c + 1 == carriers.size() ? big_n : (uint32_t)((uint64_t)big_n * wacc / wsum);
-                    if (upto > given) { pob_ctx::GenLaunch& gl = plan[carriers[c]]; gl.kind = pob_ctx::GL_UNITS_ROUNDS; gl.k_first = p0 + given; gl.k_count = upto - given; given = upto; }
-                }
-                done0 = p0; done1 = p0 + big_n;
-            }
-            if (done0 > 0) plan.push_back({pob_ctx::GL_ROUNDS, 0, 0, 0, 0, done0});
-            if (done1 < h->nperms) plan.push_back({pob_ctx::GL_ROUNDS, 0, 0, 0, done1, h->nperms - done1});
-        }
+        // the round expansion: ONE launch at the end (nothing of the generation reads a round block)
+        if (h->nperms) plan.push_back({pob_ctx::GL_ROUNDS, 0, 0, 0, 0, h->nperms});
         if (getenv("POB_DEBUG_LEVELS")) {       // (diagnostic: the in-order launch list with the unit kinds of every launch)
             fprintf(stderr, "---- in-order launch plan %d (%s), %d levels\n", variant, fused ? "fused" : "one launch per kernel", nlev);
             for (const pob_ctx::GenLaunch& gl : plan) {
@@ -685,16 +706,6 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         }
         h->chk_narrow.count = (uint32_t)h->order.size() - h->chk_narrow.first;
         std::stable_sort(h->order.begin() + h->chk_narrow.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
-    }
-
-    {   // fused evaluation: the four wide families as ONE list (they share a launch with the round evaluation, g_check_wide.hip), longest unit first
-        h->chk_wide = pob_ctx::Seg{0, 0, (uint32_t)h->order.size(), 0};
-        for (uint32_t u = 0; u < pl.units.size(); u++) {
-            const uint32_t f = fam_of(pl.units[u].kind);
-            if ((pl.units[u].flags & UNIT_CHECK) && (f == F_RANGE || f == F_SELROW || f == F_LD || f == F_SC)) h->order.push_back(u);
-        }
-        h->chk_wide.count = (uint32_t)h->order.size() - h->chk_wide.first;
-        std::stable_sort(h->order.begin() + h->chk_wide.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
     }
 
     HIPC(hipSetDevice(device));
@@ -866,7 +877,7 @@ int pob_upload_inputs(pob_handle h, const uint8_t* fr_inputs, const int32_t* sm_
     if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, h->s_upload));
     if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm[t], sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, h->s_upload));
     HIPC(hipStreamSynchronize(h->s_upload));
-    h->in_next = t; h->n_next = n; h->upload_pending = false; h->have_next = true;
+    h->in_next = t; h->n_next = n; h->upload_pending = false; h->have_next = true; h->in_bytes[t] = false;
     return POB_OK;
 }
 
@@ -881,27 +892,32 @@ int pob_upload_inputs_async(pob_handle h, const uint8_t* fr_inputs, const int32_
     if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
     if (h->plan.nsm_in) HIPC(hipMemcpyAsync(h->d_in_sm[t], sm_inputs, (uint64_t)n * h->plan.nsm_in * 4, hipMemcpyHostToDevice, su));
     HIPC(hipEventRecord(h->ev_upload, su));
-    h->in_next = t; h->n_next = n; h->upload_pending = true; h->have_next = true;
+    h->in_next = t; h->n_next = n; h->upload_pending = true; h->have_next = true; h->in_bytes[t] = false;
     return POB_OK;
 }
 
 static int upload8(pob_ctx* h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n, hipStream_t su, bool async) {
     const int t = h->in_cur ^ 1;
     const uint64_t nsm = h->plan.nsm_in;
+    const bool bytes_only = h->circuit == POB_CIRCUIT_PROOF_OF_BURN;
     if (async) { if (h->upload_pending) HIPC(hipStreamWaitEvent(su, h->ev_upload, 0)); if (h->in_done_rec[t]) HIPC(hipStreamWaitEvent(su, h->ev_in_done[t], 0)); }
     else { if (h->upload_pending) HIPC(hipEventSynchronize(h->ev_upload)); if (h->in_done_rec[t]) HIPC(hipEventSynchronize(h->ev_in_done[t])); }
     if (h->plan.nfr_in) HIPC(hipMemcpyAsync(h->d_in_fr[t], fr_inputs, (uint64_t)n * h->plan.nfr_in * 32, hipMemcpyHostToDevice, su));
     if (nsm) {
         HIPC(hipMemcpyAsync(h->d_in_sm8[t], sm8, (uint64_t)n * nsm, hipMemcpyHostToDevice, su));
         HIPC(hipMemcpyAsync(h->d_in_exc[t], exc, (uint64_t)n * POB_EXC_CAP * sizeof(pob_sm_exc_t), hipMemcpyHostToDevice, su));
-        const uint64_t total = (uint64_t)n * nsm;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total / 16 + 255) / 256 + 1, 1024);
-        hipLaunchKernelGGL(k_widen_sm8, dim3(blocks), dim3(256), 0, su, h->d_in_sm8[t], h->d_in_sm[t], total);
-        hipLaunchKernelGGL(k_apply_exc, dim3((n * POB_EXC_CAP + 255) / 256), dim3(256), 0, su, h->d_in_exc[t], h->d_in_sm[t], n, (uint32_t)nsm);
-        HIPC(hipGetLastError());
+        // ProofOfBurn: nothing else -- the generation's first kernel (and the evaluation's input check) read the byte form (k_inputs8).  The other circuits' kernels
+        // read the packed int32 rows themselves (gadget mains: their inputs ARE the packed rows), so the bytes are widened here, on the upload stream
+        if (!bytes_only) {
+            const uint64_t total = (uint64_t)n * nsm;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((total / 16 + 255) / 256 + 1, 1024);
+            hipLaunchKernelGGL(k_widen_sm8, dim3(blocks), dim3(256), 0, su, h->d_in_sm8[t], h->d_in_sm[t], total);
+            hipLaunchKernelGGL(k_apply_exc, dim3((n * POB_EXC_CAP + 255) / 256), dim3(256), 0, su, h->d_in_exc[t], h->d_in_sm[t], n, (uint32_t)nsm);
+            HIPC(hipGetLastError());
+        }
     }
     if (async) { HIPC(hipEventRecord(h->ev_upload, su)); } else HIPC(hipStreamSynchronize(su));
-    h->in_next = t; h->n_next = n; h->upload_pending = async; h->have_next = true;
+    h->in_next = t; h->n_next = n; h->upload_pending = async; h->have_next = true; h->in_bytes[t] = bytes_only && nsm;
     return POB_OK;
 }
 int pob_upload_inputs8(pob_handle h, const uint8_t* fr_inputs, const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t n) {
@@ -956,7 +972,6 @@ int pob_generate(pob_handle h, void* stream_) {
             case pob_ctx::GL_UNITS: launch_g_gen(A, gl.cls, gl.count, G, st); break;
             case pob_ctx::GL_CHAIN: launch_k_chain(K, false, gl.k_count, G, st); break;
             case pob_ctx::GL_POS_CHAIN: launch_pos_chain(A, K, gl.count, gl.k_count, G, st); break;
-            case pob_ctx::GL_UNITS_ROUNDS: launch_gen_level(A, K, gl.count, gl.k_count, G, st); break;
             default: launch_k_rounds(K, false, gl.k_count, G, st); break;
             }
         }
@@ -1068,31 +1083,18 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // one stream: the Keccak round evaluation (the batch's one bandwidth-bound kernel) first, then the sponge chains, the inputs and the eight families
         // (the round evaluation on a high-priority stream of the device, forked and joined per batch, was measured: 4 / 6 / 8 / 12 calculators in flight
         //  2.39 / 2.04 / 1.91 / 2.14 ms per step against 2.19 / 2.09 / 1.87 / 2.07 here, the kernel 0.49-0.74 against 0.42-0.80 ms: nothing; removed)
-        KArgs K = kargs(h); K.first = 0;
-        const bool sponges = !h->plan.sponges.empty();
-        if (h->fused) {
-            // two launches: the round evaluation interleaved with the wide families' units | the narrow families' units with the sponge-chain evaluation behind them
+        if (!h->plan.sponges.empty()) {
+            KArgs K = kargs(h); K.first = 0;
             if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
-            A.first = h->chk_wide.first;
-            if (h->chk_wide.count || sponges) launch_check_wide(A, K, h->chk_wide.count, sponges ? h->nperms : 0, G, st);
+            launch_k_rounds(K, true, h->nperms, G, st);
             if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
-            launch_inputs(h, true, G, st);
-            A.first = h->chk_narrow.first;
-            if (h->chk_narrow.count || sponges) launch_check_narrow_chain(A, K, h->chk_narrow.count, sponges ? h->nperms : 0, G, st);
-            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == F_GM) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
-        } else {
-            if (sponges) {
-                if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
-                launch_k_rounds(K, true, h->nperms, G, st);
-                if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
-                launch_k_chain(K, true, h->nperms, G, st);
-            }
-            launch_inputs(h, true, G, st);
-            // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
-            //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
-            if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
-            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+            launch_k_chain(K, true, h->nperms, G, st);
         }
+        launch_inputs(h, true, G, st);
+        // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
+        //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
+        if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
+        for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));

@@ -692,9 +692,13 @@ class WitnessCalculator:
             return [int.from_bytes(b[32 * k:32 * k + 32], "little") for k in range(nout)]
         raise RuntimeError("empty witness")
 
-    def witness_payload(self, idx: int = 0) -> np.ndarray:
-        """canonical 32-byte LE values of witness `idx` (the .wtns section 2 payload) as a uint8 array"""
-        out = np.empty(32 * self.nwitness, dtype=np.uint8)
+    def witness_payload(self, idx: int = 0, out: np.ndarray | None = None) -> np.ndarray:
+        """canonical 32-byte LE values of witness `idx` (the .wtns section 2 payload) as a uint8 array; `out`: a caller's buffer of that size to fill (a caller that
+        looks at many witnesses reuses one: a fresh 6.9 GB array is two seconds of page faults)"""
+        if out is None:
+            out = np.empty(32 * self.nwitness, dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.size != 32 * self.nwitness or not out.flags.c_contiguous:
+            raise ValueError("out: a contiguous uint8 array of 32 bytes per wire")
         self._ck(self.lib.pob_emit_witness(self.h, idx, out.ctypes.data, out.nbytes))
         return out
 
@@ -748,8 +752,7 @@ class WitnessCalculator:
 
     def set_inorder(self, on=True):
         """every launch of this calculator on the caller's stream, in dependency order, no side streams (pob_set_inorder): for jobs that keep several calculators in flight.
-        on = 3: the same with FUSED launches -- independent kernels of the batch share a launch (the Poseidon blocks with the header's sponge chain, slices of the round
-        expansion with the levels behind it, the round evaluation with the wide evaluation families, the chain evaluation with the narrow ones)"""
+        on = 3: the same with the FUSED launch -- the Poseidon blocks share a launch with the header's / layers' sponge chain, which does not depend on them"""
         self._ck(self.lib.pob_set_inorder(self.h, int(on)))
 
     def emit_selfcheck(self, enable: bool = True):

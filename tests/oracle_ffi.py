@@ -198,3 +198,68 @@ def keccak256(data: bytes) -> bytes:
     out = ctypes.create_string_buffer(32)
     lib().oracle_keccak256(bytes(data), len(data), out)
     return out.raw
+
+
+# ---------------------------------------------------------------------------- many oracle runs at once (the GPU tests: ~2 s and 6.9 GB per production witness, one thread each)
+def payload_digest(arr) -> str:
+    """128-bit digest of a canonical payload (numpy uint8 / bytes-like): what two processes compare instead of shipping gigabytes to each other"""
+    import xxhash
+    h = xxhash.xxh3_128()
+    mv = memoryview(arr).cast("B")
+    step = 1 << 26
+    for i in range(0, len(mv), step):
+        h.update(mv[i:i + step])
+    return h.hexdigest()
+
+
+class Brief:
+    """what a worker process hands back of one oracle run: verdict, message, outputs, wire count, digest of the payload (valid witnesses, on request)"""
+    __slots__ = ("failed", "msg", "outs", "nwitness", "digest")
+
+    def __init__(self, failed, msg, outs, nwitness, digest):
+        self.failed, self.msg, self.outs, self.nwitness, self.digest = failed, msg, outs, nwitness, digest
+
+    def outputs(self):
+        return self.outs
+
+
+def _brief_worker(args):
+    main, inputs, want_digest = args
+    r = run(main, inputs)
+    d = payload_digest(r.witness_numpy()) if (want_digest and not r.failed) else None
+    out = (r.failed, r.msg, None if r.failed else r.outputs(), r.nwitness, d)
+    lib().oracle_free()
+    return out
+
+
+class OraclePool:
+    """worker PROCESSES (spawned: the parent holds a HIP context; the oracle keeps one global witness, so threads cannot share it) that run the oracle beside whatever
+    the test does on the GPU: `jobs = pool.submit(main, inputs, digest=True)` returns at once, `pool.collect(jobs)` gives one Brief per input, in order"""
+
+    def __init__(self, procs: int | None = None):
+        import multiprocessing as mp
+        import os
+        if procs is None:
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                quota = os.cpu_count() if q == "max" else max(1, int(q) // int(per))
+            except Exception:
+                quota = os.cpu_count() or 2
+            procs = max(2, min(8, quota - 1))
+        build()                                   # (once, in the parent: the workers only load the library)
+        self.pool = mp.get_context("spawn").Pool(procs)
+
+    def submit(self, main: str, inputs, digest: bool = False):
+        return [self.pool.apply_async(_brief_worker, ((main, inp, digest),)) for inp in inputs]
+
+    def collect(self, jobs, timeout: float = 900.0):
+        return [Brief(*j.get(timeout)) for j in jobs]
+
+    def close(self):
+        self.pool.terminate(); self.pool.join()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

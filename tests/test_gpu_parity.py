@@ -323,6 +323,17 @@ def _mutations(base, rng):
     return out
 
 
+def _assert_payload(calc, idx, main, inp, brief, buf, label):
+    """the whole canonical payload of witness idx equals the oracle's: the GPU's bytes (emitted into the caller's reused buffer) against the digest a worker process took of the
+    oracle's (tests/oracle_ffi.py OraclePool); on a mismatch the oracle runs again, here, to name the first differing wire"""
+    assert brief.nwitness == calc.nwitness, label
+    gpu = calc.witness_payload(idx, out=buf)
+    if O.payload_digest(gpu) != brief.digest:
+        ref = O.run(main, inp).witness_numpy()
+        assert np.array_equal(gpu, ref), f"{label}: first differing wire {_first_diff(gpu, ref)}"
+        raise AssertionError(f"{label}: the digests differ but the payloads do not")
+
+
 @pytest.mark.parametrize("depth", [2, 4])
 def test_failure_sets_match_oracle(pkg, depth):
     """one GPU batch of ~40 mutated inputs (a failing lane must not disturb its neighbours): pass/fail and the public output
@@ -332,19 +343,21 @@ def test_failure_sets_match_oracle(pkg, depth):
     params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
     base = gen.synthetic_batch(1, depth=depth, seed=99 + depth, distinct_keys=1, params=params).inputs[0]
     cases = _mutations(base, random.Random(5))
-    calc = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
-    res = calc.calculate([c[1] for c in cases], check=True)
+    with O.OraclePool() as pool:                  # the oracle's ~40 runs in worker processes, beside the GPU's batch
+        jobs = pool.submit(POB_FIX, [c[1] for c in cases], digest=True)
+        calc = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
+        res = calc.calculate([c[1] for c in cases], check=True)
+        oras = pool.collect(jobs)
     n_fail = 0
-    for i, ((label, inp), r) in enumerate(zip(cases, res)):
-        ora = O.run(POB_FIX, inp)
+    buf = np.empty(32 * calc.nwitness, dtype=np.uint8)
+    for i, ((label, inp), r, ora) in enumerate(zip(cases, res, oras)):
         exp = None if ora.failed else ora.outputs()
         got = r.outputs if r.ok else None
         assert got == exp, f"{label}: GPU {got} vs oracle {exp} ({r.message()})"
         n_fail += exp is None
         if r.ok:
             assert r.check_status == 0 and r.bad_wire is None, label
-            gpu, ref = calc.witness_payload(i), ora.witness_numpy()      # every valid mutation: the whole payload, not only the output
-            assert np.array_equal(gpu, ref), f"{label}: first differing wire {_first_diff(gpu, ref)}"
+            _assert_payload(calc, i, POB_FIX, inp, ora, buf, label)      # every valid mutation: the whole payload, not only the output
     assert exp is not None or n_fail > 0
     assert 15 < n_fail < len(cases) - 5          # the mutation set really exercises both outcomes
     calc.close()
@@ -367,8 +380,10 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
     assert len(set(pos)) == len(cases)
     for (label, inp), q in zip(cases, pos):
         inputs[q] = inp
+    pool = O.OraclePool()                                        # the oracle's 46 production runs (2 s, 6.9 GB each) in worker processes, beside the GPU's work
+    jobs = pool.submit(PROD, [c[1] for c in cases], digest=True)
     calc = pkg.WitnessCalculator(PROD, max_batch=n)
-    calc.set_inorder(3)                                          # in order, fused launches: the schedule bench.py runs
+    calc.set_inorder(3)                                          # in order, fused launch: the schedule bench.py runs
     res = calc.calculate(inputs, check=True)
     tracks = pkg.WitnessCalculator(PROD, max_batch=n)
     res_t = tracks.calculate(inputs, check=True)
@@ -380,8 +395,9 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
     for q in range(n):                                            # the untouched neighbours
         if q not in is_case:
             assert res[q].ok and res[q].outputs == [batch.commitments[q]] and res[q].check_status == 0 and res[q].bad_wire is None, q
-    for (label, inp), q in zip(cases, pos):
-        ora = O.run(PROD, inp)
+    oras = pool.collect(jobs); pool.close()
+    buf = np.empty(32 * calc.nwitness, dtype=np.uint8)
+    for ((label, inp), q), ora in zip(zip(cases, pos), oras):
         r = res[q]
         exp = None if ora.failed else ora.outputs()
         assert (r.outputs if r.ok else None) == exp, f"{label}: GPU {r.outputs if r.ok else r.message()} vs oracle {exp if exp else ora.msg}"
@@ -393,11 +409,8 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
                 assert r.status <= ((code_of[m.group(1)] << 12) | int(m.group(2))), f"{label}: {r.message()} vs oracle {ora.msg}"
         else:
             assert r.check_status == 0 and r.bad_wire is None, label
-            gpu, ref = calc.witness_payload(q), ora.witness_numpy()
-            assert np.array_equal(gpu, ref), f"{label}: first differing wire {_first_diff(gpu, ref)}"
+            _assert_payload(calc, q, PROD, inp, ora, buf, label)
             n_valid_payloads += 1
-            del gpu, ref
-        del ora
     assert n_fail > 15 and n_valid_payloads >= 8, (n_fail, n_valid_payloads)
     calc.close()
 
@@ -407,7 +420,7 @@ def test_max_depth_and_ragged_batches(pkg):
     batch sizes that are not multiples of the 64-witness group; batch of one."""
     from proof_of_burn_amd import inputs as gen
     main = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
-    deep = gen.synthetic_batch(3, depth=16, seed=4242, distinct_keys=1)
+    deep = gen.synthetic_batch(3, depth=16, seed=4242, distinct_keys=1, pow_device=0)      # (the 3-zero-byte proof of work on the GPU: 2^24 hashes, the same key the host search finds -- test_pow_search_gpu_matches_host)
     shallow = gen.synthetic_batch(67, depth=8, seed=77, distinct_keys=2)
     calc = pkg.WitnessCalculator(main, max_batch=70)
     for batch in (deep.inputs + shallow.inputs, shallow.inputs[:1], shallow.inputs[:65]):
@@ -841,14 +854,16 @@ def test_seeded_differential_fixture_instantiation(pkg):
     for depth, n, seed in ((2, 21, 1001), (3, 21, 2002), (4, 22, 3003)):
         bt = gen.synthetic_batch(n, depth=depth, seed=seed, distinct_keys=3, params=params)
         inputs += bt.inputs; commitments += bt.commitments
-    calc = pkg.WitnessCalculator(POB_FIX, max_batch=64)
-    res = calc.calculate(inputs, check=True)
-    for i, (r, c) in enumerate(zip(res, commitments)):
+    with O.OraclePool() as pool:                  # the oracle's 64 runs in worker processes, beside the GPU's batch
+        jobs = pool.submit(POB_FIX, inputs, digest=True)
+        calc = pkg.WitnessCalculator(POB_FIX, max_batch=64)
+        res = calc.calculate(inputs, check=True)
+        oras = pool.collect(jobs)
+    buf = np.empty(32 * calc.nwitness, dtype=np.uint8)
+    for i, (r, c, ora) in enumerate(zip(res, commitments, oras)):
         assert r.ok and r.outputs == [c] and r.check_status == 0 and r.bad_wire is None, (i, r)
-        ora = O.run(POB_FIX, inputs[i])
         assert not ora.failed and ora.outputs() == [c]
-        gpu, ref = calc.witness_payload(i), ora.witness_numpy()
-        assert np.array_equal(gpu, ref), f"witness {i}: first differing wire {_first_diff(gpu, ref)}"
+        _assert_payload(calc, i, POB_FIX, inputs[i], ora, buf, f"witness {i}")
     calc.close()
 
 

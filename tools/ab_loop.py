@@ -23,14 +23,16 @@ def main():
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--nbatches", type=int, default=4)
     ap.add_argument("--alone", action="store_true", help="also time the whole evaluation / generation of one calculator alone and the family kernels")
     a = ap.parse_args()
     import numpy as np
     from proof_of_burn_amd import PinnedInputs, inputs as gen
-    args = BM.parse_args(["--gpus", "1"])
+    args = BM.parse_args(["--gpus", "1", "--batch", str(a.batch)])
     job = BM.Job(args)
     B = job.B
-    batches = [gen.synthetic_batch(B, depth=a.depth, seed=0xB0B, distinct_keys=16, first=b * B, pow_device=job.dev if a.depth > 12 else None) for b in range(4)]
+    batches = [gen.synthetic_batch(B, depth=a.depth, seed=0xB0B, distinct_keys=16, first=b * B, pow_device=job.dev if a.depth > 12 else None) for b in range(a.nbatches)]
     expect = [BM._expect(np, bt) for bt in batches]
     pinned = None
     points = [tuple(int(x) for x in p.split(":")) for p in a.points.split(",")]
@@ -43,9 +45,9 @@ def main():
                 for pin, bt in zip(pinned, batches):
                     lp.calcs[0].pack_json([json.dumps(i).encode() for i in bt.inputs], out=pin)
             lp.set_inputs(pinned, expect)
-            lp.run(depth + 4); job.fence()
+            lp.run(max(depth, 1) + 2); job.fence()
             lp.probe(True)
-            s, _, _ = lp.timed(a.steps, 2, k0=depth + 4)
+            s, _, _ = lp.timed(a.steps, 2, k0=max(depth, 1) + 2)
             k = float(np.mean(lp.kchk_ms)) if lp.kchk_ms else 0.0
             lp.probe(False)
             extra = ""
@@ -63,7 +65,7 @@ def main():
                 t_gen = span(lambda: c0.generate(st0.cuda_stream))
                 fams = {f: round(c0.time_kernel(300 + f, iters=5, stream=st0.cuda_stream), 4) for f in range(8)}
                 extra = f" | alone: evaluation {t_eval:.3f} ms generation {t_gen:.3f} ms K_CHK {c0.time_kernel(1, iters=5, stream=st0.cuda_stream):.4f} K_GEN {c0.time_kernel(0, iters=5, stream=st0.cuda_stream):.4f} families {fams}"
-            print(f"round {r} {a.label} depth {depth} fused {ss}: {s / a.steps * 1e3:.3f} ms/step  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
+            print(f"round {r} {a.label} depth {depth} fused {ss}: {s / a.steps * 1e3:.3f} ms/step = {s / a.steps * 1e3 * 1024 / B:.3f} ms per 1024  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
             lp.close()
             del lp
     for pin in pinned:

@@ -9,8 +9,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from proof_of_burn_amd import WitnessCalculator, inputs as gen  # noqa: E402
 
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
-batch = gen.synthetic_batch(1024, depth=10, seed=0xB0B, distinct_keys=16)
-calc = WitnessCalculator(MAIN, max_batch=1024)
+NB = int(os.environ.get("POB_PMC_BATCH", "1024"))      # (8192: what every launch costs when it fills the machine -- its THROUGHPUT cost, not its latency)
+batch = gen.synthetic_batch(NB, depth=10, seed=0xB0B, distinct_keys=16)
+calc = WitnessCalculator(MAIN, max_batch=NB)
 if os.environ.get("POB_PMC_INORDER", "3") != "0":
     calc.set_inorder(int(os.environ.get("POB_PMC_INORDER", "3")))          # 3: the schedule bench.py runs (in order, fused launches); 1: one launch per kernel
 for _ in range(2):
