@@ -33,7 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job n
 
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-DEFAULT_DEPTH = 8                                                    # in-order calculators in flight (the fastest depth measured: profiles/round6_experiments.txt)
+DEFAULT_DEPTH = 12                                                   # in-order calculators in flight: the fastest depth measured (4 / 6 / 8 / 10 / 12 / 16: profiles/round6_experiments.txt)
 PMC_FILES = ("round6_pmc_k_rounds.json", "round5_pmc_k_rounds.json")
 
 
@@ -113,7 +113,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-emission", action="store_true", help="skip the .wtns emission throughput measurements")
     ap.add_argument("--no-single", action="store_true", help="skip the single-calculator / e2e / bare-pipeline legs after the timed region")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the other-depths / depth16 / strong_slice legs after the timed region")
-    ap.add_argument("--other-depths", default="4,12", help="pipeline depths measured beside the default one after the timed region (rank 0 of a 1-GPU run)")
+    ap.add_argument("--other-depths", default="4,8", help="pipeline depths measured beside the default one after the timed region (rank 0 of a 1-GPU run)")
     ap.add_argument("--probe-after", action="store_true", help="record the HIP events around the Keccak round evaluation kernel in 16 extra steps after the timed region instead of inside it")
     ap.add_argument("--dbg-no-upload", action="store_true", help="experiment: upload each calculator's inputs once, not per batch")
     ap.add_argument("--dbg-no-fetch", action="store_true", help="experiment: no per-batch record fetch / validation inside the loop")
@@ -755,7 +755,6 @@ def main():
         latency = leg_single_witness_latency(job) if rank == 0 and world == 1 and not args.no_emission else None
         cpu = cpu_baseline(batches[0], info, args.cpu_samples) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
         if rank == 0:
-            deeper = depths.get("12") or (next(iter(depths.values())) if depths else None)
             line = {
                 "metric": "proof_of_burn witnesses/sec", "value": round(GB * args.steps / dt, 1), "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if job.strong else "weak",
@@ -783,7 +782,7 @@ def main():
                                               "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
                 "ranks": ranks,
                 "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "tracks_pipeline": tracks_pipeline, "kernel_pipeline_only": bare, "single_witness_latency": latency,
-                "depth16": depth16, "strong_slice": strong_slice, "deeper_pipeline": deeper, "other_depths": depths or None, "e2e_from_json": e2e,
+                "depth16": depth16, "strong_slice": strong_slice, "other_depths": depths or None, "e2e_from_json": e2e,
             }
             print(json.dumps(line), flush=True)
     loop.close()

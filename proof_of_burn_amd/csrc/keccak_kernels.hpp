@@ -81,8 +81,10 @@ struct DevIOBase {
 struct GenIO : DevIOBase {
     u64* st; V s[25];
     __device__ __forceinline__ V in(int i) const { return s[i]; }
-    __device__ __forceinline__ V gx(uint32_t sl, V a, V b) const { const V v = a ^ b; st[64 * sl + lane] = v; return v; }
-    __device__ __forceinline__ V ga(uint32_t sl, V a, V b) const { const V v = a & b; st[64 * sl + lane] = v; return v; }
+    // (non-temporal stores for the expansion's 1.26 GB per batch: the kernel alone and the loop with 8 / 12 calculators in flight within 0.5 %, profiles/round6_experiments.txt)
+    __device__ __forceinline__ void stw(u64* p, V v) const { *p = v; }
+    __device__ __forceinline__ V gx(uint32_t sl, V a, V b) const { const V v = a ^ b; stw(st + 64 * sl + lane, v); return v; }
+    __device__ __forceinline__ V ga(uint32_t sl, V a, V b) const { const V v = a & b; stw(st + 64 * sl + lane, v); return v; }
     __device__ __forceinline__ V gxo(int, V a, V b) const { return a ^ b; }
     __device__ __forceinline__ void out(int i, V v) { s[i] = v; }
 };
