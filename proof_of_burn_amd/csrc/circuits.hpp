@@ -219,7 +219,7 @@ template <class P> HD void iseq_derived(P& p, Cur c, S a, S b) {
     const S x = (S)((uint32_t)b - (uint32_t)a);
     p.derived(c.w + 4, x); p.derived_inv(c.w + 5, x, true);
 }
-template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t lo, uint32_t hi) {
+template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t lo, uint32_t hi, bool assert_src = false, SmRef also = SmRef{0, 0}) {
     const uint32_t m = 136 * r.mb, cnt = hi - lo, ln = p.lane_id();     // cnt <= 16 bytes
     const S inLen = p.get(r.inLen), nb = p.get(r.numBlocks);
     const S last = (S)((uint32_t)nb * 136u - 1u);
@@ -246,6 +246,22 @@ template <class P> GD void kb_range(P& p, const KBRefs& r, SmRef src, uint32_t l
         sm_commit(p, rr, h, sv);
 #pragma unroll
         for (int q = 0; q < 16; q++) vs[q] = P::is_check ? h.s[q] : sv[q];        // the evaluator's later expressions see the STORED in[i]
+        // assert_src: the source array has an AssertByteString of its own in the circuit (the layers, the header: proof_of_burn.circom:102,106 and SubstringCheck's
+        // assert on the same layer bytes, substring_check.circom:37) whose wires are all derived: generation and evaluation hold its assert HERE, on the bytes this
+        // range has just loaded -- as range units of their own (rounds 1-5: 595 of them) they read every layer row a second and a third time
+        if (assert_src) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) p.require_lane((uint32_t)sv[q] < 256u, FAILCODE(T_NUM2BITS, 38));
+        }
+        // also: another template's copy of the same source bytes (LeafDetector.layer[] <== the layer, merkle_patricia_trie_leaf.circom:248), written / compared from the
+        // values this range holds -- one read of the layer row serves KeccakBytes.in, both AssertByteStrings and the leaf detector's copy
+        if (also.w) {
+            SmRef ar[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) ar[q] = also + (lo + ((uint32_t)q < cnt ? (uint32_t)q : cnt - 1));
+            const SmLoaded<16> ha = sm_load(p, ar);
+            sm_commit(p, ar, ha, sv);
+        }
     }
 #pragma unroll
     for (uint32_t t = 0; t < 16; t++) if (t < cnt) {
@@ -456,7 +472,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
     } break;
     UCASE(U_KB_RANGE) {           // a[0] = kb index, a[1..2] = src ref, a[3..4] = byte range
         SmRef src = {d.a[1], d.a[2]};
-        kb_range(p, L.kbs[d.a[0]], src, d.a[3], d.a[4]);
+        kb_range(p, L.kbs[d.a[0]], src, d.a[3], d.a[4], d.a[5] != 0, SmRef{d.a[6], d.a[7]});
     } break;
     UCASE(U_KB_SELROW) { kb_selrow(p, L.kbs[d.a[0]], d.a[1], d.a[2], d.a[3]); } break;
     UCASE(U_KB_POST) { kb_post(p, L.kbs[d.a[0]]); } break;
@@ -796,11 +812,9 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         gBurnAddress(p, pos_off(5), L.prefix[0], bk, ra, bec, L.fp_n2be32, ps, &hc);
         // addressBytes, Fit(20, 136) [out[136] | in[20]] and the Keccak block: the 20 bytes again, written per witness (nothing read back)
         SmRef fo = p.sms(136), fi = p.sms(20);
-        for (int i = 0; i < 136; i++) {
-            const S by = i < 20 ? canon_byte(hc, 31 - i) : 0;
-            if (i < 20) { p.put(L.bah.addressBytes + i, by); p.put(fi + i, by); }
-            p.put(fo + i, by); p.put(L.bah.block + i, by);
-        }
+        auto ab_byte = [&](int i) { return i < 20 ? canon_byte(hc, 31 - i) : (S)0; };
+        sm_puts<P, 8>(p, L.bah.addressBytes, 20, ab_byte); sm_puts<P, 8>(p, fi, 20, ab_byte);
+        sm_puts<P, 8>(p, fo, 136, ab_byte); sm_puts<P, 8>(p, L.bah.block, 136, ab_byte);
         KBRefs r = L.kbs[L.bah.kb];
         kb_head(p, 1, (S)20, r);
         if (P::is_count) L.kbs[L.bah.kb] = r;
@@ -858,13 +872,11 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
         const uint64_t tag = 0x333035372D504945ULL;      // "EIP-7503", first character in the low byte
         for (int i = 0; i < 8; i++) p.put(L.pw.eip + i, p.put(e + i, (S)((tag >> (8 * i)) & 0xff)));
         SmRef co = p.sms(104), ci = p.sms(104);          // ConcatFixed4(32,32,32,8) :28-48  [out | a,b,c,d]
-        for (int i = 0; i < 104; i++) {
-            SmRef s = i < 32 ? L.pw.keyBytes + i : i < 64 ? L.pw.raBytes + (i - 32) : i < 96 ? L.pw.becBytes + (i - 64) : L.pw.eip + (i - 96);
-            S v;       // generation: the three byte strings are written beside this unit (CK_N2BE), so the bytes come from the canonical values
-            if constexpr (P::is_gen) v = i < 32 ? canon_byte(cb, 31 - i) : i < 64 ? canon_byte(cr, 63 - i) : i < 96 ? canon_byte(ce, 95 - i) : (S)((tag >> (8 * (i - 96))) & 0xff);
-            else v = p.get(s);
-            p.put(L.pw.hin + i, p.put(co + i, p.put(ci + i, v)));
-        }
+        auto cat_byte = [&](int i) -> S {     // generation: the three byte strings are written beside this unit (CK_N2BE), so the bytes come from the canonical values
+            if constexpr (P::is_gen) return i < 32 ? canon_byte(cb, 31 - i) : i < 64 ? canon_byte(cr, 63 - i) : i < 96 ? canon_byte(ce, 95 - i) : (S)((tag >> (8 * (i - 96))) & 0xff);
+            else return p.get(i < 32 ? L.pw.keyBytes + i : i < 64 ? L.pw.raBytes + (i - 32) : i < 96 ? L.pw.becBytes + (i - 64) : L.pw.eip + (i - 96));
+        };
+        sm_puts<P, 8>(p, ci, 104, cat_byte); sm_puts<P, 8>(p, co, 104, cat_byte); sm_puts<P, 8>(p, L.pw.hin, 104, cat_byte);
         SmRef f = gFitS(p, 104, 136, L.pw.hin);
         copy_n(p, L.pw.block, f, (int)(136));
         KBRefs kr = L.kbs[L.pw.kb];
@@ -1108,11 +1120,12 @@ struct Plan {
         for (uint32_t part = 0; part < 4; part++) record(CK_CAT, stage, cc[part < 3 ? part : 2], part, (uint32_t)La, (uint32_t)Lb, c0.w, c0.s);
     }
     // AssertByteString(N)(src) as range units; p.cur = start of the AssertByteString block
-    void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32) {
+    // (emit_only: the assert itself is held by the KeccakBytes range units that load the same bytes -- kb_range(assert_src) --, the units only write the derived wires)
+    void abs_units(uint32_t stage, uint32_t N, SmRef src, uint32_t chunk = 32, bool emit_only = false) {
         CountP chk; chk.cur = p.cur; gAssertByteString(chk, (int)N, src);
         const uint32_t own_w = p.dvs(N);
         const Cur c0 = p.cur;
-        for (uint32_t lo = 0; lo < N; lo += chunk) record(U_ABS_RANGE, stage, c0, own_w, 0, src.w, src.i, lo, std::min(lo + chunk, N));
+        for (uint32_t lo = 0; lo < N; lo += chunk) { record(U_ABS_RANGE, stage, c0, own_w, 0, src.w, src.i, lo, std::min(lo + chunk, N)); if (emit_only) units.back().flags = UNIT_EMIT; }
         p.cur = cur_add(c0, FP_ABITS8, N);
         expect_cursor("AssertByteString", p.cur, chk.cur);
     }
@@ -1142,12 +1155,12 @@ struct Plan {
         unit(U_KB_POST, range_stage + 2, kb);
         if (range_stage + 1 > max_stage) max_stage = range_stage + 1;
     }
-    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst, uint32_t len_input = 0, bool has_dst = true) {
+    void keccak_bytes(uint32_t kb, int mb, uint32_t stage, SmRef src, SmRef len, SmRef dst, uint32_t len_input = 0, bool has_dst = true, bool assert_src = false, SmRef also = SmRef{0, 0}) {
         L.kbs[kb].mb = mb;
         const Cur start = p.cur;
         unit(U_KB_HEAD, stage, kb, len.w, len.i, len_input);
         const uint32_t m = 136 * mb;
-        for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage + 1, start, kb, src.w, src.i, lo, std::min(lo + 16, m));
+        for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage + 1, start, kb, src.w, src.i, lo, std::min(lo + 16, m), assert_src ? 1u : 0u, also.w, also.i);
         keccak_tail(kb, stage + 1, dst, has_dst);
     }
     // byte-range units of a KeccakBytes whose head ran inside another unit at `head_stage`
@@ -1156,13 +1169,13 @@ struct Plan {
         for (uint32_t lo = 0; lo < m; lo += 16) record(U_KB_RANGE, stage, p.cur, kb, src.w, src.i, lo, std::min(lo + 16, m));
     }
     // LeafDetector(N)(src, len) -> dst, as head (stage), 4 selectors x ranges (stage+1), tail (stage+2)
-    void leaf_detector(uint32_t inst, uint32_t stage, SmRef src, SmRef len, BitRef dst) {
+    void leaf_detector(uint32_t inst, uint32_t stage, SmRef src, SmRef len, BitRef dst, bool copy_units = true) {      // copy_units false: the layer's KeccakBytes ranges write layer[] too (kb_range `also`)
         const uint32_t N = 136 * L.pob.NB;
         CountP chk; chk.cur = p.cur; gLeafDetector(chk, (int)N, src, 0);
         L.lds[inst].src = src; L.lds[inst].len_src = len; L.lds[inst].dst = dst;
         unit(U_LD_HEAD, stage, inst);
         expect_cursor("LeafDetector", p.cur, chk.cur);
-        for (uint32_t lo = 0; lo < N; lo += 32) record(U_LD_COPY, stage, p.cur, inst, lo, std::min(lo + 32, N));
+        if (copy_units) for (uint32_t lo = 0; lo < N; lo += 32) record(U_LD_COPY, stage, p.cur, inst, lo, std::min(lo + 32, N));
         for (uint32_t k = 0; k < 4; k++) for (uint32_t lo = 0; lo < N; lo += 34) record(U_LD_SELR, stage + 1, p.cur, inst, k, lo, std::min(lo + 34, N));
         record(U_LD_TAIL, stage + 2, p.cur, inst);
     }
@@ -1255,15 +1268,15 @@ struct Plan {
         unit(U_POB_INPUT_FR, 0);
         for (uint32_t k = 0; k < nsm_in; k += 256) unit(U_POB_INPUT, 0, k, std::min(k + 256, nsm_in));
         for (int k = 0; k < 5; k++) unit(U_POB_RANGE, TB + 1, k);
-        for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, TP + 1, i); abs_units(TP + 1, LB, M.layers + i * LB); }
-        unit(U_POB_HDR_ASSERT, TP + 1); abs_units(TP + 1, HBy, M.blockHeader);
+        for (int i = 0; i < Ln; i++) { unit(U_POB_LAYER_ASSERT, TP + 1, i); abs_units(TP + 1, LB, M.layers + i * LB, 32, true); }
+        unit(U_POB_HDR_ASSERT, TP + 1); abs_units(TP + 1, HBy, M.blockHeader, 32, true);
         // The three Poseidon blocks (:113, :116, burn_address.circom:55) run in TB + 1 as U_POS_WIDE units (state spread over lanes);
         // the composites that continue from their outputs follow in TB + 2, with the Num2BigEndianBytes blocks beside them (CK_N2BE).
         unit(U_POB_POSEIDONS, TB + 2, 0);
         unit(U_POB_POSEIDONS, TB + 2, 1);
         burn_address_hash(TB + 2);                             // :119
         L.kb_hdr = L.nkb++;
-        keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot);       // :122  (the length: the input's WIRE -- the input kernel runs ahead of every stage; a batch in the byte form has no packed int32 rows to read)
+        keccak_bytes(L.kb_hdr, prm.HB, 0, M.blockHeader, M.blockHeaderLen, M.blockRoot, 0, true, true);       // :122  (the length: the input's WIRE -- the input kernel runs ahead of every stage; a batch in the byte form has no packed int32 rows to read)
         for (int j = 0; j < 5; j++) unit(U_POB_N2B, TN + 1, j);                                    // :132-136
         public_commitment(6, TQ + 1);                                                           // :137  (track 6: pre 1, ranges 2, sponge 3, rows/post 4, commitment 5)
         {   // SelectorArray1D(L, LB)(layers, numLayers - 1) :142-143
@@ -1280,8 +1293,8 @@ struct Plan {
         L.kb_layer0 = L.nkb; L.nkb += Ln;
         L.nsc = Ln;
         for (int i = 0; i < Ln; i++) {                                                          // :157-181
-            leaf_detector(i, TP + 1, M.layers + i * LB, M.layerLens + i, M.isLeaf + i);
-            keccak_bytes(L.kb_layer0 + i, prm.NB, 0, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i);
+            leaf_detector(i, TP + 1, M.layers + i * LB, M.layerLens + i, M.isLeaf + i, false);
+            keccak_bytes(L.kb_layer0 + i, prm.NB, 0, M.layers + i * LB, M.layerLens + i, M.layerKeccaks + 32 * i, 0, true, true, L.lds[i].layer);
             const Cur start = p.cur;
             unit(U_POB_LAYER_POST, 5, i);
             if (i > 0) {
@@ -1289,8 +1302,10 @@ struct Plan {
                 CountP chk; chk.cur = start; { gFitS(chk, 32, 31, M.layerKeccaks); gSubstringCheck(chk, LB, 31, M.layers, 0, M.reducedLayerKeccaks); }
                 expect_cursor("SubstringCheck", p.cur, chk.cur);
                 const SmRef src = M.layers + (i - 1) * LB;
-                for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32)
+                for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) {       // (SubstringCheck's assert on layer i - 1's bytes: held by that layer's KeccakBytes ranges too)
                     record(U_ABS_RANGE, TP + 1, sc.c_abs_main, sc.abs_main_in.w, sc.abs_main_in.i, src.w, src.i, lo, std::min<uint32_t>(lo + 32, LB));
+                    units.back().flags = UNIT_EMIT;
+                }
                 // M[] depends on the layer's INPUT bytes only (not on any hash): with the byte asserts it runs on track 5, beside the expansion
                 for (uint32_t lo = 0; lo < (uint32_t)LB; lo += 32) record(U_SC_M, TP + 1, start, i, lo, std::min<uint32_t>(lo + 32, LB));
                 const uint32_t kk = LB - 31 + 1;

@@ -303,17 +303,21 @@ template <class P> GD BitRef gNum2BitsStrict(P& p, const F& in, BV* vout = nullp
 // the segments in sequence with the state in registers; the evaluator runs EACH segment as its own wavefront from the STORED
 // output wires of the block before it (every relation of a round is local given stored wires).
 struct PosOff { uint32_t C, S, M, Pm; int rp; };
-#define POS_PCH 4                                                   // partial rounds per evaluator segment
+#define POS_PCH 2                                                   // partial rounds per evaluator segment
+// Segments: 0 head | 1..8: the four first-half full rounds, each as (Sigma x T + Ark) | (Mix) | 9..: the partial rounds in chunks of POS_PCH | six: the three second-half full
+// rounds, two parts each | the tail.  Every segment ends in a block [out[T] | in[T]] (Ark, Mix, MixS), so the state entering the next one is the T stored wires at its
+// cursor - 2T.  (Rounds 2-5: whole full rounds and chunks of 4 -- 40 and 48 Montgomery products per wavefront, the longest units of the narrow evaluation kernel; now 25.)
 HD uint32_t pos_nchunks(int rp) { return (uint32_t)(rp + POS_PCH - 1) / POS_PCH; }
-HD uint32_t pos_nseg(int rp) { return 1 + 4 + pos_nchunks(rp) + 3 + 1; }
+HD uint32_t pos_nseg(int rp) { return 1 + 8 + pos_nchunks(rp) + 6 + 1; }
 HD uint32_t pos_wires(int T, int rp) { return (4 * T + 1) + 7 * 8 * T + (uint32_t)rp * (4 + 2 * T) + (5 * T + 1); }
 // FR-wire offset of segment `seg` inside the Poseidon block
 HD uint32_t pos_seg_off(int T, int rp, uint32_t seg) {
-    const uint32_t nch = pos_nchunks(rp), head = 4 * T + 1, full = 8 * T, part = 4 + 2 * T;
+    const uint32_t nch = pos_nchunks(rp), head = 4 * T + 1, full = 8 * T, part = 4 + 2 * T, partA = 6 * T;
     if (seg == 0) return 0;
-    if (seg <= 5) return head + (seg - 1) * full;                                   // seg 5 = first partial chunk
-    if (seg < 5 + nch) return head + 4 * full + (seg - 5) * POS_PCH * part;
-    return head + 4 * full + (uint32_t)rp * part + (seg - 5 - nch) * full;             // second-half full rounds, then the tail
+    if (seg < 9) return head + ((seg - 1) >> 1) * full + (((seg - 1) & 1) ? partA : 0);
+    if (seg < 9 + nch) return head + 4 * full + (seg - 9) * POS_PCH * part;
+    const uint32_t q = seg - 9 - nch;                                              // second-half full rounds (q < 6), then the tail (q = 6)
+    return head + 4 * full + (uint32_t)rp * part + (q >> 1) * full + ((q & 1) ? partA : 0);
 }
 // A state element is a VALUE for generation / counting / emission.  The evaluator never holds the state in registers: there a state
 // element is a STORED WIRE (+ an optional round constant still to be added) that is loaded where a relation uses it, so a segment
@@ -369,12 +373,13 @@ template <class P, int T> GD void gMixS(P& p, const PosOff& k, int r, typename P
 #pragma unroll
     for (int j = 1; j < T; j++) st[j] = pv_at(p, o + j, p.put(o + j, fr_add(pv_get(p, in[j]), fr_mul(pv_get(p, in[0]), p.kconst(base + T + j - 1)))));
 }
-// one full round: T Sigma, ark (constants at C + cr), mix with matrix `mat`
-template <class P, int T> GD void gPosFull(P& p, const PosOff& k, int cr, uint32_t mat, typename PosSt<P>::type* st) {
+// one full round in two parts: T Sigma + ark (constants at C + cr) | mix with matrix `mat`
+template <class P, int T> GD void gPosFullPart(P& p, const PosOff& k, int cr, uint32_t mat, uint32_t part, typename PosSt<P>::type* st) {
+    if (part == 0) {
 #pragma unroll
-    for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
-    gArk<P, T>(p, k, cr, st);
-    gMix<P, T>(p, mat, st);
+        for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
+        gArk<P, T>(p, k, cr, st);
+    } else gMix<P, T>(p, mat, st);
 }
 template <class P, int T> GD void gPosPartial(P& p, const PosOff& k, int r, typename PosSt<P>::type* st) {
     st[0] = pv_addc(p, gSigma(p, st[0]), k.C + 5 * T + r);
@@ -393,12 +398,11 @@ template <class P, int T> GD void gPoseidonSeg0(P& p, const PosOff& k, const F* 
 }
 template <class P, int T> GD void gPoseidonSeg(P& p, const PosOff& k, Cur base, uint32_t seg, typename PosSt<P>::type* st) {
     const uint32_t nch = pos_nchunks(k.rp);
-    if (seg <= 3) gPosFull<P, T>(p, k, (int)seg * T, k.M, st);
-    else if (seg == 4) gPosFull<P, T>(p, k, 4 * T, k.Pm, st);
-    else if (seg < 5 + nch) {
-        const int r0 = (int)(seg - 5) * POS_PCH, r1 = r0 + POS_PCH < k.rp ? r0 + POS_PCH : k.rp;
+    if (seg < 9) { const uint32_t r = (seg - 1) >> 1; gPosFullPart<P, T>(p, k, (int)(r + 1) * T, r == 3 ? k.Pm : k.M, (seg - 1) & 1, st); }
+    else if (seg < 9 + nch) {
+        const int r0 = (int)(seg - 9) * POS_PCH, r1 = r0 + POS_PCH < k.rp ? r0 + POS_PCH : k.rp;
         for (int r = r0; r < r1; r++) gPosPartial<P, T>(p, k, r, st);
-    } else if (seg < 5 + nch + 3) gPosFull<P, T>(p, k, 5 * T + k.rp + (int)(seg - 5 - nch) * T, k.M, st);
+    } else if (seg < 9 + nch + 6) { const uint32_t q = seg - 9 - nch; gPosFullPart<P, T>(p, k, 5 * T + k.rp + (int)(q >> 1) * T, k.M, q & 1, st); }
     else {
 #pragma unroll
         for (int j = 0; j < T; j++) st[j] = gSigma(p, st[j]);
@@ -1000,10 +1004,8 @@ template <class P> GD SmRef gNum2LittleEndianBytesF(P& p, int N, const F& in, F*
     bv_put(p, ba, 8 * N, v);
     const Cur kids = p.cur;                                  // N x Bits2Num(8)
     bv_put_children(p, kids.w, kids.b, 9, 1, 8, 8 * N, v);
-    for (int j = 0; j < N; j++) {
-        const S by = canon_byte(c, j);
-        p.put(o + j, p.put(SmRef{kids.w + 9 * j, kids.s + j}, by));
-    }
+    sm_puts_at<P, 8>(p, N, [&](int j) { return SmRef{kids.w + 9u * (uint32_t)j, kids.s + (uint32_t)j}; }, [&](int j) { return canon_byte(c, j); });      // Bits2Num(8).out x N
+    sm_puts<P, 8>(p, o, N, [&](int j) { return canon_byte(c, j); });                                                                                         // out[] <== them
     p.cur = Cur{kids.w + 9u * N, kids.b + 8u * N, kids.s + (uint32_t)N, kids.f, kids.q};
     if (cout) *cout = c;
     return o;
@@ -1018,10 +1020,14 @@ template <class P> GD SmRef gNum2BigEndianBytesFv(P& p, int N, const F& in, SmRe
     F c;
     gNum2LittleEndianBytesF(p, N, x, &c);
     SmRef ro, ri;
-    for (int j = 0; j < N; j++) p.put(le + j, canon_byte(c, j));
+    auto le_byte = [&](int j) { return canon_byte(c, j); };
+    auto be_byte = [&](int j) { return canon_byte(c, N - 1 - j); };
+    sm_puts<P, 8>(p, le, N, le_byte);
     ro = p.sms(N); ri = p.sms(N);
-    for (int j = 0; j < N; j++) { const S by = canon_byte(c, j); p.put(ri + j, by); p.put(ro + (N - 1 - j), by); }
-    for (int j = 0; j < N; j++) { const S by = canon_byte(c, N - 1 - j); p.put(o + j, by); if (has_also) p.put(also_ref + j, by); }
+    sm_puts<P, 8>(p, ri, N, le_byte);
+    sm_puts<P, 8>(p, ro, N, be_byte);
+    sm_puts<P, 8>(p, o, N, be_byte);
+    if (has_also) sm_puts<P, 8>(p, also_ref, N, be_byte);
     if (cout) *cout = c;
     (void)also;
     return o;
@@ -1349,7 +1355,8 @@ template <class P> GD SmRef gBurnAddress(P& p, const PosOff& k5, const F& prefix
     F c;
     gNum2BigEndianBytesFU(p, 32, h, hash, fp_n2be32, pos_out, &hb, &c);   // hashBytes[i] = big-endian byte i = little-endian byte 31 - i, written per witness
     SmRef fo = p.sms(20), fi = p.sms(32);                // Fit(32, 20)  [out[20] | in[32]]
-    for (int i = 0; i < 32; i++) { const S by = canon_byte(c, 31 - i); p.put(fi + i, by); if (i < 20) { p.put(fo + i, by); p.put(o + i, by); } }
+    auto be_byte = [&](int i) { return canon_byte(c, 31 - i); };
+    sm_puts<P, 8>(p, fi, 32, be_byte); sm_puts<P, 8>(p, fo, 20, be_byte); sm_puts<P, 8>(p, o, 20, be_byte);
     if (hash_canon) *hash_canon = c;
     return o;
 }

@@ -165,6 +165,23 @@ template <class P, int N> HD __attribute__((always_inline)) void sm_commit(P& p,
         for (int k = 0; k < N; k++) p.put(r[k], v[k]);
     }
 }
+// n SM wires ref(i) := val(i), BATCH at a time: the evaluator's loads of a batch are requested together, ahead of their compares (as single puts in a loop that is not
+// unrolled every wire is its own memory round trip -- the compare of one is resolved before the next load is issued: 0.4-0.5 us per wire; the byte conversions and the fixed
+// concatenations of the BN254 composites were 100-300 such wires in a row: their evaluation units the longest of the narrow kernel)
+template <class P, int BATCH, class RefFn, class ValFn> HD __attribute__((always_inline)) void sm_puts_at(P& p, int n, RefFn ref, ValFn val) {
+    for (int i0 = 0; i0 < n; i0 += BATCH) {
+        SmRef rr[BATCH]; S vv[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) rr[q] = ref(i0 + q < n ? i0 + q : n - 1);       // (a short last batch repeats its last wire: same wire, same value)
+        const SmLoaded<BATCH> h = sm_load(p, rr);
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) vv[q] = val(i0 + q < n ? i0 + q : n - 1);
+        sm_commit(p, rr, h, vv);
+    }
+}
+template <class P, int BATCH, class ValFn> HD __attribute__((always_inline)) void sm_puts(P& p, SmRef base, int n, ValFn val) {
+    sm_puts_at<P, BATCH>(p, n, [&](int i) { return base + (uint32_t)i; }, val);
+}
 // Lane-distributed bit vector of up to 256 BIT wires: bit 64q + k lives in lane k of r[q] as that wire's 64-witness mask.  A
 // decomposition (Num2Bits and everything copied from it) is built ONCE from the witnesses' canonical values and then written /
 // verified as runs -- no wire of it is ever read back.

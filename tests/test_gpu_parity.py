@@ -460,7 +460,7 @@ def test_two_ranks_on_one_gpu_equal_a_single_rank_run(pkg, tmp_path):
     equal a single-rank run of the same 1024 seeds (the two ranks with bench.py's default four in-order calculators in flight each, the
     single rank with one calculator).  bench.py itself asserts validity, commitments and a clean evaluator per rank."""
     a, b = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
-    quick = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single"]
+    quick = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single", "--no-extra-legs"]
     two = _run_bench(["--gpus", "2", "--batch", "512", "--dump-results", a] + quick, {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
     one = _run_bench(["--gpus", "1", "--batch", "1024", "--pipeline", "0", "--dump-results", b] + quick)
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak" and two["config"]["rccl_ranks"] == 2
@@ -470,7 +470,11 @@ def test_two_ranks_on_one_gpu_equal_a_single_rank_run(pkg, tmp_path):
     assert not ra[:, :4].any() and (ra[:, 4:12] == 0xFF).all()       # every status 0, every verdict clean
     # BASELINE config 4 as written: ONE global batch split over the ranks (strong scaling), uneven split included
     c = str(tmp_path / "strong.npy")
-    st = _run_bench(["--gpus", "2", "--total-batch", "1023", "--dump-results", c] + quick, {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=2)
+    # ... started WITHOUT a launcher: `python bench.py --gpus 2 ...` starts its two ranks itself (bench.launch_ranks), rank 0 prints the one line
+    env_clean = {k: "" for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") if k in os.environ}
+    assert not env_clean, "the test process itself runs under a launcher"
+    st = _run_bench(["--gpus", "2", "--total-batch", "1023", "--dump-results", c] + quick, {"POB_FORCE_DEVICE": "0", "POB_DIST_BACKEND": "gloo"}, nproc=1)
+    assert st["n_gpus"] == 2 and st["ranks"]["launched_by"] == "bench.py itself" and st["ranks"]["rccl_ranks"] == 2
     rc = np.load(c)
     assert st["scaling"] == "strong" and rc.shape == (1023, 44) and not rc[:, :4].any() and (rc[:, 4:12] == 0xFF).all()
     assert st["config"]["validated_witnesses"] == 3 * 512 and len({bytes(x) for x in rc[:, 12:]}) == 1023       # (rank 0's slice: 512 of the 1023; all commitments differ)
@@ -502,7 +506,7 @@ def test_max_depth_config5_payload_and_bench(pkg):
     r = calc.calculate([again], check=True)[0]
     assert r.ok and r.outputs == [deep.commitments[1]] and r.check_status == 0 and r.bad_wire is None
     calc.close()
-    line = _run_bench(["--gpus", "1", "--depth", "16", "--batch", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single",
+    line = _run_bench(["--gpus", "1", "--depth", "16", "--batch", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-emission", "--no-single", "--no-extra-legs", "--pipeline", "4",
                        "--distinct-keys", "2", "--distinct-batches", "2"])
     assert "16-layer" in line["config"]["workload"] and line["value"] > 0
 
