@@ -166,6 +166,13 @@ int pob_results_device(pob_handle h, void** d_status, void** d_outputs);
 #define POB_RECORD_BYTES 44
 #define POB_NOT_EVALUATED 0xFFFFFFFEu
 int pob_results_records_device(pob_handle h, void** d_records);
+/* The multi-GPU path's ONE collective for a host that is not Python (bench.py does the same through torch.distributed): all-gather of this handle's device records
+ * over RCCL.  comm = the caller's ncclComm_t (one rank per GPU, created by the caller: ncclCommInitRank), stream = the stream the collective runs on (ordered behind
+ * the handle's last evaluation -- or generation -- by an event), d_out = device memory for nranks x n_per_rank x POB_RECORD_BYTES bytes; every rank passes the same
+ * n_per_rank (>= its batch: uneven slices pad, distributed.py gather_records shows the trimming).  librccl.so is loaded on first use (dlopen: the library has no
+ * link-time dependency on it); POB_E_STATE if it cannot be loaded, POB_E_HIP with the RCCL error text in pob_last_error otherwise.
+ * Replaces: nothing in the reference (one witness per process, Makefile:4-5); SURVEY.md 8e.                                                                     */
+int pob_gather_records(pob_handle h, void* comm, void* stream, void* d_out, uint32_t n_per_rank);
 /* Per-batch, host-visible verdicts without stalling the device: the kernel that packs the records also writes them straight into pinned
  * host memory owned by the handle (two buffers alternating per batch: no copy, no copy stream).  pob_results_fetch marks the CURRENT
  * batch's buffer as the one to read; pob_results_wait blocks until that buffer is written -- an event of this handle, recorded behind its

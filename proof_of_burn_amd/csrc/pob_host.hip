@@ -1212,6 +1212,34 @@ int pob_results_device(pob_handle h, void** d_status, void** d_outputs) {
     return POB_OK;
 }
 
+// ---- the record gather over RCCL for C-ABI hosts.  librccl is dlopen'ed: no link-time dependency (the CPU shim of the tests and single-GPU users never need it)
+#include <dlfcn.h>
+typedef int (*pob_nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*pob_nccl_errstr_t)(int);
+static pob_nccl_allgather_t g_nccl_allgather = nullptr; static pob_nccl_errstr_t g_nccl_errstr = nullptr; static bool g_nccl_tried = false;
+int pob_gather_records(pob_handle h, void* comm, void* stream_, void* d_out, uint32_t n_per_rank) {
+    if (!h || !comm || !d_out || n_per_rank == 0 || n_per_rank > h->groups * 64) return POB_E_ARG;
+    if (!h->generated) return POB_E_STATE;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_nccl_tried) {
+            g_nccl_tried = true;
+            void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) { g_nccl_allgather = (pob_nccl_allgather_t)dlsym(lib, "ncclAllGather"); g_nccl_errstr = (pob_nccl_errstr_t)dlsym(lib, "ncclGetErrorString"); }
+        }
+    }
+    if (!g_nccl_allgather) { h->err = "librccl.so could not be loaded (pob_gather_records)"; return POB_E_STATE; }
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : own_stream(h);
+    // behind the batch's records: the evaluation's collect if one was enqueued since the generation, else the generation's
+    if (h->evaluated && h->check_done_rec) { if (h->chk_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_check_done, 0)); }
+    else if (h->gen_done_rec && h->gen_stream != st) HIPC(hipStreamWaitEvent(st, h->ev_gen_done, 0));
+    const int rc = g_nccl_allgather(h->d_records, d_out, (size_t)n_per_rank * POB_RECORD_BYTES, /* ncclUint8 */ 1, comm, st);
+    if (rc != 0) { h->err = std::string("ncclAllGather: ") + (g_nccl_errstr ? g_nccl_errstr(rc) : "error"); return POB_E_HIP; }
+    return POB_OK;
+}
+
 int pob_results_records_device(pob_handle h, void** d_records) {
     if (!h || !d_records) return POB_E_ARG;
     *d_records = h->d_records;

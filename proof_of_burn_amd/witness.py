@@ -174,6 +174,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_results.argtypes = [vp, vp, vp, vp, vp]
     lib.pob_results_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     lib.pob_results_records_device.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.pob_gather_records.argtypes = [vp, vp, vp, vp, ctypes.c_uint32]
     lib.pob_emit_witness.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64]
     lib.pob_write_wtns.argtypes = [vp, ctypes.c_uint32, ctypes.c_char_p]
     lib.pob_emit_begin.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
@@ -204,7 +205,7 @@ def load_library() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_close", "pob_get_info", "pob_strerror", "pob_upload_inputs", "pob_upload_inputs_async", "pob_host_alloc", "pob_host_free", "pob_pack_json", "pob_pack_json_batch",
                     "pob_upload_inputs8", "pob_upload_inputs8_async", "pob_narrow_inputs", "pob_pack_json_batch8",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
-                    "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_emit_witness",
+                    "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_gather_records", "pob_emit_witness",
                     "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_alias", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
@@ -843,6 +844,12 @@ class WitnessCalculator:
         a = ctypes.c_void_p()
         self._ck(self.lib.pob_results_records_device(self.h, ctypes.byref(a)))
         return a.value
+
+
+    def gather_records_rccl(self, comm: int, out_ptr: int, n_per_rank: int, stream: int = 0):
+        """the multi-GPU path's one collective through the C ABI (pob_gather_records): all-gather of this calculator's device records over the caller's ncclComm_t into
+        device memory at out_ptr (nranks x n_per_rank x 44 bytes), on `stream`, ordered behind the batch's evaluation"""
+        self._ck(self.lib.pob_gather_records(self.h, ctypes.c_void_p(comm), ctypes.c_void_p(stream), ctypes.c_void_p(out_ptr), n_per_rank))
 
     def results_device_ptrs(self):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()

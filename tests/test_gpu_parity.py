@@ -849,6 +849,41 @@ calc.close()
     assert r.returncode == 0 and "rccl ranks 1 nccl" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+def test_c_abi_record_gather_over_rccl_world_of_one(pkg):
+    """pob_gather_records: the multi-GPU path's one collective for a host that is not Python -- the library dlopens librccl and all-gathers the calculator's device records
+    over the CALLER's ncclComm_t.  Here: a communicator of one rank made through ctypes (ncclGetUniqueId / ncclCommInitRank, as a C host would), a batch with one failing
+    witness, the gathered bytes == the records the host reads; on a node the same call runs with nranks = 8."""
+    import ctypes
+    import torch
+    s = _suite("test_spend")
+    inputs = [c["input"] for c in s["cases"]]
+    calc = pkg.WitnessCalculator("Spend(31)", max_batch=len(inputs))
+    res = calc.calculate(inputs, check=True)
+    assert any(not r.ok for r in res) and any(r.ok for r in res)
+    rccl = ctypes.CDLL("librccl.so.1")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    n = len(inputs)
+    out = torch.zeros((n, 44), dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.Stream()
+    calc.gather_records_rccl(comm.value, out.data_ptr(), n, st.cuda_stream)
+    st.synchronize()
+    calc.fetch_records()
+    rec = calc.wait_records()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :4].copy().view(np.uint32)[:, 0], rec["status"]) and np.array_equal(got[:, 12:], rec["commitment"])
+    assert np.array_equal(got[:, 4:8].copy().view(np.uint32)[:, 0], rec["check_status"])
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    calc.close()
+
+
 def test_seeded_differential_fixture_instantiation(pkg):
     """64 random VALID proofs of depths 2..4 on the fixture instantiation (seeded): outputs, clean evaluator and the WHOLE canonical payload
     of every one of them against the oracle"""
