@@ -538,20 +538,6 @@ def leg_roofline(job, loop, info, kchk_in_step, ms_step, probe_steps):
     ev1.record(st0)
     cuda.synchronize()
     t_check_pass = ev0.elapsed_time(ev1) / 5
-    # ... and with the TRACK schedule (the lowest latency for ONE batch: the Keccak round evaluation on the caller's stream, the G families on the device's side streams beside it)
-    t_check_tracks = None
-    if loop.inorder and not loop.link:
-        calc0.set_inorder(0)
-        for _ in range(2):
-            calc0.constraint_check(st0.cuda_stream)
-        cuda.synchronize()
-        ev0.record(st0)
-        for _ in range(5):
-            calc0.constraint_check(st0.cuda_stream)
-        ev1.record(st0)
-        cuda.synchronize()
-        t_check_tracks = ev0.elapsed_time(ev1) / 5
-        calc0.set_inorder(3 if args.fused else 1)
     resident = int(info.group_bytes) * groups
     traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
@@ -580,10 +566,7 @@ def leg_roofline(job, loop, info, kchk_in_step, ms_step, probe_steps):
                            "avg_ms": round(t_gen, 4)},
             "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone, in-order schedule (one stream: the launches follow each other)", "bytes": resident,
                            "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),
-                           "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "track_schedule": ({"what": "the same evaluation with the calculator's track schedule (pob_set_inorder(h, 0): the G families on side streams BESIDE the Keccak round evaluation)",
-                                               "ms": round(t_check_tracks, 3), "achieved": round(resident / (t_check_tracks * 1e-3) / 1e9, 1),
-                                               "frac": round(resident / (t_check_tracks * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if t_check_tracks else None)},
+                           "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "step": {"what": "generate (write the resident vector once) + evaluate (read it once) per timed step", "bytes": 2 * resident,
                      "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 

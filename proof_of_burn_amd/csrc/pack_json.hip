@@ -15,6 +15,9 @@
 // batch of 1 024 texts is 0.5 ms of parsing on the cores of a GPU box -- starting and joining threads per call cost more than that) and write straight
 // into the caller's (pinned) arrays.  Default width: the CPUs this process may run on (its affinity mask: a rank pinned to its GPU's NUMA node
 // gets that node's cores) divided by LOCAL_WORLD_SIZE when a launcher set it, so that the ranks of a node do not each start a full-width loader.
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -373,6 +376,9 @@ class LoaderPool {
     std::vector<std::thread> th;
     const std::function<void(uint32_t)>* job = nullptr; uint64_t gen = 0; uint32_t want = 0, taken = 0, done = 0; bool stop = false;
     void loop() {
+        // a pool thread yields to the thread that drives the GPU: when the loader fills every CPU the process may use (a service loop parsing batch k + 2 beside the
+        // device's batch k), the enqueueing thread must not wait for a time slice -- the device would idle for it.  (Linux: nice is per thread)
+        setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(uint32_t)>* f = nullptr; uint32_t slot = 0;

@@ -83,7 +83,7 @@ typedef int hipError_t;
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
 enum { hipSuccess = 0, hipErrorUnknown = 999 };
-enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventBlockingSync = 1, hipHostMallocDefault = 0 };
 static inline const char* hipGetErrorString(hipError_t) { return "hostsim error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
