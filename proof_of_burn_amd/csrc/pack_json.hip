@@ -191,27 +191,38 @@ struct Parser {
                 // follows from the comma before it, so the elements' positions come from mask arithmetic (a cycle or two each) and their values are computed
                 // independently of one another -- the one-element loop below walks a chain of load -> classify -> advance, 15 cycles per element
                 if (e - s > 80 && n + 33 <= cap && (uint32_t)(uint8_t)*s - '0' <= 9) {
-                    uint64_t D = 0, C = 0, S = 0;
+                    uint64_t D = 0, C = 0, S = 0, Z = 0;
                     for (int k = 0; k < 4; k++) {
                         const __m128i x = _mm_loadu_si128((const __m128i*)(s + 16 * k));
                         const __m128i dg = _mm_sub_epi8(x, _mm_set1_epi8('0'));
                         D |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(dg, _mm_set1_epi8(9)), dg)) << (16 * k);
                         C |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, _mm_set1_epi8(','))) << (16 * k);
                         S |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, _mm_set1_epi8(' '))) << (16 * k);
+                        Z |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(dg, _mm_setzero_si128())) << (16 * k);
                     }
                     const uint64_t O = ~(D | C | S);
-                    uint64_t Cm = O ? C & ((1ULL << __builtin_ctzll(O)) - 1) : C;
-                    unsigned start = 0; bool stop = false;
-                    while (Cm) {
-                        const unsigned p = (unsigned)__builtin_ctzll(Cm), len = p - start;
-                        if (len - 1u >= 3u) { stop = true; break; }          // (first: a run of up to 63 characters in front of the comma would shift by >= 32 below)
-                        uint32_t w; memcpy(&w, s + start, 4);
-                        const uint32_t t = w ^ 0x30303030u, mask = (1u << len) - 1;
-                        if ((((uint32_t)(D >> start)) & mask) != mask || (len > 1 && (t & 0xFF) == 0)) { stop = true; break; }
-                        const uint32_t y = (t & ((1u << (8 * len)) - 1)) << (8 * (3 - len));               // hundreds | tens | units in bytes 0 | 1 | 2
-                        dst[n++] = (int32_t)((y & 0xFF) * 100 + ((y >> 8) & 0xFF) * 10 + (y >> 16));
-                        start = p + 1 + (unsigned)(((S >> p) >> 1) & 1);
-                        Cm &= Cm - 1;
+                    // Whether an element may be taken is decided for the whole block, by mask arithmetic (round 6; round 5 tested every element: its digits, its length, its leading
+                    // zero -- half of the 28 operations an element cost).  An element is 1-3 digits, no leading zero, closed by a comma, at most one blank behind the comma:
+                    //   a blank anywhere else | a run of four or more digits | a comma not behind a digit | a zero that starts an element and is followed by a digit
+                    // and every comma below the first such place (and below the first other character) closes an element that needs no further look.
+                    const uint64_t A = C << 1;                                              // positions right behind a comma
+                    const uint64_t Es = (A & ~S) | ((A & S) << 1) | 1ull;                   // element starts (the block begins at one)
+                    const uint64_t V = (S & ~A) | (D & (D >> 1) & (D >> 2) & (D >> 3)) | (C & ~(D << 1)) | (Z & Es & (D >> 1));
+                    const uint64_t upto = O | V;
+                    uint64_t Cm = upto ? C & ((1ULL << __builtin_ctzll(upto)) - 1) : C;
+                    const bool stop = V != 0 && (!O || __builtin_ctzll(V) < __builtin_ctzll(O));      // the slow path looks at the element that is not plain
+                    unsigned start = 0;
+                    if (Cm) {
+                        const unsigned plast = 63u - (unsigned)__builtin_clzll(Cm);
+                        start = plast + 1 + (unsigned)(((S >> plast) >> 1) & 1);                        // where the text goes on behind the last element taken
+                        uint64_t Em = Es;                                                                // the i-th start belongs to the i-th comma
+                        do {
+                            const unsigned p = (unsigned)__builtin_ctzll(Cm), st = (unsigned)__builtin_ctzll(Em), len = p - st;   // 1..3
+                            uint32_t w; memcpy(&w, s + st, 4);
+                            const uint32_t y = ((w ^ 0x30303030u) << (8 * (3 - len))) & 0xFFFFFFu;           // hundreds | tens | units in bytes 0 | 1 | 2 (what follows the digits is shifted out)
+                            dst[n++] = (int32_t)((y & 0xFF) * 100 + ((y >> 8) & 0xFF) * 10 + (y >> 16));
+                            Cm &= Cm - 1; Em &= Em - 1;
+                        } while (Cm);
                     }
                     s += start;
                     if (start) {                                    // at the next element (or at whatever follows the last comma taken: the loops below decide)
