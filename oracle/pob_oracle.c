@@ -40,6 +40,8 @@ typedef struct {
     int decl_order;
     fr inv_cache[8193]; /* inverses of -4096..4096 (index k+4096), lazily filled */
     uint8_t inv_have[8193];
+    char sites[1536]; size_t sites_len;   /* EVERY failing assert / === site of the run, "Template:line;" each once, in execution order (the emitted calculator stops at the first;
+                                            the HIP path reports the LOWEST site code of a witness: the tests compare it with the lowest of these) */
 } ctx;
 
 #define W(i) (c->w[(i)])
@@ -52,6 +54,8 @@ static size_t A(ctx *c, size_t n) {
 }
 static void fail_at(ctx *c, const char *tpl, int line) {
     if (!c->failed) { c->failed = 1; snprintf(c->msg, sizeof c->msg, "Failed assert in template %s line %d", tpl, line); }
+    char one[96]; const int k = snprintf(one, sizeof one, "%s:%d;", tpl, line);
+    if (k > 0 && !strstr(c->sites, one) && c->sites_len + (size_t)k < sizeof c->sites) { memcpy(c->sites + c->sites_len, one, (size_t)k + 1); c->sites_len += (size_t)k; }
 }
 #define REQUIRE(cond, tpl, line) do { if (!(cond)) fail_at(c, tpl, line); } while (0)
 
@@ -1206,6 +1210,9 @@ static ctx *g_ctx;
 
 static uint64_t pu(const uint64_t *params, int i) { return params[4 * i]; }
 static fr pf(const uint64_t *params, int i) { fr r = {{params[4 * i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3]}}; return r; }
+
+/* the failing sites of the last run ("Template:line;..."), execution order, each once */
+const char *oracle_fail_sites(void) { return g_ctx ? g_ctx->sites : ""; }
 
 void oracle_free(void) {
     if (g_ctx) { if (g_ctx->w) munmap(g_ctx->w, g_ctx->cap * sizeof(fr)); free(g_ctx); g_ctx = NULL; }

@@ -127,6 +127,7 @@ def lib():
         _lib.oracle_wtns_into.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         _lib.oracle_wtns_write.argtypes = [ctypes.c_char_p]
         _lib.oracle_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
+        _lib.oracle_fail_sites.restype = ctypes.c_char_p
     return _lib
 
 
@@ -189,6 +190,12 @@ def run(main: str, inputs: dict, capacity: int = 0) -> Run:
     return Run(res, rc)
 
 
+def fail_sites():
+    """EVERY failing assert / === site of the last run as (template, line) pairs, in execution order (the oracle does not stop at the first)"""
+    txt = lib().oracle_fail_sites().decode()
+    return tuple((a, int(b)) for a, b in (x.split(":") for x in txt.split(";") if x))
+
+
 def run_main(main: str, inputs: dict):
     r = run(main, inputs)
     return None if r.failed else r.outputs()
@@ -214,10 +221,10 @@ def payload_digest(arr) -> str:
 
 class Brief:
     """what a worker process hands back of one oracle run: verdict, message, outputs, wire count, digest of the payload (valid witnesses, on request)"""
-    __slots__ = ("failed", "msg", "outs", "nwitness", "digest")
+    __slots__ = ("failed", "msg", "outs", "nwitness", "digest", "sites")
 
-    def __init__(self, failed, msg, outs, nwitness, digest):
-        self.failed, self.msg, self.outs, self.nwitness, self.digest = failed, msg, outs, nwitness, digest
+    def __init__(self, failed, msg, outs, nwitness, digest, sites=()):
+        self.failed, self.msg, self.outs, self.nwitness, self.digest, self.sites = failed, msg, outs, nwitness, digest, sites
 
     def outputs(self):
         return self.outs
@@ -227,7 +234,7 @@ def _brief_worker(args):
     main, inputs, want_digest = args
     r = run(main, inputs)
     d = payload_digest(r.witness_numpy()) if (want_digest and not r.failed) else None
-    out = (r.failed, r.msg, None if r.failed else r.outputs(), r.nwitness, d)
+    out = (r.failed, r.msg, None if r.failed else r.outputs(), r.nwitness, d, fail_sites())
     lib().oracle_free()
     return out
 

@@ -390,7 +390,7 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
     tracks.close()
     assert [(r.status, r.outputs) for r in res] == [(r.status, r.outputs) for r in res_t], "the two schedules disagree about a witness"
     code_of = {name: tid for tid, name in W._TPL.items()}
-    n_fail = n_valid_payloads = 0
+    n_fail = n_valid_payloads = n_status_equal = 0
     is_case = set(pos)
     for q in range(n):                                            # the untouched neighbours
         if q not in is_case:
@@ -405,13 +405,17 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
             n_fail += 1
             m = re.match(r"Failed assert in template (\w+) line (\d+)", ora.msg)
             if m and m.group(1) in code_of and r.status != W.FAIL_INPUT_RANGE:      # (an input that does not fit its int32 row fails up front, whatever the circuit would say)
-                # the oracle stops at the FIRST failing site in execution order, the device reports the LOWEST failing site
+                # the emitted calculator stops at the FIRST failing site in execution order (ora.msg), the device reports the LOWEST failing site code of the witness:
+                # never above the first one -- and EQUAL to the lowest of all the sites the oracle, which keeps going, has seen fail (round 6: oracle_fail_sites)
                 assert r.status <= ((code_of[m.group(1)] << 12) | int(m.group(2))), f"{label}: {r.message()} vs oracle {ora.msg}"
+                if all(t in code_of for t, _ in ora.sites):
+                    assert r.status == min((code_of[t] << 12) | ln for t, ln in ora.sites), f"{label}: {r.message()} vs the oracle's failing sites {ora.sites}"
+                    n_status_equal += 1
         else:
             assert r.check_status == 0 and r.bad_wire is None, label
             _assert_payload(calc, q, PROD, inp, ora, buf, label)
             n_valid_payloads += 1
-    assert n_fail > 15 and n_valid_payloads >= 8, (n_fail, n_valid_payloads)
+    assert n_fail > 15 and n_valid_payloads >= 8 and n_status_equal > 10, (n_fail, n_valid_payloads, n_status_equal)
     calc.close()
 
 

@@ -507,3 +507,31 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
         assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
         assert all(r.check_status == 0 and r.bad_wire is None for r in res if r.ok)
         calc.close()
+
+
+def test_failing_status_is_the_lowest_of_all_the_oracles_failing_sites(pkg):
+    """the emitted calculator stops at its FIRST failing assert (tests/test.py:65-68: anything on stderr = failed); the device reports, per witness, the LOWEST failing
+    site code.  The oracle keeps going after a failure and lists every failing site (oracle_fail_sites): for the reference's mutation set on the fixture instantiation the
+    device's status EQUALS the lowest of them -- same verdicts, and the same site whenever the first failing site is the lowest one"""
+    import random
+    from proof_of_burn_amd import inputs as gen, witness as W
+    from tests.test_gpu_parity import _mutations
+    params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
+    base = gen.synthetic_batch(1, depth=2, seed=101, distinct_keys=1, params=params).inputs[0]
+    cases = _mutations(base, random.Random(5))
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
+    res = calc.calculate([c[1] for c in cases])
+    code_of = {name: tid for tid, name in W._TPL.items()}
+    n_eq = n_first = 0
+    for (label, inp), r in zip(cases, res):
+        ora = O.run(POB_FIX, inp)
+        sites = O.fail_sites()
+        assert ora.failed == (not r.ok), label
+        if ora.failed and r.status != W.FAIL_INPUT_RANGE:
+            assert sites and all(t in code_of for t, _ in sites), (label, sites)
+            codes = [(code_of[t] << 12) | ln for t, ln in sites]
+            assert r.status == min(codes), f"{label}: {r.message()} vs the oracle's failing sites {sites}"
+            n_eq += 1
+            n_first += codes[0] == min(codes)
+    assert n_eq > 20 and 0 < n_first < n_eq          # both kinds occur: the first site is the lowest one / it is not
+    calc.close()
