@@ -102,8 +102,9 @@ int pob_pack_json_batch(int circuit, const uint64_t* params, int nparams, const 
  *   exc[n][POB_EXC_CAP]        per witness the (few) small inputs outside 0..255 -- layerLens[] and blockHeaderLen above 255, and whatever a caller feeds
  *                              out of range on purpose (the reference does: tests/testcases/rlp/integer.py:51-53) -- as {index in the row, int32 value};
  *                              unused slots: k = POB_EXC_NONE
- * 11.4 KB per production witness instead of 43.8.  The device widens the rows into the int32 form every kernel reads (one pass on the upload
- * stream, behind the copy): the two forms are interchangeable batch by batch, results identical.  A witness with more than POB_EXC_CAP values
+ * 11.4 KB per production witness instead of 43.8.  ProofOfBurn: the upload is three copies and nothing else -- the generation's first kernel (and the evaluation's
+ * input check) read the byte form and write / compare the inputs' wires in one pass (round 6); the other circuits' kernels read int32 rows, for them the device
+ * widens the bytes on the upload stream, behind the copy.  The two forms are interchangeable batch by batch, results identical.  A witness with more than POB_EXC_CAP values
  * outside 0..255 does not fit: pob_narrow_inputs / pob_pack_json_batch8 return POB_E_RANGE and the batch goes through the int32 entry points. */
 #define POB_EXC_CAP 32
 #define POB_EXC_NONE 0xFFFFFFFFu
@@ -254,6 +255,10 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 
 /* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
+/* Experiment hook (profiles/round6_experiments.txt 9): a non-blocking stream of `device` restricted to the compute units of cu_mask (hipExtStreamCreateWithCUMask; words x 32 bits,
+ * bit i = CU i), for callers that want to partition the device between calculators.  pob_debug_stream_destroy frees it. */
+int pob_debug_stream_create(int device, const uint32_t* cu_mask, uint32_t words, void** stream);
+void pob_debug_stream_destroy(int device, void* stream);
 /* Test hook for the constraint evaluator: corrupt ONE stored value of ONE witness (lane `lane` of group `group`) of storage class
  * `cls` at storage index `index` (the wire's rank within its class): BIT: flips the bit if xor_mask & 1; SM: int32 ^= xor_mask;
  * FR: 32-bit limb `sub` (Montgomery form) ^= xor_mask.  (Derived and alias wires -- pob_info_t.n_derived / n_alias -- have no storage

@@ -1762,6 +1762,16 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
     return POB_OK;
 }
 
+int pob_debug_stream_create(int device, const uint32_t* cu_mask, uint32_t words, void** stream) {
+    if (!cu_mask || !words || !stream) return POB_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return POB_E_HIP;
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, words, cu_mask) != hipSuccess) return POB_E_HIP;
+    *stream = (void*)st;
+    return POB_OK;
+}
+void pob_debug_stream_destroy(int device, void* stream) { if (stream && hipSetDevice(device) == hipSuccess) hipStreamDestroy((hipStream_t)stream); }
+
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask) {
     if (!h || group >= h->groups || bit_index >= h->plan.total.b) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));

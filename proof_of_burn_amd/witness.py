@@ -206,7 +206,7 @@ EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_clo
                     "pob_upload_inputs8", "pob_upload_inputs8_async", "pob_narrow_inputs", "pob_pack_json_batch8",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_gather_records", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_alias", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_stream_create", "pob_debug_stream_destroy", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_alias", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--nbatches", type=int, default=4)
+    ap.add_argument("--cumask", default="none", help="none | parity: calculator c on the CUs with index parity c % 2 | quarters: c % 4 of every 4 CUs | halves: lower / upper half of the CU indices")
     ap.add_argument("--alone", action="store_true", help="also time the whole evaluation / generation of one calculator alone and the family kernels")
     a = ap.parse_args()
     import numpy as np
@@ -44,6 +45,23 @@ def main():
                 pinned = [PinnedInputs(lp.calcs[0], B) for _ in batches]
                 for pin, bt in zip(pinned, batches):
                     lp.calcs[0].pack_json([json.dumps(i).encode() for i in bt.inputs], out=pin)
+            if a.cumask != "none":          # partition the device between the calculators: every calculator's stream restricted to a share of the compute units
+                import ctypes
+                from proof_of_burn_amd import witness as W
+                lib = W.load_library()
+                lib.pob_debug_stream_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+                ncu, words = 256, 8
+                class Raw:
+                    def __init__(self, ptr): self.cuda_stream = ptr
+                for c in range(depth):
+                    if a.cumask == "parity": cus = [i for i in range(ncu) if i % 2 == c % 2]
+                    elif a.cumask == "quarters": cus = [i for i in range(ncu) if i % 4 == c % 4]
+                    else: cus = [i for i in range(ncu) if (i < ncu // 2) == (c % 2 == 0)]
+                    m = (ctypes.c_uint32 * words)()
+                    for i in cus: m[i >> 5] |= 1 << (i & 31)
+                    p = ctypes.c_void_p()
+                    assert lib.pob_debug_stream_create(job.dev, m, words, ctypes.byref(p)) == 0
+                    lp.streams[c] = Raw(p.value)
             lp.set_inputs(pinned, expect)
             lp.run(max(depth, 1) + 2); job.fence()
             lp.probe(True)
@@ -65,7 +83,7 @@ def main():
                 t_gen = span(lambda: c0.generate(st0.cuda_stream))
                 fams = {f: round(c0.time_kernel(300 + f, iters=5, stream=st0.cuda_stream), 4) for f in range(8)}
                 extra = f" | alone: evaluation {t_eval:.3f} ms generation {t_gen:.3f} ms K_CHK {c0.time_kernel(1, iters=5, stream=st0.cuda_stream):.4f} K_GEN {c0.time_kernel(0, iters=5, stream=st0.cuda_stream):.4f} families {fams}"
-            print(f"round {r} {a.label} depth {depth} fused {ss}: {s / a.steps * 1e3:.3f} ms/step = {s / a.steps * 1e3 * 1024 / B:.3f} ms per 1024  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
+            print(f"round {r} {a.label} cumask {a.cumask} depth {depth} fused {ss}: {s / a.steps * 1e3:.3f} ms/step = {s / a.steps * 1e3 * 1024 / B:.3f} ms per 1024  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
             lp.close()
             del lp
     for pin in pinned:
