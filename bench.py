@@ -394,7 +394,7 @@ def _expect(np, batch):
 
 
 # ------------------------------------------------------------------------------------------------ legs after the timed region
-def leg_e2e_from_json(job, loop, texts, nsteps):
+def leg_e2e_from_json(job, loop, texts, nsteps, ms_step_packed_ahead=None):
     """the path from input.json TEXT, in the clock (reference Makefile:4-5: the calculator's unit of work starts at the JSON file): the same service loop, but every batch is
     parsed from its texts by the native loader (pob_pack_json_batch8 on the persistent loader pool) INSIDE the timed region -- a host thread packs batch k + 2 into a ring of
     pinned buffers while the device works on batches k, k - 1, ...; the loop waits for the packer only if it has fallen behind"""
@@ -438,7 +438,8 @@ def leg_e2e_from_json(job, loop, texts, nsteps):
                     "memory) -> H2D -> generate -> evaluate -> records validated; a host thread parses batch k + 2 while the device works on batch k",
             "steps": nsteps, "ms_per_step": round(dte / nsteps * 1e3, 3), "value": round(job.GB * nsteps / dte, 1), "unit": "witnesses/s", "validated_witnesses": nsteps * loop.B,
             "loader_ms_per_batch": round(loader_ms, 3), "loader_witnesses_per_s": round(loop.B / max(loader_ms, 1e-9) * 1e3, 1), "host_waited_for_loader_ms_per_step": round(stall / nsteps * 1e3, 3),
-            "bound": ("loader: the device loop waited for the packer most of every step -- host CPU time, see loader_cpu" if stall > 0.3 * dte else "device (the loader keeps ahead)"),
+            "bound": ("device (the loader keeps ahead: within 5 % of the step with the inputs packed ahead)" if (ms_step_packed_ahead and dte / nsteps * 1e3 <= 1.05 * ms_step_packed_ahead)
+                      else "loader: the device loop waited for the packer -- host CPU time, see loader_cpu" if stall > 0.3 * dte else "device (the loader keeps ahead)"),
             "loader_cpu": {"host_cpus_visible": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(), "what": "a batch of 1 024 production input.json texts (40 KB, 10 900 values each) is "
                            "loader_ms_per_batch x the loader's threads of CPU time; a host that grants this process Q CPUs packs at most Q / that many batches per second"}}
 
@@ -717,7 +718,7 @@ def main():
     # ---- legs after the timed region, same run, same box
     e2e = bare = single = tracks_pipeline = None
     if PIPE and INORDER and not args.no_single and loop.fetch_each:
-        e2e = leg_e2e_from_json(job, loop, texts, max(args.steps, 40))
+        e2e = leg_e2e_from_json(job, loop, texts, max(args.steps, 40), ms_step)
     if PIPE and not args.no_single and loop.fetch_each:
         bare = leg_kernel_pipeline_only(job, loop)
     if PIPE and not args.no_single:
