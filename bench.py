@@ -34,7 +34,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job n
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 DEFAULT_DEPTH = 12                                                   # in-order calculators in flight: the fastest depth measured (4 / 6 / 8 / 10 / 12 / 16: profiles/round6_experiments.txt)
-PMC_FILES = ("round6_pmc_k_rounds.json", "round5_pmc_k_rounds.json")
+PMC_FILES = ("round6_pmc_k_rounds_gc.json", "round6_pmc_k_rounds.json", "round5_pmc_k_rounds.json")
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (the oracle, test infrastructure: this leg only)
@@ -103,8 +103,9 @@ def parse_args(argv=None):
                     help="inorder: every calculator enqueues its whole batch in dependency order on ONE stream (pob_set_inorder) and --pipeline of them are in flight; "
                          "tracks: round 2-3's schedule, two linked calculators (pob_set_partner) whose tracks run on the device's side streams")
     ap.add_argument("--pipeline", type=int, default=-1, help=f"calculators in flight, each on consecutive batches (default: {DEFAULT_DEPTH} in-order ones / 2 linked track ones; 0 = one calculator, no pipeline)")
-    ap.add_argument("--fused", type=int, default=1, choices=[0, 1],
-                    help="1 (default): in-order calculators with fused launches (pob_set_inorder(h, 3): independent kernels of a batch share a launch); 0: one launch per kernel, round 5's schedule")
+    ap.add_argument("--fused", type=int, default=3, choices=[0, 1, 2, 3],
+                    help="default 3.  bit 0: in-order calculators with the fused Poseidon + sponge-chain launch (pob_set_inorder bit 1); bit 1: the Keccak round blocks are evaluated by the "
+                         "launch that writes them (pob_set_inorder bit 2: the evaluation's loads come from L2 / the Infinity Cache); 0: one launch per kernel, round 5's schedule")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
     ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
@@ -242,7 +243,12 @@ class ServiceLoop:
     pinned host memory, every record validated on the host; at N > 1 one all-gather of the device records.  Pipeline: batch k is generated by calculator k % depth while batch k-1 is
     evaluated by the one before; the host validates the oldest batch after it has enqueued the newest, so the device never waits for the host."""
 
-    def __init__(self, job: Job, main: str, depth: int, inorder: bool = True, fused: bool = True):
+    @staticmethod
+    def inorder_mode(fused: int) -> int:
+        """pob_set_inorder's argument for --fused: bit 0 of `fused` = the Poseidon + sponge-chain launch, bit 1 = the round blocks evaluated by the launch that writes them"""
+        return 1 | (2 if int(fused) & 1 else 0) | (4 if int(fused) & 2 else 0)
+
+    def __init__(self, job: Job, main: str, depth: int, inorder: bool = True, fused: int = 1):
         import numpy as np
         from proof_of_burn_amd import WitnessCalculator
         self.job, self.np, self.main = job, np, main
@@ -252,7 +258,7 @@ class ServiceLoop:
         self.calcs = [WitnessCalculator(main, max_batch=self.B, device=job.dev) for _ in range(self.depth)]
         if inorder:
             for c in self.calcs:
-                c.set_inorder(3 if fused else 1)
+                c.set_inorder(self.inorder_mode(fused))
         # (high priority: the callers' streams carry the main track of the generation, whose chain bounds the read phase; -0.3 % on the step)
         self.streams = [cuda.Stream(device=job.dev, priority=-1) for _ in self.calcs]     # (not the legacy default stream: it synchronises with every blocking stream)
         records_of = D.host_records if job.args.shim else D.device_records
@@ -478,7 +484,7 @@ def legs_track_schedule(job, loop):
     if not loop.link:
         loop.calcs[0].set_partner(None)
         for c in loop.calcs[:2]:
-            c.set_inorder(3 if job.args.fused else 1)
+            c.set_inorder(ServiceLoop.inorder_mode(job.args.fused))
     loop.active = loop.depth
     return single, tracks
 
@@ -486,7 +492,7 @@ def legs_track_schedule(job, loop):
 def leg_other_depth(job, main, depth, pinned, expect, nsteps=96):
     """the same service loop with another number of in-order calculators in flight: throughput and the round evaluation kernel's in-step duration"""
     np = __import__("numpy")
-    lp = ServiceLoop(job, main, depth, True, bool(job.args.fused))
+    lp = ServiceLoop(job, main, depth, True, job.args.fused)
     lp.set_inputs(pinned, expect)
     lp.run(depth + 2); job.fence()
     lp.probe(True)
@@ -517,59 +523,95 @@ def leg_other_inputs(job, loop, texts_of, batches, nsteps, what):
 
 
 def leg_roofline(job, loop, info, kchk_in_step, ms_step, probe_steps):
-    """roofline of the dominant kernel: Keccak round constraint evaluation, HBM-read bound.  Algorithmic bytes per launch = every resident array the launch covers, once."""
+    """roofline of the dominant kernel, HBM bound.  --fused bit 1 (default): k_rounds_gc, the launch that expands the Keccak round blocks AND evaluates them (the probe events of
+    the timed region bracket it); else k_rounds_check, the round evaluation as a launch of its own.  Algorithmic bytes per launch: what the work has to store / to load, stated
+    in `bytes_convention`; `traffic`: what reached HBM (PMC passes committed under profiles/)."""
     cuda, args = job.cuda, job.args
+    gc = bool(args.fused & 2) and loop.inorder
     groups = (loop.B + 63) // 64
     calc0, st0 = loop.calcs[0], loop.streams[0]
     t_chk = calc0.time_kernel(1, iters=5, stream=st0.cuda_stream)
     t_gen = calc0.time_kernel(0, iters=5, stream=st0.cuda_stream)
-    # a wavefront of k_rounds_check covers k = info.kchk_rounds consecutive rounds of a permutation: midRound[r0] once, then per round the 76 stored gate-output
-    # arrays + the stored midRound[r+1] (which stays in registers as the next round's input): 101 k + 25 arrays of 512 B, every resident array of the chunk counted ONCE
+    t_gc = calc0.time_kernel(6, iters=5, stream=st0.cuda_stream)
+    arr = 64 * 8                                          # one `signal x[64]` array of 64 witnesses: 512 B
+    # k_rounds_check: a wavefront covers k = info.kchk_rounds consecutive rounds of a permutation: midRound[r0] once, then per round the 76 stored gate-output arrays + the stored
+    # midRound[r+1] (which stays in registers as the next round's input): 101 k + 25 arrays, every resident array of the chunk counted ONCE
     kr = int(info.kchk_rounds)
-    launch_bytes = info.n_perms * (24 // kr) * (101 * kr + 25) * 64 * 8 * groups
-    launch_bytes_r4 = info.n_perms * 24 * 126 * 64 * 8 * groups
-    alone = launch_bytes / (t_chk * 1e-3) / 1e9
+    chk_bytes = info.n_perms * (24 // kr) * (101 * kr + 25) * arr * groups
+    launch_bytes_r4 = info.n_perms * 24 * 126 * arr * groups
+    # k_rounds_gen: 8 rounds per wavefront: 8 x 76 arrays stored, midRound[r0] loaded.  k_rounds_gc: g rounds per wavefront: per round 76 arrays stored (the expansion) and
+    # 101 loaded (the evaluation: the 76 back + the stored midRound[r+1]), midRound[r0] once
+    gen_bytes = info.n_perms * 3 * (8 * 76 + 25) * arr * groups
+    g = int(info.kgc_rounds)
+    gc_store, gc_load = info.n_perms * 24 * 76 * arr * groups, info.n_perms * (24 // g) * (101 * g + 25) * arr * groups
+    gc_once = info.n_perms * (24 // g) * (101 * g + 25) * arr * groups        # every resident array of the chunk once, whether written, evaluated or both
+    launch_bytes, t_alone = (gc_store + gc_load, t_gc) if gc else (chk_bytes, t_chk)
+    alone = launch_bytes / (t_alone * 1e-3) / 1e9
     in_step = launch_bytes / (kchk_in_step * 1e-3) / 1e9 if kchk_in_step else None
-    # whole evaluation pass and whole step against the resident vector (write once, read once)
-    ev0, ev1 = cuda.Event(enable_timing=True), cuda.Event(enable_timing=True)
-    cuda.synchronize()
-    ev0.record(st0)
-    for _ in range(5):
-        calc0.constraint_check(st0.cuda_stream)
-    ev1.record(st0)
-    cuda.synchronize()
-    t_check_pass = ev0.elapsed_time(ev1) / 5
+    # the whole evaluation of a resident vector as a pass of its own (round kernel included: after a first, untimed pass nothing stands for "evaluated with the expansion"),
+    # and one lone batch generated + evaluated the way the loop does it
+    def span(fn, n=5):
+        ev0, ev1 = cuda.Event(enable_timing=True), cuda.Event(enable_timing=True)
+        cuda.synchronize()
+        ev0.record(st0)
+        for _ in range(n):
+            fn()
+        ev1.record(st0)
+        cuda.synchronize()
+        return ev0.elapsed_time(ev1) / n
+    calc0.constraint_check(st0.cuda_stream)
+    t_check_pass = span(lambda: calc0.constraint_check(st0.cuda_stream))
+    t_lone = span(lambda: (calc0.generate(st0.cuda_stream), calc0.constraint_check(st0.cuda_stream)))
     resident = int(info.group_bytes) * groups
-    traffic, pmc_file = None, None                        # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
+    traffic, pmc_file, pmc_key = None, None, "k_rounds_gc" if gc else "k_rounds_check"      # HBM bytes per launch of the dominant kernel from the committed PMC passes (not measured in this run)
     try:
-        pmc_file = next(p for p in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", p)))
-        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-            pmc = json.load(f)
-        traffic = int(pmc["k_rounds_check"]["hbm_read_bytes_per_launch"] * groups / pmc["groups"])
+        for cand in PMC_FILES:
+            path = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(path):
+                with open(path) as f:
+                    pmc = json.load(f)
+                if pmc_key in pmc:
+                    pmc_file = cand
+                    traffic = int((pmc[pmc_key]["hbm_read_bytes_per_launch"] + (pmc[pmc_key].get("hbm_write_bytes_per_launch", 0) if gc else 0)) * groups / pmc["groups"])
+                    break
     except Exception:
         pass
     # `achieved` / `frac`: the kernel as it runs IN the timed loop (HIP events on its own stream around every launch, averaged over the timed
     # steps), i.e. beside the other batches' kernels; `frac_alone`: the same kernel alone on an idle device (5 back-to-back launches)
-    return {"bound": "hbm", "kernel": "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
-            "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
-            "measured": ((f"in {probe_steps} more batches of the same pipelined service loop right after the timed region" if args.probe_after else "in the timed region, every step")
-                         + f": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel); {loop.depth} calculators in flight"
-                         + (", fused launches: the events bracket the launch the kernel shares with the wide evaluation families" if args.fused else "")) if in_step else "alone",
-            "avg_ms": round(kchk_in_step if kchk_in_step else t_chk, 4),
-            "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_chk, 4),
-            "traffic": traffic,
-            "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel, scaled to this launch's groups; not measured in this run)" if traffic else None,
-            "bytes_per_launch": launch_bytes, "rounds_per_wavefront": kr,
-            "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
-                                f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
-            "gen_kernel": {"kernel": "k_rounds_gen, alone (8 rounds per wavefront: 8 x 76 arrays written, midRound[r0] read)", "achieved": round(info.n_perms * 3 * (8 * 76 + 25) * 64 * 8 * groups / (t_gen * 1e-3) / 1e9, 1),
-                           "avg_ms": round(t_gen, 4)},
-            "check_pass": {"what": "whole pob_constraint_check over the resident vector (all G families + Keccak rounds + chains), alone, in-order schedule (one stream: the launches follow each other)", "bytes": resident,
-                           "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1),
-                           "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "step": {"what": "generate (write the resident vector once) + evaluate (read it once) per timed step", "bytes": 2 * resident,
-                     "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    out = {"bound": "hbm",
+           "kernel": "k_rounds_gc (Keccak-f round blocks: expansion + constraint evaluation in one launch)" if gc else "k_rounds<CHECK> (Keccak-f round constraint evaluation)",
+           "achieved": round(in_step if in_step else alone, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round((in_step if in_step else alone) / HBM_PEAK_GBS, 4),
+           "measured": ((f"in {probe_steps} more batches of the same pipelined service loop right after the timed region" if args.probe_after else "in the timed region, every step")
+                        + f": HIP events on the kernel's own stream around each of its launches, mean over them (pob_probe_check_kernel); {loop.depth} calculators in flight") if in_step else "alone",
+           "avg_ms": round(kchk_in_step if kchk_in_step else t_alone, 4),
+           "frac_alone": round(alone / HBM_PEAK_GBS, 4), "achieved_alone": round(alone, 1), "avg_ms_alone": round(t_alone, 4),
+           "traffic": traffic,
+           "traffic_source": (f"profiles/{pmc_file} (separate rocprofv3 --pmc FETCH_SIZE" + (" and WRITE_SIZE passes" if gc else " pass") + " over this kernel, scaled to this launch's groups; not measured in this run)") if traffic else None,
+           "bytes_per_launch": launch_bytes}
+    if gc:
+        out.update({"rounds_per_wavefront": g,
+                    "bytes_convention": f"ALGORITHMIC bytes of the two jobs the launch does: the expansion stores permutations x 24 rounds x 76 arrays x 512 B x groups = {gc_store} B, the evaluation "
+                                        f"loads permutations x {24 // g} chunks x (101 x {g} + 25) arrays = {gc_load} B of stored values (the sum of what k_rounds_gen stores and k_rounds_check loads).  Of the "
+                                        f"loads, the {gc_store} B the wavefront has just stored come back from L2, so HBM sees less than the algorithmic bytes (`traffic`); counting every resident "
+                                        f"array of the launch ONCE, written or evaluated or both: {gc_once} B (`each_once`)",
+                    "each_once": {"bytes": gc_once, "frac": round(gc_once / ((kchk_in_step if kchk_in_step else t_alone) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frac_alone": round(gc_once / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "hbm_traffic_frac_alone": round(traffic / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "as_two_launches": {"what": "the two kernels this launch replaces, alone: k_rounds_gen (8 rounds per wavefront) and k_rounds_check (pob_constraint_check's round kernel: what evaluates a "
+                                                "resident vector when no launch has just written it)",
+                                        "gen_ms": round(t_gen, 4), "gen_GBps": round(gen_bytes / (t_gen * 1e-3) / 1e9, 1), "check_ms": round(t_chk, 4), "check_GBps": round(chk_bytes / (t_chk * 1e-3) / 1e9, 1),
+                                        "check_frac": round(chk_bytes / (t_chk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "check_bytes": chk_bytes}})
+    else:
+        out.update({"rounds_per_wavefront": kr,
+                    "bytes_convention": f"resident arrays covered, each once: permutations x {24 // kr} chunks x (101 x {kr} + 25) arrays x 512 B x groups; round 4's line counted 126 arrays per "
+                                        f"round (every midRound state twice) = {launch_bytes_r4} B for this launch",
+                    "gen_kernel": {"kernel": "k_rounds_gen, alone (8 rounds per wavefront: 8 x 76 arrays written, midRound[r0] read)", "achieved": round(gen_bytes / (t_gen * 1e-3) / 1e9, 1), "avg_ms": round(t_gen, 4)}})
+    out["check_pass"] = {"what": "whole pob_constraint_check over a resident vector (all G families + Keccak rounds + chains) as a pass of its own, alone, in-order schedule (one stream: the launches follow each other)",
+                         "bytes": resident, "ms": round(t_check_pass, 3), "achieved": round(resident / (t_check_pass * 1e-3) / 1e9, 1), "frac": round(resident / (t_check_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    out["lone_batch"] = {"what": "ONE batch generated and evaluated by one calculator alone on the device (latency: its launches follow each other on one stream)", "ms": round(t_lone, 3)}
+    out["step"] = {"what": "generate (write the resident vector once) + evaluate (read it once) per timed step", "bytes": 2 * resident,
+                   "achieved": round(2 * resident / (ms_step * 1e-3) / 1e9, 1), "frac": round(2 * resident / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def leg_emission(calc0, info):
@@ -654,7 +696,7 @@ def main():
         batches = [gen.synthetic_batch(B, depth=args.depth, seed=0xB0B, distinct_keys=args.distinct_keys, first=b * GB + job.first0,
                                        pow_device=job.dev if args.depth > 12 else None) for b in range(NB)]
     t_synth = (time.time() - t0) / NB
-    loop = ServiceLoop(job, MAIN_, NC, INORDER, bool(args.fused))
+    loop = ServiceLoop(job, MAIN_, NC, INORDER, args.fused)
     calc0 = loop.calcs[0]
     info = calc0.info
     # ---- the loader: input.json texts -> packed rows in pinned memory, natively on the host cores (pob_pack_json_batch8); the Python packer beside it
@@ -773,7 +815,7 @@ def main():
                            "canonical_bytes_per_witness": int(info.n_witness) * 32,
                            "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
                                                                                          + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused),
+                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused & 1), "rounds_evaluated_with_expansion": bool(args.fused & 2) and INORDER,
                            "setup": f"before the {args.warmup} warm-up steps every one of the {NC} calculators has passed one batch (first touch of its buffers, its stream's hardware queue)", "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
                            "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                            "rccl_ranks": ranks["rccl_ranks"], "dist_backend": job.backend,

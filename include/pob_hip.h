@@ -44,7 +44,8 @@ typedef struct {
     uint32_t kchk_rounds;        /* consecutive rounds of a permutation that ONE wavefront of the round evaluation covers (k_rounds_check): it fetches
                                     midRound[r0] once and then 101 arrays per round, the verified midRound[r+1] staying in registers as the next round's
                                     input -- (101 k + 25) / k arrays of 512 B per (64 witnesses, round)                                               */
-    uint32_t reserved_;
+    uint32_t kgc_rounds;         /* ... that one wavefront of the launch which expands AND evaluates the round blocks covers (k_rounds_gc, pob_set_inorder bit 2): per round
+                                    76 arrays stored and loaded back + the 25 of the stored midRound[r+1], midRound[r0] once                             */
 } pob_info_t;
 
 /* Replaces `component main = ProofOfBurn(...)` / `Spend(...)` + circom -c + make (reference
@@ -148,7 +149,12 @@ int pob_set_partner(pob_handle h, pob_handle partner);
  * costs 0.1-0.3 ms on this runtime, a dependent kernel boundary on one stream 1.5 us): the units of every track that are ready at the same depth of the stage graph
  * leave in ONE launch.  A batch takes longer by itself; a job that keeps several calculators in flight, each on a stream of its own, fills the machine with them.
  * on = 3 -- IN ORDER with the FUSED launch (what bench.py runs): the lane-spread Poseidon blocks share a launch with the sponge chain that does not depend on them
- * (header and layers); the units that continue from the blocks' outputs follow one level later.  A lone batch's launches: 3.03 -> 2.61 ms; same wires, same records. */
+ * (header and layers); the units that continue from the blocks' outputs follow one level later.  A lone batch's launches: 3.03 -> 2.61 ms; same wires, same records.
+ * on | 4 -- the Keccak ROUND BLOCKS ARE EVALUATED BY THE LAUNCH THAT WRITES THEM (k_rounds_gc): the wavefront that has stored the 76 gate-output arrays of a round loads them
+ * back -- from L2 / the Infinity Cache instead of HBM -- together with the stored midRound[r+1] and checks every XOR / AND gate of the round on the loaded operands, as
+ * pob_constraint_check's round kernel does; pob_constraint_check then skips that kernel (1.77 of the 2.27 GB it would read per 1 024 production witnesses); the input rows are compared with the
+ * inputs by the launch that writes them (k_inputs MODE 2) and the evaluation's input check is skipped likewise -- unless a debug poke touched the vector in between.
+ * Same records, same failing sites. */
 int pob_set_inorder(pob_handle h, int on);
 
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.
@@ -246,7 +252,7 @@ int pob_emit_measure_ex(pob_handle h, uint32_t first_idx, uint32_t count, uint64
  * the current batch.  which: 0 = Keccak round expansion (generate), 1 = Keccak round constraint evaluation,
  * 2 = G-unit constraint evaluation (every family, back to back), 3 = sponge chain (generate); 100 + k / 200 + k = evaluation /
  * generation of all units of kind k (circuits.hpp UnitKind) alone on the device; 300 + f = the evaluation kernel of family f
- * (circuits.hpp Fam) alone (tools/unit_times.py).                                                                */
+ * (circuits.hpp Fam) alone (tools/unit_times.py); 6 = round expansion + evaluation in one launch (k_rounds_gc).  */
 int pob_time_kernel(pob_handle h, int which, int iters, void* stream, float* avg_ms);
 /* Measurement INSIDE a running job: enable = 1 makes every following pob_constraint_check record HIP events (on the stream the kernel is
  * launched on) around its Keccak round evaluation kernel -- the dominant kernel as it runs in the step, beside the other batch's
@@ -255,6 +261,12 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 
 /* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
+/* Test hook for the evaluation that rides with the generation (pob_set_inorder bit 2): in the NEXT pob_generate of this in-order calculator ONE store reaches memory corrupted
+ * while the generating wavefront goes on with the right value -- cls = POB_CLASS_BIT: the BIT-class word `index` of group `group`, which must be a gate output of a
+ * KeccakfRound block, XORed with `mask` (bit l = witness l of the group); cls = POB_CLASS_SM: the input row at SM rank `index` (ProofOfBurn mains), bit 0 flipped for the witnesses of `mask`.
+ * The launch's own evaluation, which works on what it LOADS, must flag exactly those witnesses at *wire (may be NULL): the round block's first wire / the input's wire.
+ * POB_E_ARG: no such store.  One generation, then disarmed. */
+int pob_debug_store_fault(pob_handle h, int cls, uint32_t group, uint64_t index, uint64_t mask, uint32_t* wire);
 /* Experiment hook (profiles/round6_experiments.txt 9): a non-blocking stream of `device` restricted to the compute units of cu_mask (hipExtStreamCreateWithCUMask; words x 32 bits,
  * bit i = CU i), for callers that want to partition the device between calculators.  pob_debug_stream_destroy frees it. */
 int pob_debug_stream_create(int device, const uint32_t* cu_mask, uint32_t words, void** stream);

@@ -20,8 +20,10 @@ struct Fr { uint32_t l[8]; };
 // opaque use of a VGPR value: a point the compiler cannot move the computation of x across (tests/hostsim builds for x86)
 #ifdef POB_HOSTSIM
 #define POB_OPAQUE(x) asm volatile("" : "+r"(x))
+#define POB_OPAQUE_S(x) asm volatile("" : "+r"(x))
 #else
 #define POB_OPAQUE(x) asm volatile("" : "+v"(x))
+#define POB_OPAQUE_S(x) asm volatile("" : "+s"(x))      // a wavefront-uniform value (scalar registers)
 #endif
 
 // p, R = 2^256 mod p (Montgomery 1), R2 = 2^512 mod p, -p^-1 mod 2^32

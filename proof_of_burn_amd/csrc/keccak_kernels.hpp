@@ -328,14 +328,17 @@ static inline bool keccak_round_alias_table(uint16_t* tab) {
 // (<= 128 VGPRs: the small sponges of a side track must fit the slot a k_rounds wave frees, see g_gen_heavy_small.hip)
 // (every kernel of this file is a BODY -- a device function of the launch arguments and the (item, group) of its wavefront -- plus a __global__ wrapper, so that a launch
 //  can carry the wavefronts of several independent kernels: fused launches, g_*.hip)
-template <bool CHECK> __device__ __forceinline__ void chain_body(const KArgs A, uint32_t bx, uint32_t by) {
-    const uint32_t lane = threadIdx.x;
+// (Round 6 let the chain's evaluation ride with it like k_rounds_gc's -- every array loaded back behind its store and compared: the compiler requests a block's 400 arrays at once
+//  (961 spilled VGPRs); with the compares pinned per group of ~25 loads the serial chain waits 14 more round trips per block: a lone generation 1.83 -> 3.38 ms, the loop with 12
+//  in flight 1.11 -> 1.16 ms per step.  Not kept: k_chain_check stays a launch of the evaluation; profiles/round6_experiments.txt 16.)
+__device__ __forceinline__ void chain_body(const KArgs A, uint32_t bx, uint32_t by) {
+    const uint32_t lane = threadIdx.x & 63u;              // (a wavefront of a wider workgroup in the fused launch, g_gen_poswide.hip)
     const SpongeDesc sp = A.sponges[A.first + bx];
     u64* G = A.bits + (uint64_t)by * A.group_stride;
-    u64 st[25], bad = 0;
+    u64 st[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = 0;
-    auto put = [&](uint32_t idx, u64 v) { if (CHECK) bad |= G[idx + lane] ^ v; else G[idx + lane] = v; };
+    auto put = [&](uint32_t idx, u64 v) { G[idx + lane] = v; };
     for (uint32_t b = 0; b < sp.n; b++) {
         const uint32_t Ab = sp.abs_b + b * ABSORB_BITS;
         u64 blk[17], aux[25];
@@ -349,8 +352,7 @@ template <bool CHECK> __device__ __forceinline__ void chain_body(const KArgs A, 
             const u64 o = st[i] ^ blk[i];
             const uint32_t X = Ab + ABSORB_OWN + 384 * i;
             put(X, o); put(X + 64, st[i]); put(X + 128, blk[i]);
-            if (CHECK) { const u64* q = G + X + 192 + 3 * lane; bad |= (q[0] ^ o) | (q[1] ^ st[i]) | (q[2] ^ blk[i]); }
-            else { u64* q = G + X + 192 + 3 * lane; q[0] = o; q[1] = st[i]; q[2] = blk[i]; }
+            { u64* q = G + X + 192 + 3 * lane; q[0] = o; q[1] = st[i]; q[2] = blk[i]; }
             aux[i] = o;
         }
 #pragma unroll
@@ -368,13 +370,8 @@ template <bool CHECK> __device__ __forceinline__ void chain_body(const KArgs A, 
     }
 #pragma unroll
     for (int i = 0; i < 25; i++) put(sp.fs_b + sp.n * 1600 + 64 * i, st[i]);
-    if (CHECK) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
-        if ((bad >> lane) & 1) atomicMin(&A.bad_wire[by * 64 + lane], sp.abs_w);
-    }
 }
-template <bool CHECK> __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) { chain_body<CHECK>(A, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(64, 3) k_chain(KArgs A) { chain_body(A, blockIdx.x, blockIdx.y); }
 
 // (round 5 tried TWO wavefronts per (group, sponge), each on the 32-bit half of every word -- 32-bit logic, one ds_bpermute per rotation: the header's 17-block chain
 //  0.433 -> 0.336 ms alone, but the step went from 1.57-1.60 / 1.39 to 1.67 / 1.52-1.53 ms with 4 / 8 in flight: twice the wavefronts storing 4-byte halves of every
@@ -477,6 +474,80 @@ template <int KR> __global__ void __launch_bounds__(64) k_rounds_gen(KArgs A) { 
         } \
     } } while (0)
 template <bool NT, int KR, int WAVES, int DP> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_check(KArgs A) { POB_ROUNDS_CHECK_BODY(A, blockIdx.x, blockIdx.y, NT, KR, DP); }
+
+// Generation AND constraint evaluation of the round blocks in one launch (in-order calculators, pob_set_inorder bit 2).  The wavefront of (permutation, KR rounds, group)
+// stores each of the 76 gate-output arrays of a round and requests the SAME array back from memory right behind the store; DP gates later the loaded array is compared with
+// the value the gate's definition gives.  midRound[r+1], which k_chain wrote, is loaded and compared with the round's computed output the same way.  The footprint between a
+// store and its load is DP x 512 B per wavefront -- it stays in the XCD's L2 (write-back, write-allocate), so the evaluation's 1.77 GB per 1 024 production witnesses never
+// come back from HBM: what the launch moves there is the expansion's 1.26 GB of stores and the 0.44 GB of stored states.
+// What is evaluated: for every stored array X of the block, loaded(X) == def(X) on the COMPUTED operands, starting from the LOADED midRound[r0].  By induction over the walk
+// every operand's loaded value equals its computed one, so every XOR / AND gate of the round holds between the stored wires -- the relations k_rounds_check evaluates on
+// loaded operands; a stored word that differs from its definition is reported at the same wire (the round block's first).  The load's base pointer takes an opaque zero
+// offset, so no load can be replaced by the value stored before it: the ISA holds 76 stores and 101 loads per round (tools/isa_counts.py).
+// (First version, profiles/round6_experiments.txt 14: generate a whole round, then k_rounds_check's walk over it with the input state parked in LDS -- 38.9 KB between store
+//  and load per wavefront, 10 MB per XCD: the loads missed L2 and the launch took as long as the two kernels it replaced, 0.50 ms.)
+// FAULT (tests only): the store at BIT word A.fault_word of group A.fault_group is XORed with A.fault_mask on its way to memory while the walk goes on with the right
+// value -- what the evaluation must then flag.
+template <int DP, bool FAULT, bool NTM> struct GcIOT : DevIOBase {
+    u64* st; const u64* ld; const u64* out_; u64 bad; V s[25];
+    V ring[DP], pend[DP];                      // the loaded array of gate q and the value its definition gave, q % DP
+    const u64* fault; u64 fault_mask;
+    __device__ __forceinline__ V in(int i) const { return s[i]; }
+    template <bool STORE> __device__ __forceinline__ V twin(int want, V v) {
+        const int q = kchk_pos(want), k = q % DP;
+        if (q >= DP) bad |= ring[k] ^ pend[k];
+        if constexpr (STORE) {
+            u64* p = st + want + lane;
+            V w = v;
+            if constexpr (FAULT) { if (p == fault) w ^= fault_mask; }
+            *p = w;
+            ring[k] = ld[want + lane];
+        } else ring[k] = NTM ? __builtin_nontemporal_load(out_ + (-want - 1) + lane) : out_[(-want - 1) + lane];
+        pend[k] = v;
+        __builtin_amdgcn_sched_barrier(0);
+        return v;
+    }
+    __device__ __forceinline__ V gx(uint32_t sl, V a, V b) { return twin<true>(64 * (int)sl, a ^ b); }
+    __device__ __forceinline__ V ga(uint32_t sl, V a, V b) { return twin<true>(64 * (int)sl, a & b); }
+    __device__ __forceinline__ V gxo(int i, V a, V b) { return twin<false>(-(64 * i) - 1, a ^ b); }
+    __device__ __forceinline__ void out(int i, V v) { s[i] = v; }
+    __device__ __forceinline__ void end_round() {       // the last DP gates of the walk
+#pragma unroll
+        for (int k = 0; k < DP; k++) bad |= ring[k] ^ pend[k];
+    }
+};
+template <int KR, int DP, int WAVES, bool FAULT, bool NTM> __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(WAVES) k_rounds_gc(KArgs A) {
+    static_assert(24 % KR == 0, "a chunk does not straddle two permutations");
+    static_assert(DP >= 1 && DP <= KCHK_LOADS, "loads in flight");
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pi = A.first + blockIdx.x / (24 / KR), r0 = blockIdx.x % (24 / KR) * KR;
+    const SpongeDesc sp = A.sponges[A.perm_sponge[pi]];
+    const uint32_t Ab = sp.abs_b + A.perm_block[pi] * ABSORB_BITS;
+    u64* G = A.bits + (uint64_t)blockIdx.y * A.group_stride;
+    const u64* mid = G + Ab + AB_KECCAKF + KF_MID + 1600 * r0;
+    GcIOT<DP, FAULT, NTM> io; io.lane = lane; io.bad = 0;
+    if constexpr (FAULT) { io.fault = blockIdx.y == A.fault_group ? G + A.fault_word : nullptr; io.fault_mask = A.fault_mask; }
+#pragma unroll
+    for (int i = 0; i < 25; i++) io.s[i] = mid[64 * i + lane];
+    io.st = G + Ab + AB_DIRECT + r0 * KR_BITS;
+#pragma unroll 1
+    for (uint32_t r = r0; r < r0 + KR; r++) {
+        uint32_t zero = 0;
+        POB_OPAQUE_S(zero);                    // (an opaque OFFSET: the pointer stays a global-memory one, but is no longer provably the one stored through)
+        io.ld = io.st + zero; mid += 1600; io.out_ = mid;
+        io.refresh();
+        round_walk(io, (int)r);
+        io.end_round();
+        io.st += KR_BITS;
+        if (__any(io.bad != 0)) {              // (corrupted stores only) which witnesses, and the round block the mismatch belongs to
+            u64 bad = io.bad;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
+            if ((bad >> lane) & 1) atomicMin(&A.bad_wire[blockIdx.y * 64 + lane], sp.abs_w + A.perm_block[pi] * ABSORB_WIRES + AB_KECCAKF + KF_ROUNDS + r * KECCAKF_ROUND_WIRES);
+            io.bad = 0;
+        }
+    }
+}
 
 // the 64-witness word of the wire at offset o of an Absorb block whose storage starts at BIT rank ab (A = this group's slab); *neg: the
 // wire is the complement of that word

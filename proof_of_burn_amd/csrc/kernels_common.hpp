@@ -31,6 +31,7 @@ struct KArgs {
     const uint32_t* perm_block;
     uint32_t* bad_wire;        // per witness: lowest inconsistent wire (CheckIO)
     uint32_t first, count;
+    uint32_t fault_group; uint64_t fault_word, fault_mask;   // k_rounds_gc<FAULT> (tests): the store at BIT word fault_word of group fault_group goes out XORed with fault_mask
 };
 
 // grid = (nunits, ngroups) wavefronts.  Generation: one kernel per scheduling class (light | SubstringCheck BN254 | the other BN254
@@ -61,7 +62,10 @@ void launch_g_emit_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStre
 void launch_pos_chain(const GArgs& A, const KArgs& K, uint32_t npos, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
+// generation + evaluation of the round blocks in one launch (keccak_kernels.hpp k_rounds_gc); fault: the tests' instantiation that corrupts one store
+void launch_k_rounds_gc(const KArgs& K, uint32_t nperms, uint32_t ngroups, bool fault, hipStream_t st);
 int pob_kchk_rounds();        // rounds per wavefront of the round evaluation (k_keccak.hip)
+int pob_kgc_rounds();         // ... of the launch that expands AND evaluates the round blocks (k_rounds_gc)
 void launch_k_emit_bits(const u64* G, uint8_t* out, uint32_t wire_base, uint32_t bit_base, uint32_t count, uint32_t sel, hipStream_t st);
 // reduced form: wires [wire0, wire0 + count) with BIT ranks from bit_base; kept wires land at out + 32 * (rank - k0) when rank - k0 < kn
 void launch_k_emit_bits_red(const u64* G, uint8_t* out, uint32_t wire0, uint32_t bit_base, uint32_t count, uint32_t sel, const unsigned long long* rbits, const uint32_t* rpre, uint32_t k0, uint32_t kn, hipStream_t st);

@@ -59,7 +59,13 @@ __global__ void k_collect(const uint32_t* fr, uint64_t fr_stride, uint32_t out_i
 // other batch's round expansion -- at the head of every narrow chain of the generation.  CHECK: the stored rows against the inputs
 // (the relation `wire === input`, the evaluator's U_POB_INPUT).  grid = (ceil(nsm / 64), groups).
 extern __shared__ uint32_t g_lds[];
-template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32_t* in_sm, uint32_t nsm, int32_t* sm, uint64_t sm_stride, uint32_t s0, uint32_t w0, uint32_t* bad_wire) {
+// MODE 0: generation; 1: evaluation (the CHECK above); 2: generation whose evaluation rides with it (in-order calculators, pob_set_inorder bit 2): the rows are stored, LOADED
+// back through a pointer the compiler cannot identify with the one stored through, and compared with the inputs
+#define POB_OPAQUE_PTR(p, T) ({ uint32_t zero_ = 0; POB_OPAQUE_S(zero_); (T)(p) + zero_; })
+// (fault_k / fault_g / fault_lanes, MODE 2, tests: input row fault_k of group fault_g reaches memory with bit 0 flipped for the witnesses of fault_lanes; 0xFFFFFFFF = none)
+template <int MODE> __global__ void __launch_bounds__(64) k_inputs(const int32_t* in_sm, uint32_t nsm, int32_t* sm, uint64_t sm_stride, uint32_t s0, uint32_t w0, uint32_t* bad_wire,
+                                                                   uint32_t fault_k, uint32_t fault_g, uint64_t fault_lanes) {
+    constexpr bool CHECK = MODE == 1;
     int32_t* t = (int32_t*)g_lds;                         // [64 witnesses][65]
     const uint32_t lane = threadIdx.x, k0 = blockIdx.x * 64, g = blockIdx.y;
     const int32_t* src = in_sm + (uint64_t)g * 64 * nsm;
@@ -71,18 +77,23 @@ template <bool CHECK> __global__ void __launch_bounds__(64) k_inputs(const int32
     for (uint32_t kk = 0; kk < nk; kk++) {
         const int32_t v = t[lane * 65 + kk];
         if (CHECK) { if (dst[kk * 64 + lane] != v && bad == 0xFFFFFFFFu) bad = w0 + k0 + kk; }
-        else dst[kk * 64 + lane] = v;
+        else dst[kk * 64 + lane] = (MODE == 2 && k0 + kk == fault_k && g == fault_g && ((fault_lanes >> lane) & 1)) ? v ^ 1 : v;
     }
-    if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
+    if (MODE == 2) {
+        const int32_t* back = POB_OPAQUE_PTR(dst, const int32_t*);
+        for (uint32_t kk = 0; kk < nk; kk++) if (back[kk * 64 + lane] != t[lane * 65 + kk] && bad == 0xFFFFFFFFu) bad = w0 + k0 + kk;
+    }
+    if (MODE) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
 }
-static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st);
+static void launch_inputs(pob_ctx* h, int mode, uint32_t G, hipStream_t st);
 // The same from the BYTE FORM of a batch (pob_upload_inputs8*: u8 rows + POB_EXC_CAP exception slots per witness), in ONE pass: a workgroup reads 64 witnesses x 128 inputs as
 // bytes (32 per thread), widens them into an LDS tile, lays the group's exception slots that fall into its 128 inputs over the tile, and writes (CHECK: compares) the 128 SM
 // rows, lane = witness.  Rounds 4-5 widened the whole batch into an int32 copy of the packed inputs first (k_widen_sm8 + k_apply_exc on the upload stream: 11 MB read, 45 MB
 // written) and transposed that copy (45 MB read, 45 MB written): per batch two launches and 90 MB of traffic that this pass does not have.  grid = (ceil(nsm / 128), groups).
 #define IN8_K 128
-template <bool CHECK> __global__ void __launch_bounds__(256) k_inputs8(const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t nsm, uint32_t n, int32_t* sm, uint64_t sm_stride, uint32_t s0,
-                                                                        uint32_t w0, uint32_t* bad_wire) {
+template <int MODE> __global__ void __launch_bounds__(256) k_inputs8(const uint8_t* sm8, const pob_sm_exc_t* exc, uint32_t nsm, uint32_t n, int32_t* sm, uint64_t sm_stride, uint32_t s0,
+                                                                      uint32_t w0, uint32_t* bad_wire, uint32_t fault_k, uint32_t fault_g, uint64_t fault_lanes) {
+    constexpr bool CHECK = MODE == 1;
     int32_t* t = (int32_t*)g_lds;                         // [64 witnesses][IN8_K + 1]
     const uint32_t tid = threadIdx.x, k0 = blockIdx.x * IN8_K, g = blockIdx.y;
     {   // bytes: thread = (witness row, 32-byte segment)
@@ -110,9 +121,13 @@ template <bool CHECK> __global__ void __launch_bounds__(256) k_inputs8(const uin
     for (uint32_t kk = 32 * q; kk < 32 * q + 32 && k0 + kk < nsm; kk++) {
         const int32_t v = t[lane * (IN8_K + 1) + kk];
         if (CHECK) { if (dst[kk * 64 + lane] != v && bad == 0xFFFFFFFFu) bad = w0 + k0 + kk; }
-        else dst[kk * 64 + lane] = v;
+        else dst[kk * 64 + lane] = (MODE == 2 && k0 + kk == fault_k && g == fault_g && ((fault_lanes >> lane) & 1)) ? v ^ 1 : v;
     }
-    if (CHECK) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
+    if (MODE == 2) {
+        const int32_t* back = POB_OPAQUE_PTR(dst, const int32_t*);
+        for (uint32_t kk = 32 * q; kk < 32 * q + 32 && k0 + kk < nsm; kk++) if (back[kk * 64 + lane] != t[lane * (IN8_K + 1) + kk] && bad == 0xFFFFFFFFu) bad = w0 + k0 + kk;
+    }
+    if (MODE) { if (bad != 0xFFFFFFFFu) atomicMin(&bad_wire[g * 64 + lane], bad); }
 }
 // pob_upload_inputs8*: the byte rows widened into the int32 rows every kernel reads (four values per thread when the row length allows aligned words), then the
 // exception slots on top (values outside 0..255: lengths, deliberately out-of-range test inputs)
@@ -369,6 +384,12 @@ struct pob_ctx {
     //  interleaved with the wide evaluation families, the chain evaluation behind the narrow families: such a launch lasts about the SUM of its parts (a latency-bound
     //  wavefront makes next to no progress while the memory system is saturated), the loop did not move; removed.  profiles/round6_experiments.txt)
     bool fused = false;
+    // EVALUATION THAT RIDES WITH THE GENERATION (pob_set_inorder bit 2): the generation's last launch is k_rounds_gc -- every round block is evaluated by the wavefront that has
+    // just written it, its loads served by L2 -- and the input rows are compared with the inputs by the launch that writes them (k_inputs MODE 2); the evaluation that follows
+    // skips those two kernels.  rode: the resident vector is the one those launches evaluated (cleared by every debug poke: the evaluation then runs k_rounds_check and the
+    // input check over the vector as it is)
+    bool gc = false, rode = false;
+    bool fault_armed = false; int fault_cls = 0; uint32_t fault_group = 0; uint64_t fault_word = 0, fault_mask = 0;     // pob_debug_store_fault (tests)
     struct GenLaunch { uint32_t kind, cls, first, count, k_first, k_count; };
     enum { GL_UNITS = 0, GL_CHAIN = 1, GL_POS_CHAIN = 2, GL_ROUNDS = 4 };
     std::vector<GenLaunch> gen_plan[2];
@@ -383,7 +404,9 @@ struct pob_ctx {
     // service loop: asynchronous input upload (own stream, pob_upload_inputs_async) and per-batch result records into pinned memory
     hipStream_t s_upload = nullptr;                         // = the pool's upload stream
     hipEvent_t ev_upload = nullptr, ev_rec[2] = {nullptr, nullptr};   // ev_rec[s]: the records of buffer s are written
-    bool kchk_rec = false; hipEvent_t ev_kchk[2] = {nullptr, nullptr};         // timing events around the Keccak round evaluation of the last pob_constraint_check (pob_probe_check_kernel)
+    // timing events around the Keccak round evaluation (pob_probe_check_kernel): one pair per record slot -- the kernel of the batch whose records sit in slot s -- because the
+    // evaluation that rides with the expansion records them in pob_generate, and the caller reads the previous batch's pair after it has enqueued the next generation
+    bool kchk_rec[2] = {false, false}; hipEvent_t ev_kchk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint8_t* h_records[2] = {nullptr, nullptr}; int rec_slot = 0, fetch_slot = 0; uint32_t rec_n[2] = {0, 0}; bool upload_pending = false, have_next = false, fetch_pending = false;
 };
 
@@ -446,19 +469,20 @@ static void launch_g_emit(const GArgs& A, uint32_t cls, uint32_t nunits, hipStre
     if (cls == 5) launch_g_emit_gm(A, nunits, 1, st); else if (cls == 3) launch_g_emit_sc(A, nunits, 1, st); else if (cls) launch_g_emit_heavy(A, nunits, 1, st); else launch_g_emit_light(A, nunits, 1, st);
 }
 
-static void launch_inputs(pob_ctx* h, bool check, uint32_t G, hipStream_t st) {
+static void launch_inputs(pob_ctx* h, int mode, uint32_t G, hipStream_t st) {      // mode: 0 generation, 1 evaluation, 2 generation + its evaluation (k_inputs)
     if (h->circuit != POB_CIRCUIT_PROOF_OF_BURN || !h->plan.nsm_in) return;
     const SmRef r0 = h->plan.L.pm.numLeafAddressNibbles;  // the small inputs are contiguous SM ranks / wire indices from here (declaration order)
+    const uint32_t fk = (mode == 2 && h->fault_armed && h->fault_cls == POB_CLASS_SM) ? (uint32_t)h->fault_word - r0.i : 0xFFFFFFFFu;     // pob_debug_store_fault: the input row
     if (h->in_bytes[h->in_cur]) {
         const dim3 grid8((h->plan.nsm_in + IN8_K - 1) / IN8_K, G);
         const size_t lds = 64 * (IN8_K + 1) * 4;
-        if (check) hipLaunchKernelGGL(k_inputs8<true>, grid8, dim3(256), lds, st, h->d_in_sm8[h->in_cur], h->d_in_exc[h->in_cur], h->plan.nsm_in, h->n, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
-        else hipLaunchKernelGGL(k_inputs8<false>, grid8, dim3(256), lds, st, h->d_in_sm8[h->in_cur], h->d_in_exc[h->in_cur], h->plan.nsm_in, h->n, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid8, dim3(256), lds, st, h->d_in_sm8[h->in_cur], h->d_in_exc[h->in_cur], h->plan.nsm_in, h->n, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad, fk, h->fault_group, h->fault_mask); };
+        if (mode == 1) go(k_inputs8<1>); else if (mode == 2) go(k_inputs8<2>); else go(k_inputs8<0>);
         return;
     }
     const dim3 grid((h->plan.nsm_in + 63) / 64, G);
-    if (check) hipLaunchKernelGGL(k_inputs<true>, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
-    else hipLaunchKernelGGL(k_inputs<false>, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(64), 64 * 65 * 4, st, h->d_in_sm[h->in_cur], h->plan.nsm_in, h->d_sm, (uint64_t)h->plan.total.s * 64, r0.i, r0.w, h->d_bad, fk, h->fault_group, h->fault_mask); };
+    if (mode == 1) go(k_inputs<1>); else if (mode == 2) go(k_inputs<2>); else go(k_inputs<0>);
 }
 static Fr limbs_to_mont(const uint64_t* l) {
     Fr c; for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
@@ -541,7 +565,7 @@ static void fill_info(const Plan& pl, uint32_t nperms, uint32_t max_batch, pob_i
     info->group_bytes = (uint64_t)pl.total.b * 8 + (uint64_t)pl.total.s * 256 + (uint64_t)pl.total.f * 2048;      // (derived wires take no storage)
     info->n_derived = pl.total.q;
     info->n_alias = (uint64_t)nperms * ABSORB_ALIAS;
-    info->kchk_rounds = (uint32_t)pob_kchk_rounds(); info->reserved_ = 0;
+    info->kchk_rounds = (uint32_t)pob_kchk_rounds(); info->kgc_rounds = (uint32_t)pob_kgc_rounds();
     info->keccak_bit_wires = 0;
     for (const SpongeDesc& s : pl.sponges) info->keccak_bit_wires += (uint64_t)s.n * (ABSORB_WIRES + 2 * 1088) + (uint64_t)(s.n + 1) * 1600;
 }
@@ -831,7 +855,7 @@ void pob_close(pob_handle h) {
     for (int k = 0; k < 2; k++) { if (h->h_records[k]) hipHostFree(h->h_records[k]); if (h->ev_rec[k]) hipEventDestroy(h->ev_rec[k]); }
     if (h->ev_upload) hipEventDestroy(h->ev_upload);
     for (hipEvent_t e : h->ev_in_done) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_kchk) if (e) hipEventDestroy(e);
+    for (auto& pr : h->ev_kchk) for (hipEvent_t e : pr) if (e) hipEventDestroy(e);
     if (h->partner && h->partner->partner == h) h->partner->partner = nullptr;
     if (h->em.s_copy) hipStreamDestroy(h->em.s_copy);
     if (h->pool) {
@@ -965,16 +989,29 @@ int pob_generate(pob_handle h, void* stream_) {
     if (h->inorder) {
         GArgs A = gargs(h);
         KArgs K = kargs(h);
-        launch_inputs(h, false, G, st);
+        if (h->gc && h->rode) HIPC(hipMemsetAsync(h->d_bad, 0xFF, (size_t)G * 64 * 4, st));     // a generation whose verdict nobody collected
+        h->rode = false;
+        launch_inputs(h, h->gc ? 2 : 0, G, st);
+        const bool kf = h->gc && h->fault_armed && h->fault_cls == POB_CLASS_BIT;
+        K.fault_group = h->fault_group; K.fault_word = h->fault_word; K.fault_mask = h->fault_mask;
         for (const pob_ctx::GenLaunch& gl : h->gen_plan[h->fused ? 1 : 0]) {
             A.first = gl.first; K.first = gl.k_first;
             switch (gl.kind) {
             case pob_ctx::GL_UNITS: launch_g_gen(A, gl.cls, gl.count, G, st); break;
             case pob_ctx::GL_CHAIN: launch_k_chain(K, false, gl.k_count, G, st); break;
             case pob_ctx::GL_POS_CHAIN: launch_pos_chain(A, K, gl.count, gl.k_count, G, st); break;
-            default: launch_k_rounds(K, false, gl.k_count, G, st); break;
+            default:
+                if (h->gc) {
+
+                    if (h->ev_kchk[h->rec_slot][0]) { HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][0], st)); h->kchk_rec[h->rec_slot] = true; }
+                    launch_k_rounds_gc(K, gl.k_count, G, kf, st);
+                    if (h->ev_kchk[h->rec_slot][1]) HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][1], st));
+                    h->rode = true;
+                } else launch_k_rounds(K, false, gl.k_count, G, st);
+                break;
             }
         }
+        h->fault_armed = false;
         HIPC(hipEventRecord(h->ev_g_done, st));
         HIPC(hipGetLastError());
         { int rc = enqueue_collect(h, st, false); if (rc) return rc; }
@@ -1054,7 +1091,7 @@ int pob_generate(pob_handle h, void* stream_) {
         }
         return POB_OK;
     };
-    launch_inputs(h, false, G, st);                       // the small inputs' wires (tile transpose): ahead of stage 0, whose forks wait for the stream
+    launch_inputs(h, 0, G, st);                           // the small inputs' wires (tile transpose): ahead of stage 0, whose forks wait for the stream
     { int rc = run_track(0); if (rc) return rc; }
     HIPC(hipEventRecord(h->ev_g_done, st));              // every stage of the G side is enqueued behind this point of st (the joined tracks included)
     for (hipEvent_t e : pending) HIPC(hipStreamWaitEvent(st, e, 0));
@@ -1083,14 +1120,18 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // one stream: the Keccak round evaluation (the batch's one bandwidth-bound kernel) first, then the sponge chains, the inputs and the eight families
         // (the round evaluation on a high-priority stream of the device, forked and joined per batch, was measured: 4 / 6 / 8 / 12 calculators in flight
         //  2.39 / 2.04 / 1.91 / 2.14 ms per step against 2.19 / 2.09 / 1.87 / 2.07 here, the kernel 0.49-0.74 against 0.42-0.80 ms: nothing; removed)
+        const bool rode = h->rode;          // the round blocks and the input rows were evaluated by the launches that wrote them
+        h->rode = false;
         if (!h->plan.sponges.empty()) {
             KArgs K = kargs(h); K.first = 0;
-            if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], st)); h->kchk_rec = true; }
-            launch_k_rounds(K, true, h->nperms, G, st);
-            if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], st));
+            if (!rode) {             // (else: every round block was evaluated by the launch that wrote it, k_rounds_gc, and nothing has touched the vector since)
+                if (h->ev_kchk[h->rec_slot][0]) { HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][0], st)); h->kchk_rec[h->rec_slot] = true; }
+                launch_k_rounds(K, true, h->nperms, G, st);
+                if (h->ev_kchk[h->rec_slot][1]) HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][1], st));
+            }
             launch_k_chain(K, true, h->nperms, G, st);
         }
-        launch_inputs(h, true, G, st);
+        if (!rode) launch_inputs(h, 1, G, st);
         // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
         //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
         if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
@@ -1108,7 +1149,7 @@ int pob_constraint_check(pob_handle h, void* stream_) {
     HIPC(hipEventRecord(h->ev_fork, st));
     for (int k = 0; k < 2; k++) {
         HIPC(hipStreamWaitEvent(side[k], h->ev_fork, 0));
-        if (k == 1) launch_inputs(h, true, G, side[k]);
+        if (k == 1) launch_inputs(h, 1, G, side[k]);
         for (uint32_t fam : side_plan[k])
             for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == fam) { A.first = sg.first; launch_g_check(A, fam, sg.count, G, side[k]); }
     }
@@ -1120,9 +1161,9 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // result collection on the caller's stream.  A lone handle: on the caller's stream.
         hipStream_t sk = h->partner ? h->stream_k : st;
         if (sk != st) HIPC(hipStreamWaitEvent(sk, h->ev_g_done, 0));
-        if (h->ev_kchk[0]) { HIPC(hipEventRecord(h->ev_kchk[0], sk)); h->kchk_rec = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
+        if (h->ev_kchk[h->rec_slot][0]) { HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][0], sk)); h->kchk_rec[h->rec_slot] = true; }   // measurement (pob_probe_check_kernel): the dominant kernel inside the step
         launch_k_rounds(K, true, h->nperms, G, sk);
-        if (h->ev_kchk[1]) HIPC(hipEventRecord(h->ev_kchk[1], sk));
+        if (h->ev_kchk[h->rec_slot][1]) HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][1], sk));
         // (pipeline: the narrow sponge-chain evaluation -- 84 wavefronts per group, 0.18 ms -- on an evaluation stream beside the families, not in
         //  order between the two chip-filling kernels of the streaming stream, where the machine idled for its duration: -0.02 ms, three interleaved pairs)
         launch_k_chain(K, true, h->nperms, G, h->partner ? side[1] : sk);
@@ -1157,7 +1198,7 @@ int pob_set_partner(pob_handle h, pob_handle partner) {
 int pob_set_inorder(pob_handle h, int on) {
     if (!h) return POB_E_ARG;
     if (on && h->partner) { h->err = "an in-order calculator has no partner: unlink first (pob_set_partner(h, NULL))"; return POB_E_STATE; }
-    h->inorder = on != 0; h->fused = (on & 2) != 0;
+    h->inorder = on != 0; h->fused = (on & 2) != 0; h->gc = (on & 4) != 0;
     return POB_OK;
 }
 
@@ -1710,12 +1751,15 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms) {
     if (!h) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
     if (ms) {
-        if (!h->ev_kchk[0] || !h->kchk_rec) { h->err = "no timed evaluation yet"; return POB_E_STATE; }
-        HIPC(hipEventSynchronize(h->ev_kchk[1]));
-        HIPC(hipEventElapsedTime(ms, h->ev_kchk[0], h->ev_kchk[1]));
+        // the newest pair whose kernel has run: this slot's, or -- the next generation is already enqueued -- the other one's
+        uint32_t sl = h->rec_slot;
+        if (!h->kchk_rec[sl] || hipEventQuery(h->ev_kchk[sl][1]) != hipSuccess) sl ^= 1;
+        if (!h->ev_kchk[sl][0] || !h->kchk_rec[sl]) { h->err = "no timed evaluation yet"; return POB_E_STATE; }
+        HIPC(hipEventSynchronize(h->ev_kchk[sl][1]));
+        HIPC(hipEventElapsedTime(ms, h->ev_kchk[sl][0], h->ev_kchk[sl][1]));
     }
-    if (enable && !h->ev_kchk[0]) { HIPC(hipEventCreate(&h->ev_kchk[0])); HIPC(hipEventCreate(&h->ev_kchk[1])); }
-    if (!enable) { for (hipEvent_t& e : h->ev_kchk) if (e) { hipEventDestroy(e); e = nullptr; } h->kchk_rec = false; }
+    if (enable && !h->ev_kchk[0][0]) for (auto& pr : h->ev_kchk) for (hipEvent_t& e : pr) HIPC(hipEventCreate(&e));
+    if (!enable) { for (auto& pr : h->ev_kchk) for (hipEvent_t& e : pr) if (e) { hipEventDestroy(e); e = nullptr; } h->kchk_rec[0] = h->kchk_rec[1] = false; }
     return POB_OK;
 }
 
@@ -1746,6 +1790,7 @@ int pob_time_kernel(pob_handle h, int which, int iters, void* stream_, float* av
         else if (which >= 100) launch_g_check(A, sel_fam, nsel, G, st);
         else if (which == 0) launch_k_rounds(K, false, h->nperms, G, st);
         else if (which == 1) launch_k_rounds(K, true, h->nperms, G, st);
+        else if (which == 6) launch_k_rounds_gc(K, h->nperms, G, false, st);
         else if (which == 2) {
             for (const pob_ctx::Seg& sg : h->chk_segs) {
                 A.first = sg.first;
@@ -1772,9 +1817,32 @@ int pob_debug_stream_create(int device, const uint32_t* cu_mask, uint32_t words,
 }
 void pob_debug_stream_destroy(int device, void* stream) { if (stream && hipSetDevice(device) == hipSuccess) hipStreamDestroy((hipStream_t)stream); }
 
+int pob_debug_store_fault(pob_handle h, int cls, uint32_t group, uint64_t index, uint64_t mask, uint32_t* wire) {
+    if (!h || group >= h->groups) return POB_E_ARG;
+    if (!h->inorder || !h->gc) { h->err = "pob_debug_store_fault: the calculator's generation carries no evaluation (pob_set_inorder bit 2)"; return POB_E_STATE; }
+    bool found = false;
+    if (cls == POB_CLASS_BIT) {
+        if (index >= h->plan.total.b) return POB_E_ARG;
+        for (const SpongeDesc& sp : h->plan.sponges) {
+            if (index < sp.abs_b || index >= sp.abs_b + (uint64_t)sp.n * ABSORB_BITS) continue;
+            const uint32_t b = (uint32_t)((index - sp.abs_b) / ABSORB_BITS), o = (uint32_t)((index - sp.abs_b) % ABSORB_BITS);
+            if (o < AB_DIRECT) break;          // (the sponge chain's own words: their evaluation is a launch of pob_constraint_check, k_chain_check)
+            if (wire) *wire = sp.abs_w + b * ABSORB_WIRES + AB_DIRECT + (o - AB_DIRECT) / KR_BITS * KECCAKF_ROUND_WIRES;     // (AB_DIRECT: every wire of the block ahead of the round blocks is stored, so it is their wire offset too)
+            found = true; break;
+        }
+    } else if (cls == POB_CLASS_SM && h->circuit == POB_CIRCUIT_PROOF_OF_BURN) {
+        const SmRef r0 = h->plan.L.pm.numLeafAddressNibbles;
+        if (index >= r0.i && index < r0.i + h->plan.nsm_in) { found = true; if (wire) *wire = r0.w + (uint32_t)(index - r0.i); }
+    }
+    if (!found) { h->err = "pob_debug_store_fault: not a stored word whose evaluation rides with its generation"; return POB_E_ARG; }
+    h->fault_armed = true; h->fault_cls = cls; h->fault_group = group; h->fault_word = index; h->fault_mask = mask;
+    return POB_OK;
+}
+
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask) {
     if (!h || group >= h->groups || bit_index >= h->plan.total.b) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
+    h->rode = false;
     hipLaunchKernelGGL(k_xor_word, dim3(1), dim3(1), 0, own_stream(h), h->d_bits + (uint64_t)group * h->plan.total.b + bit_index, mask);
     HIPC(hipStreamSynchronize(own_stream(h)));
     return POB_OK;
@@ -1783,6 +1851,7 @@ int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_
 int pob_debug_poke(pob_handle h, int cls, uint32_t group, uint64_t index, uint32_t sub, uint32_t lane, uint32_t xor_mask) {
     if (!h || group >= h->groups || lane >= 64) return POB_E_ARG;
     HIPC(hipSetDevice(h->device));
+    h->rode = false;
     const Cur t = h->plan.total;
     if (cls == POB_CLASS_BIT) {
         if (index >= t.b) return POB_E_ARG;

@@ -14,7 +14,9 @@
 // The HBM layout is untouched (limb planes [wire][limb][64 witnesses]): a lane stores its element's wires for its witness, the
 // 8 witnesses of a wave are 32 contiguous bytes of a row.  Evaluation (CK_POS_SEG units) and emission keep the lane = witness code.
 //
-// Generation only.  One workgroup = one wavefront = (unit, group, 8-witness slice).
+// Generation only.  One wavefront = (unit, group, 8-witness slice); a workgroup = POSW_WAVES wavefronts = consecutive slices of ONE unit, which share one copy of the
+// constants of the unit's T in LDS (22 KB for T = 5: with a copy per wavefront -- round 5 -- the LDS held five wavefronts per CU, and beside other calculators' Poseidon
+// blocks that occupancy, not the multiplier, bounded the launch).
 #pragma once
 #include "kernels_common.hpp"
 
@@ -153,16 +155,20 @@ template <int T> __device__ __forceinline__ void posw_run(const GArgs& A, const 
     }
 }
 
-// bx = 8 * unit + witness slice (unit = position in the launch's list), g = group
+// bx = 8 * unit + witness slice (unit = position in the launch's list), g = group; the wavefronts of a workgroup have the same unit
+#ifndef POSW_WAVES
+#define POSW_WAVES 4
+#endif
+static_assert(8 % POSW_WAVES == 0, "the slices of a workgroup belong to one unit");
 __device__ __forceinline__ void poswide_body(const GArgs& A, uint32_t bx, uint32_t g) {
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const UnitDesc* dp = A.units + POB_UNI(A.order[A.first + (bx >> 3)]);
     const int T = (int)POB_UNI(dp->a[0]);
     const PosWDesc d = {POB_UNI(dp->cur.f), POB_UNI(dp->a[1]), POB_UNI(dp->a[2]), POB_UNI(dp->a[3]), POB_UNI(dp->a[4]), POB_UNI(dp->a[5]), POB_UNI(dp->a[6])};
     const PosOff k = pos_off(T);
     const uint32_t kend = T == 3 ? POS_OFF_C_4 : T == 4 ? POS_OFF_C_5 : POS_TABLE_LEN;     // the constants of one T are contiguous
-    for (uint32_t i = lane; i < (kend - k.C) * 8; i += 64) g_lds[i] = A.pos_tab[(size_t)k.C * 8 + i];
+    for (uint32_t i = threadIdx.x; i < (kend - k.C) * 8; i += blockDim.x) g_lds[i] = A.pos_tab[(size_t)k.C * 8 + i];
     __syncthreads();
     PosWide W;
     uint32_t* frp = A.fr + (uint64_t)g * A.fr_stride;
@@ -173,7 +179,7 @@ __device__ __forceinline__ void poswide_body(const GArgs& A, uint32_t bx, uint32
     W.ktab = g_lds; W.kbase = k.C;
     if (T == 3) posw_run<3>(A, d, W, lane); else if (T == 4) posw_run<4>(A, d, W, lane); else posw_run<5>(A, d, W, lane);
 }
-// grid = (8 * nunits, ngroups)
-__global__ void __launch_bounds__(64, 1) k_poseidon_wide(GArgs A) { poswide_body(A, blockIdx.x, blockIdx.y); }
+// grid = (8 / POSW_WAVES * nunits, ngroups) workgroups of POSW_WAVES wavefronts
+__global__ void __launch_bounds__(64 * POSW_WAVES) k_poseidon_wide(GArgs A) { poswide_body(A, POSW_WAVES * blockIdx.x + (threadIdx.x >> 6), blockIdx.y); }
 static_assert(POS_TABLE_LEN - POS_OFF_C_5 >= POS_OFF_C_5 - POS_OFF_C_4 && POS_TABLE_LEN - POS_OFF_C_5 >= POS_OFF_C_4 - POS_OFF_C_3, "the T = 5 constants are the largest set");
 #define POSW_LDS_BYTES ((POS_TABLE_LEN - POS_OFF_C_5) * 32u)

@@ -116,7 +116,7 @@ class PobInfo(ctypes.Structure):
                 ("n_units", ctypes.c_uint32), ("n_sponges", ctypes.c_uint32), ("n_perms", ctypes.c_uint32),
                 ("n_stages", ctypes.c_uint32), ("max_batch", ctypes.c_uint32),
                 ("group_bytes", ctypes.c_uint64), ("keccak_bit_wires", ctypes.c_uint64), ("n_derived", ctypes.c_uint64), ("n_alias", ctypes.c_uint64),
-                ("kchk_rounds", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
+                ("kchk_rounds", ctypes.c_uint32), ("kgc_rounds", ctypes.c_uint32)]
 
 
 # one result record (include/pob_hip.h POB_RECORD_BYTES = 44)
@@ -184,6 +184,7 @@ def load_library() -> ctypes.CDLL:
     lib.pob_time_kernel.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.pob_probe_check_kernel.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     lib.pob_debug_xor_bits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
+    lib.pob_debug_store_fault.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     lib.pob_debug_poke.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.pob_debug_emit_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.pob_emit_selfcheck.argtypes = [vp, ctypes.c_int]
@@ -206,7 +207,7 @@ EXPORTED_SYMBOLS = ["pob_plan_info", "pob_gadget_template", "pob_open", "pob_clo
                     "pob_upload_inputs8", "pob_upload_inputs8_async", "pob_narrow_inputs", "pob_pack_json_batch8",
                     "pob_results_fetch", "pob_results_wait", "pob_emit_begin_reduced", "pob_reduced_map_pin", "pob_write_wtns_reduced", "pob_emit_measure_ex", "pob_generate",
                     "pob_constraint_check", "pob_sync", "pob_set_partner", "pob_results", "pob_results_device", "pob_results_records_device", "pob_gather_records", "pob_emit_witness",
-                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_stream_create", "pob_debug_stream_destroy", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_alias", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
+                    "pob_write_wtns", "pob_emit_begin", "pob_emit_next", "pob_emit_queue", "pob_emit_measure", "pob_time_kernel", "pob_probe_check_kernel", "pob_debug_xor_bits", "pob_debug_store_fault", "pob_debug_stream_create", "pob_debug_stream_destroy", "pob_debug_poke", "pob_debug_ref", "pob_debug_emit_counters", "pob_debug_fr_inv", "pob_emit_selfcheck", "pob_emit_selfcheck_alias", "pob_emit_selfcheck_result", "pob_set_inorder", "pob_keccak256", "pob_pow_search", "pob_pow_search_gpu"]
 
 
 def plan_info(main: str) -> PobInfo:
@@ -753,7 +754,9 @@ class WitnessCalculator:
 
     def set_inorder(self, on=True):
         """every launch of this calculator on the caller's stream, in dependency order, no side streams (pob_set_inorder): for jobs that keep several calculators in flight.
-        on = 3: the same with the FUSED launch -- the Poseidon blocks share a launch with the header's / layers' sponge chain, which does not depend on them"""
+        on = 3: the same with the FUSED launch -- the Poseidon blocks share a launch with the header's / layers' sponge chain, which does not depend on them;
+        on | 4: the Keccak round blocks are evaluated by the launch that writes them (k_rounds_gc: the evaluation's loads come from L2 / the Infinity Cache), and
+        constraint_check skips its round kernel unless a debug poke touched the vector in between"""
         self._ck(self.lib.pob_set_inorder(self.h, int(on)))
 
     def emit_selfcheck(self, enable: bool = True):
@@ -825,6 +828,17 @@ class WitnessCalculator:
     def poke(self, cls: int, index: int, lane: int, xor_mask: int = 1, sub: int = 0, group: int = 0):
         """XOR one stored value of one witness of the resident vector (storage class, rank in the class, lane)"""
         self._ck(self.lib.pob_debug_poke(self.h, cls, group, index, sub, lane, xor_mask))
+
+    def store_fault(self, index: int, lane_mask: int, group: int = 0, cls: int = 0):
+        """arm ONE corrupted store of the next generation (pob_debug_store_fault; calculators with set_inorder(... | 4)): a round block's BIT word (cls CLASS_BIT) or an
+        input's SM row (cls CLASS_SM).  Returns the wire the evaluation that rides with the generation must report for the witnesses of lane_mask, or None if no
+        such store exists"""
+        w = ctypes.c_uint32()
+        rc = self.lib.pob_debug_store_fault(self.h, cls, group, index, lane_mask, ctypes.byref(w))
+        if rc == -1 and "not a stored word" in self.lib.pob_strerror(self.h).decode():
+            return None
+        self._ck(rc)
+        return int(w.value)
 
     def emit_counters(self, reset: bool = True) -> dict:
         """IsZero.inv wires written by the emitter since the last reset, by path (pob_debug_emit_counters)"""

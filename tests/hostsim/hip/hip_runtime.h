@@ -42,8 +42,9 @@ bool hs_any(bool pred);
 #define __ballot(p) hs_ballot(p)
 #define __any(p) hs_any(p)
 #define __shfl(v, src, w) hs_shfl((uint32_t)(v), (uint32_t)(src))
-#define __shfl_xor(v, m, w) hs_shfl((uint32_t)(v), (uint32_t)threadIdx.x ^ (uint32_t)(m))
-#define __syncthreads() ((void)hs_any(false))
+#define __shfl_xor(v, m, w) hs_shfl((uint32_t)(v), ((uint32_t)threadIdx.x & 63u) ^ (uint32_t)(m))
+void hs_sync();                                // the whole block meets (ballots / shuffles / readlane: the calling fiber's wavefront, 64 consecutive threads)
+#define __syncthreads() hs_sync()
 #define __builtin_amdgcn_readlane(v, l) ((int)hs_readlane((uint32_t)(v), (uint32_t)(l)))
 #define __builtin_amdgcn_readfirstlane(v) ((int)hs_readfirstlane((uint32_t)(v)))
 #define __builtin_amdgcn_ds_bpermute(addr, v) ((int)hs_shfl((uint32_t)(v), ((uint32_t)(addr) >> 2) & 63u))

@@ -691,7 +691,7 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
     calcs = [pkg.WitnessCalculator(PROD, max_batch=n) for _ in range(4)]
     streams = [torch.cuda.Stream() for _ in calcs]
     for k, c in enumerate(calcs):
-        c.set_inorder(3 if k % 2 else 1)         # (1: one launch per kernel; 3: fused launches -- what bench.py runs: calculators 1 and 3, one of them emits the payload below)
+        c.set_inorder((1, 7, 5, 3)[k])           # (1: one launch per kernel; 3: the fused Poseidon + chain launch; | 4: the round blocks evaluated by the launch that writes them; 7 = what bench.py runs)
     for rnd in range(2):
         for k, c in enumerate(calcs):
             c.upload(batches[(k + rnd) % 3].inputs)
@@ -701,16 +701,68 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
             got = [(r.status, r.outputs, r.check_status, r.bad_wire) for r in c.results(with_check=True)]
             assert got == want[(k + rnd) % 3], (rnd, k)
     ora = O.run(PROD, batches[0].inputs[n - 1])
-    idx0 = next(k for k in range(4) if (k + 1) % 3 == 0)         # the calculator that holds batch 0 after round 1 (k = 2: one launch per kernel)
+    idx0 = next(k for k in range(4) if (k + 1) % 3 == 0)         # the calculator that holds batch 0 after round 1 (k = 2: one launch per kernel, rounds evaluated with their expansion)
     gpu = calcs[idx0].witness_payload(n - 1)
     assert np.array_equal(gpu, ora.witness_numpy()), f"first differing wire {_first_diff(gpu, ora.witness_numpy())}"
-    # ... and the same batch generated by a calculator with FUSED launches: every wire of the same witness again
+    # ... and the same batch generated by the calculator that runs bench.py's schedule (fused launch, round blocks evaluated by the launch that writes them): every wire again
     calcs[1].upload(batches[0].inputs); calcs[1].generate(streams[1].cuda_stream); calcs[1].constraint_check(streams[1].cuda_stream)
     assert [(r.status, r.outputs, r.check_status, r.bad_wire) for r in calcs[1].results(with_check=True)] == want[0]
     gpu = calcs[1].witness_payload(n - 1)
     assert np.array_equal(gpu, ora.witness_numpy()), f"fused launches: first differing wire {_first_diff(gpu, ora.witness_numpy())}"
     for c in calcs:
         c.close()
+
+
+def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
+    """pob_set_inorder(h, 7), production instantiation, 130 witnesses: k_rounds_gc stores every gate-output array of a round block and compares what it LOADS back with the
+    gate's definition; the input rows are loaded back by the launch that stores them likewise.  One store per generation reaches memory corrupted (pob_debug_store_fault: the
+    wavefront goes on with the right value): exactly the witnesses of the mask are flagged -- at the round block's first wire, at the input's wire -- by the generation's own
+    launches (the evaluation that follows runs neither kernel), in all three groups; the next clean generation reports nothing, the standalone evaluation of the clean vector
+    (after a poke and its undoing) reports nothing either"""
+    from proof_of_burn_amd import inputs as gen
+    n = 130
+    bt = gen.synthetic_batch(n, depth=10, seed=0x77, distinct_keys=2)
+    calc = pkg.WitnessCalculator(PROD, max_batch=n)
+    calc.set_inorder(7)
+    res = calc.calculate(bt.inputs, check=True)
+    assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in res) and [r.outputs[0] for r in res] == bt.commitments
+    nbit = int(calc.info.n_bit)
+    rng = np.random.default_rng(23)
+    tried, wires = 0, set()
+    for bit_index in rng.integers(0, nbit, 400).tolist():
+        group = tried % 3
+        lanes = int(rng.integers(1, 1 << 63)) if group < 2 else int(rng.integers(1, 4))       # group 2 holds witnesses 128 and 129
+        want = calc.store_fault(bit_index, lanes, group=group)
+        if want is None:
+            continue
+        calc.generate(); calc.constraint_check()
+        got = [r.bad_wire for r in calc.results(with_check=True)]
+        exp = [want if k // 64 == group and (lanes >> (k % 64)) & 1 else None for k in range(n)]
+        assert got == exp, (bit_index, group, hex(lanes), want, [(k, g) for k, g in enumerate(got) if g != exp[k]][:6])
+        tried += 1; wires.add(want)
+        if tried >= 36:
+            break
+    assert tried >= 36 and len(wires) >= 12
+    first = next(i for i in range(int(calc.info.n_sm)) if calc.store_fault(i, 0, cls=calc.CLASS_SM) is not None)       # the first input row
+    nrows = next(k for k in range(1, int(calc.info.n_sm)) if calc.store_fault(first + k, 0, cls=calc.CLASS_SM) is None)
+    assert nrows == 1 + 16 * 544 + 16 + 1 + 16 * 136 + 1 + 1     # numLeafAddressNibbles, layers, layerLens, numLayers, blockHeader, blockHeaderLen, byteSecurityRelax (proof_of_burn.circom:43-72)
+    for k in sorted(set([0, nrows - 1] + rng.integers(0, nrows, 10).tolist())):
+        group = k % 3
+        lanes = int(rng.integers(1, 1 << 63)) if group < 2 else int(rng.integers(1, 4))
+        want = calc.store_fault(first + k, lanes, group=group, cls=calc.CLASS_SM)
+        calc.generate(); calc.constraint_check()
+        got = [r.bad_wire for r in calc.results(with_check=True)]
+        exp = [want if j // 64 == group and (lanes >> (j % 64)) & 1 else None for j in range(n)]
+        assert got == exp, (k, group, hex(lanes), want, [(j, g) for j, g in enumerate(got) if g != exp[j]][:6])
+    calc.generate(); calc.constraint_check()
+    assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in calc.results(with_check=True))
+    idx = int(calc.info.n_bit) // 2
+    calc.poke(calc.CLASS_BIT, idx, 5); calc.constraint_check()
+    flagged = [k for k, r in enumerate(calc.results(with_check=True)) if r.bad_wire is not None or r.check_status != 0]
+    assert flagged == [5]
+    calc.poke(calc.CLASS_BIT, idx, 5); calc.constraint_check()
+    assert all(r.bad_wire is None and r.check_status == 0 for r in calc.results(with_check=True))
+    calc.close()
 
 
 def test_generation_and_evaluation_on_different_streams(pkg):
@@ -727,7 +779,7 @@ def test_generation_and_evaluation_on_different_streams(pkg):
     ref.close()
     assert want[1][70][0] != 0 and all(w[0] == 0 and w[2] == 0 for w in want[0])
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    for inorder in (0, 1, 3):
+    for inorder in (0, 1, 3, 7):
         c = pkg.WitnessCalculator(PROD, max_batch=n)
         c.set_inorder(inorder)
         for rnd in range(2):

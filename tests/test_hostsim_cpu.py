@@ -471,9 +471,11 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
     of the stage graph in one launch per kernel class).  The shim executes launches one after the other in enqueue order -- which is exactly what an in-order stream
     does -- so a level that ran ahead of something it reads would show here: reference outputs, evaluator clean, payload == the oracle's, for Spend(31), the fixture
     instantiation (all tracks) and a Keccak gadget main"""
-    for main, suite, mode in (("Spend(31)", "test_spend", 1), ("Spend(31)", "test_spend", 3), (POB_FIX, "test_proof_of_burn", 1), (POB_FIX, "test_proof_of_burn", 3)):
+    for main, suite, mode in (("Spend(31)", "test_spend", 1), ("Spend(31)", "test_spend", 3), ("Spend(31)", "test_spend", 5), (POB_FIX, "test_proof_of_burn", 1), (POB_FIX, "test_proof_of_burn", 3),
+                              (POB_FIX, "test_proof_of_burn", 7)):
         # mode 3: FUSED launches (the Poseidon blocks with the header's sponge chain, slices of the round expansion with the levels behind it, the round evaluation interleaved
         # with the wide evaluation families, the chain evaluation behind the narrow ones): the same wires from fewer, fuller launches
+        # mode | 4: the round blocks evaluated by the launch that writes them (k_rounds_gc); the evaluation proper skips its round kernel -- unless a poke came in between
         s = _suite(suite)
         calc = pkg.WitnessCalculator(main, max_batch=8)
         calc.set_inorder(mode)
@@ -507,6 +509,56 @@ def test_inorder_schedule_equals_the_track_schedule(pkg):
         assert [r.outputs if r.ok else None for r in res] == [c["expected"] for c in s["cases"]]
         assert all(r.check_status == 0 and r.bad_wire is None for r in res if r.ok)
         calc.close()
+
+
+def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
+    """pob_set_inorder(... | 4): k_rounds_gc writes a round block and evaluates it from what it LOADS back; the input rows (k_inputs MODE 2) likewise.  A store that reaches
+    memory corrupted while the generating wavefront goes on with the right value (pob_debug_store_fault) must be flagged for exactly the witnesses of the mask -- at the round
+    block's first wire or the input's wire -- by the generation's own launches (the evaluation that follows runs neither kernel), and the next, clean generation reports nothing"""
+    s = _suite("test_spend")
+    ok_case = next(c for c in s["cases"] if c["expected"] is not None)
+    calc = pkg.WitnessCalculator("Spend(31)", max_batch=5)
+    calc.set_inorder(5)
+    nbit = int(calc.info.n_bit)
+    rng = np.random.default_rng(11)
+    tried, kinds = 0, set()
+    for bit_index in rng.integers(0, nbit, 400).tolist():
+        lanes = int(rng.integers(1, 32))                     # any subset of the 5 witnesses
+        want = calc.store_fault(bit_index, lanes)
+        if want is None:
+            continue                                         # not a word of a round block: nothing armed
+        res = calc.calculate([ok_case["input"]] * 5, check=True)
+        assert [r.bad_wire for r in res] == [want if (lanes >> k) & 1 else None for k in range(5)], (bit_index, lanes, want, [r.bad_wire for r in res])
+        kinds.add(want)
+        tried += 1
+        if tried >= 30:
+            break
+    assert tried >= 30 and len(kinds) >= 10                   # many different round blocks
+    res = calc.calculate([ok_case["input"]] * 5, check=True)
+    assert all(r.ok and r.bad_wire is None and r.check_status == 0 for r in res)
+    # a generation whose verdict nobody collects does not leak into the next batch's records
+    assert calc.store_fault(bit_index, 1) is not None
+    calc.calculate([ok_case["input"]] * 5, check=False)
+    res = calc.calculate([ok_case["input"]] * 5, check=True)
+    assert all(r.ok and r.bad_wire is None and r.check_status == 0 for r in res)
+    calc.close()
+    # the input rows of a ProofOfBurn main: compared with the inputs by the launch that writes them (k_inputs MODE 2).  A corrupted row is READ by the generation that follows
+    # (the witness built on it may fail its asserts): what is asserted is the evaluator's verdict -- the input's wire, for exactly the witnesses of the mask
+    s = _suite("test_proof_of_burn")
+    ok_case = next(c for c in s["cases"] if c["expected"] is not None)
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=3)
+    calc.set_inorder(7)
+    first = next(i for i in range(int(calc.info.n_sm)) if calc.store_fault(i, 0, cls=EC.SM) is not None)
+    nrows = next(k for k in range(1, int(calc.info.n_sm)) if calc.store_fault(first + k, 0, cls=EC.SM) is None)
+    assert nrows > 2000                                      # layers[4][544] + blockHeader[680] + the scalars
+    for k in sorted(set([0, nrows - 1] + rng.integers(0, nrows, 6).tolist())):
+        lanes = int(rng.integers(1, 8))
+        want = calc.store_fault(first + k, lanes, cls=EC.SM)
+        res = calc.calculate([ok_case["input"]] * 3, check=True)
+        assert [r.bad_wire for r in res] == [want if (lanes >> j) & 1 else None for j in range(3)], (k, lanes, want, [r.bad_wire for r in res])
+    res = calc.calculate([ok_case["input"]] * 3, check=True)
+    assert all(r.ok and r.bad_wire is None and r.check_status == 0 for r in res)
+    calc.close()
 
 
 def test_failing_status_is_the_lowest_of_all_the_oracles_failing_sites(pkg):

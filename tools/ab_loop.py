@@ -40,7 +40,7 @@ def main():
     for r in range(a.rounds):
         for depth, ss in points:
             args.fused = ss
-            lp = BM.ServiceLoop(job, BM.MAIN, depth, True, bool(ss))
+            lp = BM.ServiceLoop(job, BM.MAIN, depth, True, ss)
             if pinned is None:
                 pinned = [PinnedInputs(lp.calcs[0], B) for _ in batches]
                 for pin, bt in zip(pinned, batches):
@@ -82,7 +82,7 @@ def main():
                 t_eval = span(lambda: c0.constraint_check(st0.cuda_stream))
                 t_gen = span(lambda: c0.generate(st0.cuda_stream))
                 fams = {f: round(c0.time_kernel(300 + f, iters=5, stream=st0.cuda_stream), 4) for f in range(8)}
-                extra = f" | alone: evaluation {t_eval:.3f} ms generation {t_gen:.3f} ms K_CHK {c0.time_kernel(1, iters=5, stream=st0.cuda_stream):.4f} K_GEN {c0.time_kernel(0, iters=5, stream=st0.cuda_stream):.4f} families {fams}"
+                extra = f" | alone: evaluation {t_eval:.3f} ms generation {t_gen:.3f} ms K_CHK {c0.time_kernel(1, iters=5, stream=st0.cuda_stream):.4f} K_GEN {c0.time_kernel(0, iters=5, stream=st0.cuda_stream):.4f} K_GC {c0.time_kernel(6, iters=5, stream=st0.cuda_stream):.4f} families {fams}"
             print(f"round {r} {a.label} cumask {a.cumask} depth {depth} fused {ss}: {s / a.steps * 1e3:.3f} ms/step = {s / a.steps * 1e3 * 1024 / B:.3f} ms per 1024  {B * a.steps / s:.0f} w/s  K_CHK in step {k:.4f} ms{extra}", flush=True)
             lp.close()
             del lp

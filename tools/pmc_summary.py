@@ -20,6 +20,8 @@ def per_launch(path, counter, kernel_like):
             join rocpd_kernel_dispatch{sfx} d on p.event_id = d.event_id join rocpd_info_kernel_symbol{sfx} k on d.kernel_id = k.id
             join rocpd_info_pmc{sfx} i on p.pmc_id = i.id where k.kernel_name like ? and i.name = ? order by d.start"""
     rows = [r for r in cur.execute(q, (kernel_like, counter)).fetchall()]
+    if not rows:
+        return None
     full = max(r[0] for r in rows)
     vals = [r[2] for r in rows if r[0] == full]
     return {"launches": len(vals), "grid_x_threads": full, "groups": rows[0][1], "avg_kb": sum(vals) / len(vals)}
@@ -43,6 +45,19 @@ def main(fetch_db, write_db, out):
     for k in ("k_rounds_check", "k_rounds_gen"):
         d = res[k]
         d["traffic_over_algorithmic"] = round((d.get("hbm_read_bytes_per_launch") or d.get("hbm_write_bytes_per_launch")) / d["algorithmic_bytes_per_launch"], 4)
+    # round 6: the launch that expands AND evaluates the round blocks (k_rounds_gc, keccak_kernels.hpp): algorithmic = the expansion's stores + the evaluation's loads; the loads of
+    # what the wavefront has just stored are served by L2, so the traffic is BELOW the algorithmic bytes -- by how much is what these passes measure
+    gcf, gcw = per_launch(fetch_db, "FETCH_SIZE", "%k_rounds_gc%"), per_launch(write_db, "WRITE_SIZE", "%k_rounds_gc%")
+    if gcf and gcw:
+        items = gcf["grid_x_threads"] // 64
+        KGC = 24 * (chunks // (24 // KCHK)) // items            # rounds per wavefront: permutations x 24 rounds / items
+        store, load = items * groups * KGC * 76 * 64 * 8, items * groups * (101 * KGC + 25) * 64 * 8
+        rd, wr = gcf["avg_kb"] * 1024 * 2, gcw["avg_kb"] * 1024
+        res["k_rounds_gc"] = {"fetch_size_kb_raw": gcf["avg_kb"], "write_size_kb_raw": gcw["avg_kb"], "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                              "algorithmic_store_bytes_per_launch": store, "algorithmic_load_bytes_per_launch": load, "rounds_per_wavefront": KGC,
+                              "stored_states_bytes_per_launch": load - store,         # midRound[r0] + every midRound[r+1]: loads that no store of the launch precedes
+                              "loads_of_own_stores_served_by_cache": round(1 - (rd - (load - store)) / store, 4),
+                              "traffic_over_algorithmic": round((rd + wr) / (store + load), 4)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
