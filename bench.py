@@ -34,7 +34,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # every stream of the job n
 MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"      # circuits/main_proof_of_burn.circom:27
 HBM_PEAK_GBS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 DEFAULT_DEPTH = 12                                                   # in-order calculators in flight: the fastest depth measured (4 / 6 / 8 / 10 / 12 / 16: profiles/round6_experiments.txt)
-PMC_FILES = ("round6_pmc_k_rounds_gc.json", "round6_pmc_k_rounds.json", "round5_pmc_k_rounds.json")
+PMC_FILES = ("round6_pmc_k_rounds.json", "round5_pmc_k_rounds.json")
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (the oracle, test infrastructure: this leg only)

@@ -371,7 +371,9 @@ __device__ __forceinline__ void chain_body(const KArgs A, uint32_t bx, uint32_t 
 #pragma unroll
     for (int i = 0; i < 25; i++) put(sp.fs_b + sp.n * 1600 + 64 * i, st[i]);
 }
+#ifdef POB_KECCAK_TU          // (the non-template kernels are defined in ONE translation unit, k_keccak.hip; the bodies and the template kernels wherever they are used)
 __global__ void __launch_bounds__(64, 3) k_chain(KArgs A) { chain_body(A, blockIdx.x, blockIdx.y); }
+#endif
 
 // (round 5 tried TWO wavefronts per (group, sponge), each on the 32-bit half of every word -- 32-bit logic, one ds_bpermute per rotation: the header's 17-block chain
 //  0.433 -> 0.336 ms alone, but the step went from 1.57-1.60 / 1.39 to 1.67 / 1.52-1.53 ms with 4 / 8 in flight: twice the wavefronts storing 4-byte halves of every
@@ -410,7 +412,7 @@ __device__ __forceinline__ void chain_check_body(const KArgs A, uint32_t bx, uin
     for (int o = 32; o > 0; o >>= 1) { bad |= ((u64)__shfl_xor((uint32_t)(bad >> 32), o, 64) << 32) | __shfl_xor((uint32_t)bad, o, 64); }
     if ((bad >> lane) & 1) atomicMin(&A.bad_wire[by * 64 + lane], sp.abs_w + b * ABSORB_WIRES);
 }
-#ifdef POB_KECCAK_TU          // (the non-template kernels are defined in ONE translation unit, k_keccak.hip; the bodies and the template kernels wherever they are used)
+#ifdef POB_KECCAK_TU
 __global__ void __launch_bounds__(64) POB_WAVES_PER_SIMD(4) k_chain_check(KArgs A) { chain_check_body(A, blockIdx.x, blockIdx.y); }
 #endif
 

@@ -441,13 +441,16 @@ uint32_t default_threads() {
     if (!n) n = std::thread::hardware_concurrency();
     if (!n) n = 1;
     // a container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us): more runnable threads than the quota are throttled, not faster (the GPU boxes of this project
-    // show 256 CPUs and grant 16: 64 threads took 10 ms for a batch that 32 parsed in 2.9 ms)
+    // show 256 CPUs and grant 16: 64 threads took 10 ms for a batch that 32 parsed in 2.9 ms, round 4)
     {
         long quota = -1, period = 100000;
         if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[32]; if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max")) quota = atol(q); fclose(f); }
         else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g);
             if (FILE* h2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h2, "%ld", &period) != 1) period = 100000; fclose(h2); } }
-        if (quota > 0 && period > 0) { const uint32_t q = (uint32_t)((quota + period - 1) / period); if (q && q < n) { n = q; quota_cut = true; } }      // (a quota is the container's: its ranks share it)
+        // the pool is 1.5 x the quota wide: in a service loop its threads work in bursts (a batch of 1 024 is 11.5 ms of CPU time per 1.05 ms step: 11 CPUs on average), and a burst
+        // finishes sooner on more threads -- 16 / 20 / 24 / 32 threads under a quota of 16: 0.92-1.07 / 0.77-0.94 / 0.72-0.76 / 0.64-0.96 ms per batch inside the loop, the last with
+        // throttled steps (profiles/round6_experiments.txt 19)
+        if (quota > 0 && period > 0) { const uint32_t q = (uint32_t)((quota + period - 1) / period), w = q + q / 2; if (q && w < n) { n = w; quota_cut = true; } }      // (a quota is the container's: its ranks share it)
     }
     if (const char* e = getenv("POB_LOADER_THREADS")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }
     // the ranks of a node share its cores: divide by LOCAL_WORLD_SIZE -- unless this process has been pinned to its share already (distributed.bind_rank_to_gpu_numa)

@@ -12,8 +12,8 @@ MAIN = "ProofOfBurn(16, 4, 16, 50, 31, 2, 10 ** 19, 10 ** 20)"
 NB = int(os.environ.get("POB_PMC_BATCH", "1024"))      # (8192: what every launch costs when it fills the machine -- its THROUGHPUT cost, not its latency)
 batch = gen.synthetic_batch(NB, depth=10, seed=0xB0B, distinct_keys=16)
 calc = WitnessCalculator(MAIN, max_batch=NB)
-if os.environ.get("POB_PMC_INORDER", "3") != "0":
-    calc.set_inorder(int(os.environ.get("POB_PMC_INORDER", "3")))          # 3: the schedule bench.py runs (in order, fused launches); 1: one launch per kernel
+if os.environ.get("POB_PMC_INORDER", "7") != "0":
+    calc.set_inorder(int(os.environ.get("POB_PMC_INORDER", "7")))          # 7: the schedule bench.py runs (in order, fused launch, evaluation riding with the generation); 3 / 1: without
 for _ in range(2):
     res = calc.calculate(batch.inputs, check=True)
     assert all(r.ok and r.check_status == 0 for r in res)

@@ -11,7 +11,7 @@ def short(n):
         if key in n:
             return lab
     if 'k_rounds' in n:
-        return 'K_CHK' if 'k_rounds_check' in n else 'K_GEN'
+        return 'K_GC' if 'k_rounds_gc' in n else 'K_CHK' if 'k_rounds_check' in n else 'K_GEN'
     if 'g_units' in n:
         return ('gCHK' if 'CheckP' in n else 'gEMIT' if 'EmitP' in n else 'gGEN') + '[' + n.split('Lj')[1].split('E')[0] + ']'
     for key, lab in (('poseidon', 'posWide'), ('k_chain_check', 'chainC'), ('k_chain', 'chainG'), ('k_inputs', 'inputs'), ('k_collect', 'collect')):
