@@ -9,7 +9,7 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-UNITS = ["g_gen_poswide.hip", "g_emit_light.hip", "g_emit_heavy.hip", "g_check_pos.hip", "g_check_n2b.hip", "g_gen_n2b.hip", "g_gen_light.hip", "g_gen_all.hip", "g_check_narrow.hip", "g_check_rl.hip", "g_check_ld.hip", "g_check_misc.hip", "g_check_sc.hip", "g_gen_sc.hip", "g_check_range.hip", "g_check_selrow.hip", "k_keccak.hip", "pob_host.hip", "pack_json.hip", "g_gen_gm.hip", "g_check_gm.hip", "g_emit_gm.hip"]
+UNITS = ["g_gen_poswide.hip", "g_emit_light.hip", "g_emit_heavy.hip", "g_check_pos.hip", "g_check_n2b.hip", "g_gen_n2b.hip", "g_gen_light.hip", "g_gen_all.hip", "g_gen_all_ride.hip", "g_check_narrow.hip", "g_check_rl.hip", "g_check_ld.hip", "g_check_misc.hip", "g_check_sc.hip", "g_gen_sc.hip", "g_check_range.hip", "g_check_selrow.hip", "k_keccak.hip", "pob_host.hip", "pack_json.hip", "g_gen_gm.hip", "g_check_gm.hip", "g_emit_gm.hip"]
 HEADERS = ["fr_dev.hpp", "policy.hpp", "gadgets.hpp", "circuits.hpp", "kernels_common.hpp", "g_units.hpp", "keccak_kernels.hpp", "poseidon_wide.hpp", "gadget_mains.hpp",
            "poseidon_consts.h", os.path.join("..", "..", "include", "pob_hip.h")]
 # (host pass at -O1: the only host code of any size is the layout planner, which runs once per pob_open)

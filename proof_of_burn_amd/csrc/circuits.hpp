@@ -433,6 +433,14 @@ template <class P> GD void L_pc_declare(P& p, CircuitLayout& L, int N) {
 HD bool unit_is_heavy(uint32_t k) { return fam_of(k) >= F_SC; }
 HD bool unit_gen_is_heavy(uint32_t k) { return gen_fam_of(k) >= F_SC; }
 
+template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L);
+#ifdef __HIPCC__
+// a riding generation kernel (policy.hpp GenPT<true>) runs its RLP units on the plain policy: their evaluation stays a launch of pob_constraint_check
+template <uint32_t MASK, bool FAULT> GD void unit_run_ride(GenPT<true, FAULT>& p, const UnitDesc& d, CircuitLayout& L) {
+    if constexpr ((MASK >> F_RL) & 1u) { if (gen_fam_of(d.kind) == F_RL) { unit_run<GenPT<false>, FAM_BIT(F_RL)>(plain_view(p), d, L); return; } }
+    unit_run<GenPT<true, FAULT>, MASK & ~FAM_BIT(F_RL)>(p, d, L);
+}
+#endif
 template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {
 
     const PobMain& M = L.pm;

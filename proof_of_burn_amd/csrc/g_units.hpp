@@ -19,6 +19,7 @@ template <class P, uint32_t MASK> __device__ __forceinline__ void g_units_body(c
     p.m.in_fr = A.in_fr + (uint64_t)g * 64 * A.nfr_in * 32;
     p.m.in_sm = A.in_sm + (uint64_t)g * 64 * A.nsm_in;
     p.m.lane = lane; p.m.lane4 = lane * 4;
+    p.m.fault_cls = g == A.fault_group ? A.fault_cls : 0xFFFFFFFFu; p.m.fault_idx = A.fault_idx; p.m.fault_lanes = A.fault_lanes;
     {   // raw buffer resources (gfx9 word3: 32-bit data format); BIT ranks index 8-byte words: i << 3 < 2^32 needs bits_stride < 2^29
         const uint64_t nb = A.bits_stride * 8, ns = A.sm_stride * 4, nf = A.fr_stride * 4;
         p.m.rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.m.bits, 0, (int)(nb > 0xFFFFFFFFull ? 0xFFFFFFFFull : nb), 0x00020000);
@@ -27,20 +28,28 @@ template <class P, uint32_t MASK> __device__ __forceinline__ void g_units_body(c
     }
     p.m.pos_tab = A.pos_tab;
     p.decl_order = A.L->decl_order;
-    if constexpr (P::is_gen) p.status = 0;
+    if constexpr (P::is_gen) { p.status = 0; if constexpr (P::ride) p.ride_init(); }
     if constexpr (P::is_check) { p.status = 0; p.bad_wire = 0xFFFFFFFFu; p.pend_s = p.pend_x = p.rdiff = 0; p.pend_w = 0; p.attribute = false; }
     if constexpr (P::is_emit) { p.out = A.emit_out; p.sel = A.emit_sel; p.w0 = A.emit_w0; p.wn = A.emit_wn; p.probe = A.emit_probe; p.rbits = A.emit_rbits; p.rpre = A.emit_rpre; p.ctr = A.emit_counters; p.sites = A.emit_sites; p.sites_cap = A.emit_sites_cap; p.unit = A.order[A.first + ux]; }
     for (int pass = 0;; pass++) {
         const UnitDesc d = A.units[A.order[A.first + ux]];      // (re-read for the replay: nothing of it stays live across the body)
         if constexpr ((MASK & ~FAM_LIGHT) == 0) { if (d.cost >= 2500) __builtin_amdgcn_s_setprio(2); }     // long serial light units (RLP assembly, ...)
-        unit_run<P, MASK>(p, d, *A.L);
+        if constexpr (P::is_gen) { if constexpr (P::ride) unit_run_ride<MASK>(p, d, *A.L); else unit_run<P, MASK>(p, d, *A.L); }
+        else unit_run<P, MASK>(p, d, *A.L);
         if constexpr (P::is_check) {      // a lane-distributed run differed: replay the unit attributing wire by wire
             p.run_flush();
             if (pass == 0 && __ballot(p.rdiff != 0)) { p.attribute = true; continue; }
         }
         break;
     }
-    if constexpr (P::is_gen) { if (p.status) atomicMin(&A.status[g * 64 + lane], p.status); }
+    if constexpr (P::is_gen) {
+        if (p.status) atomicMin(&A.status[g * 64 + lane], p.status);
+        if constexpr (P::ride) {        // the evaluation that rode with the unit: its pending compares, then the verdict where CheckP would have put it
+            p.ride_flush();
+            if (p.status) atomicMin(&A.chk_status[g * 64 + lane], p.status);
+            if (p.bad_wire != 0xFFFFFFFFu) atomicMin(&A.bad_wire[g * 64 + lane], p.bad_wire);
+        }
+    }
     if constexpr (P::is_check) {
         if (p.status) atomicMin(&A.chk_status[g * 64 + lane], p.status);
         if (p.bad_wire != 0xFFFFFFFFu) atomicMin(&A.bad_wire[g * 64 + lane], p.bad_wire);

@@ -22,6 +22,7 @@ struct GArgs {
     const unsigned long long* emit_rbits; const uint32_t* emit_rpre;   // reduced witness: kept-wire bitmap + per-word rank (policy.hpp EmitP); null = O0 payload
     uint32_t* emit_sites; uint32_t emit_sites_cap;     // self-check site-recording pass (policy.hpp EmitP::sites)
     uint32_t* emit_counters;                           // which of the emitter's inverse paths ran (policy.hpp EmitP::ctr, pob_debug_emit_counters)
+    uint32_t fault_cls, fault_group, fault_idx; uint64_t fault_lanes;      // pob_debug_store_fault (tests): the riding kernels' FAULT instantiations (policy.hpp GenPT<true, true>, poseidon_wide.hpp); fault_cls 0xFFFFFFFF = none
 };
 struct KArgs {
     u64* bits;                 // BIT slabs, all groups
@@ -39,9 +40,11 @@ struct KArgs {
 // per family (circuits.hpp Fam); emission: light | BN254 | SubstringCheck.
 void launch_g_gen_light(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_sc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
-void launch_pos_wide(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
+void launch_pos_wide(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st, bool ride = false, bool fault = false);      // ride: every element stored is loaded back and compared (poseidon_wide.hpp)
 void launch_g_gen_n2b(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_gen_all(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);       // light | BN254 | SubstringCheck units in one kernel (in-order calculators)
+void launch_g_gen_all_ride(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);  // ... whose evaluation rides with them (policy.hpp GenPT<true>)
+void launch_g_gen_all_ride_fault(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);      // ... with one corrupted store (tests)
 void launch_g_check_narrow(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);  // MISC | RL | POS | N2B evaluation families in one kernel (in-order calculators)
 void launch_g_check_misc(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_check_range(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
@@ -59,7 +62,7 @@ void launch_g_gen_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStrea
 void launch_g_check_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 void launch_g_emit_gm(const GArgs& A, uint32_t nunits, uint32_t ngroups, hipStream_t st);
 // fused launch of the in-order schedule: npos Poseidon blocks + nsponges sponge chains from K.first in one launch (g_gen_poswide.hip)
-void launch_pos_chain(const GArgs& A, const KArgs& K, uint32_t npos, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
+void launch_pos_chain(const GArgs& A, const KArgs& K, uint32_t npos, uint32_t nsponges, uint32_t ngroups, hipStream_t st, bool ride = false, bool fault = false);
 void launch_k_chain(const KArgs& K, bool check, uint32_t nsponges, uint32_t ngroups, hipStream_t st);
 void launch_k_rounds(const KArgs& K, bool check, uint32_t nperms, uint32_t ngroups, hipStream_t st);
 // generation + evaluation of the round blocks in one launch (keccak_kernels.hpp k_rounds_gc); fault: the tests' instantiation that corrupts one store

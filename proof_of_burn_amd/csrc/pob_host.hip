@@ -389,7 +389,10 @@ struct pob_ctx {
     // skips those two kernels.  rode: the resident vector is the one those launches evaluated (cleared by every debug poke: the evaluation then runs k_rounds_check and the
     // input check over the vector as it is)
     bool gc = false, rode = false;
-    bool fault_armed = false; int fault_cls = 0; uint32_t fault_group = 0; uint64_t fault_word = 0, fault_mask = 0;     // pob_debug_store_fault (tests)
+    // ... and so does the evaluation of everything else but the sponge chains (the two main circuits: every G unit's stores are loaded back and compared, policy.hpp GenPT<true>,
+    // poseidon_wide.hpp PosWideT<true>): pob_constraint_check then runs k_chain_check and collects the records
+    bool rode_g = false;
+    bool fault_armed = false, fault_g = false; int fault_cls = 0; uint32_t fault_group = 0; uint64_t fault_word = 0, fault_mask = 0;     // pob_debug_store_fault (tests)
     struct GenLaunch { uint32_t kind, cls, first, count, k_first, k_count; };
     enum { GL_UNITS = 0, GL_CHAIN = 1, GL_POS_CHAIN = 2, GL_ROUNDS = 4 };
     std::vector<GenLaunch> gen_plan[2];
@@ -444,9 +447,11 @@ static hipStream_t own_stream(pob_ctx* h);      // the handle's own stream (call
 #define N_GEN_CLASSES 6
 #define CLS_ALL 6          // in-order calculators: classes 0, 1 and 3 of a level in one launch (g_gen_all.hip)
 static uint32_t unit_class(uint32_t kind, bool gen = false) { return fam_of(kind) == F_GM ? 5 : kind == U_POS_WIDE ? 4 : fam_of(kind) == F_SC ? 3 : (gen ? unit_gen_is_heavy(kind) : unit_is_heavy(kind)) ? 1 : 0; }
-static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st) {
+static void launch_g_gen(const GArgs& A, uint32_t cls, uint32_t nunits, uint32_t ngroups, hipStream_t st, bool ride = false, bool fault = false) {      // ride: the units' evaluation rides with them (policy.hpp GenPT<true>)
     if (cls == 5) launch_g_gen_gm(A, nunits, ngroups, st);
-    else if (cls == 4) launch_pos_wide(A, nunits, ngroups, st);
+    else if (cls == 4) launch_pos_wide(A, nunits, ngroups, st, ride, fault);
+    else if (cls == CLS_ALL && ride && fault) launch_g_gen_all_ride_fault(A, nunits, ngroups, st);
+    else if (cls == CLS_ALL && ride) launch_g_gen_all_ride(A, nunits, ngroups, st);
     else if (cls == 3) launch_g_gen_sc(A, nunits, ngroups, st);
     else if (cls == 1) launch_g_gen_n2b(A, nunits, ngroups, st);
     else if (cls == CLS_ALL) launch_g_gen_all(A, nunits, ngroups, st);
@@ -472,7 +477,7 @@ static void launch_g_emit(const GArgs& A, uint32_t cls, uint32_t nunits, hipStre
 static void launch_inputs(pob_ctx* h, int mode, uint32_t G, hipStream_t st) {      // mode: 0 generation, 1 evaluation, 2 generation + its evaluation (k_inputs)
     if (h->circuit != POB_CIRCUIT_PROOF_OF_BURN || !h->plan.nsm_in) return;
     const SmRef r0 = h->plan.L.pm.numLeafAddressNibbles;  // the small inputs are contiguous SM ranks / wire indices from here (declaration order)
-    const uint32_t fk = (mode == 2 && h->fault_armed && h->fault_cls == POB_CLASS_SM) ? (uint32_t)h->fault_word - r0.i : 0xFFFFFFFFu;     // pob_debug_store_fault: the input row
+    const uint32_t fk = (mode == 2 && h->fault_armed && !h->fault_g && h->fault_cls == POB_CLASS_SM) ? (uint32_t)h->fault_word - r0.i : 0xFFFFFFFFu;     // pob_debug_store_fault: the input row
     if (h->in_bytes[h->in_cur]) {
         const dim3 grid8((h->plan.nsm_in + IN8_K - 1) / IN8_K, G);
         const size_t lds = 64 * (IN8_K + 1) * 4;
@@ -497,6 +502,7 @@ static GArgs gargs(pob_ctx* h) {
     A.pos_tab = h->d_pos; A.inv_lut = h->d_inv; A.pow256 = h->d_pow256; A.npow256 = h->npow256; A.in_fr = h->d_in_fr[h->in_cur]; A.in_sm = h->d_in_sm[h->in_cur];
     A.nfr_in = h->plan.nfr_in; A.nsm_in = h->plan.nsm_in;
     A.status = h->d_status_raw; A.chk_status = h->d_chk; A.bad_wire = h->d_bad; A.emit_counters = h->d_emit_ctr;
+    A.fault_cls = 0xFFFFFFFFu;
     return A;
 }
 static KArgs kargs(pob_ctx* h) {
@@ -989,24 +995,31 @@ int pob_generate(pob_handle h, void* stream_) {
     if (h->inorder) {
         GArgs A = gargs(h);
         KArgs K = kargs(h);
-        if (h->gc && h->rode) HIPC(hipMemsetAsync(h->d_bad, 0xFF, (size_t)G * 64 * 4, st));     // a generation whose verdict nobody collected
-        h->rode = false;
+        if (h->gc && h->rode) { HIPC(hipMemsetAsync(h->d_bad, 0xFF, (size_t)G * 64 * 4, st)); HIPC(hipMemsetAsync(h->d_chk, 0xFF, (size_t)G * 64 * 4, st)); }     // a generation whose verdict nobody collected
+        h->rode = false; h->rode_g = false;
+#ifdef POB_AB_NO_RIDE_G
+        const bool ride_g = false;
+#else
+        const bool ride_g = h->gc && (h->circuit == POB_CIRCUIT_PROOF_OF_BURN || h->circuit == POB_CIRCUIT_SPEND);
+#endif
         launch_inputs(h, h->gc ? 2 : 0, G, st);
-        const bool kf = h->gc && h->fault_armed && h->fault_cls == POB_CLASS_BIT;
+        const bool kf = h->gc && h->fault_armed && !h->fault_g && h->fault_cls == POB_CLASS_BIT;
+        const bool gf = ride_g && h->fault_armed && h->fault_g;             // pob_debug_store_fault on a store of a G unit: the riding kernels' FAULT instantiations
+        if (gf) { A.fault_cls = (uint32_t)h->fault_cls; A.fault_group = h->fault_group; A.fault_idx = (uint32_t)h->fault_word; A.fault_lanes = h->fault_mask; }
         K.fault_group = h->fault_group; K.fault_word = h->fault_word; K.fault_mask = h->fault_mask;
         for (const pob_ctx::GenLaunch& gl : h->gen_plan[h->fused ? 1 : 0]) {
             A.first = gl.first; K.first = gl.k_first;
             switch (gl.kind) {
-            case pob_ctx::GL_UNITS: launch_g_gen(A, gl.cls, gl.count, G, st); break;
+            case pob_ctx::GL_UNITS: launch_g_gen(A, gl.cls, gl.count, G, st, ride_g, gf); break;
             case pob_ctx::GL_CHAIN: launch_k_chain(K, false, gl.k_count, G, st); break;
-            case pob_ctx::GL_POS_CHAIN: launch_pos_chain(A, K, gl.count, gl.k_count, G, st); break;
+            case pob_ctx::GL_POS_CHAIN: launch_pos_chain(A, K, gl.count, gl.k_count, G, st, ride_g, gf); break;
             default:
                 if (h->gc) {
 
                     if (h->ev_kchk[h->rec_slot][0]) { HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][0], st)); h->kchk_rec[h->rec_slot] = true; }
                     launch_k_rounds_gc(K, gl.k_count, G, kf, st);
                     if (h->ev_kchk[h->rec_slot][1]) HIPC(hipEventRecord(h->ev_kchk[h->rec_slot][1], st));
-                    h->rode = true;
+                    h->rode = true; h->rode_g = ride_g;
                 } else launch_k_rounds(K, false, gl.k_count, G, st);
                 break;
             }
@@ -1120,8 +1133,8 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         // one stream: the Keccak round evaluation (the batch's one bandwidth-bound kernel) first, then the sponge chains, the inputs and the eight families
         // (the round evaluation on a high-priority stream of the device, forked and joined per batch, was measured: 4 / 6 / 8 / 12 calculators in flight
         //  2.39 / 2.04 / 1.91 / 2.14 ms per step against 2.19 / 2.09 / 1.87 / 2.07 here, the kernel 0.49-0.74 against 0.42-0.80 ms: nothing; removed)
-        const bool rode = h->rode;          // the round blocks and the input rows were evaluated by the launches that wrote them
-        h->rode = false;
+        const bool rode = h->rode, rode_g = h->rode && h->rode_g;          // the round blocks and the input rows (rode_g: and every G unit) were evaluated by the launches that wrote them
+        h->rode = false; h->rode_g = false;
         if (!h->plan.sponges.empty()) {
             KArgs K = kargs(h); K.first = 0;
             if (!rode) {             // (else: every round block was evaluated by the launch that wrote it, k_rounds_gc, and nothing has touched the vector since)
@@ -1134,8 +1147,12 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         if (!rode) launch_inputs(h, 1, G, st);
         // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
         //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
-        if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
-        for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        if (rode_g) {       // of the G units only the RLP family's evaluation is left (its units generate on the plain policy, circuits.hpp unit_run_ride)
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == F_RL) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        } else {
+            if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
+            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        }
         { int rc = enqueue_collect(h, st, true); if (rc) return rc; }
         HIPC(hipEventRecord(h->ev_check_done, st)); h->check_done_rec = true; h->evaluated = true; h->chk_stream = st; h->chk_ordered = true;
         HIPC(hipEventRecord(h->ev_in_done[h->in_cur], st));
@@ -1834,7 +1851,16 @@ int pob_debug_store_fault(pob_handle h, int cls, uint32_t group, uint64_t index,
         const SmRef r0 = h->plan.L.pm.numLeafAddressNibbles;
         if (index >= r0.i && index < r0.i + h->plan.nsm_in) { found = true; if (wire) *wire = r0.w + (uint32_t)(index - r0.i); }
     }
-    if (!found) { h->err = "pob_debug_store_fault: not a stored word whose evaluation rides with its generation"; return POB_E_ARG; }
+    // anything else: a store of a G unit (policy.hpp GenPT<true, true> / poseidon_wide.hpp): armed without knowing the wire -- or whether a riding unit stores the word at all
+    // (the sponge chains' words, the RLP units' wires and the words no unit of this instantiation writes are not): *wire = 0xFFFFFFFF
+    h->fault_g = !found;
+    if (!found) {
+        const Cur t = h->plan.total;
+        if (!(h->circuit == POB_CIRCUIT_PROOF_OF_BURN || h->circuit == POB_CIRCUIT_SPEND) || (cls == POB_CLASS_BIT ? index >= t.b : cls == POB_CLASS_SM ? index >= t.s : cls == POB_CLASS_FR ? index >= t.f : true)) {
+            h->err = "pob_debug_store_fault: not a stored word whose evaluation rides with its generation"; return POB_E_ARG;
+        }
+        if (wire) *wire = 0xFFFFFFFFu;
+    }
     h->fault_armed = true; h->fault_cls = cls; h->fault_group = group; h->fault_word = index; h->fault_mask = mask;
     return POB_OK;
 }

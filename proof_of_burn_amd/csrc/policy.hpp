@@ -295,6 +295,7 @@ struct DevMem {
     const int32_t* in_sm;     //                              SM inputs [64 lanes][nsm]
     uint32_t nfr_in, nsm_in, npow256;
     uint32_t lane;
+    uint32_t fault_cls, fault_idx; uint64_t fault_lanes;      // GenPT<true, true> (tests, pob_debug_store_fault): the store of storage class / rank reaches memory corrupted for these witnesses
     // buffer resources over the three slabs: a wire access is `buffer_load/store v, v_lane_offset, s[rsrc], s_wire_offset offen`
     // -- the per-wire part of the address stays scalar, no 64-bit per-lane address arithmetic (or registers) per access
     __amdgpu_buffer_rsrc_t rs_bits, rs_sm, rs_fr;
@@ -404,24 +405,87 @@ struct DevPol : PolBase {
     __device__ __forceinline__ S input_sm(uint32_t k) { return m.in_sm[(size_t)m.lane * m.nsm_in + k]; }
 };
 
-struct GenP : DevPol {
-    static constexpr bool is_gen = true, is_check = false, is_emit = false, is_count = false;
+// Generation.  RIDE (in-order calculators, pob_set_inorder bit 2: g_gen_all_ride.hip): the evaluation rides with the generation -- every wire a unit stores is LOADED back behind
+// the store and compared with the value stored; for small values, single bits and runs one load is in flight per class (the compare of a put is resolved when the NEXT put of its class
+// has issued its load, the way CheckP::run_put does it), a field element is compared at once; a mismatch marks the wire (bad_wire, the lowest per witness).  With that, every `<==` / `<--` holds between the STORED wires as it does between the
+// computed ones, and every `===` was evaluated on operands equal to the stored ones: what CheckP establishes by recomputing every unit from stored operands -- the seven G-family
+// launches of pob_constraint_check -- without a second pass over the vector (the loads hit L2: the store is a few instructions old).  A debug poke, or a vector that no launch has
+// just written, is evaluated by CheckP as before.
+template <bool RIDE, bool FAULT = false> struct GenPT : DevPol {
+    static constexpr bool is_gen = true, is_check = false, is_emit = false, is_count = false, ride = RIDE;
+    // FAULT (tests): what goes to memory for the armed (class, rank): bit 0 of the value flipped for the witnesses of fault_lanes -- the unit goes on with the right value
+    __device__ __forceinline__ bool hit(uint32_t cls, uint32_t i) const { return FAULT && m.fault_cls == cls && m.fault_idx == i; }
     uint32_t status;   // this lane's first failing assert (0 = none yet)
-    __device__ __forceinline__ B put(BitRef r, B v) { st(r, v); return v; }
-    __device__ __forceinline__ S put(SmRef r, S v) { st(r, v); return v; }
-    __device__ __forceinline__ F put(FrRef r, const F& v) { st(r, v); return v; }
-    __device__ __forceinline__ B hint(BitRef r, B v) { st(r, v); return v; }
-    __device__ __forceinline__ S hint(SmRef r, S v) { st(r, v); return v; }
-    __device__ __forceinline__ F hint(FrRef r, const F& v) { st(r, v); return v; }
-    __device__ __forceinline__ void raw_put(FrRef r, const F& v) { st(r, v); }
+    // RIDE: lowest wire whose loaded value differs from the value stored (per lane), and the one pending compare per class
+    uint32_t bad_wire;
+    S ps_l, ps_v; uint32_t ps_w;                  // SM: loaded, stored, wire
+    B pb_l, pb_v; uint32_t pb_w;                  // BIT (one wave-uniform word)
+    B pr_l, pr_x; uint32_t pr_w;                  // lane-distributed run: lane k holds wire pr_w's 64-witness mask
+    __device__ __forceinline__ void ride_init() { bad_wire = 0xFFFFFFFFu; ps_l = ps_v = 0; ps_w = 0; pb_l = pb_v = 0; pb_w = 0; pr_l = pr_x = 0; pr_w = 0; }
+    __device__ __forceinline__ void mark(bool bad, uint32_t w) { if (bad && w < bad_wire) bad_wire = w; }
+    __device__ __forceinline__ void res_s() { mark(ps_l != ps_v, ps_w); }
+    __device__ __forceinline__ void res_b() { mark(((pb_l ^ pb_v) >> m.lane) & 1, pb_w); }
+    __device__ __forceinline__ void res_r() { if (__ballot((pr_l ^ pr_x) != 0)) ride_attribute(); }
+    // end of the unit: the pending compares; a run that differed is attributed wire by wire (corrupted stores only)
+    __device__ __forceinline__ void ride_flush() {
+        res_s(); res_b(); res_r();
+        ps_l = ps_v = 0; pb_l = pb_v = 0; pr_l = pr_x = 0;
+    }
+    __device__ __forceinline__ B put(BitRef r, B v) {
+        st(r, hit(0, r.i) ? v ^ m.fault_lanes : v);
+        if constexpr (RIDE) { const B l = run_ld_off(POB_UNI(r.i) << 3); __builtin_amdgcn_sched_barrier(0); res_b(); pb_l = l; pb_v = v; pb_w = r.w; }
+        return v;
+    }
+    __device__ __forceinline__ S put(SmRef r, S v) {
+        st(r, (hit(1, r.i) && ((m.fault_lanes >> m.lane) & 1)) ? v ^ 1 : v);
+        if constexpr (RIDE) { const S l = ld(r); __builtin_amdgcn_sched_barrier(0); res_s(); ps_l = l; ps_v = v; ps_w = r.w; }
+        return v;
+    }
+    __device__ __forceinline__ F put(FrRef r, const F& v) {
+        if (hit(2, r.i) && ((m.fault_lanes >> m.lane) & 1)) { F w = v; w.l[0] ^= 1u; st(r, w); } else st(r, v);
+        if constexpr (RIDE) {
+            const F l = ld(r); mark(!fr_eq(l, v), r.w); POB_OPAQUE(bad_wire);      // (resolved at once: a pending field element is 16 VGPRs the kernel does not have at four wavefronts per SIMD)
+        }
+        return v;
+    }
+    __device__ __forceinline__ B hint(BitRef r, B v) { return put(r, v); }
+    __device__ __forceinline__ S hint(SmRef r, S v) { return put(r, v); }
+    __device__ __forceinline__ F hint(FrRef r, const F& v) { return put(r, v); }
+    __device__ __forceinline__ void raw_put(FrRef r, const F& v) { put(r, v); }
     __device__ __forceinline__ void require(B ok, uint32_t code) { if (!bit(ok) && status == 0) status = code; }
     __device__ __forceinline__ void require_lane(bool ok, uint32_t code) { if (!ok && status == 0) status = code; }
-    __device__ __forceinline__ void run_put(uint32_t n, uint32_t, uint32_t i, B x) {
-        pob_v2i q; q.x = (int)(uint32_t)x; q.y = (int)(uint32_t)(x >> 32);
-        __builtin_amdgcn_raw_buffer_store_b64(q, m.rs_bits, (int)run_off(n, i), 0, 0);
+    __device__ __forceinline__ void run_put(uint32_t n, uint32_t w, uint32_t i, B x) {
+        const B xs = hit(0, i) ? x ^ m.fault_lanes : x;       // (i: this lane's BIT rank)
+        pob_v2i q; q.x = (int)(uint32_t)xs; q.y = (int)(uint32_t)(xs >> 32);
+        const uint32_t off = run_off(n, i);
+        __builtin_amdgcn_raw_buffer_store_b64(q, m.rs_bits, (int)off, 0, 0);
         POB_WAVE_FENCE();
+        if constexpr (RIDE) {
+            const B l = run_ld_off(off);                    // (inactive lanes read 0 ...)
+            __builtin_amdgcn_sched_barrier(0);
+            res_r();
+            pr_l = l; pr_x = m.lane < n ? x : 0; pr_w = w;  // (... and expect 0)
+        }
+    }
+    // a run differed (a corrupted store): which wires, for which witnesses -- lane j holds the difference mask of wire pr_w(j)
+    __device__ __forceinline__ void ride_attribute() {
+        const B d = pr_l ^ pr_x;
+        uint64_t act = __ballot(d != 0);
+        while (act) {
+            const int j = __builtin_ctzll(act); act &= act - 1;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d >> 32), j);
+            const uint32_t wj = (uint32_t)__builtin_amdgcn_readlane((int)pr_w, j);
+            if (((((B)hi << 32) | lo) >> m.lane) & 1) mark(true, wj);
+        }
     }
 };
+typedef GenPT<false> GenP;
+typedef GenPT<true> GenRideP;
+typedef GenPT<true, true> GenRideFaultP;
+// the same policy object without the riding evaluation (the two instantiations differ in code only, not in layout): the RLP units of a riding kernel run on it -- with the
+// pending compares in registers their long byte loops spill 164 VGPRs -- and keep their evaluation in pob_constraint_check (g_check_rl.hip)
+static_assert(sizeof(GenPT<false>) == sizeof(GenPT<true>) && sizeof(GenPT<false>) == sizeof(GenPT<true, true>), "one layout");
+template <bool FAULT> __device__ __forceinline__ GenPT<false>& plain_view(GenPT<true, FAULT>& p) { return *reinterpret_cast<GenPT<false>*>(&p); }
 
 // slow path of CheckP::run_put (by value: the policy object stays in registers): lane j holds the difference mask d of wire w
 __device__ __forceinline__ uint32_t check_attribute_run(B d, uint32_t w, uint32_t lane, uint32_t bad_wire) {

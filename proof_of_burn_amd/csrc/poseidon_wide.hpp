@@ -25,22 +25,40 @@ extern __shared__ uint32_t g_lds[];
 // which wires feed the block (FR ranks; POSW_NONE = absent).  Input 0 is always POSEIDON_PREFIX + pre (constants.circom:3-14).
 #define POSW_NONE 0xFFFFFFFFu
 
-struct PosWide {
+// RIDE (in-order calculators, pob_set_inorder bit 2): the evaluation rides with the generation as in policy.hpp GenPT<true> -- every element a lane stores is loaded back behind
+// the store and compared with the value stored, one load (8 limbs) in flight; a mismatch marks the element's wire (the lowest per lane; poswide_body reduces over the 8 lanes of a
+// witness).  With it the Poseidon segments of pob_constraint_check (CK_POS_SEG: the stored states recomputed from stored operands) need not run.
+template <bool RIDE, bool FAULT = false> struct PosWideT {
     __amdgpu_buffer_rsrc_t rs;     // the group's FR slab
     uint32_t slot4;                // witness slot (0..63) * 4
     bool act;                      // this lane's state slot is in use (element < T)
     const uint32_t* ktab;          // Poseidon table of this T in LDS, indexed from the first constant of T
     uint32_t kbase;                // table index of that first constant
+    uint32_t w_of_f;               // wire index of FR rank f inside the block = f + w_of_f (the block's wires are all field elements, in rank order)
+    uint32_t w_also;               // ... of the caller's copy of the hash (outside the block): reported at the block's first wire
+    mutable Fr pl, pv; mutable uint32_t pw, bad;      // RIDE: the pending compare (loaded, stored, wire) and the lowest wire that differed
+    uint32_t fault_f; bool fault_me;                  // FAULT (tests, pob_debug_store_fault): FR rank whose store reaches memory with bit 0 flipped, for this lane's witness
+    __device__ __forceinline__ void ride_init() { pl = pv = fr_zero(); pw = 0; bad = 0xFFFFFFFFu; }
+    __device__ __forceinline__ void ride_resolve() const { if (!fr_eq(pl, pv) && pw < bad) bad = pw; POB_OPAQUE(bad); }
     __device__ __forceinline__ Fr ld(uint32_t f) const {
         Fr v; const uint32_t off = act ? (f << 11) + slot4 : 0xFFFFF000u;       // inactive: past the slab, reads 0
 #pragma unroll
         for (int k = 0; k < 8; k++) v.l[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off + 256u * k), 0, 0);
         return v;
     }
-    __device__ __forceinline__ void st(bool on, uint32_t f, const Fr& v) const {
+    __device__ __forceinline__ void st(bool on, uint32_t f, const Fr& v, bool also = false) const {
         const uint32_t off = on ? (f << 11) + slot4 : 0xFFFFF000u;              // off: past the slab, dropped
+        const uint32_t flip = (FAULT && fault_me && f == fault_f) ? 1u : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b32((int)v.l[k], rs, (int)(off + 256u * k), 0, 0);
+        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b32((int)(k == 0 ? v.l[0] ^ flip : v.l[k]), rs, (int)(off + 256u * k), 0, 0);
+        if constexpr (RIDE) {
+            Fr l;                                                               // (off: reads 0 ...)
+#pragma unroll
+            for (int k = 0; k < 8; k++) l.l[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off + 256u * k), 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ride_resolve();
+            pl = l; pv = on ? v : fr_zero(); pw = also ? w_also : f + w_of_f;   // (... and expects 0)
+        }
     }
     __device__ __forceinline__ Fr kc(uint32_t idx) const {                      // table constant (per-lane index)
         Fr v; const uint32_t* q = ktab + (size_t)(idx - kbase) * 8;
@@ -49,6 +67,7 @@ struct PosWide {
         return v;
     }
 };
+typedef PosWideT<false> PosWide;
 __device__ __forceinline__ Fr posw_from(const Fr& v, uint32_t src_lane) {      // every lane := lane src_lane's element
     Fr r;
 #pragma unroll
@@ -62,7 +81,7 @@ __device__ __forceinline__ Fr posw_group_sum(Fr v, uint32_t lane) {            /
 }
 
 // off = FR rank of the round's first wire; cr = index of its Ark constants; mat = matrix
-template <int T> __device__ __forceinline__ Fr posw_full(const PosWide& W, uint32_t lane, uint32_t j, Fr x, uint32_t off, uint32_t cr, uint32_t mat) {
+template <int T, class PW> __device__ __forceinline__ Fr posw_full(const PW& W, uint32_t lane, uint32_t j, Fr x, uint32_t off, uint32_t cr, uint32_t mat) {
     // T x Sigma [out | in | in2, in4], Ark [out[T] | in[T]], Mix [out[T] | in[T]]
     const Fr x2 = fr_mul(x, x), x4 = fr_mul(x2, x2), x5 = fr_mul(x4, x);
     const uint32_t sg = off + 4 * j;
@@ -80,7 +99,7 @@ template <int T> __device__ __forceinline__ Fr posw_full(const PosWide& W, uint3
 
 // the unit's descriptor as scalars (read through the scalar cache: the unit index is wave-uniform)
 struct PosWDesc { uint32_t base, pre, in2, in3, in4, sub, also; };
-template <int T> __device__ __forceinline__ void posw_run(const GArgs& A, const PosWDesc& d, const PosWide& W, uint32_t lane) {
+template <int T, class PW> __device__ __forceinline__ void posw_run(const GArgs& A, const PosWDesc& d, const PW& W, uint32_t lane) {
     const PosOff k = pos_off(T);
     const uint32_t j = lane & 7u, base = d.base;
     const bool act = W.act, l0 = j == 0;
@@ -93,7 +112,7 @@ template <int T> __device__ __forceinline__ void posw_run(const GArgs& A, const 
         POB_OPAQUE(a2); POB_OPAQUE(a3); POB_OPAQUE(a4);           // (left alone, the selects become a dynamically indexed table in scratch)
         const uint32_t aj = a2 | a3 | a4;
         const uint32_t src = (j >= 2 && j < (uint32_t)T) ? aj : POSW_NONE;
-        PosWide Wi = W; Wi.act = src != POSW_NONE;
+        PosWideT<false> Wi; Wi.rs = W.rs; Wi.slot4 = W.slot4; Wi.act = src != POSW_NONE;
         const Fr v = Wi.ld(src);
         if (src != POSW_NONE) x = v;
         const uint32_t sub = (j == (uint32_t)T - 1) ? d.sub : POSW_NONE;
@@ -151,7 +170,7 @@ template <int T> __device__ __forceinline__ void posw_run(const GArgs& A, const 
         W.st(act && l0, off + 4 * T, h);
         W.st(act && l0, base + T, h);
         W.st(act && l0, base, h);
-        W.st(act && l0 && d.also != POSW_NONE, d.also, h);
+        W.st(act && l0 && d.also != POSW_NONE, d.also, h, true);
     }
 }
 
@@ -160,7 +179,7 @@ template <int T> __device__ __forceinline__ void posw_run(const GArgs& A, const 
 #define POSW_WAVES 4
 #endif
 static_assert(8 % POSW_WAVES == 0, "the slices of a workgroup belong to one unit");
-__device__ __forceinline__ void poswide_body(const GArgs& A, uint32_t bx, uint32_t g) {
+template <bool RIDE, bool FAULT = false> __device__ __forceinline__ void poswide_body(const GArgs& A, uint32_t bx, uint32_t g) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63u;
     const UnitDesc* dp = A.units + POB_UNI(A.order[A.first + (bx >> 3)]);
@@ -170,16 +189,26 @@ __device__ __forceinline__ void poswide_body(const GArgs& A, uint32_t bx, uint32
     const uint32_t kend = T == 3 ? POS_OFF_C_4 : T == 4 ? POS_OFF_C_5 : POS_TABLE_LEN;     // the constants of one T are contiguous
     for (uint32_t i = threadIdx.x; i < (kend - k.C) * 8; i += blockDim.x) g_lds[i] = A.pos_tab[(size_t)k.C * 8 + i];
     __syncthreads();
-    PosWide W;
+    PosWideT<RIDE, FAULT> W;
     uint32_t* frp = A.fr + (uint64_t)g * A.fr_stride;
     const uint64_t nf = A.fr_stride * 4;
     W.rs = __builtin_amdgcn_make_buffer_rsrc(frp, 0, (int)(nf > 0xFFFFF000ull ? 0xFFFFF000ull : nf), 0x00020000);
     W.slot4 = (8 * (bx & 7u) + (lane >> 3)) * 4;
     W.act = (lane & 7u) < (uint32_t)T;
     W.ktab = g_lds; W.kbase = k.C;
+    W.w_of_f = POB_UNI(dp->cur.w) - d.base; W.w_also = POB_UNI(dp->cur.w);
+    if constexpr (RIDE) W.ride_init();
+    if constexpr (FAULT) { W.fault_f = A.fault_idx; W.fault_me = A.fault_cls == 2 && g == A.fault_group && ((A.fault_lanes >> (8 * (bx & 7u) + (lane >> 3))) & 1); }
     if (T == 3) posw_run<3>(A, d, W, lane); else if (T == 4) posw_run<4>(A, d, W, lane); else posw_run<5>(A, d, W, lane);
+    if constexpr (RIDE) {          // the last pending compare; the lowest differing wire over the 8 lanes (elements) of a witness, reported by its first lane
+        W.ride_resolve();
+        uint32_t b = W.bad;
+#pragma unroll
+        for (uint32_t m = 4; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ m) << 2), (int)b); b = o < b ? o : b; }
+        if ((lane & 7u) == 0 && b != 0xFFFFFFFFu) atomicMin(&A.bad_wire[g * 64 + 8 * (bx & 7u) + (lane >> 3)], b);
+    }
 }
 // grid = (8 / POSW_WAVES * nunits, ngroups) workgroups of POSW_WAVES wavefronts
-__global__ void __launch_bounds__(64 * POSW_WAVES) k_poseidon_wide(GArgs A) { poswide_body(A, POSW_WAVES * blockIdx.x + (threadIdx.x >> 6), blockIdx.y); }
+template <bool RIDE, bool FAULT> __global__ void __launch_bounds__(64 * POSW_WAVES) k_poseidon_wide(GArgs A) { poswide_body<RIDE, FAULT>(A, POSW_WAVES * blockIdx.x + (threadIdx.x >> 6), blockIdx.y); }
 static_assert(POS_TABLE_LEN - POS_OFF_C_5 >= POS_OFF_C_5 - POS_OFF_C_4 && POS_TABLE_LEN - POS_OFF_C_5 >= POS_OFF_C_4 - POS_OFF_C_3, "the T = 5 constants are the largest set");
 #define POSW_LDS_BYTES ((POS_TABLE_LEN - POS_OFF_C_5) * 32u)

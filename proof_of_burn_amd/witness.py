@@ -829,10 +829,13 @@ class WitnessCalculator:
         """XOR one stored value of one witness of the resident vector (storage class, rank in the class, lane)"""
         self._ck(self.lib.pob_debug_poke(self.h, cls, group, index, sub, lane, xor_mask))
 
+    UNKNOWN_WIRE = 0xFFFFFFFF
+
     def store_fault(self, index: int, lane_mask: int, group: int = 0, cls: int = 0):
-        """arm ONE corrupted store of the next generation (pob_debug_store_fault; calculators with set_inorder(... | 4)): a round block's BIT word (cls CLASS_BIT) or an
-        input's SM row (cls CLASS_SM).  Returns the wire the evaluation that rides with the generation must report for the witnesses of lane_mask, or None if no
-        such store exists"""
+        """arm ONE corrupted store of the next generation (pob_debug_store_fault; calculators with set_inorder(... | 4)): the word of storage class cls at rank `index`.
+        Returns the wire the evaluation that rides with the generation must report for the witnesses of lane_mask -- known for a round block's BIT word and an input's SM
+        row; UNKNOWN_WIRE for any other word: a store of a G unit if a riding unit stores it at all (then exactly the witnesses of lane_mask are flagged, at the wire
+        itself), nothing happens otherwise -- or None if no such word exists"""
         w = ctypes.c_uint32()
         rc = self.lib.pob_debug_store_fault(self.h, cls, group, index, lane_mask, ctypes.byref(w))
         if rc == -1 and "not a stored word" in self.lib.pob_strerror(self.h).decode():

@@ -383,12 +383,13 @@ def test_failure_sets_match_oracle_at_the_production_instantiation(pkg):
     pool = O.OraclePool()                                        # the oracle's 46 production runs (2 s, 6.9 GB each) in worker processes, beside the GPU's work
     jobs = pool.submit(PROD, [c[1] for c in cases], digest=True)
     calc = pkg.WitnessCalculator(PROD, max_batch=n)
-    calc.set_inorder(3)                                          # in order, fused launch: the schedule bench.py runs
+    calc.set_inorder(7)                                          # in order, fused launch, the evaluation riding with the generation: the schedule bench.py runs
     res = calc.calculate(inputs, check=True)
     tracks = pkg.WitnessCalculator(PROD, max_batch=n)
     res_t = tracks.calculate(inputs, check=True)
     tracks.close()
-    assert [(r.status, r.outputs) for r in res] == [(r.status, r.outputs) for r in res_t], "the two schedules disagree about a witness"
+    # ... whose records -- the evaluator's verdict included -- are those of the track schedule's separate evaluation pass, valid and failing witnesses alike
+    assert [(r.status, r.outputs, r.check_status, r.bad_wire) for r in res] == [(r.status, r.outputs, r.check_status, r.bad_wire) for r in res_t], "the two schedules disagree about a witness"
     code_of = {name: tid for tid, name in W._TPL.items()}
     n_fail = n_valid_payloads = n_status_equal = 0
     is_case = set(pos)
@@ -733,7 +734,8 @@ def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
         group = tried % 3
         lanes = int(rng.integers(1, 1 << 63)) if group < 2 else int(rng.integers(1, 4))       # group 2 holds witnesses 128 and 129
         want = calc.store_fault(bit_index, lanes, group=group)
-        if want is None:
+        if want == calc.UNKNOWN_WIRE:
+            calc.store_fault(bit_index, 0, group=group)      # (a word outside the round blocks: the G units' part below; disarm)
             continue
         calc.generate(); calc.constraint_check()
         got = [r.bad_wire for r in calc.results(with_check=True)]
@@ -743,8 +745,8 @@ def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
         if tried >= 36:
             break
     assert tried >= 36 and len(wires) >= 12
-    first = next(i for i in range(int(calc.info.n_sm)) if calc.store_fault(i, 0, cls=calc.CLASS_SM) is not None)       # the first input row
-    nrows = next(k for k in range(1, int(calc.info.n_sm)) if calc.store_fault(first + k, 0, cls=calc.CLASS_SM) is None)
+    first = next(i for i in range(int(calc.info.n_sm)) if calc.store_fault(i, 0, cls=calc.CLASS_SM) != calc.UNKNOWN_WIRE)       # the first input row
+    nrows = next(k for k in range(1, int(calc.info.n_sm)) if calc.store_fault(first + k, 0, cls=calc.CLASS_SM) == calc.UNKNOWN_WIRE)
     assert nrows == 1 + 16 * 544 + 16 + 1 + 16 * 136 + 1 + 1     # numLeafAddressNibbles, layers, layerLens, numLayers, blockHeader, blockHeaderLen, byteSecurityRelax (proof_of_burn.circom:43-72)
     for k in sorted(set([0, nrows - 1] + rng.integers(0, nrows, 10).tolist())):
         group = k % 3
@@ -754,6 +756,24 @@ def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
         got = [r.bad_wire for r in calc.results(with_check=True)]
         exp = [want if j // 64 == group and (lanes >> (j % 64)) & 1 else None for j in range(n)]
         assert got == exp, (k, group, hex(lanes), want, [(j, g) for j, g in enumerate(got) if g != exp[j]][:6])
+    # the G units' own stores (policy.hpp GenPT<true, true>, poseidon_wide.hpp PosWideT<true, true>): where a riding unit stores the word, exactly the witnesses of the mask are
+    # flagged; a word of the sponge chains, of the RLP units (plain policy: their evaluation is a launch of pob_constraint_check) or of no unit flags nobody outside the mask
+    sizes = calc.class_sizes()
+    hit = {calc.CLASS_BIT: 0, calc.CLASS_SM: 0, calc.CLASS_FR: 0}
+    for cls in (calc.CLASS_BIT, calc.CLASS_SM, calc.CLASS_FR):
+        # (BIT: 97 % of the class are Keccak's words; the first ranks are G-unit wires -- flags, selector rows, decompositions -- between the first sponges' blocks)
+        for t, idx in enumerate(rng.integers(0, min(sizes[cls], 40000) if cls == calc.CLASS_BIT else sizes[cls], 120 if cls == calc.CLASS_BIT else 30).tolist()):
+            group = t % 3
+            lanes = int(rng.integers(1, 1 << 63)) if group < 2 else int(rng.integers(1, 4))
+            if calc.store_fault(idx, lanes, group=group, cls=cls) != calc.UNKNOWN_WIRE:
+                calc.store_fault(idx, 0, group=group, cls=cls)
+                continue
+            calc.generate(); calc.constraint_check()
+            flagged = [j for j, r in enumerate(calc.results(with_check=True)) if r.bad_wire is not None]
+            exp = [j for j in range(n) if j // 64 == group and (lanes >> (j % 64)) & 1]
+            assert set(flagged) <= set(exp), (cls, idx, group, hex(lanes), [j for j in flagged if j not in exp][:6])
+            hit[cls] += flagged == exp
+    assert hit[calc.CLASS_BIT] >= 4 and hit[calc.CLASS_SM] >= 10 and hit[calc.CLASS_FR] >= 15, hit
     calc.generate(); calc.constraint_check()
     assert all(r.ok and r.check_status == 0 and r.bad_wire is None for r in calc.results(with_check=True))
     idx = int(calc.info.n_bit) // 2

@@ -525,8 +525,9 @@ def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
     for bit_index in rng.integers(0, nbit, 400).tolist():
         lanes = int(rng.integers(1, 32))                     # any subset of the 5 witnesses
         want = calc.store_fault(bit_index, lanes)
-        if want is None:
-            continue                                         # not a word of a round block: nothing armed
+        if want == calc.UNKNOWN_WIRE:
+            calc.store_fault(bit_index, 0)                   # (a word outside the round blocks: the G units' part below; disarm)
+            continue
         res = calc.calculate([ok_case["input"]] * 5, check=True)
         assert [r.bad_wire for r in res] == [want if (lanes >> k) & 1 else None for k in range(5)], (bit_index, lanes, want, [r.bad_wire for r in res])
         kinds.add(want)
@@ -548,8 +549,8 @@ def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
     ok_case = next(c for c in s["cases"] if c["expected"] is not None)
     calc = pkg.WitnessCalculator(POB_FIX, max_batch=3)
     calc.set_inorder(7)
-    first = next(i for i in range(int(calc.info.n_sm)) if calc.store_fault(i, 0, cls=EC.SM) is not None)
-    nrows = next(k for k in range(1, int(calc.info.n_sm)) if calc.store_fault(first + k, 0, cls=EC.SM) is None)
+    first = next(i for i in range(int(calc.info.n_sm)) if calc.store_fault(i, 0, cls=EC.SM) != calc.UNKNOWN_WIRE)
+    nrows = next(k for k in range(1, int(calc.info.n_sm)) if calc.store_fault(first + k, 0, cls=EC.SM) == calc.UNKNOWN_WIRE)
     assert nrows > 2000                                      # layers[4][544] + blockHeader[680] + the scalars
     for k in sorted(set([0, nrows - 1] + rng.integers(0, nrows, 6).tolist())):
         lanes = int(rng.integers(1, 8))
@@ -558,6 +559,48 @@ def test_evaluation_riding_with_the_generation_flags_a_corrupted_store(pkg):
         assert [r.bad_wire for r in res] == [want if (lanes >> j) & 1 else None for j in range(3)], (k, lanes, want, [r.bad_wire for r in res])
     res = calc.calculate([ok_case["input"]] * 3, check=True)
     assert all(r.ok and r.bad_wire is None and r.check_status == 0 for r in res)
+    # the G units' own stores (policy.hpp GenPT<true, true>, poseidon_wide.hpp): words drawn from every storage class.  Where a riding unit stores the word, exactly the
+    # witnesses of the mask are flagged (the wire is the corrupted word's own: a later unit that READS the corrupted word builds on it consistently); a word of the sponge
+    # chains, of the RLP units (plain policy: their evaluation is a launch of pob_constraint_check, which then sees a vector whose defining unit wrote something else) or of no
+    # unit at all flags whatever pob_constraint_check's remaining launches make of it -- never a witness outside the mask
+    sizes = calc.class_sizes()
+    hit = {EC.BIT: 0, EC.SM: 0, EC.FR: 0}
+    for cls in (EC.BIT, EC.SM, EC.FR):
+        for idx in rng.integers(0, min(sizes[cls], 30000) if cls == EC.BIT else sizes[cls], 40).tolist():      # (BIT: the first ranks are G-unit wires; 97 % of the class are Keccak's)
+            lanes = int(rng.integers(1, 8))
+            want = calc.store_fault(idx, lanes, cls=cls)
+            if want != calc.UNKNOWN_WIRE:
+                calc.store_fault(idx, 0, cls=cls)            # (a round block's word / an input row: covered above)
+                continue
+            res = calc.calculate([ok_case["input"]] * 3, check=True)
+            flagged = [j for j, r in enumerate(res) if r.bad_wire is not None]
+            assert all((lanes >> j) & 1 for j in flagged), (cls, idx, lanes, [(r.bad_wire, r.check_status) for r in res])
+            hit[cls] += flagged == [j for j in range(3) if (lanes >> j) & 1]
+    assert hit[EC.BIT] >= 8 and hit[EC.SM] >= 15 and hit[EC.FR] >= 25, hit
+    res = calc.calculate([ok_case["input"]] * 3, check=True)
+    assert all(r.ok and r.bad_wire is None and r.check_status == 0 for r in res)
+    calc.close()
+
+
+def test_riding_evaluation_gives_the_records_of_the_evaluation_pass_on_the_mutation_set(pkg):
+    """the reference's mutation set on the fixture instantiation (valid and failing inputs alike): an in-order calculator whose evaluation rides with its generation
+    (pob_set_inorder(h, 7): Keccak round blocks, input rows, every G unit but the RLP family) reports, witness by witness, the records of the track schedule's separate
+    evaluation pass -- status, outputs, the evaluator's verdict (check_status: the same failing site) and bad_wire (none: every vector is consistent)"""
+    import random
+    from proof_of_burn_amd import inputs as gen
+    from tests.test_gpu_parity import _mutations
+    params = (4, 4, 5, 20, 31, 2, 10 ** 18, 10 ** 19)
+    base = gen.synthetic_batch(1, depth=2, seed=101, distinct_keys=1, params=params).inputs[0]
+    cases = _mutations(base, random.Random(5))
+    ref = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
+    want = [(r.status, r.outputs, r.check_status, r.bad_wire) for r in ref.calculate([c[1] for c in cases], check=True)]
+    ref.close()
+    assert sum(1 for w in want if w[0] != 0) > 20 and sum(1 for w in want if w[0] == 0) > 5
+    calc = pkg.WitnessCalculator(POB_FIX, max_batch=len(cases))
+    calc.set_inorder(7)
+    for _ in range(2):
+        got = [(r.status, r.outputs, r.check_status, r.bad_wire) for r in calc.calculate([c[1] for c in cases], check=True)]
+        assert got == want, [(cases[k][0], g, w) for k, (g, w) in enumerate(zip(got, want)) if g != w][:4]
     calc.close()
 
 
