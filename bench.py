@@ -104,8 +104,9 @@ def parse_args(argv=None):
                          "tracks: round 2-3's schedule, two linked calculators (pob_set_partner) whose tracks run on the device's side streams")
     ap.add_argument("--pipeline", type=int, default=-1, help=f"calculators in flight, each on consecutive batches (default: {DEFAULT_DEPTH} in-order ones / 2 linked track ones; 0 = one calculator, no pipeline)")
     ap.add_argument("--fused", type=int, default=3, choices=[0, 1, 2, 3],
-                    help="default 3.  bit 0: in-order calculators with the fused Poseidon + sponge-chain launch (pob_set_inorder bit 1); bit 1: the Keccak round blocks are evaluated by the "
-                         "launch that writes them (pob_set_inorder bit 2: the evaluation's loads come from L2 / the Infinity Cache); 0: one launch per kernel, round 5's schedule")
+                    help="default 3.  bit 0: in-order calculators with the fused Poseidon + sponge-chain launch (pob_set_inorder bit 1); bit 1: the evaluation rides with the generation "
+                         "(pob_set_inorder bit 2: the Keccak round blocks, the input rows and the G units' wires are loaded back from L2 and compared by the launches that store them; of the "
+                         "evaluation pass the sponge chains' and the RLP family's kernels are left); 0: one launch per kernel, round 5's schedule")
     ap.add_argument("--depth", type=int, default=10, help="MPT proof depth of the synthetic inputs (16 = BASELINE config 5)")
     ap.add_argument("--distinct-keys", type=int, default=16, help="distinct PoW burn keys tiled over a global batch")
     ap.add_argument("--distinct-batches", type=int, default=4, help="different input batches cycled through the steps (every one is uploaded anew each time)")
@@ -815,7 +816,10 @@ def main():
                            "canonical_bytes_per_witness": int(info.n_witness) * 32,
                            "parallelism": f"one slice per GPU x{world}, " + ((f"{NC} in-order calculators in flight, one stream each, on consecutive batches of {B}" if INORDER else f"two linked track-schedule calculators pipelined over consecutive batches of {B}")
                                                                                          + " (fill and drain inside the timed region)" if PIPE else f"one calculator of {B} per GPU"),
-                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused & 1), "rounds_evaluated_with_expansion": bool(args.fused & 2) and INORDER,
+                           "schedule": args.schedule, "calculators_in_flight": NC, "fused_launches": bool(args.fused & 1), "evaluation_rides_with_generation": bool(args.fused & 2) and INORDER,
+                           "evaluation": ("every stored word of the Keccak round blocks, the input rows and the G units is loaded back (from L2) and compared with its definition by the launch that "
+                                          "stores it; pob_constraint_check runs the sponge chains' and the RLP family's evaluation kernels and collects the records (DESIGN.md 4.1, 4.3)")
+                                         if (args.fused & 2) and INORDER else "pob_constraint_check: a separate pass over the resident vector",
                            "setup": f"before the {args.warmup} warm-up steps every one of the {NC} calculators has passed one batch (first touch of its buffers, its stream's hardware queue)", "rank_bound_to_cpus": (len(job.bound_cpus) if job.bound_cpus else None),
                            "validated_witnesses": validated_timed, "h2d_bytes_per_step": int(h2d_per_step),
                            "rccl_ranks": ranks["rccl_ranks"], "dist_backend": job.backend,

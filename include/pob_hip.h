@@ -153,8 +153,9 @@ int pob_set_partner(pob_handle h, pob_handle partner);
  * on | 4 -- the Keccak ROUND BLOCKS ARE EVALUATED BY THE LAUNCH THAT WRITES THEM (k_rounds_gc): the wavefront that has stored the 76 gate-output arrays of a round loads them
  * back -- from L2 / the Infinity Cache instead of HBM -- together with the stored midRound[r+1] and checks every XOR / AND gate of the round on the loaded operands, as
  * pob_constraint_check's round kernel does; pob_constraint_check then skips that kernel (1.77 of the 2.27 GB it would read per 1 024 production witnesses); the input rows are compared with the
- * inputs by the launch that writes them (k_inputs MODE 2) and the evaluation's input check is skipped likewise -- unless a debug poke touched the vector in between.
- * Same records, same failing sites. */
+ * inputs by the launch that writes them (k_inputs MODE 2), and -- for the two main circuits -- every G unit's stores are loaded back and compared by the unit itself
+ * (policy.hpp GenPT<true>, poseidon_wide.hpp PosWideT<true>; the RLP units excepted): of the evaluation pass pob_constraint_check then runs the sponge chains' kernel and the
+ * RLP family's and collects the records -- unless a debug poke touched the vector in between, in which case it runs everything.  Same records, same failing sites. */
 int pob_set_inorder(pob_handle h, int on);
 
 /* Replaces "stderr non-empty => failure" + the output dump patched in by tests/test.py:36-54.
@@ -262,10 +263,11 @@ int pob_probe_check_kernel(pob_handle h, int enable, float* ms);
 /* Test hook: XOR `mask` into the stored word of BIT-class storage index `bit_index` of witness group `group`. */
 int pob_debug_xor_bits(pob_handle h, uint32_t group, uint64_t bit_index, uint64_t mask);
 /* Test hook for the evaluation that rides with the generation (pob_set_inorder bit 2): in the NEXT pob_generate of this in-order calculator ONE store reaches memory corrupted
- * while the generating wavefront goes on with the right value -- cls = POB_CLASS_BIT: the BIT-class word `index` of group `group`, which must be a gate output of a
- * KeccakfRound block, XORed with `mask` (bit l = witness l of the group); cls = POB_CLASS_SM: the input row at SM rank `index` (ProofOfBurn mains), bit 0 flipped for the witnesses of `mask`.
- * The launch's own evaluation, which works on what it LOADS, must flag exactly those witnesses at *wire (may be NULL): the round block's first wire / the input's wire.
- * POB_E_ARG: no such store.  One generation, then disarmed. */
+ * while the generating wavefront goes on with the right value: the word of storage class `cls` at rank `index` of group `group`, for the witnesses of `mask` (bit l = witness l of
+ * the group): a BIT word XORed with `mask`, an SM value / the lowest limb of an FR element with bit 0 flipped.  The launch's own evaluation, which works on what it LOADS, must
+ * flag exactly those witnesses.  *wire (may be NULL) = the wire it must report where the hook knows it -- a gate output of a KeccakfRound block: the block's first wire; an input
+ * row of a ProofOfBurn main: the input's wire -- else 0xFFFFFFFF: a store of a G unit (reported at the wire itself) if a riding unit stores the word at all (the sponge chains'
+ * words and the RLP units' wires are stored by launches that do not evaluate).  POB_E_ARG: no such word.  One generation, then disarmed. */
 int pob_debug_store_fault(pob_handle h, int cls, uint32_t group, uint64_t index, uint64_t mask, uint32_t* wire);
 /* Experiment hook (profiles/round6_experiments.txt 9): a non-blocking stream of `device` restricted to the compute units of cu_mask (hipExtStreamCreateWithCUMask; words x 32 bits,
  * bit i = CU i), for callers that want to partition the device between calculators.  pob_debug_stream_destroy frees it. */

@@ -77,7 +77,9 @@ HD constexpr uint32_t fam_of(uint32_t k) {
 // the kernel a unit's GENERATION is compiled into may differ from its evaluation / emission family: PublicCommitment's head is a long BIT/SM unit whose
 // generation needs more than the light kernel's 64 VGPRs (it spilled 12) -- it is generated by the <= 128-VGPR kernel, evaluated and emitted where it was
 HD constexpr uint32_t gen_fam_of(uint32_t k) { return k == U_PC_PRE ? (uint32_t)F_N2B : fam_of(k); }
-#define UCASE(K) case K: if constexpr (((MASK) >> (P::is_gen ? gen_fam_of(K) : fam_of(K))) & 1u)
+// (a riding generation policy does not instantiate the unit kinds that run on the plain policy inside its kernel: ride_keeps_evaluation, below)
+HD constexpr bool ride_keeps_evaluation(uint32_t kind) { return fam_of(kind) == F_RL; }
+#define UCASE(K) case K: if constexpr ((((MASK) >> (P::is_gen ? gen_fam_of(K) : fam_of(K))) & 1u) && !(P::ride && ride_keeps_evaluation(K)))
 
 struct PobParams { int L, NB, HB, minNib, amountBytes, powZero; Fr maxIntended, maxActual; };   // Montgomery
 struct SpendParams { int maxAmountBytes; };
@@ -435,10 +437,13 @@ HD bool unit_gen_is_heavy(uint32_t k) { return gen_fam_of(k) >= F_SC; }
 
 template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L);
 #ifdef __HIPCC__
-// a riding generation kernel (policy.hpp GenPT<true>) runs its RLP units on the plain policy: their evaluation stays a launch of pob_constraint_check
+// a riding generation kernel (policy.hpp GenPT<true>) runs the RLP family's units on the plain policy, and their evaluation stays a launch of pob_constraint_check
+// (ride_keeps_evaluation: what the host asks).  One of them -- U_RL_A, the head of RlpMerklePatriciaTrieLeaf -- spills 179 VGPRs with the pending compares in registers, the only unit
+// kind that does; with the other four riding and only U_RL_A's evaluation left the kernel has no spill either, but the RLP units are the generation's longest serial chains: a lone
+// generation 2.10 -> 2.58 ms, the loop with 8 / 16 in flight 1.06 -> 1.10 / 1.06 -> 1.10 ms, with 12 the same (profiles/round6_experiments.txt 22): the family stays plain.
 template <uint32_t MASK, bool FAULT> GD void unit_run_ride(GenPT<true, FAULT>& p, const UnitDesc& d, CircuitLayout& L) {
-    if constexpr ((MASK >> F_RL) & 1u) { if (gen_fam_of(d.kind) == F_RL) { unit_run<GenPT<false>, FAM_BIT(F_RL)>(plain_view(p), d, L); return; } }
-    unit_run<GenPT<true, FAULT>, MASK & ~FAM_BIT(F_RL)>(p, d, L);
+    if constexpr ((MASK >> F_RL) & 1u) { if (ride_keeps_evaluation(d.kind)) { unit_run<GenPT<false>, FAM_BIT(F_RL)>(plain_view(p), d, L); return; } }
+    unit_run<GenPT<true, FAULT>, MASK>(p, d, L);
 }
 #endif
 template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, CircuitLayout& L) {

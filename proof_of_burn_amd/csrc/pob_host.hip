@@ -397,6 +397,7 @@ struct pob_ctx {
     enum { GL_UNITS = 0, GL_CHAIN = 1, GL_POS_CHAIN = 2, GL_ROUNDS = 4 };
     std::vector<GenLaunch> gen_plan[2];
     Seg chk_narrow{0, 0, 0, 0};                          // in-order evaluation: the units of the four narrow families, one launch
+    Seg chk_ride_kept{0, F_RL, 0, 0};                    // ... when the G units' evaluation rode with their generation: the units whose generation did not ride (circuits.hpp ride_keeps_evaluation)
     uint32_t nlevels = 0;
     bool generated = false; uint64_t gen_count = 0;
     // two-batch pipeline (pob_set_partner): this handle's generation starts with the partner's evaluation and its Keccak expansion
@@ -736,6 +737,9 @@ int pob_open(int device, int circuit, const uint64_t* params, int nparams, uint3
         }
         h->chk_narrow.count = (uint32_t)h->order.size() - h->chk_narrow.first;
         std::stable_sort(h->order.begin() + h->chk_narrow.first, h->order.end(), [&](uint32_t a, uint32_t b) { return pl.units[a].cost > pl.units[b].cost; });
+        h->chk_ride_kept.first = (uint32_t)h->order.size();
+        for (uint32_t u = 0; u < pl.units.size(); u++) if ((pl.units[u].flags & UNIT_CHECK) && ride_keeps_evaluation(pl.units[u].kind)) h->order.push_back(u);
+        h->chk_ride_kept.count = (uint32_t)h->order.size() - h->chk_ride_kept.first;
     }
 
     HIPC(hipSetDevice(device));
@@ -997,11 +1001,7 @@ int pob_generate(pob_handle h, void* stream_) {
         KArgs K = kargs(h);
         if (h->gc && h->rode) { HIPC(hipMemsetAsync(h->d_bad, 0xFF, (size_t)G * 64 * 4, st)); HIPC(hipMemsetAsync(h->d_chk, 0xFF, (size_t)G * 64 * 4, st)); }     // a generation whose verdict nobody collected
         h->rode = false; h->rode_g = false;
-#ifdef POB_AB_NO_RIDE_G
-        const bool ride_g = false;
-#else
         const bool ride_g = h->gc && (h->circuit == POB_CIRCUIT_PROOF_OF_BURN || h->circuit == POB_CIRCUIT_SPEND);
-#endif
         launch_inputs(h, h->gc ? 2 : 0, G, st);
         const bool kf = h->gc && h->fault_armed && !h->fault_g && h->fault_cls == POB_CLASS_BIT;
         const bool gf = ride_g && h->fault_armed && h->fault_g;             // pob_debug_store_fault on a store of a G unit: the riding kernels' FAULT instantiations
@@ -1147,8 +1147,8 @@ int pob_constraint_check(pob_handle h, void* stream_) {
         if (!rode) launch_inputs(h, 1, G, st);
         // (the narrow kernel on a side stream of the calculator, forked behind the generation and joined here, was measured in round 5: 1.87-1.88 ms per step against 1.82-1.84
         //  with 4 in flight; the four wide families as ONE launch: nothing either -- profiles/round5_experiments.txt 4, 7)
-        if (rode_g) {       // of the G units only the RLP family's evaluation is left (its units generate on the plain policy, circuits.hpp unit_run_ride)
-            for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds == F_RL) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }
+        if (rode_g) {       // of the G units only the evaluation of the units that generated on the plain policy is left (circuits.hpp unit_run_ride: the RLP family)
+            if (h->chk_ride_kept.count) { A.first = h->chk_ride_kept.first; launch_g_check(A, F_RL, h->chk_ride_kept.count, G, st); }
         } else {
             if (h->chk_narrow.count) { A.first = h->chk_narrow.first; launch_g_check_narrow(A, h->chk_narrow.count, G, st); }
             for (const pob_ctx::Seg& sg : h->chk_segs) if (sg.lds != F_MISC && sg.lds != F_RL && sg.lds != F_POS && sg.lds != F_N2B) { A.first = sg.first; launch_g_check(A, sg.lds, sg.count, G, st); }

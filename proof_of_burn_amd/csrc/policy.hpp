@@ -93,7 +93,7 @@ enum : uint32_t { NOTE_POSEIDON = 1, NOTE_N2BE = 2, NOTE_SHIFTRIGHT = 3, NOTE_SH
 struct PlanNote { uint32_t what, n; Cur cur; uint32_t a[7]; };
 #define PLAN_MAX_NOTES 8
 struct CountP : PolBase {
-    static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true;
+    static constexpr bool is_gen = false, is_check = false, is_emit = false, is_count = true, ride = false;
     uint32_t nput = 0;    // wires written: the planner's cost estimate of a unit (long units are dispatched first)
     uint32_t nb = 0, ns = 0, nf = 0;      // ... by storage class (tools/plan_stats.cpp)
     PlanNote notes[PLAN_MAX_NOTES]; uint32_t nnotes = 0;
@@ -482,8 +482,8 @@ template <bool RIDE, bool FAULT = false> struct GenPT : DevPol {
 typedef GenPT<false> GenP;
 typedef GenPT<true> GenRideP;
 typedef GenPT<true, true> GenRideFaultP;
-// the same policy object without the riding evaluation (the two instantiations differ in code only, not in layout): the RLP units of a riding kernel run on it -- with the
-// pending compares in registers their long byte loops spill 164 VGPRs -- and keep their evaluation in pob_constraint_check (g_check_rl.hip)
+// the same policy object without the riding evaluation (the instantiations differ in code only, not in layout): the one unit kind that spills with the pending compares in
+// registers runs on it inside a riding kernel and keeps its evaluation in pob_constraint_check (circuits.hpp unit_run_ride)
 static_assert(sizeof(GenPT<false>) == sizeof(GenPT<true>) && sizeof(GenPT<false>) == sizeof(GenPT<true, true>), "one layout");
 template <bool FAULT> __device__ __forceinline__ GenPT<false>& plain_view(GenPT<true, FAULT>& p) { return *reinterpret_cast<GenPT<false>*>(&p); }
 
@@ -506,7 +506,7 @@ __device__ __forceinline__ uint32_t check_attribute_run(B d, uint32_t w, uint32_
 // from it.  That locality is what lets the evaluator cut the generator's serial chains (Poseidon rounds, byte conversions) into
 // independent units that start from stored wires (circuits.hpp CK_* units).
 struct CheckP : DevPol {
-    static constexpr bool is_gen = false, is_check = true, is_emit = false, is_count = false;
+    static constexpr bool is_gen = false, is_check = true, is_emit = false, is_count = false, ride = false;
     uint32_t status;     // first failing === site of this lane
     uint32_t bad_wire;   // lowest wire index whose stored value contradicts its definition (per lane)
     __device__ __forceinline__ void mark(bool bad, uint32_t w) { if (bad && w < bad_wire) bad_wire = w; }
@@ -543,7 +543,7 @@ struct CheckP : DevPol {
 
 // .wtns emitter for ONE witness of the group (lane `sel`): canonical 32-byte LE value at wire index.
 struct EmitP : DevPol {
-    static constexpr bool is_gen = false, is_check = false, is_emit = true, is_count = false;
+    static constexpr bool is_gen = false, is_check = false, is_emit = true, is_count = false, ride = false;
     uint8_t* out;      // canonical witness payload of the wires [w0, w0 + wn) (the emission window), 32 B per wire
     uint32_t sel, w0, wn, unit;
     unsigned long long* probe;      // probe pass (once per window size): which windows does this unit write to?  bit w / wn of probe[unit]
