@@ -14,7 +14,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
 QUICK = "spend_suite or run_shim or inverse_paths"
 # (the loaded library is checked too: a run that silently used the uninstrumented build would prove nothing)
 FULL = ("spend_suite or fixture_suite or pokes_in_every_class_spend or service_loop or reference_suites_on_the_shim or run_shim or gadget_mains_evaluator or "
-        "gadget_mains_seeded or production_sizes or inverse_paths or pipelined or selfcheck or inorder")
+        "gadget_mains_seeded or production_sizes or inverse_paths or pipelined or selfcheck or inorder or riding or records_of_the_evaluation")
 
 
 def main(mode="quick"):
