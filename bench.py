@@ -490,10 +490,10 @@ def legs_track_schedule(job, loop):
     return single, tracks
 
 
-def leg_other_depth(job, main, depth, pinned, expect, nsteps=96):
-    """the same service loop with another number of in-order calculators in flight: throughput and the round evaluation kernel's in-step duration"""
+def leg_other_depth(job, main, depth, pinned, expect, nsteps=96, fused=None, what=None):
+    """the same service loop with another number of in-order calculators in flight (or another --fused mode): throughput and the round evaluation kernel's in-step duration"""
     np = __import__("numpy")
-    lp = ServiceLoop(job, main, depth, True, job.args.fused)
+    lp = ServiceLoop(job, main, depth, True, job.args.fused if fused is None else fused)
     lp.set_inputs(pinned, expect)
     lp.run(depth + 2); job.fence()
     lp.probe(True)
@@ -501,7 +501,7 @@ def leg_other_depth(job, main, depth, pinned, expect, nsteps=96):
     k = float(np.mean(lp.kchk_ms)) if lp.kchk_ms else None
     lp.probe(False)
     lp.close()
-    return _rate(job, lp, s, nsteps, what=f"{depth} in-order calculators in flight, {nsteps} steps of the same service loop after the timed region",
+    return _rate(job, lp, s, nsteps, what=what or f"{depth} in-order calculators in flight, {nsteps} steps of the same service loop after the timed region",
                  calculators_in_flight=depth, round_evaluation_ms_in_step=(round(k, 4) if k else None))
 
 
@@ -766,12 +766,17 @@ def main():
         bare = leg_kernel_pipeline_only(job, loop)
     if PIPE and not args.no_single:
         single, tracks_pipeline = legs_track_schedule(job, loop)
-    depths, depth16, strong_slice = {}, None, None
+    depths, depth16, strong_slice, separate_eval = {}, None, None, None
     lone = rank == 0 and world == 1 and not job.strong and not args.no_extra_legs and loop.fetch_each and not args.shim and args.main == "proof_of_burn"
     if lone and INORDER and PIPE:
         for d in [int(x) for x in args.other_depths.split(",") if x.strip()]:
             if d != NC and d >= 2:
                 depths[str(d)] = leg_other_depth(job, MAIN_, d, pinned, expect)
+        if args.fused & 2:      # the same loop with the evaluation as a pass of its own over the resident vector (--fused 1: what the timed region did in the first half of round 6)
+            separate_eval = leg_other_depth(job, MAIN_, NC, pinned, expect, fused=args.fused & 1,
+                                            what=f"the same service loop ({NC} in flight, 96 steps) with the evaluation as a SEPARATE PASS over the resident vector (bench.py --fused {args.fused & 1}: "
+                                                 "k_rounds_gen + k_rounds_check from HBM, the input check and the seven G-family launches of pob_constraint_check) instead of riding with the generation; a process's "
+                                                 "later legs run 5-10 % slower than its timed region -- as a timed region of its own: bench.py --fused 1")
     if lone:
         # depth16: BASELINE config 5's shape on one GPU (16-layer proofs, byteSecurityRelax = 1, 3-zero-byte proof of work); strong_slice: BASELINE config 4 as one GPU sees it
         deep = [gen.synthetic_batch(B, depth=16, seed=0xD16, distinct_keys=args.distinct_keys, first=b * B, pow_device=job.dev) for b in range(2)]
@@ -829,7 +834,7 @@ def main():
                                               "host_cores": os.cpu_count(), "python_loader_witnesses_per_s_one_core": round(B / max(t_pack_py, 1e-9), 1)}},
                 "ranks": ranks,
                 "roofline": roofline, "cpu_baseline": cpu, "emission": emission, "single_calculator": single, "tracks_pipeline": tracks_pipeline, "kernel_pipeline_only": bare, "single_witness_latency": latency,
-                "depth16": depth16, "strong_slice": strong_slice, "other_depths": depths or None, "e2e_from_json": e2e,
+                "depth16": depth16, "strong_slice": strong_slice, "other_depths": depths or None, "separate_evaluation_pass": separate_eval, "e2e_from_json": e2e,
             }
             print(json.dumps(line), flush=True)
     loop.close()

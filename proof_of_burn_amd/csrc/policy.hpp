@@ -411,6 +411,9 @@ struct DevPol : PolBase {
 // computed ones, and every `===` was evaluated on operands equal to the stored ones: what CheckP establishes by recomputing every unit from stored operands -- the seven G-family
 // launches of pob_constraint_check -- without a second pass over the vector (the loads hit L2: the store is a few instructions old).  A debug poke, or a vector that no launch has
 // just written, is evaluated by CheckP as before.
+#ifndef POB_RIDE_BARRIER
+#define POB_RIDE_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <bool RIDE, bool FAULT = false> struct GenPT : DevPol {
     static constexpr bool is_gen = true, is_check = false, is_emit = false, is_count = false, ride = RIDE;
     // FAULT (tests): what goes to memory for the armed (class, rank): bit 0 of the value flipped for the witnesses of fault_lanes -- the unit goes on with the right value
@@ -433,12 +436,12 @@ template <bool RIDE, bool FAULT = false> struct GenPT : DevPol {
     }
     __device__ __forceinline__ B put(BitRef r, B v) {
         st(r, hit(0, r.i) ? v ^ m.fault_lanes : v);
-        if constexpr (RIDE) { const B l = run_ld_off(POB_UNI(r.i) << 3); __builtin_amdgcn_sched_barrier(0); res_b(); pb_l = l; pb_v = v; pb_w = r.w; }
+        if constexpr (RIDE) { const B l = run_ld_off(POB_UNI(r.i) << 3); POB_RIDE_BARRIER(); res_b(); pb_l = l; pb_v = v; pb_w = r.w; }
         return v;
     }
     __device__ __forceinline__ S put(SmRef r, S v) {
         st(r, (hit(1, r.i) && ((m.fault_lanes >> m.lane) & 1)) ? v ^ 1 : v);
-        if constexpr (RIDE) { const S l = ld(r); __builtin_amdgcn_sched_barrier(0); res_s(); ps_l = l; ps_v = v; ps_w = r.w; }
+        if constexpr (RIDE) { const S l = ld(r); POB_RIDE_BARRIER(); res_s(); ps_l = l; ps_v = v; ps_w = r.w; }
         return v;
     }
     __device__ __forceinline__ F put(FrRef r, const F& v) {
@@ -462,7 +465,7 @@ template <bool RIDE, bool FAULT = false> struct GenPT : DevPol {
         POB_WAVE_FENCE();
         if constexpr (RIDE) {
             const B l = run_ld_off(off);                    // (inactive lanes read 0 ...)
-            __builtin_amdgcn_sched_barrier(0);
+            POB_RIDE_BARRIER();
             res_r();
             pr_l = l; pr_x = m.lane < n ? x : 0; pr_w = w;  // (... and expect 0)
         }

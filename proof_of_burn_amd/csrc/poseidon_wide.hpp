@@ -55,7 +55,7 @@ template <bool RIDE, bool FAULT = false> struct PosWideT {
             Fr l;                                                               // (off: reads 0 ...)
 #pragma unroll
             for (int k = 0; k < 8; k++) l.l[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off + 256u * k), 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            POB_RIDE_BARRIER();
             ride_resolve();
             pl = l; pv = on ? v : fr_zero(); pw = also ? w_also : f + w_of_f;   // (... and expects 0)
         }
