@@ -442,7 +442,7 @@ template <class P, uint32_t MASK> GD void unit_run(P& p, const UnitDesc& d, Circ
 // kind that does; with the other four riding and only U_RL_A's evaluation left the kernel has no spill either, but the RLP units are the generation's longest serial chains: a lone
 // generation 2.10 -> 2.58 ms, the loop with 8 / 16 in flight 1.06 -> 1.10 / 1.06 -> 1.10 ms, with 12 the same (profiles/round6_experiments.txt 22): the family stays plain.
 template <uint32_t MASK, bool FAULT> GD void unit_run_ride(GenPT<true, FAULT>& p, const UnitDesc& d, CircuitLayout& L) {
-    if constexpr ((MASK >> F_RL) & 1u) { if (ride_keeps_evaluation(d.kind)) { unit_run<GenPT<false>, FAM_BIT(F_RL)>(plain_view(p), d, L); return; } }
+    if constexpr ((MASK >> F_RL) & 1u) { if (ride_keeps_evaluation(d.kind)) { GenPT<false> q = plain_of(p); unit_run<GenPT<false>, FAM_BIT(F_RL)>(q, d, L); p.status = q.status; return; } }
     unit_run<GenPT<true, FAULT>, MASK>(p, d, L);
 }
 #endif

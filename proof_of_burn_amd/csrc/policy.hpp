@@ -485,10 +485,14 @@ template <bool RIDE, bool FAULT = false> struct GenPT : DevPol {
 typedef GenPT<false> GenP;
 typedef GenPT<true> GenRideP;
 typedef GenPT<true, true> GenRideFaultP;
-// the same policy object without the riding evaluation (the instantiations differ in code only, not in layout): the one unit kind that spills with the pending compares in
-// registers runs on it inside a riding kernel and keeps its evaluation in pob_constraint_check (circuits.hpp unit_run_ride)
-static_assert(sizeof(GenPT<false>) == sizeof(GenPT<true>) && sizeof(GenPT<false>) == sizeof(GenPT<true, true>), "one layout");
-template <bool FAULT> __device__ __forceinline__ GenPT<false>& plain_view(GenPT<true, FAULT>& p) { return *reinterpret_cast<GenPT<false>*>(&p); }
+// a plain policy with the state of a riding one (memory, cursor, status): the unit kinds that generate without the riding evaluation inside a riding kernel run on it
+// (circuits.hpp unit_run_ride) and hand their status back; the copies are register moves
+template <bool FAULT> __device__ __forceinline__ GenPT<false> plain_of(const GenPT<true, FAULT>& p) {
+    GenPT<false> q;
+    static_cast<DevPol&>(q) = static_cast<const DevPol&>(p);
+    q.status = p.status;
+    return q;
+}
 
 // slow path of CheckP::run_put (by value: the policy object stays in registers): lane j holds the difference mask d of wire w
 __device__ __forceinline__ uint32_t check_attribute_run(B d, uint32_t w, uint32_t lane, uint32_t bad_wire) {
